@@ -1,0 +1,96 @@
+"""ctypes binding of libemf_hip.so (the emf_hip_* C ABI declared in include/emf_hip.h).
+
+Fails loudly when the library is missing or lacks a declared symbol -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "libemf_hip.so"
+HEADER_PATH = REPO_ROOT / "include" / "emf_hip.h"
+
+EMF_OK = 0
+
+
+class EmfImage(C.Structure):
+    """Mirror of emf_image_t: device pointer + byte pitch + size."""
+
+    _fields_ = [("data", C.c_void_p), ("pitch", C.c_size_t), ("width", C.c_int32),
+                ("height", C.c_int32)]
+
+
+class EmfHipError(RuntimeError):
+    def __init__(self, fn: str, code: int, msg: str):
+        super().__init__(f"{fn} failed with {code}: {msg}")
+        self.code = code
+
+
+_F9 = C.POINTER(C.c_float)
+_I3 = C.POINTER(C.c_int32)
+_IMG = C.POINTER(EmfImage)
+_FP = C.c_void_p  # device float*/u8* passed as integers
+_STREAM = C.c_void_p
+
+# name -> argtypes; every entry returns int.  Must cover every function in include/emf_hip.h.
+SIGNATURES = {
+    "emf_hip_abi_version": [],
+    "emf_hip_device_info": [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
+    "emf_hip_computePoints": [_IMG, _IMG, _F9, _STREAM],
+    "emf_hip_updateTSDF": [_IMG, _IMG, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, C.c_float,
+                           C.c_float, _STREAM],
+    "emf_hip_computeTSDFGrads": [_FP, _FP, _I3, _STREAM],
+    "emf_hip_raycastTSDF": [_FP, _FP, _FP, _FP, _IMG, _IMG, _IMG, _IMG, _F9, _F9, _F9, _I3,
+                            C.c_float, C.c_float, _FP, _STREAM],
+    "emf_hip_getVolumeVals": [_FP, C.c_int, _IMG, _F9, _F9, _I3, C.c_float, _IMG, _STREAM],
+    "emf_hip_updateFgBgProbs": [_IMG, _IMG, _FP, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, _STREAM],
+    "emf_hip_computeFgProbs": [_FP, _FP, _FP, _I3, _STREAM],
+    "emf_hip_maskRaycastWeights": [_FP, _FP, _FP, _I3, _STREAM],
+    "emf_hip_computeAssociation": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, _IMG, _STREAM],
+    "emf_hip_normalizeAssociation": [_IMG, C.c_int, _IMG, _IMG, _STREAM],
+    "emf_hip_sumAssociation": [_IMG, C.c_int, _IMG, _STREAM],
+    "emf_hip_compositeRaycast": [C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG,
+                                 _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
+    "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
+}
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/emf_hip.h (what the library must export)."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(emf_hip_\w+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    """Load libemf_hip.so and bind every declared entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP library has not been built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C {PKG_DIR / 'csrc'}`."
+            " There is no CPU fallback.")
+    lib = C.CDLL(os.fspath(LIB_PATH))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.emf_hip_last_error_string.argtypes = []
+    lib.emf_hip_last_error_string.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(fn_name: str, rc: int) -> None:
+    if rc != EMF_OK:
+        msg = load().emf_hip_last_error_string().decode(errors="replace")
+        raise EmfHipError(fn_name, rc, msg)

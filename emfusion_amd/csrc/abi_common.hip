@@ -1,0 +1,92 @@
+// abi_common.hip -- error plumbing, argument validation and device queries shared by every
+// emf_hip_* entry point.
+#include "common.hpp"
+
+namespace emf_hip {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_image(const emf_image_t* im, size_t elem_bytes, const char* name) {
+    if (im == nullptr) return fail(EMF_E_NULL, "%s: image view is NULL", name);
+    if (im->data == nullptr) return fail(EMF_E_NULL, "%s: data pointer is NULL", name);
+    if (im->width <= 0 || im->height <= 0)
+        return fail(EMF_E_SHAPE, "%s: bad size %d x %d", name, im->width, im->height);
+    if (im->pitch < static_cast<size_t>(im->width) * elem_bytes)
+        return fail(EMF_E_PITCH, "%s: pitch %zu < row bytes %zu", name, im->pitch,
+                    static_cast<size_t>(im->width) * elem_bytes);
+    const size_t align = elem_bytes % 4 == 0 ? 4 : 1;
+    if (im->pitch % align != 0 || reinterpret_cast<uintptr_t>(im->data) % align != 0)
+        return fail(EMF_E_PITCH, "%s: pitch/base not %zu-byte aligned", name, align);
+    return EMF_OK;
+}
+
+int check_same_size(const emf_image_t* a, const emf_image_t* b, const char* an, const char* bn) {
+    if (a->width != b->width || a->height != b->height)
+        return fail(EMF_E_SHAPE, "%s is %d x %d but %s is %d x %d", an, a->width, a->height, bn,
+                    b->width, b->height);
+    return EMF_OK;
+}
+
+int check_res(const int32_t res[3]) {
+    if (res == nullptr) return fail(EMF_E_NULL, "res is NULL");
+    if (res[0] < 2 || res[1] < 2 || res[2] < 2)
+        return fail(EMF_E_SHAPE, "volume resolution %d x %d x %d (each axis needs >= 2)", res[0],
+                    res[1], res[2]);
+    // index arithmetic is size_t on the device; keep the voxel count addressable with 4-byte elems
+    const unsigned long long n =
+        static_cast<unsigned long long>(res[0]) * res[1] * static_cast<unsigned long long>(res[2]);
+    if (n > (1ull << 36)) return fail(EMF_E_LIMIT, "volume of %llu voxels exceeds 2^36", n);
+    return EMF_OK;
+}
+
+int launch_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    return EMF_OK;
+}
+
+}  // namespace emf_hip
+
+extern "C" {
+
+int emf_hip_abi_version(void) { return EMF_HIP_ABI_VERSION; }
+
+const char* emf_hip_last_error_string(void) { return emf_hip::g_err; }
+
+int emf_hip_device_info(char* name, size_t name_len, char* arch, size_t arch_len, int* num_cus) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return emf_hip::fail(EMF_E_NODEVICE, "no HIP device visible");
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return emf_hip::fail(EMF_E_NODEVICE, "cannot query HIP device");
+    }
+    if (name && name_len) snprintf(name, name_len, "%s", prop.name);
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    return EMF_OK;
+}
+
+}  // extern "C"

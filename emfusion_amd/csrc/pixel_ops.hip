@@ -1,0 +1,571 @@
+// pixel_ops.hip -- per-pixel kernels: back-projection, trilinear volume lookups, the fused E-step
+// (association likelihood + normalisation) and raycast compositing.
+#include "common.hpp"
+
+namespace emf_hip {
+namespace {
+
+constexpr int kTileX = 64;  // one wave spans 64 consecutive pixels of a row: coalesced image I/O
+constexpr int kTileY = 4;
+
+__device__ __forceinline__ bool pixel_of(int w, int h, int& x, int& y) {
+    x = blockIdx.x * kTileX + threadIdx.x;
+    y = blockIdx.y * kTileY + threadIdx.y;
+    return x < w && y < h;
+}
+
+inline dim3 pixel_grid(int w, int h) { return dim3(ceil_div(w, kTileX), ceil_div(h, kTileY)); }
+inline dim3 pixel_block() { return dim3(kTileX, kTileY); }
+
+// ---- a1: computePoints (reference EMFusion.cu:29-47) ---------------------------------------------
+
+__global__ __launch_bounds__(256) void k_compute_points(Img<const float> depth, Img<float> points,
+                                                        int w, int h, float fx, float fy, float cx,
+                                                        float cy) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    const float d = depth.row(y)[x];
+    float* p = points.row(y) + 3 * x;
+    p[0] = (static_cast<float>(x) - cx) * d / fx;
+    p[1] = (static_cast<float>(y) - cy) * d / fy;
+    p[2] = d;
+}
+
+// ---- a2: getVolumeVals (reference TSDF.cu:662-688) -----------------------------------------------
+
+struct LookupArgs {
+    const float* vol;
+    Img<const float> points;
+    Img<float> vals;
+    int w, h;
+    M33 R;  // camera -> volume
+    V3 t;
+    I3 n;
+    float voxelSize;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_volume_vals(const LookupArgs a) {
+    int x, y;
+    if (!pixel_of(a.w, a.h, x, y)) return;
+    float out[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) out[c] = 0.f;  // fused vals.setTo(0), TSDF.cu:705
+    const float* pp = a.points.row(y) + 3 * x;
+    const V3 pc = v3(pp[0], pp[1], pp[2]);
+    if (pc.z > 0) {
+        const V3 v = to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(a.n));
+        if (!outside(v, 1.f, a.n)) {
+            const Cell c = cell_of(v, a.n);
+            const size_t sy = static_cast<size_t>(a.n.x), sz = sy * a.n.y;
+            const float* p = a.vol + c.base * CH;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch)
+                out[ch] = blend8(p[ch], p[CH + ch], p[sy * CH + ch], p[(sy + 1) * CH + ch],
+                                 p[sz * CH + ch], p[(sz + 1) * CH + ch], p[(sz + sy) * CH + ch],
+                                 p[(sz + sy + 1) * CH + ch], c.fx, c.fy, c.fz);
+        }
+    }
+    float* o = a.vals.row(y) + CH * x;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) o[c] = out[c];
+}
+
+// ---- a3-a5: association likelihood (reference TSDF.cpp:125-156, ObjTSDF.cpp:181-201) --------------
+
+struct AssocArgs {
+    const float* tsdf;
+    const float* fgProbs;  // nullptr for the background
+    Img<const float> points;
+    Img<float> out;
+    int w, h;
+    M33 R;
+    V3 t;
+    I3 n;
+    float voxelSize;
+    float c1;  // -truncdist / sigma          (TSDF.cpp:151)
+    float c2;  // 1 / (2 sigma)               (TSDF.cpp:154)
+    float alpha;
+    float c3;  // (1 - alpha) * uniPrior      (TSDF.cpp:133)
+};
+
+// One model's un-normalised association weight at one camera-frame point.
+__device__ __forceinline__ float assoc_weight(const AssocArgs& a, const V3& pc) {
+    float s = 0.f, fg = 0.f;
+    if (pc.z > 0) {
+        const V3 v = to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(a.n));
+        if (!outside(v, 1.f, a.n)) {
+            const Cell c = cell_of(v, a.n);
+            s = trilinear1(a.tsdf, c, a.n);
+            if (a.fgProbs) fg = trilinear1(a.fgProbs, c, a.n);
+        }
+    }
+    // chain of single-operator OpenCV launches, kept as separate roundings:
+    float L = fabsf(s);
+    L = L * a.c1;
+    L = expf(L);
+    L = L * a.c2;
+    if (a.fgProbs) L = L * fg;
+    float wgt = L * a.alpha;
+    wgt = wgt + a.c3;
+    return (s == 0.f) ? 0.f : wgt;  // associationMask = (lookup == 0) -> weight 0 (Q6)
+}
+
+__global__ __launch_bounds__(256) void k_assoc(const AssocArgs a) {
+    int x, y;
+    if (!pixel_of(a.w, a.h, x, y)) return;
+    const float* pp = a.points.row(y) + 3 * x;
+    a.out.row(y)[x] = assoc_weight(a, v3(pp[0], pp[1], pp[2]));
+}
+
+// ---- a6: normalisation (reference EMFusion.cpp:653-665) ------------------------------------------
+
+constexpr int kMapsPerLaunch = 16;
+
+struct MapTable {
+    Img<float> m[kMapsPerLaunch];
+    int count;
+};
+
+// mode 0: norm = m0 + m1 + ...                (first chunk)
+// mode 1: norm = norm + m0 + m1 + ...         (later chunks)
+// extra (optional) is added after the last map of the last chunk.
+__global__ __launch_bounds__(256) void k_assoc_sum(const MapTable t, Img<float> norm,
+                                                   Img<const float> extra, int w, int h,
+                                                   int accumulate) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    float s;
+    int k = 0;
+    if (accumulate) {
+        s = norm.row(y)[x];
+    } else {
+        s = t.m[0].row(y)[x];
+        k = 1;
+    }
+    for (; k < t.count; ++k) s = s + t.m[k].row(y)[x];
+    if (extra.data) s = s + extra.row(y)[x];
+    norm.row(y)[x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_assoc_divide(const MapTable t, Img<const float> norm,
+                                                      int w, int h) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    const float s = norm.row(y)[x];
+    for (int k = 0; k < t.count; ++k) {
+        float* p = t.m[k].row(y) + x;
+        *p = (s != 0.f) ? *p / s : 0.f;  // cv::cuda::divide: x / 0 := 0 (Q7)
+    }
+}
+
+// single-launch form for <= 16 maps: sum in order, optional extra, divide, optional norm output
+__global__ __launch_bounds__(256) void k_assoc_normalize(const MapTable t, Img<const float> extra,
+                                                         Img<float> norm, int w, int h) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    float v[kMapsPerLaunch];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMapsPerLaunch; ++k) {
+        if (k < t.count) {
+            v[k] = t.m[k].row(y)[x];
+            s = (k == 0) ? v[0] : s + v[k];
+        }
+    }
+    if (extra.data) s = s + extra.row(y)[x];
+    if (norm.data) norm.row(y)[x] = s;
+#pragma unroll
+    for (int k = 0; k < kMapsPerLaunch; ++k)
+        if (k < t.count) t.m[k].row(y)[x] = (s != 0.f) ? v[k] / s : 0.f;
+}
+
+// ---- a12: raycast compositing (reference EMFusion.cpp:760-794) -----------------------------------
+
+constexpr int kObjsPerLaunch = 16;
+
+struct CompositeTable {
+    Img<const float> ray[kObjsPerLaunch];
+    Img<const float> vert[kObjsPerLaunch];
+    Img<const float> nrm[kObjsPerLaunch];
+    Img<const uint8_t> seg[kObjsPerLaunch];
+    uint8_t id[kObjsPerLaunch];  // saturated object id written into the segmentation
+    int count;
+};
+
+struct CompositeArgs {
+    Img<const float> bgRay, bgVert, bgNorm;
+    Img<const uint8_t> bgMask;
+    Img<float> ray, vert, nrm, diff;
+    Img<uint8_t> seg, noObj;
+    int w, h;
+    int first, last;  // chunk position
+};
+
+__global__ __launch_bounds__(256) void k_composite(const CompositeTable t, const CompositeArgs a) {
+    int x, y;
+    if (!pixel_of(a.w, a.h, x, y)) return;
+    float r = 0.f;
+    V3 vv = v3(0.f, 0.f, 0.f), nn = v3(0.f, 0.f, 0.f);
+    uint8_t s = 0;
+    if (!a.first) {  // resume from the composite the previous chunk left
+        r = a.ray.row(y)[x];
+        const float* pv = a.vert.row(y) + 3 * x;
+        const float* pn = a.nrm.row(y) + 3 * x;
+        vv = v3(pv[0], pv[1], pv[2]);
+        nn = v3(pn[0], pn[1], pn[2]);
+        s = a.seg.row(y)[x];
+    }
+    for (int k = 0; k < t.count; ++k) {  // list order, strict '<' (Q15)
+        const float rk = t.ray[k].row(y)[x];
+        const bool take = t.seg[k].row(y)[x] != 0 && (r <= 0 || rk < r);
+        if (take) {
+            r = rk;
+            const float* pv = t.vert[k].row(y) + 3 * x;
+            const float* pn = t.nrm[k].row(y) + 3 * x;
+            vv = v3(pv[0], pv[1], pv[2]);
+            nn = v3(pn[0], pn[1], pn[2]);
+            s = t.id[k];
+        }
+    }
+    if (a.last) {
+        float d = a.diff.row(y)[x];
+        if (a.bgMask.row(y)[x]) {  // masked subtract, stale elsewhere (Q12)
+            d = r - a.bgRay.row(y)[x];
+            a.diff.row(y)[x] = d;
+        }
+        if (d > 0.05f) s = 0;  // background wins when it is > 5 cm in front
+        const uint8_t no = s == 0 ? 255 : 0;
+        if (no) {  // vertices / normals fall back to the background, the raylength does not
+            const float* pv = a.bgVert.row(y) + 3 * x;
+            const float* pn = a.bgNorm.row(y) + 3 * x;
+            vv = v3(pv[0], pv[1], pv[2]);
+            nn = v3(pn[0], pn[1], pn[2]);
+        }
+        a.noObj.row(y)[x] = no;
+    }
+    a.ray.row(y)[x] = r;
+    float* ov = a.vert.row(y) + 3 * x;
+    float* on = a.nrm.row(y) + 3 * x;
+    ov[0] = vv.x;
+    ov[1] = vv.y;
+    ov[2] = vv.z;
+    on[0] = nn.x;
+    on[1] = nn.y;
+    on[2] = nn.z;
+    a.seg.row(y)[x] = s;
+}
+
+// visibility: per-object pixel counts inside the inset rectangle (EMFusion.cpp:778-791).
+// Each workgroup builds a 256-bin LDS histogram of the segmentation, then adds the non-empty bins
+// to the owning object's counter (slot = seg value -> object index, -1 if no object has that id).
+struct SlotTable {
+    int16_t slot[256];
+};
+
+__global__ __launch_bounds__(256) void k_vis_counts(Img<const uint8_t> seg, int w, int h,
+                                                    int boundary, const SlotTable slots,
+                                                    int* __restrict__ counts) {
+    __shared__ int lh[256];
+    const int tid = threadIdx.y * kTileX + threadIdx.x;
+    lh[tid] = 0;
+    __syncthreads();
+    int x, y;
+    if (pixel_of(w, h, x, y) && x >= boundary && x < w - boundary && y >= boundary &&
+        y < h - boundary) {
+        const uint8_t s = seg.row(y)[x];
+        if (s) atomicAdd(&lh[s], 1);
+    }
+    __syncthreads();
+    const int k = slots.slot[tid];
+    if (k >= 0 && lh[tid]) atomicAdd(&counts[k], lh[tid]);
+}
+
+// ---- integrateMasks occlusion (reference EMFusion.cpp:897-900) -----------------------------------
+
+__global__ __launch_bounds__(256) void k_occluded(Img<const uint8_t> objSeg, Img<const uint8_t> seg,
+                                                  int id, Img<uint8_t> occ, int w, int h) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    const int own = (static_cast<int>(seg.row(y)[x]) == id) ? 255 : 0;
+    const int v = static_cast<int>(objSeg.row(y)[x]) - own;
+    occ.row(y)[x] = static_cast<uint8_t>(v < 0 ? 0 : v);
+}
+
+}  // namespace
+}  // namespace emf_hip
+
+using namespace emf_hip;
+
+namespace {
+
+int fill_map_table(MapTable& t, const emf_image_t* maps, int count, const emf_image_t* ref,
+                   const char* what) {
+    t.count = count;
+    for (int k = 0; k < count; ++k) {
+        EMF_TRY(check_image(&maps[k], 4, what));
+        EMF_TRY(check_same_size(&maps[k], ref, what, "maps[0]"));
+        t.m[k] = img<float>(&maps[k]);
+    }
+    return EMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emf_hip_computePoints(const emf_image_t* depth, const emf_image_t* points, const float K[9],
+                          emf_stream_t stream) {
+    EMF_TRY(check_image(depth, 4, "computePoints: depth"));
+    EMF_TRY(check_image(points, 12, "computePoints: points"));
+    EMF_TRY(check_same_size(depth, points, "depth", "points"));
+    EMF_REQUIRE_PTR(K);
+    hipLaunchKernelGGL(k_compute_points, pixel_grid(depth->width, depth->height), pixel_block(), 0,
+                       as_stream(stream), img<const float>(depth), img<float>(points),
+                       depth->width, depth->height, K[0], K[4], K[2], K[5]);
+    return launch_status("computePoints");
+}
+
+int emf_hip_getVolumeVals(const float* vol, int channels, const emf_image_t* points,
+                          const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                          float voxelSize, const emf_image_t* vals, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(vol);
+    if (channels < 1 || channels > 3)
+        return fail(EMF_E_ARG, "getVolumeVals: channels = %d, expected 1..3", channels);
+    EMF_TRY(check_image(points, 12, "getVolumeVals: points"));
+    EMF_TRY(check_image(vals, 4 * static_cast<size_t>(channels), "getVolumeVals: vals"));
+    EMF_TRY(check_same_size(points, vals, "points", "vals"));
+    EMF_REQUIRE_PTR(R_CO);
+    EMF_REQUIRE_PTR(t_CO);
+    EMF_TRY(check_res(res));
+    if (!(voxelSize > 0.f)) return fail(EMF_E_ARG, "getVolumeVals: voxelSize must be > 0");
+    LookupArgs a;
+    a.vol = vol;
+    a.points = img<const float>(points);
+    a.vals = img<float>(vals);
+    a.w = points->width;
+    a.h = points->height;
+    a.R = m33_from(R_CO);
+    a.t = v3_from(t_CO);
+    a.n = i3_from(res);
+    a.voxelSize = voxelSize;
+    const dim3 g = pixel_grid(a.w, a.h), b = pixel_block();
+    if (channels == 1) hipLaunchKernelGGL(k_volume_vals<1>, g, b, 0, as_stream(stream), a);
+    if (channels == 2) hipLaunchKernelGGL(k_volume_vals<2>, g, b, 0, as_stream(stream), a);
+    if (channels == 3) hipLaunchKernelGGL(k_volume_vals<3>, g, b, 0, as_stream(stream), a);
+    return launch_status("getVolumeVals");
+}
+
+int emf_hip_computeAssociation(const float* tsdf, const float* fgProbs, const emf_image_t* points,
+                               const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                               float voxelSize, float truncdist, float assocSigma, float alpha,
+                               float uniPrior, const emf_image_t* out, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(tsdf);
+    EMF_TRY(check_image(points, 12, "computeAssociation: points"));
+    EMF_TRY(check_image(out, 4, "computeAssociation: out"));
+    EMF_TRY(check_same_size(points, out, "points", "out"));
+    EMF_REQUIRE_PTR(R_CO);
+    EMF_REQUIRE_PTR(t_CO);
+    EMF_TRY(check_res(res));
+    if (!(voxelSize > 0.f) || !(assocSigma > 0.f))
+        return fail(EMF_E_ARG, "computeAssociation: voxelSize %g / assocSigma %g must be > 0",
+                    voxelSize, assocSigma);
+    AssocArgs a;
+    a.tsdf = tsdf;
+    a.fgProbs = fgProbs;
+    a.points = img<const float>(points);
+    a.out = img<float>(out);
+    a.w = points->width;
+    a.h = points->height;
+    a.R = m33_from(R_CO);
+    a.t = v3_from(t_CO);
+    a.n = i3_from(res);
+    a.voxelSize = voxelSize;
+    a.c1 = -truncdist / assocSigma;
+    a.c2 = 1.f / (2.f * assocSigma);
+    a.alpha = alpha;
+    a.c3 = (1 - alpha) * uniPrior;
+    hipLaunchKernelGGL(k_assoc, pixel_grid(a.w, a.h), pixel_block(), 0, as_stream(stream), a);
+    return launch_status("computeAssociation");
+}
+
+int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps,
+                                 const emf_image_t* extraSum, const emf_image_t* norm,
+                                 emf_stream_t stream) {
+    EMF_REQUIRE_PTR(maps_host);
+    if (nmaps < 1 || nmaps > EMF_MAX_MODELS)
+        return fail(EMF_E_LIMIT, "normalizeAssociation: nmaps = %d, expected 1..%d", nmaps,
+                    EMF_MAX_MODELS);
+    EMF_TRY(check_image(&maps_host[0], 4, "normalizeAssociation: maps[0]"));
+    const int w = maps_host[0].width, h = maps_host[0].height;
+    Img<const float> extra{nullptr, 0};
+    if (extraSum) {
+        EMF_TRY(check_image(extraSum, 4, "normalizeAssociation: extraSum"));
+        EMF_TRY(check_same_size(extraSum, &maps_host[0], "extraSum", "maps[0]"));
+        extra = img<const float>(extraSum);
+    }
+    Img<float> nrm{nullptr, 0};
+    if (norm) {
+        EMF_TRY(check_image(norm, 4, "normalizeAssociation: norm"));
+        EMF_TRY(check_same_size(norm, &maps_host[0], "norm", "maps[0]"));
+        nrm = img<float>(norm);
+    }
+    const dim3 g = pixel_grid(w, h), b = pixel_block();
+    if (nmaps <= kMapsPerLaunch) {
+        MapTable t;
+        EMF_TRY(fill_map_table(t, maps_host, nmaps, &maps_host[0], "normalizeAssociation: maps"));
+        hipLaunchKernelGGL(k_assoc_normalize, g, b, 0, as_stream(stream), t, extra, nrm, w, h);
+        return launch_status("normalizeAssociation");
+    }
+    // more maps than one launch carries: the running sum lives in `norm`, which is then required
+    if (!norm)
+        return fail(EMF_E_ARG, "normalizeAssociation: norm is required when nmaps > %d",
+                    kMapsPerLaunch);
+    for (int k0 = 0; k0 < nmaps; k0 += kMapsPerLaunch) {
+        const int cnt = nmaps - k0 < kMapsPerLaunch ? nmaps - k0 : kMapsPerLaunch;
+        MapTable t;
+        EMF_TRY(fill_map_table(t, maps_host + k0, cnt, &maps_host[0], "normalizeAssociation: maps"));
+        const bool lastChunk = k0 + cnt == nmaps;
+        hipLaunchKernelGGL(k_assoc_sum, g, b, 0, as_stream(stream), t, nrm,
+                           lastChunk ? extra : Img<const float>{nullptr, 0}, w, h, k0 != 0);
+    }
+    for (int k0 = 0; k0 < nmaps; k0 += kMapsPerLaunch) {
+        const int cnt = nmaps - k0 < kMapsPerLaunch ? nmaps - k0 : kMapsPerLaunch;
+        MapTable t;
+        EMF_TRY(fill_map_table(t, maps_host + k0, cnt, &maps_host[0], "normalizeAssociation: maps"));
+        hipLaunchKernelGGL(k_assoc_divide, g, b, 0, as_stream(stream), t,
+                           Img<const float>{nrm.data, nrm.pitch}, w, h);
+    }
+    return launch_status("normalizeAssociation");
+}
+
+int emf_hip_sumAssociation(const emf_image_t* maps_host, int nmaps, const emf_image_t* sum,
+                           emf_stream_t stream) {
+    EMF_REQUIRE_PTR(maps_host);
+    if (nmaps < 1 || nmaps > EMF_MAX_MODELS)
+        return fail(EMF_E_LIMIT, "sumAssociation: nmaps = %d, expected 1..%d", nmaps,
+                    EMF_MAX_MODELS);
+    EMF_TRY(check_image(sum, 4, "sumAssociation: sum"));
+    EMF_TRY(check_image(&maps_host[0], 4, "sumAssociation: maps[0]"));
+    EMF_TRY(check_same_size(sum, &maps_host[0], "sum", "maps[0]"));
+    const int w = sum->width, h = sum->height;
+    for (int k0 = 0; k0 < nmaps; k0 += kMapsPerLaunch) {
+        const int cnt = nmaps - k0 < kMapsPerLaunch ? nmaps - k0 : kMapsPerLaunch;
+        MapTable t;
+        EMF_TRY(fill_map_table(t, maps_host + k0, cnt, &maps_host[0], "sumAssociation: maps"));
+        hipLaunchKernelGGL(k_assoc_sum, pixel_grid(w, h), pixel_block(), 0, as_stream(stream), t,
+                           img<float>(sum), Img<const float>{nullptr, 0}, w, h, k0 != 0);
+    }
+    return launch_status("sumAssociation");
+}
+
+int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                             const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                             const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                             const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                             const emf_image_t* bgMask, const emf_image_t* ray,
+                             const emf_image_t* vert, const emf_image_t* norm,
+                             const emf_image_t* seg, const emf_image_t* diff,
+                             const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                             emf_stream_t stream) {
+    if (nobj < 0 || nobj > EMF_MAX_MODELS - 1)
+        return fail(EMF_E_LIMIT, "compositeRaycast: nobj = %d, expected 0..%d", nobj,
+                    EMF_MAX_MODELS - 1);
+    if (nobj > 0) {
+        EMF_REQUIRE_PTR(ids_host);
+        EMF_REQUIRE_PTR(objRay_host);
+        EMF_REQUIRE_PTR(objVert_host);
+        EMF_REQUIRE_PTR(objNorm_host);
+        EMF_REQUIRE_PTR(objSeg_host);
+        EMF_REQUIRE_PTR(visCounts);
+    }
+    EMF_TRY(check_image(bgRay, 4, "compositeRaycast: bgRay"));
+    EMF_TRY(check_image(bgVert, 12, "compositeRaycast: bgVert"));
+    EMF_TRY(check_image(bgNorm, 12, "compositeRaycast: bgNorm"));
+    EMF_TRY(check_image(bgMask, 1, "compositeRaycast: bgMask"));
+    EMF_TRY(check_image(ray, 4, "compositeRaycast: ray"));
+    EMF_TRY(check_image(vert, 12, "compositeRaycast: vert"));
+    EMF_TRY(check_image(norm, 12, "compositeRaycast: norm"));
+    EMF_TRY(check_image(seg, 1, "compositeRaycast: seg"));
+    EMF_TRY(check_image(diff, 4, "compositeRaycast: diff"));
+    EMF_TRY(check_image(noObj, 1, "compositeRaycast: noObj"));
+    const emf_image_t* all[] = {bgVert, bgNorm, bgMask, ray, vert, norm, seg, diff, noObj};
+    for (const emf_image_t* im : all) EMF_TRY(check_same_size(im, bgRay, "image", "bgRay"));
+    if (boundary < 0) return fail(EMF_E_ARG, "compositeRaycast: boundary = %d < 0", boundary);
+    const int w = bgRay->width, h = bgRay->height;
+
+    CompositeArgs a;
+    a.bgRay = img<const float>(bgRay);
+    a.bgVert = img<const float>(bgVert);
+    a.bgNorm = img<const float>(bgNorm);
+    a.bgMask = img<const uint8_t>(bgMask);
+    a.ray = img<float>(ray);
+    a.vert = img<float>(vert);
+    a.nrm = img<float>(norm);
+    a.diff = img<float>(diff);
+    a.seg = img<uint8_t>(seg);
+    a.noObj = img<uint8_t>(noObj);
+    a.w = w;
+    a.h = h;
+    const dim3 g = pixel_grid(w, h), b = pixel_block();
+    int k0 = 0;
+    do {
+        const int cnt = nobj - k0 < kObjsPerLaunch ? nobj - k0 : kObjsPerLaunch;
+        CompositeTable t;
+        t.count = cnt;
+        for (int k = 0; k < cnt; ++k) {
+            const int j = k0 + k;
+            EMF_TRY(check_image(&objRay_host[j], 4, "compositeRaycast: objRay"));
+            EMF_TRY(check_image(&objVert_host[j], 12, "compositeRaycast: objVert"));
+            EMF_TRY(check_image(&objNorm_host[j], 12, "compositeRaycast: objNorm"));
+            EMF_TRY(check_image(&objSeg_host[j], 1, "compositeRaycast: objSeg"));
+            EMF_TRY(check_same_size(&objRay_host[j], bgRay, "objRay", "bgRay"));
+            EMF_TRY(check_same_size(&objVert_host[j], bgRay, "objVert", "bgRay"));
+            EMF_TRY(check_same_size(&objNorm_host[j], bgRay, "objNorm", "bgRay"));
+            EMF_TRY(check_same_size(&objSeg_host[j], bgRay, "objSeg", "bgRay"));
+            t.ray[k] = img<const float>(&objRay_host[j]);
+            t.vert[k] = img<const float>(&objVert_host[j]);
+            t.nrm[k] = img<const float>(&objNorm_host[j]);
+            t.seg[k] = img<const uint8_t>(&objSeg_host[j]);
+            const int id = ids_host[j];
+            t.id[k] = static_cast<uint8_t>(id < 0 ? 0 : (id > 255 ? 255 : id));
+        }
+        a.first = k0 == 0;
+        a.last = k0 + cnt >= nobj;
+        hipLaunchKernelGGL(k_composite, g, b, 0, as_stream(stream), t, a);
+        k0 += cnt;
+    } while (k0 < nobj);
+    EMF_TRY(launch_status("compositeRaycast"));
+    if (nobj > 0) {
+        SlotTable slots;
+        for (int v = 0; v < 256; ++v) slots.slot[v] = -1;
+        for (int k = 0; k < nobj; ++k)  // compare(seg, id): ids outside 1..255 never match
+            if (ids_host[k] >= 1 && ids_host[k] <= 255 && slots.slot[ids_host[k]] < 0)
+                slots.slot[ids_host[k]] = static_cast<int16_t>(k);
+        const hipError_t e =
+            hipMemsetAsync(visCounts, 0, sizeof(int32_t) * nobj, as_stream(stream));
+        if (e != hipSuccess) {
+            set_error("compositeRaycast: memset visCounts: %s", hipGetErrorString(e));
+            return static_cast<int>(e);
+        }
+        hipLaunchKernelGGL(k_vis_counts, g, b, 0, as_stream(stream), img<const uint8_t>(seg), w, h,
+                           boundary, slots, visCounts);
+        return launch_status("compositeRaycast: visibility");
+    }
+    return EMF_OK;
+}
+
+int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int id,
+                         const emf_image_t* occluded, emf_stream_t stream) {
+    EMF_TRY(check_image(objSeg, 1, "occludedMask: objSeg"));
+    EMF_TRY(check_image(seg, 1, "occludedMask: seg"));
+    EMF_TRY(check_image(occluded, 1, "occludedMask: occluded"));
+    EMF_TRY(check_same_size(objSeg, seg, "objSeg", "seg"));
+    EMF_TRY(check_same_size(objSeg, occluded, "objSeg", "occluded"));
+    hipLaunchKernelGGL(k_occluded, pixel_grid(seg->width, seg->height), pixel_block(), 0,
+                       as_stream(stream), img<const uint8_t>(objSeg), img<const uint8_t>(seg), id,
+                       img<uint8_t>(occluded), seg->width, seg->height);
+    return launch_status("occludedMask");
+}
+
+}  // extern "C"

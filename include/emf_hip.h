@@ -1,0 +1,189 @@
+/*
+ * emf_hip.h -- C ABI of the MI355X-native (gfx950) EM-Fusion volumetric hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces either one of
+ * the reference's kernel-wrapper free functions (namespace emf::cuda::{TSDF,ObjTSDF,EMFusion},
+ * declared in include/EMFusion/core/cuda/{TSDF,ObjTSDF,EMFusion}.cuh) or one chain of
+ * OpenCV-CUDA element-wise launches inside emf::TSDF / emf::ObjTSDF / emf::EMFusion methods; the
+ * reference interface each one replaces is cited as file:line (relative to the reference root).
+ * INTEGRATION.md shows the C++ stub a maintainer adds on the reference side to bind GpuMat
+ * arguments to these calls.
+ *
+ * Contract for every function
+ *   - all pointers are DEVICE pointers unless the parameter is named *_host or documented so;
+ *     R / t / K / res are small HOST arrays copied into the launch arguments
+ *   - never allocates, frees or synchronises: work is enqueued on `stream` (0 = null stream) and
+ *     the call returns; launch errors surface as the return value of this or a later call
+ *   - returns EMF_OK (0), a negative EMF_E_* for rejected arguments (nothing enqueued), or a
+ *     positive hipError_t; never throws; re-entrant, no global state except a thread-local
+ *     message buffer read by emf_hip_last_error_string()
+ *   - volumes: continuous (Nz*Ny) rows x Nx cols float arrays, element (z*Ny + y, x), i.e. what
+ *     cv::cuda::createContinuous(Ny*Nz, Nx, CV_32FCn) allocates (TSDF.cpp:35-42); res = {Nx,Ny,Nz}
+ *   - images: emf_image_t = pointer + row pitch in bytes + width/height, the PtrStepSz of a GpuMat
+ *   - R row-major 3x3, t 3-vector, K row-major 3x3 intrinsics, exactly the memory of
+ *     cv::Matx33f / cv::Vec3f (TSDF.cu:417-422)
+ *   - arithmetic is IEEE binary32 in the reference's operation order with a*b+c contraction
+ *     disabled; see DESIGN.md "Numerics"
+ */
+#ifndef EMF_HIP_H
+#define EMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMF_HIP_ABI_VERSION 1
+
+/* hipStream_t without dragging HIP headers into C callers */
+typedef struct ihipStream_t* emf_stream_t;
+
+enum {
+    EMF_OK = 0,
+    EMF_E_NULL = -1,      /* a required pointer is NULL */
+    EMF_E_SHAPE = -2,     /* non-positive or inconsistent width/height/resolution */
+    EMF_E_PITCH = -3,     /* pitch smaller than a row or not a multiple of the element alignment */
+    EMF_E_ARG = -4,       /* scalar argument out of domain (voxelSize <= 0, channels not in 1..3 ...) */
+    EMF_E_LIMIT = -5,     /* count exceeds a documented limit (EMF_MAX_*) */
+    EMF_E_NODEVICE = -6   /* no HIP device / library built without device code for this GPU */
+};
+
+/* GpuMat-like image view: `data` device pointer, `pitch` bytes per row (>= width * elemsize) */
+typedef struct emf_image {
+    void* data;
+    size_t pitch;
+    int32_t width;
+    int32_t height;
+} emf_image_t;
+
+#define EMF_MAX_MODELS 256 /* background + objects handled by one batched call (seg ids are u8) */
+
+int emf_hip_abi_version(void);
+/* message for the most recent non-zero return on this thread ("" if none) */
+const char* emf_hip_last_error_string(void);
+/* 0 if a HIP device is usable, EMF_E_NODEVICE otherwise; fills name/arch (may be NULL) */
+int emf_hip_device_info(char* name, size_t name_len, char* arch, size_t arch_len, int* num_cus);
+
+/* ------------------------------------------------------------------------------------------------
+ * Level 1: one call per reference kernel wrapper (reference memory layout in, same layout out)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces emf::cuda::EMFusion::computePoints (EMFusion.cuh:39-40, EMFusion.cu:29-61).
+ * depth: f32 W x H; points: f32x3 W x H, every pixel is written (the reference's setTo(0) is
+ * therefore redundant).  Deviation: no cudaDeviceSynchronize -- stream ordered. */
+int emf_hip_computePoints(const emf_image_t* depth, const emf_image_t* points, const float K[9],
+                          emf_stream_t stream);
+
+/* Replaces emf::cuda::TSDF::updateTSDF (TSDF.cuh:115-122, TSDF.cu:327-427).
+ * depth, assocWeights: f32 W x H (same size); tsdf, weights: N^3 f32 read-modify-write. */
+int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights, float* tsdf,
+                       float* weights, const float R_OC[9], const float t_OC[3],
+                       const float K[9], const int32_t res[3], float voxelSize, float truncdist,
+                       float maxWeight, emf_stream_t stream);
+
+/* Replaces TSDF::updateGradients = tsdfGrads.setTo(0) + emf::cuda::TSDF::computeTSDFGrads
+ * (TSDF.cpp:120-123, TSDF.cuh:132-134, TSDF.cu:429-464).  grads: N^3 x 3 f32; the last index
+ * planes are written as zero by this call (no separate memset). */
+int emf_hip_computeTSDFGrads(const float* tsdf, float* grads, const int32_t res[3],
+                             emf_stream_t stream);
+
+/* Replaces emf::cuda::TSDF::raycastTSDF (TSDF.cuh:154-162, TSDF.cu:466-601).
+ * raylengths f32, vertices f32x3, normals f32x3, mask u8 (0/1), all W x H, must be PRE-ZEROED by
+ * the caller exactly as the reference does (EMFusion.cpp:727-743): pixels without a hit are not
+ * written, and a non-zero incoming raylength clips the march (TSDF.cu:496-500).
+ *   grads   : N^3 x 3 gradient volume, or NULL -> the normal is blended from forward differences
+ *             of `tsdf` on the fly (bit-identical to a volume made by emf_hip_computeTSDFGrads)
+ *   fgVolMask: NULL, or N^3 u8 -- the march then sees weights `fgVolMask ? w : 0`, which replaces
+ *             ObjTSDF::raycast's per-frame raycastWeights sweep (ObjTSDF.cpp:209-210)
+ *   stats   : NULL, or 2 x u64 device counters this call ADDS to: [0] volume samples taken by the
+ *             main march loop (the S of SURVEY.md section 8d), [1] hits */
+int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weights,
+                        const uint8_t* fgVolMask, const emf_image_t* raylengths,
+                        const emf_image_t* vertices, const emf_image_t* normals,
+                        const emf_image_t* mask, const float R_CO[9], const float t_CO[3],
+                        const float K[9], const int32_t res[3], float voxelSize, float truncdist,
+                        uint64_t* stats, emf_stream_t stream);
+
+/* Replaces emf::cuda::TSDF::getVolumeVals (TSDF.cuh:197-203, TSDF.cu:662-726).
+ * vol: N^3 x channels f32 (channels 1..3, interleaved); points f32x3; vals f32 x channels.
+ * The callee zero-fills vals for pixels without a lookup (vals.setTo(0), TSDF.cu:705). */
+int emf_hip_getVolumeVals(const float* vol, int channels, const emf_image_t* points,
+                          const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                          float voxelSize, const emf_image_t* vals, emf_stream_t stream);
+
+/* Replaces emf::cuda::ObjTSDF::updateFgBgProbs (ObjTSDF.cuh:49-56, ObjTSDF.cu:29-107).
+ * mask, occluded: u8 W x H read as bool; fgBgProbs: N^3 x 2 f32 read-modify-write. */
+int emf_hip_updateFgBgProbs(const emf_image_t* mask, const emf_image_t* occluded,
+                            const float* tsdf, const float* weights, float* fgBgProbs,
+                            const float R_OC[9], const float t_OC[3], const float K[9],
+                            const int32_t res[3], float voxelSize, emf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Level 2: one call per OpenCV-CUDA launch chain in the volume / orchestrator classes
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces ObjTSDF::computeFgProbs (ObjTSDF.cpp:218-226): split, add, divide (x/0 := 0),
+ * compare(NE)+setTo(0), compare(GT 0.5).  fgProbs N^3 f32, fgVolMask N^3 u8 (0/255). */
+int emf_hip_computeFgProbs(const float* fgBgProbs, float* fgProbs, uint8_t* fgVolMask,
+                           const int32_t res[3], emf_stream_t stream);
+
+/* Literal replacement of ObjTSDF::raycast's weight masking (ObjTSDF.cpp:209-210):
+ * raycastWeights = fgVolMask ? weights : 0.  The native path passes fgVolMask to
+ * emf_hip_raycastTSDF instead and never materialises this volume. */
+int emf_hip_maskRaycastWeights(const float* weights, const uint8_t* fgVolMask,
+                               float* raycastWeights, const int32_t res[3], emf_stream_t stream);
+
+/* Replaces TSDF::computeAssociation (TSDF.cpp:125-136) incl. TSDF::computeLaplace
+ * (TSDF.cpp:138-156) when fgProbs == NULL, and ObjTSDF::computeAssociation (ObjTSDF.cpp:181-201)
+ * otherwise: trilinear SDF lookup, Laplace likelihood, optional foreground-probability factor,
+ * mixture with the uniform prior, zero where the lookup is exactly 0.  out: f32 W x H,
+ * UN-normalised, every pixel written. */
+int emf_hip_computeAssociation(const float* tsdf, const float* fgProbs, const emf_image_t* points,
+                               const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                               float voxelSize, float truncdist, float assocSigma, float alpha,
+                               float uniPrior, const emf_image_t* out, emf_stream_t stream);
+
+/* Replaces the normalisation half of EMFusion::computeAssociationWeights (EMFusion.cpp:653-665).
+ * maps_host: HOST array of `nmaps` image views (device data), [0] = background then objects in
+ * std::map (ascending ID) order; normalised in place; x/0 := 0.
+ *   extraSum: NULL, or f32 W x H added LAST into the normaliser (the all-reduced sum of the
+ *             association maps owned by other ranks -- the multi-GPU exchange of SURVEY 8e)
+ *   norm    : NULL, or f32 W x H receiving associationNorm
+ * 1 <= nmaps <= EMF_MAX_MODELS. */
+int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps,
+                                 const emf_image_t* extraSum, const emf_image_t* norm,
+                                 emf_stream_t stream);
+
+/* Sum of `nmaps` association maps into `sum` (sequential order, maps_host[0] first): the local
+ * partial a rank contributes to the normaliser all-reduce.  sum: f32 W x H, overwritten. */
+int emf_hip_sumAssociation(const emf_image_t* maps_host, int nmaps, const emf_image_t* sum,
+                           emf_stream_t stream);
+
+/* Replaces the compositing part of EMFusion::raycast (EMFusion.cpp:760-794) in one pass.
+ * Per-object inputs are HOST arrays of `nobj` image views in std::list (creation) order; ids_host
+ * holds the object IDs written to the segmentation (saturated to u8 like cv::Scalar->uchar).
+ *   diff     : f32 W x H, the persistent diffRaylengths buffer, only updated where bgMask != 0
+ *   visCounts: device int32[nobj], overwritten with the number of pixels with seg == id inside
+ *              [boundary, W-boundary) x [boundary, H-boundary)  (EMFusion.cpp:778-791)
+ * Outputs ray/vert/norm/seg/noObj are fully overwritten (no pre-zeroing needed). */
+int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                             const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                             const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                             const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                             const emf_image_t* bgMask, const emf_image_t* ray,
+                             const emf_image_t* vert, const emf_image_t* norm,
+                             const emf_image_t* seg, const emf_image_t* diff,
+                             const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                             emf_stream_t stream);
+
+/* Replaces the occlusion mask of EMFusion::integrateMasks (EMFusion.cpp:897-900):
+ * occluded = saturate_u8(objSeg - (seg == id ? 255 : 0)).  All u8 W x H. */
+int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int id,
+                         const emf_image_t* occluded, emf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMF_HIP_H */

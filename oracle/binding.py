@@ -1,0 +1,202 @@
+"""numpy binding of the CPU oracle (oracle/emf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by emfusion_amd/.  PARITY UNPINNED (see emf_oracle.h).
+
+Arrays follow the reference layout: images (H, W[, C]) float32/uint8 C-contiguous, volumes
+(Nz, Ny, Nx[, C]).  Functions that the reference runs in place modify their array arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+_libs: dict[str, C.CDLL] = {}
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build() -> None:
+    subprocess.run(["make", "-s", "-C", str(HERE)], check=True)
+
+
+def lib(fma: bool = False) -> C.CDLL:
+    """The oracle library; ``fma=True`` loads the build with a*b+c contraction enabled."""
+    name = "libemf_oracle_fma.so" if fma else "libemf_oracle.so"
+    if name not in _libs:
+        path = HERE / name
+        if not path.exists():
+            build()
+        _libs[name] = C.CDLL(str(path))
+        _libs[name].orc_set_threads.restype = C.c_int
+    return _libs[name]
+
+
+def _c(a, dtype=np.float32):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _farr(v, n):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1))
+    assert a.size == n
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _res(vol):
+    nz, ny, nx = vol.shape[:3]
+    return (C.c_int * 3)(nx, ny, nz)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n: int, fma: bool = False) -> int:
+    return lib(fma).orc_set_threads(int(n))
+
+
+def compute_points(depth, K, fma=False):
+    depth = _c(depth)
+    h, w = depth.shape
+    pts = np.zeros((h, w, 3), np.float32)
+    lib(fma).orc_computePoints(_p(depth), _p(pts), w, h, _farr(K, 9))
+    return pts
+
+
+def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdist, max_weight,
+                fma=False):
+    depth, assoc = _c(depth), _c(assoc)
+    assert tsdf.flags.c_contiguous and weights.flags.c_contiguous
+    h, w = depth.shape
+    lib(fma).orc_updateTSDF(_p(depth), _p(assoc), w, h, _p(tsdf), _p(weights), _farr(R_OC, 9),
+                            _farr(t_OC, 3), _farr(K, 9), _res(tsdf), C.c_float(voxel_size),
+                            C.c_float(truncdist), C.c_float(max_weight))
+
+
+def compute_tsdf_grads(tsdf, fma=False):
+    tsdf = _c(tsdf)
+    grads = np.empty(tsdf.shape + (3,), np.float32)
+    lib(fma).orc_computeTSDFGrads(_p(tsdf), _p(grads), _res(tsdf))
+    return grads
+
+
+def raycast_tsdf(tsdf, grads, weights, fg_mask, w, h, R_CO, t_CO, K, voxel_size, truncdist,
+                 raylengths=None, count_steps=False, fma=False):
+    tsdf, weights = _c(tsdf), _c(weights)
+    grads = None if grads is None else _c(grads)
+    fg_mask = None if fg_mask is None else _c(fg_mask, np.uint8)
+    ray = np.zeros((h, w), np.float32) if raylengths is None else _c(raylengths).copy()
+    vert = np.zeros((h, w, 3), np.float32)
+    nrm = np.zeros((h, w, 3), np.float32)
+    mask = np.zeros((h, w), np.uint8)
+    steps = np.zeros((h, w), np.uint32) if count_steps else None
+    lib(fma).orc_raycastTSDF(_p(tsdf), _p(grads), _p(weights), _p(fg_mask), _p(ray), _p(vert),
+                             _p(nrm), _p(mask), w, h, _farr(R_CO, 9), _farr(t_CO, 3), _farr(K, 9),
+                             _res(tsdf), C.c_float(voxel_size), C.c_float(truncdist), _p(steps))
+    out = (ray, vert, nrm, mask)
+    return out + (steps,) if count_steps else out
+
+
+def get_volume_vals(vol, points, R_CO, t_CO, voxel_size, fma=False):
+    vol, points = _c(vol), _c(points)
+    ch = 1 if vol.ndim == 3 else vol.shape[3]
+    h, w = points.shape[:2]
+    vals = np.empty((h, w) if ch == 1 else (h, w, ch), np.float32)
+    lib(fma).orc_getVolumeVals(_p(vol), ch, _p(points), w, h, _farr(R_CO, 9), _farr(t_CO, 3),
+                               _res(vol), C.c_float(voxel_size), _p(vals))
+    return vals
+
+
+def update_fgbg_probs(mask, occluded, tsdf, weights, fgbg, R_OC, t_OC, K, voxel_size, fma=False):
+    mask, occluded = _c(mask, np.uint8), _c(occluded, np.uint8)
+    tsdf, weights = _c(tsdf), _c(weights)
+    assert fgbg.flags.c_contiguous and fgbg.dtype == np.float32
+    h, w = mask.shape
+    lib(fma).orc_updateFgBgProbs(_p(mask), _p(occluded), w, h, _p(tsdf), _p(weights), _p(fgbg),
+                                 _farr(R_OC, 9), _farr(t_OC, 3), _farr(K, 9), _res(tsdf),
+                                 C.c_float(voxel_size))
+
+
+def compute_fg_probs(fgbg, fma=False):
+    fgbg = _c(fgbg)
+    probs = np.empty(fgbg.shape[:3], np.float32)
+    vmask = np.empty(fgbg.shape[:3], np.uint8)
+    lib(fma).orc_computeFgProbs(_p(fgbg), _p(probs), _p(vmask), _res(fgbg))
+    return probs, vmask
+
+
+def mask_raycast_weights(weights, fg_vol_mask, fma=False):
+    weights, fg_vol_mask = _c(weights), _c(fg_vol_mask, np.uint8)
+    out = np.empty_like(weights)
+    lib(fma).orc_maskRaycastWeights(_p(weights), _p(fg_vol_mask), _p(out), _res(weights))
+    return out
+
+
+def compute_association(tsdf, fg_probs, points, R_CO, t_CO, voxel_size, truncdist, sigma, alpha,
+                        uni_prior, fma=False):
+    tsdf, points = _c(tsdf), _c(points)
+    fg_probs = None if fg_probs is None else _c(fg_probs)
+    h, w = points.shape[:2]
+    out = np.empty((h, w), np.float32)
+    lib(fma).orc_computeAssociation(_p(tsdf), _p(fg_probs), _p(points), w, h, _farr(R_CO, 9),
+                                    _farr(t_CO, 3), _res(tsdf), C.c_float(voxel_size),
+                                    C.c_float(truncdist), C.c_float(sigma), C.c_float(alpha),
+                                    C.c_float(uni_prior), _p(out))
+    return out
+
+
+def normalize_association(maps, fma=False):
+    """In place on the list of (H, W) float32 arrays; returns the normaliser."""
+    for m in maps:
+        assert m.flags.c_contiguous and m.dtype == np.float32
+    h, w = maps[0].shape
+    ptrs = (C.c_void_p * len(maps))(*[m.ctypes.data for m in maps])
+    norm = np.empty((h, w), np.float32)
+    lib(fma).orc_normalizeAssociation(ptrs, len(maps), w, h, _p(norm))
+    return norm
+
+
+def composite_raycast(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert, bg_norm, bg_mask,
+                      diff, boundary, fma=False):
+    """Returns (ray, vert, norm, seg, no_obj, vis_counts); ``diff`` is updated in place."""
+    n = len(ids)
+    h, w = bg_ray.shape
+
+    def tab(arrs, dt):
+        keep = [_c(a, dt) for a in arrs]
+        return keep, (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in keep])
+
+    k1, pr = tab(obj_ray, np.float32)
+    k2, pv = tab(obj_vert, np.float32)
+    k3, pn = tab(obj_norm, np.float32)
+    k4, ps = tab(obj_seg, np.uint8)
+    bg_ray, bg_vert, bg_norm = _c(bg_ray), _c(bg_vert), _c(bg_norm)
+    bg_mask = _c(bg_mask, np.uint8)
+    assert diff.flags.c_contiguous and diff.dtype == np.float32
+    ray = np.empty((h, w), np.float32)
+    vert = np.empty((h, w, 3), np.float32)
+    nrm = np.empty((h, w, 3), np.float32)
+    seg = np.empty((h, w), np.uint8)
+    no_obj = np.empty((h, w), np.uint8)
+    vis = np.zeros(max(n, 1), np.int32)
+    ids_arr = (C.c_int * max(n, 1))(*[int(i) for i in ids])
+    lib(fma).orc_compositeRaycast(n, ids_arr, pr, pv, pn, ps, _p(bg_ray), _p(bg_vert), _p(bg_norm),
+                                  _p(bg_mask), _p(ray), _p(vert), _p(nrm), _p(seg), _p(diff),
+                                  _p(no_obj), w, h, int(boundary), _p(vis))
+    return ray, vert, nrm, seg, no_obj, vis[:n]
+
+
+def occluded_mask(obj_seg, seg, obj_id, fma=False):
+    obj_seg, seg = _c(obj_seg, np.uint8), _c(seg, np.uint8)
+    h, w = seg.shape
+    occ = np.empty((h, w), np.uint8)
+    lib(fma).orc_occludedMask(_p(obj_seg), _p(seg), int(obj_id), _p(occ), w, h)
+    return occ
