@@ -1,0 +1,432 @@
+"""Parity of the HIP path (through the emf_hip_* C ABI) against the CPU oracle on identical
+seeded inputs, one test group per SURVEY.md section-8 row.  Integer / mask outputs must match
+bit for bit; float outputs must be within the north-star tolerance (1e-4 relative) -- and for
+the kernels whose arithmetic is IEEE-exact on both sides (no expf) the tests demand bit-identical
+floats, which is stronger and keeps real bugs from hiding inside an outlier budget.
+"""
+import numpy as np
+import pytest
+
+from tests.parity_util import assert_parity, to_dev, to_np
+from tests.scenes import Pose, camera_path, intrinsics, rel_CO, rel_OC, render_depth, rot
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 120
+K = intrinsics(W, H)
+SPHERES = [((0.25, 0.05, 1.3), 0.22), ((-0.3, -0.1, 1.6), 0.18)]
+BG = dict(n=(64, 64, 64), vox=0.04, pose=Pose(t=[0, 0, 1.28]))
+SIGMA, ALPHA, PRIOR, MAXW = 0.02, 0.8, 1.0, 64.0
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from emfusion_amd import ops as _ops
+    return _ops
+
+
+def frame(i, noise=0.002, dropout=0.01):
+    cam = camera_path(i)
+    depth, ids = render_depth(W, H, K, cam, SPHERES, noise=noise, dropout=dropout, seed=100 + i)
+    return cam, depth, ids
+
+
+def alloc_vol(res_xyz, ch=1, dtype=np.float32):
+    nx, ny, nz = res_xyz
+    return np.zeros((nz, ny, nx) if ch == 1 else (nz, ny, nx, ch), dtype)
+
+
+def integrate_both(oracle, ops, dev, res, vox, vol_pose, frames, assoc_fn=None, max_w=MAXW,
+                   pad=0):
+    """Run the same integration sequence on the oracle (numpy) and the HIP path (device)."""
+    import torch
+    tsdf, wts = alloc_vol(res), alloc_vol(res)
+    d_tsdf, d_wts = to_dev(tsdf, dev), to_dev(wts, dev)
+    for i in frames:
+        cam, depth, ids = frame(i)
+        assoc = np.ones((H, W), np.float32) if assoc_fn is None else assoc_fn(i, ids)
+        oc = rel_OC(cam, vol_pose)
+        oracle.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, K, vox, 10 * vox, max_w)
+        ops.update_tsdf(to_dev(depth, dev, pad), to_dev(assoc, dev, pad), d_tsdf, d_wts, oc.R32,
+                        oc.t32, K, vox, 10 * vox, max_w)
+    torch.cuda.synchronize()
+    return (tsdf, wts), (d_tsdf, d_wts)
+
+
+# ---- a1 ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("pad", [0, 5])
+def test_compute_points(oracle, ops, dev, pad):
+    import torch
+    _, depth, _ = frame(0)
+    want = oracle.compute_points(depth, K)
+    pts = torch.full((H, W + pad, 3), -7.0, device=dev)[:, :W]
+    ops.compute_points(to_dev(depth, dev, pad), K, pts)
+    assert_parity(to_np(pts), want, "points", exact=True)
+
+
+# ---- a7 ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("res,pad", [((64, 64, 64), 0), ((64, 64, 64), 3), ((30, 22, 18), 0),
+                                     ((36, 20, 28), 0)])
+def test_integrate_sequence(oracle, ops, dev, res, pad):
+    vox = 2.56 / max(res)
+    (tsdf, wts), (d_t, d_w) = integrate_both(oracle, ops, dev, res, vox, BG["pose"], range(3),
+                                             pad=pad)
+    assert (wts > 0).sum() > 1000 and (tsdf == -1).sum() > 10
+    assert_parity(to_np(d_t), tsdf, f"tsdf {res}", exact=True)
+    assert_parity(to_np(d_w), wts, f"weights {res}", exact=True)
+
+
+def test_integrate_association_weights_cap_and_zero_sum(oracle, ops, dev):
+    rng = np.random.default_rng(11)
+
+    def assoc(i, ids):
+        a = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        a[ids == 1] = 0.0  # w + a == 0 on first touch: voxel must stay untouched
+        return a
+
+    (tsdf, wts), (d_t, d_w) = integrate_both(oracle, ops, dev, (64, 64, 64), 0.04, BG["pose"],
+                                             range(5), assoc_fn=assoc, max_w=2.5)
+    assert wts.max() == 2.5
+    assert_parity(to_np(d_t), tsdf, "tsdf", exact=True)
+    assert_parity(to_np(d_w), wts, "weights", exact=True)
+
+
+def test_integrate_camera_behind_and_rotated_volume(oracle, ops, dev):
+    # volume partly behind the camera (pos_cam.z <= 0 branch) and rotated against the camera
+    pose = Pose(rot([1, 2, 0.5], 25), [0.1, -0.05, 0.6])
+    (tsdf, wts), (d_t, d_w) = integrate_both(oracle, ops, dev, (48, 40, 56), 0.04, pose, range(2))
+    assert_parity(to_np(d_t), tsdf, "tsdf", exact=True)
+    assert_parity(to_np(d_w), wts, "weights", exact=True)
+
+
+# ---- a8 ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("res", [(64, 64, 64), (30, 22, 18)])
+def test_tsdf_grads(oracle, ops, dev, res):
+    import torch
+    rng = np.random.default_rng(4)
+    tsdf = rng.uniform(-1, 1, (res[2], res[1], res[0])).astype(np.float32)
+    want = oracle.compute_tsdf_grads(tsdf)
+    g = torch.full(tsdf.shape + (3,), 5.0, device=dev)  # last planes must be overwritten with 0
+    ops.compute_tsdf_grads(to_dev(tsdf, dev), g)
+    assert_parity(to_np(g), want, "grads", exact=True)
+
+
+# ---- a2 ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ch", [1, 2, 3])
+def test_get_volume_vals(oracle, ops, dev, ch):
+    import torch
+    rng = np.random.default_rng(20 + ch)
+    n = (40, 32, 36)
+    vol = rng.standard_normal((n[2], n[1], n[0]) + ((ch,) if ch > 1 else ())).astype(np.float32)
+    cam, depth, _ = frame(1)
+    pts = oracle.compute_points(depth, K)
+    co = rel_CO(cam, Pose(rot([0, 1, 0], 12), [0.1, 0, 1.4]))
+    want = oracle.get_volume_vals(vol, pts, co.R32, co.t32, 0.03)
+    assert (want != 0).mean() > 0.05 and (want == 0).mean() > 0.01
+    vals = torch.full(want.shape, 9.0, device=dev)  # callee zero-fills
+    ops.get_volume_vals(to_dev(vol, dev), to_dev(pts, dev), co.R32, co.t32, 0.03, vals)
+    assert_parity(to_np(vals), want, f"vals ch={ch}", exact=True)
+
+
+# ---- a10 / a11 -----------------------------------------------------------------------------------
+
+def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False):
+    import torch
+    ray = torch.zeros((H, W), device=dev) if ray0 is None else to_dev(ray0, dev)
+    vert = torch.zeros((H, W, 3), device=dev)
+    nrm = torch.zeros((H, W, 3), device=dev)
+    mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+    ops.raycast_tsdf(to_dev(tsdf, dev), None if grads is None else to_dev(grads, dev),
+                     to_dev(wts, dev), None if fg is None else to_dev(fg, dev), ray, vert, nrm,
+                     mask, co.R32, co.t32, K, vox, 10 * vox, st)
+    torch.cuda.synchronize()
+    out = [to_np(ray), to_np(vert), to_np(nrm), to_np(mask)]
+    return out + [to_np(st)] if stats else out
+
+
+@pytest.fixture(scope="module")
+def bg_state(oracle):
+    tsdf, wts = alloc_vol(BG["n"]), alloc_vol(BG["n"])
+    for i in range(4):
+        cam, depth, _ = frame(i)
+        oc = rel_OC(cam, BG["pose"])
+        oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K,
+                           BG["vox"], 10 * BG["vox"], MAXW)
+    return tsdf, wts
+
+
+CAMS = {
+    "tracked": camera_path(4),
+    "rotated": Pose(rot([0.3, 1, 0.2], 14), [0.2, -0.1, 0.15]),
+    "inside": Pose(rot([0, 1, 0], -8), [0.0, 0.0, 0.5]),
+    "outside_oblique": Pose(rot([1, 0, 0], 20), [0.0, -0.9, -0.3]),
+}
+
+
+@pytest.mark.parametrize("cam_name", list(CAMS))
+@pytest.mark.parametrize("use_grad_volume", [False, True])
+def test_raycast_background(oracle, ops, dev, bg_state, cam_name, use_grad_volume):
+    tsdf, wts = bg_state
+    grads = oracle.compute_tsdf_grads(tsdf) if use_grad_volume else None
+    co = rel_CO(CAMS[cam_name], BG["pose"])
+    want = oracle.raycast_tsdf(tsdf, grads, wts, None, W, H, co.R32, co.t32, K, BG["vox"],
+                               10 * BG["vox"], count_steps=True)
+    got = _raycast_dev(ops, dev, tsdf, grads, wts, None, co, BG["vox"], stats=True)
+    if cam_name != "outside_oblique":
+        assert want[3].sum() > 2000
+    assert_parity(got[3], want[3], "mask", exact=True)
+    assert_parity(got[0], want[0], "raylengths", exact=True)
+    assert_parity(got[1], want[1], "vertices", exact=True)
+    assert_parity(got[2], want[2], "normals", exact=True)
+    assert int(got[4][0]) == int(want[4].sum()), "march sample count (S of the byte model)"
+    assert int(got[4][1]) == int(want[3].sum()), "hit count"
+
+
+def test_raycast_empty_and_unseen_volume(oracle, ops, dev):
+    tsdf, wts = alloc_vol((32, 32, 32)), alloc_vol((32, 32, 32))
+    co = rel_CO(Pose(), Pose(t=[0, 0, 0.8]))
+    want = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, co.R32, co.t32, K, 0.01, 0.1,
+                               count_steps=True)
+    import torch
+    got = _raycast_dev(ops, dev, tsdf, None, wts, None, co, 0.01, stats=True)
+    assert not got[3].any() and not got[0].any()
+    assert int(got[4][0]) == int(want[4].sum()) > 0
+
+
+def test_raycast_respects_previous_raylength(oracle, ops, dev, bg_state):
+    # non-zero incoming raylengths clip the march (TSDF.cu:496-500): hits behind them vanish
+    tsdf, wts = bg_state
+    co = rel_CO(CAMS["tracked"], BG["pose"])
+    ray0 = np.zeros((H, W), np.float32)
+    ray0[:, : W // 2] = 1.0
+    want = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, co.R32, co.t32, K, BG["vox"],
+                               10 * BG["vox"], raylengths=ray0)
+    got = _raycast_dev(ops, dev, tsdf, None, wts, None, co, BG["vox"], ray0=ray0)
+    assert want[3][:, : W // 2].sum() < want[3][:, W // 2:].sum()
+    for g, w_, name in zip(got, want, ["ray", "vert", "normal", "mask"]):
+        assert_parity(g, w_, name, exact=True)
+
+
+def test_raycast_object_with_foreground_mask(oracle, ops, dev):
+    cen, r = SPHERES[0]
+    res, size = (32, 32, 32), 0.8
+    vox = size / 32
+    pose = Pose(t=cen)
+    tsdf, wts, fgbg = alloc_vol(res), alloc_vol(res), alloc_vol(res, 2)
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        oc = rel_OC(cam, pose)
+        oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K, vox,
+                           10 * vox, MAXW)
+        oracle.update_fgbg_probs((ids == 1).astype(np.uint8), np.zeros((H, W), np.uint8), tsdf,
+                                 wts, fgbg, oc.R32, oc.t32, K, vox)
+    probs, vmask = oracle.compute_fg_probs(fgbg)
+    assert 0 < (vmask > 0).sum() < vmask.size
+    co = rel_CO(camera_path(3), pose)
+    want = oracle.raycast_tsdf(tsdf, None, wts, vmask, W, H, co.R32, co.t32, K, vox, 10 * vox)
+    got = _raycast_dev(ops, dev, tsdf, None, wts, vmask, co, vox)
+    assert want[3].sum() > 200
+    for g, w_, name in zip(got, want, ["ray", "vert", "normal", "mask"]):
+        assert_parity(g, w_, name, exact=True)
+    # the literal reference form (masked weights volume) gives the same image
+    import torch
+    d_masked = torch.empty_like(to_dev(wts, dev))
+    ops.mask_raycast_weights(to_dev(wts, dev), to_dev(vmask, dev), d_masked)
+    assert_parity(to_np(d_masked), oracle.mask_raycast_weights(wts, vmask), "raycastWeights",
+                  exact=True)
+    got2 = _raycast_dev(ops, dev, tsdf, None, to_np(d_masked), None, co, vox)
+    for g, w_, name in zip(got2, want, ["ray", "vert", "normal", "mask"]):
+        assert_parity(g, w_, name + " (masked volume)", exact=True)
+
+
+# ---- a13 / a14 -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("res", [(32, 32, 32), (30, 22, 18)])
+def test_fgbg_counts_and_fg_probs(oracle, ops, dev, bg_state, res):
+    import torch
+    cen, r = SPHERES[0]
+    vox = 0.8 / max(res)
+    pose = Pose(rot([0, 0, 1], 10), cen)
+    tsdf, wts, fgbg = alloc_vol(res), alloc_vol(res), alloc_vol(res, 2)
+    d_fgbg = to_dev(fgbg, dev)
+    rng = np.random.default_rng(8)
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        oc = rel_OC(cam, pose)
+        oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K, vox,
+                           10 * vox, MAXW)
+        mask = (ids == 1).astype(np.uint8) * (1 if i % 2 else 255)  # any non-zero is "true"
+        occl = (rng.random((H, W)) < 0.2).astype(np.uint8)
+        oracle.update_fgbg_probs(mask, occl, tsdf, wts, fgbg, oc.R32, oc.t32, K, vox)
+        ops.update_fgbg_probs(to_dev(mask, dev, 3), to_dev(occl, dev, 3), to_dev(tsdf, dev),
+                              to_dev(wts, dev), d_fgbg, oc.R32, oc.t32, K, vox)
+    assert fgbg[..., 0].max() >= 2 and fgbg[..., 1].max() >= 2
+    assert_parity(to_np(d_fgbg), fgbg, "fgBgProbs", exact=True)
+    probs, vmask = oracle.compute_fg_probs(fgbg)
+    d_probs = torch.full(probs.shape, 3.0, device=dev)
+    d_mask = torch.full(probs.shape, 7, dtype=torch.uint8, device=dev)
+    ops.compute_fg_probs(d_fgbg, d_probs, d_mask)
+    assert_parity(to_np(d_probs), probs, "fgProbs", exact=True)
+    assert_parity(to_np(d_mask), vmask, "fgVolMask", exact=True)
+
+
+# ---- a3-a6 ---------------------------------------------------------------------------------------
+
+def _object_state(oracle, k, res=(32, 32, 32)):
+    cen, r = SPHERES[k]
+    vox = 0.8 / res[0]
+    pose = Pose(rot([0, 1, 0], 5 * k), cen)
+    tsdf, wts, fgbg = alloc_vol(res), alloc_vol(res), alloc_vol(res, 2)
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        oc = rel_OC(cam, pose)
+        oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K, vox,
+                           10 * vox, MAXW)
+        oracle.update_fgbg_probs((ids == k + 1).astype(np.uint8), np.zeros((H, W), np.uint8), tsdf,
+                                 wts, fgbg, oc.R32, oc.t32, K, vox)
+    probs, vmask = oracle.compute_fg_probs(fgbg)
+    return dict(tsdf=tsdf, wts=wts, probs=probs, vmask=vmask, pose=pose, vox=vox)
+
+
+def test_estep_background_and_objects(oracle, ops, dev, bg_state):
+    import torch
+    tsdf, wts = bg_state
+    objs = [_object_state(oracle, 0), _object_state(oracle, 1)]
+    cam, depth, _ = frame(4)
+    pts = oracle.compute_points(depth, K)
+    d_pts = to_dev(pts, dev)
+    models = [dict(tsdf=tsdf, probs=None, pose=BG["pose"], vox=BG["vox"])] + objs
+    raw, d_maps = [], []
+    for m in models:
+        co = rel_CO(cam, m["pose"])
+        raw.append(oracle.compute_association(m["tsdf"], m["probs"], pts, co.R32, co.t32, m["vox"],
+                                              10 * m["vox"], SIGMA, ALPHA, PRIOR))
+        out = torch.full((H, W), 9.0, device=dev)
+        ops.compute_association(to_dev(m["tsdf"], dev),
+                                None if m["probs"] is None else to_dev(m["probs"], dev), d_pts,
+                                co.R32, co.t32, m["vox"], 10 * m["vox"], SIGMA, ALPHA, PRIOR, out)
+        d_maps.append(out)
+    for k, (dm, r) in enumerate(zip(d_maps, raw)):
+        # expf differs by an ulp or two between glibc and the device library
+        assert_parity(to_np(dm), r, f"un-normalised association {k}", rtol=2e-6)
+        assert np.array_equal(to_np(dm) == 0, r == 0), "association mask (exact-zero lookups)"
+    assert (raw[0] == 0).any() and (raw[1] > 0.25).any()
+    want = [r.copy() for r in raw]
+    norm = oracle.normalize_association(want)
+    d_norm = torch.empty((H, W), device=dev)
+    ops.normalize_association(d_maps, norm=d_norm)
+    assert_parity(to_np(d_norm), norm, "associationNorm", rtol=2e-6)
+    for k, (dm, wv) in enumerate(zip(d_maps, want)):
+        assert_parity(to_np(dm), wv, f"association weights {k}", rtol=RTOL_ASSOC)
+    total = sum(to_np(dm).astype(np.float64) for dm in d_maps)
+    valid = norm != 0
+    assert np.allclose(total[valid], 1.0, atol=1e-6) and np.all(total[~valid] == 0)
+
+
+RTOL_ASSOC = 4e-6
+
+
+@pytest.mark.parametrize("nmaps", [1, 5, 16, 17, 40])
+def test_normalize_exact_and_chunked(oracle, ops, dev, nmaps):
+    """The normalisation itself (sequential sum + x/0:=0 divide) is IEEE-exact: bit parity,
+    including the multi-launch path for more than 16 models."""
+    import torch
+    rng = np.random.default_rng(nmaps)
+    maps = [rng.uniform(0, 3, (H, W)).astype(np.float32) for _ in range(nmaps)]
+    for m in maps:
+        m[:7] = 0
+    d_maps = [to_dev(m, dev, 2 if i % 2 else 0) for i, m in enumerate(maps)]
+    norm = oracle.normalize_association(maps)
+    d_norm = torch.empty((H, W), device=dev)
+    ops.normalize_association(d_maps, norm=d_norm)
+    assert_parity(to_np(d_norm), norm, "norm", exact=True)
+    for k in range(nmaps):
+        assert_parity(to_np(d_maps[k]), maps[k], f"map {k}", exact=True)
+
+
+def test_sum_and_normalize_with_remote_partial(oracle, ops, dev):
+    """Multi-GPU split of the normaliser: local maps + all-reduced remote partial (extraSum)."""
+    import torch
+    rng = np.random.default_rng(3)
+    local = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(3)]
+    remote = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(20)]
+    d_remote = [to_dev(m, dev) for m in remote]
+    d_sum = torch.empty((H, W), device=dev)
+    ops.sum_association(d_remote, d_sum)
+    seq = remote[0].copy()
+    for m in remote[1:]:
+        seq = seq + m
+    assert_parity(to_np(d_sum), seq, "partial sum", exact=True)
+    d_local = [to_dev(m, dev) for m in local]
+    d_norm = torch.empty((H, W), device=dev)
+    ops.normalize_association(d_local, extra_sum=d_sum, norm=d_norm)
+    nrm = ((local[0] + local[1]) + local[2]) + seq
+    assert_parity(to_np(d_norm), nrm, "norm with remote partial", exact=True)
+    for k in range(3):
+        assert_parity(to_np(d_local[k]), local[k] / nrm, f"map {k}", exact=True)
+
+
+# ---- a12 -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nobj", [0, 2, 19])
+def test_composite_and_visibility(oracle, ops, dev, nobj):
+    import torch
+    rng = np.random.default_rng(40 + nobj)
+    ids = list(range(1, nobj + 1))
+    if nobj >= 2:
+        ids[0], ids[1] = 29, 24  # list order is creation order, not id order
+    obj_seg = [(rng.random((H, W)) < 0.3).astype(np.uint8) for _ in ids]
+    obj_ray = [(rng.uniform(0.5, 3, (H, W)).astype(np.float32) * s) for s in obj_seg]
+    if nobj >= 2:
+        obj_ray[1][:20] = obj_ray[0][:20]  # ties: the earlier object keeps the pixel
+    obj_vert = [rng.standard_normal((H, W, 3)).astype(np.float32) for _ in ids]
+    obj_norm = [rng.standard_normal((H, W, 3)).astype(np.float32) for _ in ids]
+    bg_mask = (rng.random((H, W)) < 0.8).astype(np.uint8)
+    bg_ray = rng.uniform(0.5, 3, (H, W)).astype(np.float32) * bg_mask
+    bg_vert = rng.standard_normal((H, W, 3)).astype(np.float32)
+    bg_norm = rng.standard_normal((H, W, 3)).astype(np.float32)
+    diff0 = (rng.uniform(-1, 1, (H, W)) * (rng.random((H, W)) < 0.3)).astype(np.float32)
+    diff = diff0.copy()
+    want = oracle.composite_raycast(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert,
+                                    bg_norm, bg_mask, diff, 10)
+    d = lambda a: to_dev(a, dev)
+    ray = torch.full((H, W), 5.0, device=dev)
+    vert = torch.full((H, W, 3), 5.0, device=dev)
+    nrm = torch.full((H, W, 3), 5.0, device=dev)
+    seg = torch.full((H, W), 5, dtype=torch.uint8, device=dev)
+    no_obj = torch.full((H, W), 5, dtype=torch.uint8, device=dev)
+    d_diff = d(diff0)
+    vis = torch.full((max(nobj, 1),), -1, dtype=torch.int32, device=dev)
+    ops.composite_raycast(ids, [d(a) for a in obj_ray], [d(a) for a in obj_vert],
+                          [d(a) for a in obj_norm], [d(a) for a in obj_seg], d(bg_ray), d(bg_vert),
+                          d(bg_norm), d(bg_mask), ray, vert, nrm, seg, d_diff, no_obj, 10, vis)
+    torch.cuda.synchronize()
+    names = ["ray", "vert", "norm", "seg", "noObj"]
+    for g, w_, name in zip([ray, vert, nrm, seg, no_obj], want[:5], names):
+        assert_parity(to_np(g), w_, name, exact=True)
+    assert_parity(to_np(d_diff), diff, "diffRaylengths", exact=True)
+    if nobj:
+        assert to_np(vis)[:nobj].tolist() == want[5].tolist()
+        assert want[5].sum() > 0
+
+
+def test_occluded_mask(oracle, ops, dev):
+    import torch
+    rng = np.random.default_rng(6)
+    obj_seg = (rng.random((H, W)) < 0.5).astype(np.uint8)
+    seg = rng.integers(0, 4, (H, W)).astype(np.uint8)
+    occ = torch.full((H, W), 9, dtype=torch.uint8, device=dev)
+    ops.occluded_mask(to_dev(obj_seg, dev, 1), to_dev(seg, dev), 2, occ)
+    assert_parity(to_np(occ), oracle.occluded_mask(obj_seg, seg, 2), "occluded", exact=True)
+
+
+# ---- error behaviour on the device side ----------------------------------------------------------
+
+def test_device_info_reports_gfx950(ops):
+    name, arch, cus = ops.device_info()
+    assert "gfx950" in arch and cus >= 200, (name, arch, cus)
