@@ -52,7 +52,7 @@ SIGNATURES = {
     "emf_hip_maskRaycastWeights": [_FP, _FP, _FP, _I3, _STREAM],
     "emf_hip_computeAssociation": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, _IMG, _STREAM],
-    "emf_hip_normalizeAssociation": [_IMG, C.c_int, _IMG, _IMG, _STREAM],
+    "emf_hip_normalizeAssociation": [_IMG, C.c_int, C.c_int, _IMG, _IMG, _STREAM],
     "emf_hip_sumAssociation": [_IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_compositeRaycast": [C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG,
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],

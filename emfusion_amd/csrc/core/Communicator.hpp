@@ -1,0 +1,39 @@
+// Communicator.hpp -- the two cross-GPU exchanges of the sharded path.
+//
+// The reference is single-GPU and has no communication layer; this interface is new design.
+// Object volumes are sharded round-robin over ranks (one process per GPU), the background is
+// replicated.  Per E-step ONE all-reduce(sum, f32, W*H) combines the ranks' object association
+// partials into the per-pixel normaliser; per raycast ONE all-reduce(min, u64, W*H) merges the
+// nearest-hit keys for compositing.  Both are enqueued on a HIP stream (RCCL over xGMI), never
+// synchronising the host.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+
+#include "types.hpp"
+
+namespace emf {
+
+class Communicator {
+public:
+    virtual ~Communicator() = default;
+    virtual int rank() const = 0;
+    virtual int size() const = 0;
+    virtual void allReduceSumF32(float* dev, size_t count, Stream& stream) = 0;
+    virtual void allReduceMinU64(uint64_t* dev, size_t count, Stream& stream) = 0;
+    virtual void broadcast(void* dev, size_t bytes, int root, Stream& stream) = 0;
+};
+
+/** Rank that owns an object volume: round-robin by (1-based) object id. */
+inline int ownerOf(int objectId, int worldSize) { return (objectId - 1) % worldSize; }
+
+constexpr size_t kRcclUniqueIdBytes = 128;
+
+/** Fills `out` (kRcclUniqueIdBytes) with a fresh ncclUniqueId; call on rank 0 and distribute. */
+void rcclGetUniqueId(void* out);
+/** ncclCommInitRank on the current device.  Throws HipError on failure. */
+std::shared_ptr<Communicator> makeRcclCommunicator(const void* uniqueId, int rank, int worldSize);
+
+}  // namespace emf

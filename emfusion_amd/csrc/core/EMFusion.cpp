@@ -1,0 +1,379 @@
+// EMFusion.cpp -- per-frame schedule (see EMFusion.hpp).  Reference: src/core/EMFusion.cpp.
+#include "EMFusion.hpp"
+
+#include <algorithm>
+
+namespace emf {
+
+namespace {
+enum Stamp { kStart = 0, kPoints, kEstep, kRaycast, kComposite, kIntegrate, kMasks, kNumStamps };
+}
+
+EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
+                   std::shared_ptr<Communicator> _comm)
+    : params(_params),
+      gradMode(gradients),
+      comm(std::move(_comm)),
+      background(_params.globalVolumeDims, _params.globalVoxelSize,
+                 _params.globalRelTruncDist * _params.globalVoxelSize, _params.volumePose,
+                 _params.tsdfParams, _params.frameSize, gradients),
+      depthUpload(_params.frameSize),
+      points(_params.frameSize),
+      raylengths(_params.frameSize),
+      bg_raylengths(_params.frameSize),
+      associationNorm(_params.frameSize),
+      bg_associationWeights(_params.frameSize),
+      diffRaylengths(_params.frameSize),
+      objPartialSum(_params.frameSize),
+      vertices(_params.frameSize),
+      normals(_params.frameSize),
+      bg_vertices(_params.frameSize),
+      bg_normals(_params.frameSize),
+      modelSegmentation(_params.frameSize),
+      bg_mask(_params.frameSize),
+      noObjMask(_params.frameSize),
+      occludedMask(_params.frameSize),
+      visCounts(sizeof(int32_t) * EMF_MAX_MODELS),
+      raycastStatsDev(2 * sizeof(uint64_t)) {
+    if (comm) {
+        rank = comm->rank();
+        world = comm->size();
+        hitKeys = DeviceBuffer(params.frameSize.area() * sizeof(uint64_t));
+    }
+    hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
+                           sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
+             "hipHostMalloc");
+    stamps.resize(kNumStamps);
+    for (auto& e : stamps) hipCheck(hipEventCreate(&e), "hipEventCreate");
+    Stream& s = Stream::Null();
+    // reference EMFusion.cpp:44-55: bg_mask = 0, noObjMask = 1, bg_associationWeights = 1;
+    // diffRaylengths is uninitialised memory in the reference, defined as 0 here (Q12)
+    bg_mask.setZero(s);
+    noObjMask.setTo(1, s);
+    bg_associationWeights.setTo(1.f, s);
+    diffRaylengths.setZero(s);
+    modelSegmentation.setZero(s);
+    raylengths.setZero(s);
+    vertices.setZero(s);
+    normals.setZero(s);
+    raycastStatsDev.setZero(s);
+    s.waitForCompletion();
+    streamOf(0);
+}
+
+EMFusion::~EMFusion() {
+    (void)hipDeviceSynchronize();
+    for (auto& e : stamps) (void)hipEventDestroy(e);
+    if (visCountsHost) (void)hipHostFree(visCountsHost);
+}
+
+void EMFusion::reset() {
+    synchronize();
+    pose = Affine3f::Identity();
+    background.reset(params.volumePose);
+    objects.clear();
+    objImages.clear();
+    allIds.clear();
+    vis_objs.clear();
+    for (auto it = streams.begin(); it != streams.end();)
+        it = it->first == 0 ? std::next(it) : streams.erase(it);
+    frameCount = 0;
+    nextId = 1;
+    Stream& s = Stream::Null();
+    bg_associationWeights.setTo(1.f, s);
+    diffRaylengths.setZero(s);
+    modelSegmentation.setZero(s);
+    s.waitForCompletion();
+}
+
+Stream& EMFusion::streamOf(int key) {
+    auto it = streams.find(key);
+    if (it == streams.end()) it = streams.emplace(key, Stream()).first;
+    return it->second;
+}
+
+bool EMFusion::ownsObject(int id) const { return ownerOf(id, world) == rank; }
+
+ObjTSDF* EMFusion::findObject(int id) {
+    for (auto& o : objects)
+        if (o.getID() == id) return &o;
+    return nullptr;
+}
+
+const DeviceImage<float>* EMFusion::getObjAssociation(int id) const {
+    auto it = objImages.find(id);
+    return it == objImages.end() ? nullptr : &it->second.associationWeights;
+}
+
+const DeviceImage<float>* EMFusion::getObjRaylengths(int id) const {
+    auto it = objImages.find(id);
+    return it == objImages.end() ? nullptr : &it->second.raylengths;
+}
+
+int EMFusion::addObject(const Vec3f& center, float volSize) {
+    return addObject(center, volSize, params.objVolumeDims);
+}
+
+int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
+    if (static_cast<int>(allIds.size()) >= EMF_MAX_MODELS - 1)
+        throw HipError("EMFusion::addObject: too many objects", EMF_E_LIMIT);
+    const int id = nextId++;
+    allIds.push_back(id);
+    // new objects are aligned with the world frame; only the centre matters for the pose
+    // (reference EMFusion.cpp:541-547)
+    if (ownsObject(id)) {
+        const Affine3f obj_pose(Matx33f::eye(), center);
+        const float vox = volSize / static_cast<float>(res[0]);
+        objects.emplace_back(id, res, vox, params.objRelTruncDist * vox, obj_pose,
+                             params.tsdfParams, params.frameSize, gradMode);
+        createObj(id);
+        streamOf(id);
+    }
+    vis_objs.insert(id);  // a new object integrates its first frame (Q18)
+    return id;
+}
+
+void EMFusion::createObj(int id) {
+    // reference EMFusion.cpp:908-920
+    ObjImages im;
+    im.raylengths = DeviceImage<float>(params.frameSize);
+    im.vertices = DeviceImage<float, 3>(params.frameSize);
+    im.normals = DeviceImage<float, 3>(params.frameSize);
+    im.modelSegmentation = DeviceImage<uint8_t>(params.frameSize);
+    im.associationWeights = DeviceImage<float>(params.frameSize);
+    Stream& s = Stream::Null();
+    im.modelSegmentation.setZero(s);
+    im.associationWeights.setTo(1.f, s);
+    im.raylengths.setZero(s);
+    s.waitForCompletion();
+    objImages.emplace(id, std::move(im));
+}
+
+void EMFusion::forkVolumeStreams() {
+    main.record();
+    for (auto& kv : streams) kv.second.waitOn(main);
+}
+
+void EMFusion::joinVolumeStreams() {
+    for (auto& kv : streams) main.waitFor(kv.second);
+}
+
+float EMFusion::stamp(int slot) {
+    if (timingsOn) hipCheck(hipEventRecord(stamps[slot], main.get()), "hipEventRecord");
+    return 0.f;
+}
+
+void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+
+void EMFusion::enableRaycastStats(bool on) {
+    statsOn = on;
+    raycastStatsDev.setZero(main);
+}
+
+std::array<uint64_t, 2> EMFusion::raycastStats() {
+    synchronize();
+    std::array<uint64_t, 2> h{};
+    raycastStatsDev.download(h.data(), main);
+    return h;
+}
+
+void EMFusion::processFrame(const RGBD& frame) {
+    if (frame.size.width != params.frameSize.width || frame.size.height != params.frameSize.height)
+        throw HipError("EMFusion::processFrame: frame size differs from Params::frameSize",
+                       EMF_E_SHAPE);
+    depthUpload.upload(frame.depth, main);  // reference EMFusion.cpp:72
+    runSchedule(depthUpload.view(), pending);
+}
+
+void EMFusion::processFrame(const emf_image_t& depthDev, const FrameInputs& in) {
+    runSchedule(depthDev, in);
+}
+
+void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
+    depth = depthDev;
+    stamp(kStart);
+    {
+        const emf_image_t pv = points.view();
+        emfCheck(emf_hip_computePoints(&depth, &pv, params.intr.val, main.abi()),
+                 "computePoints");
+    }
+    stamp(kPoints);
+
+    auto applyObjectPoses = [&]() {
+        for (auto& obj : objects) {
+            auto it = in.obj_poses.find(obj.getID());
+            if (it != in.obj_poses.end()) obj.setPose(it->second);
+        }
+    };
+
+    if (frameCount > 0) {
+        // Q17: the E-step runs three times per frame around the two tracking stages
+        // (reference EMFusion.cpp:79, 687, 87).  Tracking itself is outside this build; its
+        // results arrive as in.cam_pose / in.obj_poses at the points where it would update them.
+        computeAssociationWeights();
+        pose = in.cam_pose;  // background (camera) tracking result
+        computeAssociationWeights();
+        applyObjectPoses();  // object tracking results
+        computeAssociationWeights();
+        stamp(kEstep);
+        raycast();
+    } else {
+        pose = in.cam_pose;
+        applyObjectPoses();
+        stamp(kEstep);
+        stamp(kRaycast);
+        stamp(kComposite);
+    }
+
+    integrateDepth();
+    stamp(kIntegrate);
+
+    if (in.runMasks && !in.masks.empty()) integrateMasks(in.masks);
+    stamp(kMasks);
+
+    if (timingsOn) {
+        hipCheck(hipEventSynchronize(stamps[kMasks]), "hipEventSynchronize");
+        auto ms = [&](int a, int b) {
+            float t = 0.f;
+            hipCheck(hipEventElapsedTime(&t, stamps[a], stamps[b]), "hipEventElapsedTime");
+            return t;
+        };
+        timings.points = ms(kStart, kPoints);
+        timings.estep = ms(kPoints, kEstep);
+        timings.raycast = ms(kEstep, kRaycast);
+        timings.composite = ms(kRaycast, kComposite);
+        timings.integrate = ms(kComposite, kIntegrate);
+        timings.masks = ms(kIntegrate, kMasks);
+        timings.total = ms(kStart, kMasks);
+    }
+    ++frameCount;
+}
+
+void EMFusion::computeAssociationWeights() {
+    const emf_image_t pv = points.view();
+    forkVolumeStreams();
+    background.computeAssociation(pv, pose, bg_associationWeights.view(), streamOf(0));
+    for (auto& obj : objects)
+        obj.computeAssociation(pv, pose, objImages.at(obj.getID()).associationWeights.view(),
+                               streamOf(obj.getID()));
+    joinVolumeStreams();
+
+    // normalisation: background first, then objects in ascending id (std::map) order
+    std::vector<emf_image_t> maps;
+    maps.push_back(bg_associationWeights.view());
+    for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
+    const emf_image_t nv = associationNorm.view();
+    if (world == 1) {
+        emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()),
+                                              static_cast<int>(maps.size()), nullptr, &nv,
+                                              main.abi()),
+                 "normalizeAssociation");
+        return;
+    }
+    // sharded objects: local partial -> one all-reduce over xGMI -> normalise locally
+    const emf_image_t sv = objPartialSum.view();
+    if (maps.size() > 1) {
+        emfCheck(emf_hip_sumAssociation(maps.data() + 1, static_cast<int>(maps.size()) - 1, &sv,
+                                        main.abi()),
+                 "sumAssociation");
+    } else {
+        objPartialSum.setZero(main);
+    }
+    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), main);
+    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
+                                          main.abi()),
+             "normalizeAssociation");
+}
+
+void EMFusion::raycast() {
+    vis_objs.clear();
+    uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
+    forkVolumeStreams();
+    {
+        Stream& s = streamOf(0);
+        bg_raylengths.setZero(s);
+        bg_vertices.setZero(s);
+        bg_normals.setZero(s);
+        bg_mask.setZero(s);
+        background.raycast(pose, params.intr, bg_raylengths.view(), bg_vertices.view(),
+                           bg_normals.view(), bg_mask.view(), s, stats);
+    }
+    for (auto& obj : objects) {
+        Stream& s = streamOf(obj.getID());
+        ObjImages& im = objImages.at(obj.getID());
+        im.raylengths.setZero(s);
+        im.vertices.setZero(s);
+        im.normals.setZero(s);
+        im.modelSegmentation.setZero(s);
+        obj.raycast(pose, params.intr, im.raylengths.view(), im.vertices.view(),
+                    im.normals.view(), im.modelSegmentation.view(), s, stats);
+    }
+    joinVolumeStreams();
+    stamp(kRaycast);
+
+    if (world > 1)
+        throw HipError("EMFusion::raycast: cross-GPU compositing is not wired up yet", EMF_E_ARG);
+
+    // compositing in list (creation) order + visibility counts, one fused pass
+    std::vector<int32_t> ids;
+    std::vector<emf_image_t> oray, overt, onorm, oseg;
+    for (auto& obj : objects) {
+        ObjImages& im = objImages.at(obj.getID());
+        ids.push_back(obj.getID());
+        oray.push_back(im.raylengths.view());
+        overt.push_back(im.vertices.view());
+        onorm.push_back(im.normals.view());
+        oseg.push_back(im.modelSegmentation.view());
+    }
+    const emf_image_t v_bgRay = bg_raylengths.view(), v_bgVert = bg_vertices.view(),
+                      v_bgNorm = bg_normals.view(), v_bgMask = bg_mask.view(),
+                      v_ray = raylengths.view(), v_vert = vertices.view(),
+                      v_norm = normals.view(), v_seg = modelSegmentation.view(),
+                      v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
+    const int nobj = static_cast<int>(ids.size());
+    emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(), onorm.data(),
+                                      oseg.data(), &v_bgRay, &v_bgVert, &v_bgNorm, &v_bgMask,
+                                      &v_ray, &v_vert, &v_norm, &v_seg, &v_diff, &v_noObj,
+                                      params.boundary, visCounts.as<int32_t>(), main.abi()),
+             "compositeRaycast");
+    stamp(kComposite);
+    if (nobj > 0) {
+        hipCheck(hipMemcpyAsync(visCountsHost, visCounts.data(), sizeof(int32_t) * nobj,
+                                hipMemcpyDeviceToHost, main.get()),
+                 "visCounts D2H");
+        main.waitForCompletion();  // the visible set gates integrateDepth (EMFusion.cpp:869-872)
+        for (int k = 0; k < nobj; ++k)
+            if (visCountsHost[k] > params.visibilityThresh) vis_objs.insert(ids[k]);
+    }
+}
+
+void EMFusion::integrateDepth() {
+    forkVolumeStreams();
+    background.integrate(depth, bg_associationWeights.view(), pose, params.intr, streamOf(0));
+    background.updateGradients(streamOf(0));
+    for (auto& obj : objects) {
+        if (!vis_objs.count(obj.getID())) continue;
+        Stream& s = streamOf(obj.getID());
+        obj.integrate(depth, objImages.at(obj.getID()).associationWeights.view(), pose,
+                      params.intr, s);
+        obj.updateGradients(s);
+    }
+    joinVolumeStreams();
+}
+
+void EMFusion::integrateMasks(const std::map<int, emf_image_t>& matches) {
+    const emf_image_t segv = modelSegmentation.view();
+    const emf_image_t occv = occludedMask.view();
+    for (auto& obj : objects) {
+        auto it = matches.find(obj.getID());
+        if (it == matches.end()) continue;
+        // pixels where this object's own raycast hit but another model is in front are not
+        // used for the foreground statistics (reference EMFusion.cpp:897-900)
+        const emf_image_t objSeg = objImages.at(obj.getID()).modelSegmentation.view();
+        emfCheck(emf_hip_occludedMask(&objSeg, &segv, obj.getID(), &occv, main.abi()),
+                 "occludedMask");
+        obj.integrateMask(it->second, occv, pose, params.intr, main);
+    }
+}
+
+}  // namespace emf

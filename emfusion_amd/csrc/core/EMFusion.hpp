@@ -1,0 +1,165 @@
+// EMFusion.hpp -- emf::EMFusion: per-frame schedule over one background volume + N object volumes.
+//
+// Keeps the orchestration surface of the reference's emf::EMFusion for the volumetric hot path
+// (reference include/EMFusion/core/EMFusion.h:47-510, src/core/EMFusion.cpp:28-129, 635-670,
+// 726-795, 865-906): processFrame() runs computePoints -> E-step -> [pose update] -> E-step ->
+// raycast -> integrateDepth -> integrateMasks in the reference's order, with one HIP stream per
+// volume (reference EMFusion.h:471) joined by events instead of host synchronisation.
+//
+// Outside this build's scope, and therefore supplied by the caller: camera / object poses
+// (tracking), object creation and masks (Mask R-CNN + lifecycle, f-3), depth
+// pre-filtering (f-2).  processFrame(RGBD) is kept for the reference call site
+// (apps/EM-Fusion.cpp:152); it consumes poses / masks registered with setFrameInputs().
+#pragma once
+
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <vector>
+
+#include "Communicator.hpp"
+#include "ObjTSDF.hpp"
+#include "TSDF.hpp"
+
+namespace emf {
+
+/** Host-side RGB-D frame (stand-in for emf::RGBD, reference include/EMFusion/utils/data.h). */
+struct RGBD {
+    Size size;
+    const float* depth = nullptr;   // metres, W x H, row-major, host memory
+    const uint8_t* rgb = nullptr;   // optional, unused by the volumetric path
+};
+
+/** What tracking and Mask R-CNN would have produced for one frame. */
+struct FrameInputs {
+    Affine3f cam_pose;                       // camera -> world for this frame
+    std::map<int, Affine3f> obj_poses;       // object id -> volume-centre -> world
+    std::map<int, emf_image_t> masks;        // object id -> u8 0/1 mask (device), mask frames only
+    bool runMasks = false;                   // this frame is a mask frame (frame % maskRCNNFrames)
+};
+
+/** Per-stage GPU time of the last processed frame (milliseconds, from HIP events). */
+struct FrameTimings {
+    float points = 0, estep = 0, raycast = 0, composite = 0, integrate = 0, masks = 0, total = 0;
+};
+
+class EMFusion {
+public:
+    explicit EMFusion(const Params& params, TSDF::Gradients gradients = TSDF::Gradients::OnTheFly,
+                      std::shared_ptr<Communicator> comm = nullptr);
+    ~EMFusion();
+
+    /** Drop all objects and clear the background (reference EMFusion.cpp:58-68). */
+    void reset();
+
+    /**
+     * Create an object volume centred at `center` (world) with edge length `volSize` metres --
+     * the geometric tail of the reference's initNewObjVolume (EMFusion.cpp:541-557).  With more
+     * than one rank every rank must issue the same calls; only the owning rank allocates the
+     * volume.  Returns the object id (1-based, creation order = compositing order).
+     */
+    int addObject(const Vec3f& center, float volSize);
+    int addObject(const Vec3f& center, float volSize, const Vec3i& res);
+
+    /** Poses / masks the next processFrame(RGBD) call consumes. */
+    void setFrameInputs(const FrameInputs& in) { pending = in; }
+
+    /** Reference entry point (EMFusion.cpp:70): uploads the depth map, then runs the schedule. */
+    void processFrame(const RGBD& frame);
+    /** Same schedule on a depth map already resident in device memory (f32 W x H). */
+    void processFrame(const emf_image_t& depthDev, const FrameInputs& in);
+
+    // ---- the four path stages; public so they can be driven and timed one by one ----
+    /** E-step over all models (reference EMFusion.cpp:635-670). */
+    void computeAssociationWeights();
+    /** Raycast all models + compositing + visibility (reference EMFusion.cpp:726-795). */
+    void raycast();
+    /** Fuse depth into the background and every visible object (reference EMFusion.cpp:865-889). */
+    void integrateDepth();
+    /** fg/bg update of the matched objects (reference EMFusion.cpp:891-906). */
+    void integrateMasks(const std::map<int, emf_image_t>& matches);
+
+    /** Block until everything enqueued so far has finished. */
+    void synchronize();
+
+    // ---- state access ----
+    int frameIndex() const { return frameCount; }
+    const Params& getParams() const { return params; }
+    TSDF& getBackground() { return background; }
+    std::list<ObjTSDF>& getObjects() { return objects; }
+    ObjTSDF* findObject(int id);
+    const std::set<int>& visibleObjects() const { return vis_objs; }
+    std::vector<int> objectIds() const { return allIds; }
+    bool ownsObject(int id) const;
+    const FrameTimings& lastTimings() const { return timings; }
+    void enableTimings(bool on) { timingsOn = on; }
+    /** Device counters [march samples, hits] accumulated by raycast() while enabled. */
+    void enableRaycastStats(bool on);
+    std::array<uint64_t, 2> raycastStats();
+
+    // device images of the last frame (valid until the next call)
+    const DeviceImage<float, 3>& getPoints() const { return points; }
+    const DeviceImage<float>& getBgAssociation() const { return bg_associationWeights; }
+    const DeviceImage<float>* getObjAssociation(int id) const;
+    const DeviceImage<float>& getAssociationNorm() const { return associationNorm; }
+    const DeviceImage<float>& getRaylengths() const { return raylengths; }
+    const DeviceImage<float, 3>& getVertices() const { return vertices; }
+    const DeviceImage<float, 3>& getNormals() const { return normals; }
+    const DeviceImage<uint8_t>& getModelSegmentation() const { return modelSegmentation; }
+    const DeviceImage<float>& getBgRaylengths() const { return bg_raylengths; }
+    const DeviceImage<float>* getObjRaylengths(int id) const;
+    Stream& mainStream() { return main; }
+
+private:
+    struct ObjImages {
+        DeviceImage<float> raylengths;
+        DeviceImage<float, 3> vertices, normals;
+        DeviceImage<uint8_t> modelSegmentation;
+        DeviceImage<float> associationWeights;
+    };
+
+    void createObj(int id);
+    void runSchedule(const emf_image_t& depthDev, const FrameInputs& in);
+    void forkVolumeStreams();
+    void joinVolumeStreams();
+    Stream& streamOf(int key);
+    float stamp(int slot);
+
+    Params params;
+    TSDF::Gradients gradMode;
+    std::shared_ptr<Communicator> comm;
+    int rank = 0, world = 1;
+
+    TSDF background;
+    std::list<ObjTSDF> objects;          // objects owned by this rank, creation order
+    std::vector<int> allIds;             // every object id of the job, creation order
+    std::map<int, ObjImages> objImages;  // per owned object
+    std::map<int, Stream> streams;       // key 0 = background, else object id
+    Stream main;
+    Affine3f pose;                       // current camera pose
+    std::set<int> vis_objs;
+    int frameCount = 0;
+    int nextId = 1;
+    FrameInputs pending;
+
+    // frame-sized device images (reference EMFusion.h:447-489)
+    emf_image_t depth{};  // view of the current depth map
+    DeviceImage<float> depthUpload;
+    DeviceImage<float, 3> points;
+    DeviceImage<float> raylengths, bg_raylengths, associationNorm, bg_associationWeights,
+        diffRaylengths, objPartialSum;
+    DeviceImage<float, 3> vertices, normals, bg_vertices, bg_normals;
+    DeviceImage<uint8_t> modelSegmentation, bg_mask, noObjMask, occludedMask;
+    DeviceBuffer visCounts;      // int32 per object
+    DeviceBuffer hitKeys;        // u64 W x H, multi-GPU composite merge
+    DeviceBuffer raycastStatsDev;  // 2 x u64
+    int32_t* visCountsHost = nullptr;  // pinned
+    bool statsOn = false;
+
+    bool timingsOn = false;
+    FrameTimings timings;
+    std::vector<hipEvent_t> stamps;
+};
+
+}  // namespace emf

@@ -1,0 +1,68 @@
+// ObjTSDF.hpp -- emf::ObjTSDF: an object volume = TSDF + per-voxel foreground probability.
+//
+// Keeps the per-frame surface of the reference's emf::ObjTSDF (reference
+// include/EMFusion/core/ObjTSDF.h:40-216, src/core/ObjTSDF.cpp:167-226): integrateMask,
+// computeAssociation (foreground-weighted), raycast (foreground-masked weights), computeFgProbs
+// and the getters.  resize() and the existence / class-probability bookkeeping belong to the
+// object lifecycle and are not part of this build.
+#pragma once
+
+#include "TSDF.hpp"
+
+namespace emf {
+
+class ObjTSDF : public TSDF {
+public:
+    ObjTSDF(Vec3i volumeRes, float voxelSize, float truncdist, Affine3f pose, TSDFParams params,
+            Size frameSize, Gradients gradients = Gradients::OnTheFly);
+    /** Same, with a caller-chosen ID (multi-GPU runs number objects globally). */
+    ObjTSDF(int id, Vec3i volumeRes, float voxelSize, float truncdist, Affine3f pose,
+            TSDFParams params, Size frameSize, Gradients gradients = Gradients::OnTheFly);
+
+    bool operator==(const ObjTSDF& o) const { return id == o.id; }
+    bool operator!=(const ObjTSDF& o) const { return id != o.id; }
+    int getID() const { return id; }
+
+    /** Also clears the fg/bg counts (reference ObjTSDF.cpp:58-61) and the derived volumes. */
+    void reset(const Affine3f& pose) override;
+
+    /**
+     * Accumulate fg/bg counts from a 0/1 mask and refresh the foreground probability
+     * (reference ObjTSDF::integrateMask, ObjTSDF.cpp:167-179).  mask, occluded: u8 W x H.
+     */
+    void integrateMask(const emf_image_t& mask, const emf_image_t& occluded_mask,
+                       const Affine3f& cam_pose, const Matx33f& intr,
+                       Stream& stream = Stream::Null());
+
+    /** Association likelihood times interpolated foreground probability (ObjTSDF.cpp:181-201). */
+    void computeAssociation(const emf_image_t& points, const Affine3f& cam_pose,
+                            const emf_image_t& associationWeights,
+                            Stream& stream = Stream::Null());
+
+    /**
+     * Raycast seeing only foreground voxels (reference ObjTSDF::raycast, ObjTSDF.cpp:203-216).
+     * The foreground mask is applied inside the weight gather; no raycastWeights volume is built.
+     */
+    void raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_image_t& raylengths,
+                 const emf_image_t& vertices, const emf_image_t& normals, const emf_image_t& mask,
+                 Stream& stream = Stream::Null(), uint64_t* stats = nullptr) override;
+
+    /** fgProbs = fg / (fg + bg), fgVolMask = fgProbs > 0.5 (reference ObjTSDF.cpp:218-226). */
+    void computeFgProbs(Stream& stream = Stream::Null());
+
+    std::vector<float> getFgProbVol();
+    std::vector<uint8_t> getFgVolMask();
+    std::vector<float> getFgBgCounts() const;
+
+    const float* fgProbsPtr() const { return fgProbs.as<float>(); }
+    const uint8_t* fgVolMaskPtr() const { return fgVolMask.as<uint8_t>(); }
+
+private:
+    static int nextID;
+    int id;
+    DeviceBuffer fgBgProbs;  // N^3 x 2 f32 counts
+    DeviceBuffer fgProbs;    // N^3 f32
+    DeviceBuffer fgVolMask;  // N^3 u8 (0/255)
+};
+
+}  // namespace emf

@@ -1,0 +1,100 @@
+// TSDF.hpp -- emf::TSDF: one TSDF volume with its per-frame operations.
+//
+// Keeps the method surface of the reference's emf::TSDF for the per-frame volumetric path
+// (reference include/EMFusion/core/TSDF.h:39-330, src/core/TSDF.cpp:28-168): constructor
+// arguments, integrate / updateGradients / raycast / computeAssociation / reset and the getters.
+// Every method enqueues hand-written gfx950 kernels through the emf_hip_* C ABI on the given
+// stream and returns; nothing here computes on the host.  Tracking (prepareTracking ...
+// syncTrack) and meshing are outside this build's scope.
+#pragma once
+
+#include <vector>
+
+#include "data.hpp"
+#include "types.hpp"
+
+namespace emf {
+
+class TSDF {
+public:
+    /** How raycast() obtains the surface normal. */
+    enum class Gradients {
+        OnTheFly,     // blend forward differences of the TSDF at the hit (no gradient volume)
+        Materialized  // keep the reference's N^3 x 3 gradient volume, rebuilt by updateGradients()
+    };
+
+    TSDF(Vec3i volumeRes, float voxelSize, float truncdist, Affine3f pose, TSDFParams params,
+         Size frameSize, Gradients gradients = Gradients::OnTheFly);
+    virtual ~TSDF() = default;
+    TSDF(TSDF&&) = default;
+    TSDF& operator=(TSDF&&) = default;
+
+    /** Zero the volume (tsdf, weights, gradients) and set its pose (reference TSDF.cpp:77-82). */
+    virtual void reset(const Affine3f& pose);
+
+    void getCorners(Vec3f& low, Vec3f& high) const;
+    Vec3f getVolumeSize() const;
+    Vec3i getVolumeRes() const { return volumeRes; }
+    float getVoxelSize() const { return voxelSize; }
+    float getTruncDist() const { return truncdist; }
+    Affine3f getPose() const { return pose; }
+    /** Externally supplied pose (stands in for the tracking update of syncTrack()). */
+    void setPose(const Affine3f& p) { pose = p; }
+    size_t voxels() const {
+        return static_cast<size_t>(volumeRes[0]) * volumeRes[1] * volumeRes[2];
+    }
+
+    /**
+     * Fuse one depth frame, weighted per pixel by the association weights
+     * (reference TSDF::integrate, TSDF.cpp:108-118).  depth, weights: f32 W x H device images.
+     */
+    void integrate(const emf_image_t& depth, const emf_image_t& weights, const Affine3f& cam_pose,
+                   const Matx33f& intr, Stream& stream = Stream::Null());
+
+    /**
+     * Refresh the gradient volume (reference TSDF::updateGradients, TSDF.cpp:120-123).  A no-op in
+     * Gradients::OnTheFly mode, where raycast() differences the TSDF directly.
+     */
+    void updateGradients(Stream& stream = Stream::Null());
+
+    /**
+     * Ray-march the volume from cam_pose (reference TSDF::raycast, TSDF.cpp:158-168).  The four
+     * outputs must be zeroed by the caller beforehand, as in the reference.
+     */
+    virtual void raycast(const Affine3f& cam_pose, const Matx33f& intr,
+                         const emf_image_t& raylengths, const emf_image_t& vertices,
+                         const emf_image_t& normals, const emf_image_t& mask,
+                         Stream& stream = Stream::Null(), uint64_t* stats = nullptr);
+
+    /**
+     * Un-normalised association likelihood of the camera-frame points with this volume
+     * (reference TSDF::computeAssociation + computeLaplace, TSDF.cpp:125-156), one fused kernel.
+     */
+    void computeAssociation(const emf_image_t& points, const Affine3f& cam_pose,
+                            const emf_image_t& associationWeights,
+                            Stream& stream = Stream::Null());
+
+    /** Host copies in the reference layout, (Nz*Ny) rows x Nx cols (TSDF.cpp:398-408). */
+    std::vector<float> getTSDF() const;
+    std::vector<float> getWeightsVol() const;
+
+    const float* tsdfPtr() const { return tsdfVol.as<float>(); }
+    const float* weightsPtr() const { return tsdfWeights.as<float>(); }
+    const float* gradsPtr() const { return tsdfGrads.empty() ? nullptr : tsdfGrads.as<float>(); }
+    Gradients gradientMode() const { return gradMode; }
+
+protected:
+    TSDFParams params;
+    Vec3i volumeRes;
+    float voxelSize;
+    float truncdist;
+    Affine3f pose;  // volume-centre frame -> world
+    Gradients gradMode;
+    Size frameSize;
+
+    DeviceBuffer tsdfVol;      // N^3 f32
+    DeviceBuffer tsdfWeights;  // N^3 f32
+    DeviceBuffer tsdfGrads;    // N^3 x 3 f32, only in Materialized mode
+};
+
+}  // namespace emf

@@ -1,0 +1,362 @@
+// capi.cpp -- extern "C" handle API of include/emf_fusion.h over the C++ host classes.
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+
+#include "EMFusion.hpp"
+#include "SyntheticScene.hpp"
+#include "emf_fusion.h"
+
+using namespace emf;
+
+struct emf_comm {
+    std::shared_ptr<Communicator> impl;
+};
+struct emf_fusion {
+    std::unique_ptr<EMFusion> impl;
+};
+struct emf_synth {
+    std::unique_ptr<SyntheticScene> impl;
+};
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int report(const std::exception& e) {
+    std::snprintf(g_err, sizeof(g_err), "%s", e.what());
+    if (const auto* he = dynamic_cast<const HipError*>(&e)) return he->code() ? he->code() : -100;
+    return -100;
+}
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return EMF_OK;
+    } catch (const std::exception& e) {
+        return report(e);
+    } catch (...) {
+        std::snprintf(g_err, sizeof(g_err), "unknown exception");
+        return -100;
+    }
+}
+
+int nullArg(const char* fn, const char* what) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s is NULL", fn, what);
+    return EMF_E_NULL;
+}
+
+#define REQ(p)                                  \
+    do {                                        \
+        if (!(p)) return nullArg(__func__, #p); \
+    } while (0)
+
+Matx33f m33(const float* a) {
+    return Matx33f(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* emf_fusion_last_error_string(void) { return g_err; }
+
+void emf_fusion_default_params(emf_fusion_params_t* p) {
+    if (!p) return;
+    const Params d;
+    p->width = d.frameSize.width;
+    p->height = d.frameSize.height;
+    std::memcpy(p->K, d.intr.val, sizeof(p->K));
+    std::memcpy(p->bg_res, d.globalVolumeDims.val, sizeof(p->bg_res));
+    p->bg_voxel_size = d.globalVoxelSize;
+    p->bg_rel_truncdist = d.globalRelTruncDist;
+    std::memcpy(p->volume_pose_t, d.volumePose.translation().val, sizeof(p->volume_pose_t));
+    std::memcpy(p->obj_res, d.objVolumeDims.val, sizeof(p->obj_res));
+    p->obj_rel_truncdist = d.objRelTruncDist;
+    p->max_tsdf_weight = d.tsdfParams.maxTSDFWeight;
+    p->assoc_sigma = d.tsdfParams.assocSigma;
+    p->alpha = d.tsdfParams.alpha;
+    p->uni_prior = d.tsdfParams.uniPrior;
+    p->visibility_thresh = d.visibilityThresh;
+    p->boundary = d.boundary;
+    p->mask_frames = d.maskRCNNFrames;
+    p->materialize_gradients = 0;
+}
+
+int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion_t** out) {
+    REQ(p);
+    REQ(out);
+    return guarded([&] {
+        Params q;
+        q.frameSize = Size(p->width, p->height);
+        q.intr = m33(p->K);
+        q.globalVolumeDims = Vec3i(p->bg_res[0], p->bg_res[1], p->bg_res[2]);
+        q.globalVoxelSize = p->bg_voxel_size;
+        q.globalRelTruncDist = p->bg_rel_truncdist;
+        q.volumePose = Affine3f().translate(
+            Vec3f(p->volume_pose_t[0], p->volume_pose_t[1], p->volume_pose_t[2]));
+        q.objVolumeDims = Vec3i(p->obj_res[0], p->obj_res[1], p->obj_res[2]);
+        q.objRelTruncDist = p->obj_rel_truncdist;
+        q.tsdfParams.maxTSDFWeight = p->max_tsdf_weight;
+        q.tsdfParams.assocSigma = p->assoc_sigma;
+        q.tsdfParams.alpha = p->alpha;
+        q.tsdfParams.uniPrior = p->uni_prior;
+        q.visibilityThresh = p->visibility_thresh;
+        q.boundary = p->boundary;
+        q.maskRCNNFrames = p->mask_frames;
+        auto h = std::make_unique<emf_fusion>();
+        h->impl = std::make_unique<EMFusion>(
+            q, p->materialize_gradients ? TSDF::Gradients::Materialized : TSDF::Gradients::OnTheFly,
+            comm ? comm->impl : nullptr);
+        *out = h.release();
+    });
+}
+
+void emf_fusion_destroy(emf_fusion_t* h) { delete h; }
+
+int emf_fusion_reset(emf_fusion_t* h) {
+    REQ(h);
+    return guarded([&] { h->impl->reset(); });
+}
+
+int emf_fusion_add_object(emf_fusion_t* h, const float center[3], float vol_size,
+                          int32_t* id_out) {
+    REQ(h);
+    REQ(center);
+    return guarded([&] {
+        const int id = h->impl->addObject(Vec3f(center[0], center[1], center[2]), vol_size);
+        if (id_out) *id_out = id;
+    });
+}
+
+int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, const float cam_R[9],
+                             const float cam_t[3], int nposes, const int32_t* pose_ids,
+                             const float* obj_R, const float* obj_t, int nmasks,
+                             const int32_t* mask_ids, const emf_image_t* masks, int run_masks) {
+    REQ(h);
+    REQ(depth_dev);
+    REQ(cam_R);
+    REQ(cam_t);
+    if (nposes > 0) {
+        REQ(pose_ids);
+        REQ(obj_R);
+        REQ(obj_t);
+    }
+    if (nmasks > 0) {
+        REQ(mask_ids);
+        REQ(masks);
+    }
+    return guarded([&] {
+        FrameInputs in;
+        in.cam_pose = Affine3f(m33(cam_R), Vec3f(cam_t[0], cam_t[1], cam_t[2]));
+        for (int i = 0; i < nposes; ++i)
+            in.obj_poses[pose_ids[i]] = Affine3f(
+                m33(obj_R + 9 * i), Vec3f(obj_t[3 * i], obj_t[3 * i + 1], obj_t[3 * i + 2]));
+        for (int i = 0; i < nmasks; ++i) in.masks[mask_ids[i]] = masks[i];
+        in.runMasks = run_masks != 0;
+        h->impl->processFrame(*depth_dev, in);
+    });
+}
+
+int emf_fusion_stage_estep(emf_fusion_t* h) {
+    REQ(h);
+    return guarded([&] { h->impl->computeAssociationWeights(); });
+}
+int emf_fusion_stage_raycast(emf_fusion_t* h) {
+    REQ(h);
+    return guarded([&] { h->impl->raycast(); });
+}
+int emf_fusion_stage_integrate(emf_fusion_t* h) {
+    REQ(h);
+    return guarded([&] { h->impl->integrateDepth(); });
+}
+
+int emf_fusion_synchronize(emf_fusion_t* h) {
+    REQ(h);
+    return guarded([&] { h->impl->synchronize(); });
+}
+
+int emf_fusion_enable_timings(emf_fusion_t* h, int on) {
+    REQ(h);
+    h->impl->enableTimings(on != 0);
+    return EMF_OK;
+}
+
+int emf_fusion_last_timings(emf_fusion_t* h, emf_frame_timings_t* out) {
+    REQ(h);
+    REQ(out);
+    const FrameTimings& t = h->impl->lastTimings();
+    *out = emf_frame_timings_t{t.points, t.estep, t.raycast, t.composite, t.integrate, t.masks,
+                               t.total};
+    return EMF_OK;
+}
+
+int emf_fusion_enable_raycast_stats(emf_fusion_t* h, int on) {
+    REQ(h);
+    return guarded([&] { h->impl->enableRaycastStats(on != 0); });
+}
+
+int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]) {
+    REQ(h);
+    REQ(counters);
+    return guarded([&] {
+        const auto c = h->impl->raycastStats();
+        counters[0] = c[0];
+        counters[1] = c[1];
+    });
+}
+
+int emf_fusion_get_image(emf_fusion_t* h, int which, int obj_id, emf_image_t* view) {
+    REQ(h);
+    REQ(view);
+    EMFusion& f = *h->impl;
+    auto missing = [&]() {
+        std::snprintf(g_err, sizeof(g_err), "get_image: object %d is not held by this rank", obj_id);
+        return EMF_E_ARG;
+    };
+    switch (which) {
+        case EMF_IMG_POINTS: *view = f.getPoints().view(); return EMF_OK;
+        case EMF_IMG_BG_ASSOC: *view = f.getBgAssociation().view(); return EMF_OK;
+        case EMF_IMG_OBJ_ASSOC: {
+            const auto* im = f.getObjAssociation(obj_id);
+            if (!im) return missing();
+            *view = im->view();
+            return EMF_OK;
+        }
+        case EMF_IMG_ASSOC_NORM: *view = f.getAssociationNorm().view(); return EMF_OK;
+        case EMF_IMG_RAYLENGTHS: *view = f.getRaylengths().view(); return EMF_OK;
+        case EMF_IMG_VERTICES: *view = f.getVertices().view(); return EMF_OK;
+        case EMF_IMG_NORMALS: *view = f.getNormals().view(); return EMF_OK;
+        case EMF_IMG_SEGMENTATION: *view = f.getModelSegmentation().view(); return EMF_OK;
+        case EMF_IMG_BG_RAYLENGTHS: *view = f.getBgRaylengths().view(); return EMF_OK;
+        case EMF_IMG_OBJ_RAYLENGTHS: {
+            const auto* im = f.getObjRaylengths(obj_id);
+            if (!im) return missing();
+            *view = im->view();
+            return EMF_OK;
+        }
+        default:
+            std::snprintf(g_err, sizeof(g_err), "get_image: unknown selector %d", which);
+            return EMF_E_ARG;
+    }
+}
+
+int emf_fusion_get_volume(emf_fusion_t* h, int which, int obj_id, void** dev_ptr, int32_t res[3]) {
+    REQ(h);
+    REQ(dev_ptr);
+    REQ(res);
+    EMFusion& f = *h->impl;
+    TSDF* vol = obj_id == 0 ? static_cast<TSDF*>(&f.getBackground()) : f.findObject(obj_id);
+    if (!vol) {
+        std::snprintf(g_err, sizeof(g_err), "get_volume: object %d is not held by this rank", obj_id);
+        return EMF_E_ARG;
+    }
+    const Vec3i r = vol->getVolumeRes();
+    res[0] = r[0];
+    res[1] = r[1];
+    res[2] = r[2];
+    ObjTSDF* obj = obj_id == 0 ? nullptr : static_cast<ObjTSDF*>(vol);
+    switch (which) {
+        case EMF_VOL_TSDF: *dev_ptr = const_cast<float*>(vol->tsdfPtr()); return EMF_OK;
+        case EMF_VOL_WEIGHTS: *dev_ptr = const_cast<float*>(vol->weightsPtr()); return EMF_OK;
+        case EMF_VOL_FGPROBS:
+            if (obj) {
+                *dev_ptr = const_cast<float*>(obj->fgProbsPtr());
+                return EMF_OK;
+            }
+            break;
+        case EMF_VOL_FGMASK:
+            if (obj) {
+                *dev_ptr = const_cast<uint8_t*>(obj->fgVolMaskPtr());
+                return EMF_OK;
+            }
+            break;
+        default: break;
+    }
+    std::snprintf(g_err, sizeof(g_err), "get_volume: selector %d not available for id %d", which,
+                  obj_id);
+    return EMF_E_ARG;
+}
+
+int emf_fusion_visible_objects(emf_fusion_t* h, int32_t* ids, int cap, int* n) {
+    REQ(h);
+    REQ(n);
+    int c = 0;
+    for (int id : h->impl->visibleObjects()) {
+        if (c < cap && ids) ids[c] = id;
+        ++c;
+    }
+    *n = c < cap ? c : cap;
+    return EMF_OK;
+}
+
+int emf_fusion_frame_index(emf_fusion_t* h) { return h ? h->impl->frameIndex() : EMF_E_NULL; }
+
+int emf_fusion_owns_object(emf_fusion_t* h, int obj_id) {
+    return h && h->impl->ownsObject(obj_id) ? 1 : 0;
+}
+
+int emf_comm_unique_id(void* out128) {
+    REQ(out128);
+    return guarded([&] { rcclGetUniqueId(out128); });
+}
+
+int emf_comm_create(const void* unique_id128, int rank, int world, emf_comm_t** out) {
+    REQ(unique_id128);
+    REQ(out);
+    return guarded([&] {
+        auto c = std::make_unique<emf_comm>();
+        c->impl = makeRcclCommunicator(unique_id128, rank, world);
+        *out = c.release();
+    });
+}
+
+void emf_comm_destroy(emf_comm_t* c) { delete c; }
+
+int emf_synth_create(int width, int height, const float K[9], int num_spheres, uint64_t seed,
+                     float noise_sigma, float dropout, emf_synth_t** out) {
+    REQ(K);
+    REQ(out);
+    return guarded([&] {
+        auto s = std::make_unique<emf_synth>();
+        s->impl = std::make_unique<SyntheticScene>(Size(width, height), m33(K), num_spheres, seed,
+                                                   noise_sigma, dropout);
+        *out = s.release();
+    });
+}
+
+void emf_synth_destroy(emf_synth_t* s) { delete s; }
+
+int emf_synth_render(emf_synth_t* s, int frame, float* depth, uint8_t* ids) {
+    REQ(s);
+    REQ(depth);
+    return guarded([&] { s->impl->render(frame, depth, ids); });
+}
+
+int emf_synth_camera_pose(emf_synth_t* s, int frame, float R[9], float t[3]) {
+    REQ(s);
+    REQ(R);
+    REQ(t);
+    const Affine3f p = s->impl->cameraPose(frame);
+    std::memcpy(R, p.rotation().val, 9 * sizeof(float));
+    std::memcpy(t, p.translation().val, 3 * sizeof(float));
+    return EMF_OK;
+}
+
+int emf_synth_sphere(emf_synth_t* s, int k, int frame, float center[3], float* radius,
+                     float* volume_size) {
+    REQ(s);
+    if (k < 0 || k >= s->impl->numSpheres()) {
+        std::snprintf(g_err, sizeof(g_err), "emf_synth_sphere: index %d out of range", k);
+        return EMF_E_ARG;
+    }
+    const Vec3f c = s->impl->sphereCenter(k, frame);
+    if (center) std::memcpy(center, c.val, 3 * sizeof(float));
+    if (radius) *radius = s->impl->sphere(k).radius;
+    if (volume_size) *volume_size = s->impl->objectVolumeSize(k);
+    return EMF_OK;
+}
+
+}  // extern "C"

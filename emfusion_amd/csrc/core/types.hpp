@@ -130,14 +130,17 @@ public:
     hipStream_t get() const { return s_; }
     emf_stream_t abi() const { return reinterpret_cast<emf_stream_t>(s_); }
     void waitForCompletion() const;
-    // make this stream wait for everything currently enqueued on `other` (event, no host sync)
-    void waitFor(const Stream& other);
+    // record this stream's event at its current tail (one event per stream, re-recorded)
+    void record();
+    // make this stream wait for `other`'s last record() (device-side, no host sync)
+    void waitOn(const Stream& other);
+    // = other.record() + waitOn(other)
+    void waitFor(Stream& other);
 
 private:
     hipStream_t s_ = nullptr;
     bool owned_ = false;
-    hipEvent_t ev_ = nullptr;  // lazily created, used by waitFor() callers on *this* stream
-    friend class StreamJoin;
+    hipEvent_t ev_ = nullptr;  // lazily created by record()
 };
 
 // Continuous device buffer (what cv::cuda::createContinuous gives): RAII over hipMalloc.

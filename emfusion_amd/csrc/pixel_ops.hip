@@ -159,25 +159,42 @@ __global__ __launch_bounds__(256) void k_assoc_divide(const MapTable t, Img<cons
     }
 }
 
-// single-launch form for <= 16 maps: sum in order, optional extra, divide, optional norm output
-__global__ __launch_bounds__(256) void k_assoc_normalize(const MapTable t, Img<const float> extra,
-                                                         Img<float> norm, int w, int h) {
+// single-launch form for <= 16 maps: sum the first nsum in order, optional extra, divide all,
+// optional norm output
+__global__ __launch_bounds__(256) void k_assoc_normalize(const MapTable t, int nsum,
+                                                         Img<const float> extra, Img<float> norm,
+                                                         int w, int h) {
     int x, y;
     if (!pixel_of(w, h, x, y)) return;
     float v[kMapsPerLaunch];
     float s = 0.f;
+    bool started = false;
 #pragma unroll
     for (int k = 0; k < kMapsPerLaunch; ++k) {
         if (k < t.count) {
             v[k] = t.m[k].row(y)[x];
-            s = (k == 0) ? v[0] : s + v[k];
+            if (k < nsum) {
+                s = started ? s + v[k] : v[k];
+                started = true;
+            }
         }
     }
-    if (extra.data) s = s + extra.row(y)[x];
+    if (extra.data) {
+        const float e = extra.row(y)[x];
+        s = started ? s + e : e;
+    }
     if (norm.data) norm.row(y)[x] = s;
 #pragma unroll
     for (int k = 0; k < kMapsPerLaunch; ++k)
         if (k < t.count) t.m[k].row(y)[x] = (s != 0.f) ? v[k] / s : 0.f;
+}
+
+// norm = extra (used when no local map enters the sum)
+__global__ __launch_bounds__(256) void k_copy_map(Img<const float> src, Img<float> dst, int w,
+                                                  int h) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    dst.row(y)[x] = src.row(y)[x];
 }
 
 // ---- a12: raycast compositing (reference EMFusion.cpp:760-794) -----------------------------------
@@ -389,13 +406,18 @@ int emf_hip_computeAssociation(const float* tsdf, const float* fgProbs, const em
     return launch_status("computeAssociation");
 }
 
-int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps,
+int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps, int nsum,
                                  const emf_image_t* extraSum, const emf_image_t* norm,
                                  emf_stream_t stream) {
     EMF_REQUIRE_PTR(maps_host);
     if (nmaps < 1 || nmaps > EMF_MAX_MODELS)
         return fail(EMF_E_LIMIT, "normalizeAssociation: nmaps = %d, expected 1..%d", nmaps,
                     EMF_MAX_MODELS);
+    if (nsum < 0 || nsum > nmaps)
+        return fail(EMF_E_ARG, "normalizeAssociation: nsum = %d, expected 0..nmaps (%d)", nsum,
+                    nmaps);
+    if (nsum == 0 && !extraSum)
+        return fail(EMF_E_ARG, "normalizeAssociation: nsum == 0 needs extraSum");
     EMF_TRY(check_image(&maps_host[0], 4, "normalizeAssociation: maps[0]"));
     const int w = maps_host[0].width, h = maps_host[0].height;
     Img<const float> extra{nullptr, 0};
@@ -414,18 +436,22 @@ int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps,
     if (nmaps <= kMapsPerLaunch) {
         MapTable t;
         EMF_TRY(fill_map_table(t, maps_host, nmaps, &maps_host[0], "normalizeAssociation: maps"));
-        hipLaunchKernelGGL(k_assoc_normalize, g, b, 0, as_stream(stream), t, extra, nrm, w, h);
+        hipLaunchKernelGGL(k_assoc_normalize, g, b, 0, as_stream(stream), t, nsum, extra, nrm, w,
+                           h);
         return launch_status("normalizeAssociation");
     }
     // more maps than one launch carries: the running sum lives in `norm`, which is then required
     if (!norm)
         return fail(EMF_E_ARG, "normalizeAssociation: norm is required when nmaps > %d",
                     kMapsPerLaunch);
-    for (int k0 = 0; k0 < nmaps; k0 += kMapsPerLaunch) {
-        const int cnt = nmaps - k0 < kMapsPerLaunch ? nmaps - k0 : kMapsPerLaunch;
+    if (nsum == 0) {
+        hipLaunchKernelGGL(k_copy_map, g, b, 0, as_stream(stream), extra, nrm, w, h);
+    }
+    for (int k0 = 0; k0 < nsum; k0 += kMapsPerLaunch) {
+        const int cnt = nsum - k0 < kMapsPerLaunch ? nsum - k0 : kMapsPerLaunch;
         MapTable t;
         EMF_TRY(fill_map_table(t, maps_host + k0, cnt, &maps_host[0], "normalizeAssociation: maps"));
-        const bool lastChunk = k0 + cnt == nmaps;
+        const bool lastChunk = k0 + cnt == nsum;
         hipLaunchKernelGGL(k_assoc_sum, g, b, 0, as_stream(stream), t, nrm,
                            lastChunk ? extra : Img<const float>{nullptr, 0}, w, h, k0 != 0);
     }

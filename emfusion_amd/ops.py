@@ -1,12 +1,12 @@
-"""Thin wrappers that hand PyTorch-ROCm device tensors to the emf_hip_* C ABI.
+"""Thin wrappers that hand device arrays (emfusion_amd.devmem.DeviceArray) to the emf_hip_* C ABI.
 
-PyTorch is plumbing here (device memory + streams); all arithmetic happens inside
-libemf_hip.so.  Every wrapper enqueues on the current torch stream unless ``stream`` (a raw
-hipStream_t integer) is given, and never synchronises.
+Harness-side plumbing only: all arithmetic happens inside libemf_hip.so.  Every wrapper enqueues
+on the null stream unless ``stream`` (a raw hipStream_t integer of the product's HIP runtime) is
+given, and never synchronises.
 
-Layout conventions (see include/emf_hip.h): images are (H, W) or (H, W, C) tensors whose last
-dims are contiguous (row pitch = stride(0)); volumes are contiguous tensors of shape
-(Nz, Ny, Nx) or (Nz, Ny, Nx, C); ``res`` is (Nx, Ny, Nz).
+Layout conventions (see include/emf_hip.h): images are (H, W) or (H, W, C) arrays, rows possibly
+padded (pitch); volumes are contiguous arrays of shape (Nz, Ny, Nx) or (Nz, Ny, Nx, C);
+``res`` is (Nx, Ny, Nz).
 """
 from __future__ import annotations
 
@@ -14,18 +14,16 @@ import ctypes as C
 from typing import Optional, Sequence
 
 import numpy as np
-import torch
 
 from . import _lib
 from ._lib import EmfImage, check
+from .devmem import DeviceArray
 
 _L = _lib.load()
 
 
 def _stream(stream: Optional[int]) -> C.c_void_p:
-    if stream is None:
-        stream = torch.cuda.current_stream().cuda_stream
-    return C.c_void_p(stream)
+    return C.c_void_p(stream or 0)
 
 
 def _f(values, n: int):
@@ -34,35 +32,31 @@ def _f(values, n: int):
     return (C.c_float * n)(*a.tolist())
 
 
-def _res(t: torch.Tensor):
+def _res(t: DeviceArray):
     nz, ny, nx = t.shape[0], t.shape[1], t.shape[2]
     return (C.c_int32 * 3)(nx, ny, nz)
 
 
-def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
-    return C.c_void_p(0 if t is None else t.data_ptr())
+def _ptr(t: Optional[DeviceArray]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.ptr)
 
 
-def _vol(t: torch.Tensor, dtype, channels: int = 1) -> torch.Tensor:
-    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), "volume must be a contiguous device tensor"
-    assert t.dim() == (3 if channels == 1 else 4), f"volume rank {t.dim()} for {channels} channel(s)"
+def _vol(t: DeviceArray, dtype, channels: int = 1) -> DeviceArray:
+    assert isinstance(t, DeviceArray) and t.dtype == np.dtype(dtype) and not t.padded, \
+        "volume must be a contiguous device array"
+    assert len(t.shape) == (3 if channels == 1 else 4), f"volume rank for {channels} channel(s)"
     if channels > 1:
         assert t.shape[3] == channels
     return t
 
 
-def image_view(t: torch.Tensor) -> EmfImage:
-    """emf_image_t over an (H, W[, C]) device tensor; rows may be padded (stride(0) is the pitch)."""
-    assert t.is_cuda, "image must live in device memory"
-    assert t.dim() in (2, 3)
-    if t.dim() == 3:
-        assert t.stride(2) == 1 and t.stride(1) == t.shape[2], "channels must be interleaved"
-    else:
-        assert t.stride(1) == 1
-    return EmfImage(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[1], t.shape[0])
+def image_view(t: DeviceArray) -> EmfImage:
+    """emf_image_t over an (H, W[, C]) device array; rows may be padded."""
+    assert isinstance(t, DeviceArray) and len(t.shape) in (2, 3)
+    return EmfImage(t.ptr, t.pitch, t.shape[1], t.shape[0])
 
 
-def _views(ts: Sequence[torch.Tensor]):
+def _views(ts: Sequence[DeviceArray]):
     arr = (EmfImage * max(len(ts), 1))()
     for i, t in enumerate(ts):
         arr[i] = image_view(t)
@@ -78,8 +72,8 @@ def compute_points(depth, K, points, stream=None):
 
 def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdist, max_weight,
                 stream=None):
-    _vol(tsdf, torch.float32)
-    _vol(weights, torch.float32)
+    _vol(tsdf, np.float32)
+    _vol(weights, np.float32)
     check("emf_hip_updateTSDF",
           _L.emf_hip_updateTSDF(C.byref(image_view(depth)), C.byref(image_view(assoc)), _ptr(tsdf),
                                 _ptr(weights), _f(R_OC, 9), _f(t_OC, 3), _f(K, 9), _res(tsdf),
@@ -87,22 +81,22 @@ def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdis
 
 
 def compute_tsdf_grads(tsdf, grads, stream=None):
-    _vol(tsdf, torch.float32)
-    _vol(grads, torch.float32, 3)
+    _vol(tsdf, np.float32)
+    _vol(grads, np.float32, 3)
     check("emf_hip_computeTSDFGrads",
           _L.emf_hip_computeTSDFGrads(_ptr(tsdf), _ptr(grads), _res(tsdf), _stream(stream)))
 
 
 def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, mask, R_CO, t_CO, K,
                  voxel_size, truncdist, stats=None, stream=None):
-    _vol(tsdf, torch.float32)
-    _vol(weights, torch.float32)
+    _vol(tsdf, np.float32)
+    _vol(weights, np.float32)
     if grads is not None:
-        _vol(grads, torch.float32, 3)
+        _vol(grads, np.float32, 3)
     if fg_mask is not None:
-        _vol(fg_mask, torch.uint8)
+        _vol(fg_mask, np.uint8)
     if stats is not None:
-        assert stats.is_cuda and stats.dtype == torch.int64 and stats.numel() >= 2
+        assert stats.dtype == np.dtype(np.uint64) and stats.shape[0] >= 2
     check("emf_hip_raycastTSDF",
           _L.emf_hip_raycastTSDF(_ptr(tsdf), _ptr(grads), _ptr(weights), _ptr(fg_mask),
                                  C.byref(image_view(raylengths)), C.byref(image_view(vertices)),
@@ -112,8 +106,8 @@ def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, m
 
 
 def get_volume_vals(vol, points, R_CO, t_CO, voxel_size, vals, stream=None):
-    channels = 1 if vol.dim() == 3 else vol.shape[3]
-    _vol(vol, torch.float32, channels)
+    channels = 1 if len(vol.shape) == 3 else vol.shape[3]
+    _vol(vol, np.float32, channels)
     check("emf_hip_getVolumeVals",
           _L.emf_hip_getVolumeVals(_ptr(vol), channels, C.byref(image_view(points)), _f(R_CO, 9),
                                    _f(t_CO, 3), _res(vol), voxel_size, C.byref(image_view(vals)),
@@ -122,9 +116,9 @@ def get_volume_vals(vol, points, R_CO, t_CO, voxel_size, vals, stream=None):
 
 
 def update_fgbg_probs(mask, occluded, tsdf, weights, fgbg, R_OC, t_OC, K, voxel_size, stream=None):
-    _vol(tsdf, torch.float32)
-    _vol(weights, torch.float32)
-    _vol(fgbg, torch.float32, 2)
+    _vol(tsdf, np.float32)
+    _vol(weights, np.float32)
+    _vol(fgbg, np.float32, 2)
     check("emf_hip_updateFgBgProbs",
           _L.emf_hip_updateFgBgProbs(C.byref(image_view(mask)), C.byref(image_view(occluded)),
                                      _ptr(tsdf), _ptr(weights), _ptr(fgbg), _f(R_OC, 9),
@@ -133,18 +127,18 @@ def update_fgbg_probs(mask, occluded, tsdf, weights, fgbg, R_OC, t_OC, K, voxel_
 
 
 def compute_fg_probs(fgbg, fg_probs, fg_vol_mask, stream=None):
-    _vol(fgbg, torch.float32, 2)
-    _vol(fg_probs, torch.float32)
-    _vol(fg_vol_mask, torch.uint8)
+    _vol(fgbg, np.float32, 2)
+    _vol(fg_probs, np.float32)
+    _vol(fg_vol_mask, np.uint8)
     check("emf_hip_computeFgProbs",
           _L.emf_hip_computeFgProbs(_ptr(fgbg), _ptr(fg_probs), _ptr(fg_vol_mask), _res(fg_probs),
                                     _stream(stream)))
 
 
 def mask_raycast_weights(weights, fg_vol_mask, out, stream=None):
-    _vol(weights, torch.float32)
-    _vol(fg_vol_mask, torch.uint8)
-    _vol(out, torch.float32)
+    _vol(weights, np.float32)
+    _vol(fg_vol_mask, np.uint8)
+    _vol(out, np.float32)
     check("emf_hip_maskRaycastWeights",
           _L.emf_hip_maskRaycastWeights(_ptr(weights), _ptr(fg_vol_mask), _ptr(out), _res(weights),
                                         _stream(stream)))
@@ -152,9 +146,9 @@ def mask_raycast_weights(weights, fg_vol_mask, out, stream=None):
 
 def compute_association(tsdf, fg_probs, points, R_CO, t_CO, voxel_size, truncdist, sigma, alpha,
                         uni_prior, out, stream=None):
-    _vol(tsdf, torch.float32)
+    _vol(tsdf, np.float32)
     if fg_probs is not None:
-        _vol(fg_probs, torch.float32)
+        _vol(fg_probs, np.float32)
     check("emf_hip_computeAssociation",
           _L.emf_hip_computeAssociation(_ptr(tsdf), _ptr(fg_probs), C.byref(image_view(points)),
                                         _f(R_CO, 9), _f(t_CO, 3), _res(tsdf), voxel_size,
@@ -163,12 +157,13 @@ def compute_association(tsdf, fg_probs, points, R_CO, t_CO, voxel_size, truncdis
     return out
 
 
-def normalize_association(maps, extra_sum=None, norm=None, stream=None):
+def normalize_association(maps, extra_sum=None, norm=None, nsum=None, stream=None):
     views = _views(maps)
+    nsum = len(maps) if nsum is None else int(nsum)
     ex = C.byref(image_view(extra_sum)) if extra_sum is not None else None
     nr = C.byref(image_view(norm)) if norm is not None else None
     check("emf_hip_normalizeAssociation",
-          _L.emf_hip_normalizeAssociation(views, len(maps), ex, nr, _stream(stream)))
+          _L.emf_hip_normalizeAssociation(views, len(maps), nsum, ex, nr, _stream(stream)))
 
 
 def sum_association(maps, out, stream=None):
@@ -183,7 +178,7 @@ def composite_raycast(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert
     n = len(ids)
     ids_arr = (C.c_int32 * max(n, 1))(*[int(i) for i in ids])
     if n:
-        assert vis_counts.is_cuda and vis_counts.dtype == torch.int32 and vis_counts.numel() >= n
+        assert vis_counts.dtype == np.dtype(np.int32) and vis_counts.shape[0] >= n
     check("emf_hip_compositeRaycast",
           _L.emf_hip_compositeRaycast(n, ids_arr, _views(obj_ray), _views(obj_vert),
                                       _views(obj_norm), _views(obj_seg),

@@ -1,0 +1,325 @@
+"""ctypes binding of libemf_fusion.so (include/emf_fusion.h): the C++ host classes
+emf::EMFusion / TSDF / ObjTSDF, the RCCL communicator and the synthetic RGB-D stream.
+
+Harness-side only (tests/, bench.py).  All per-frame work happens in C++/HIP; this module moves
+pointers.  Fails loudly if the library is missing -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import devmem
+from ._lib import EmfImage, PKG_DIR, REPO_ROOT
+
+LIB_PATH = PKG_DIR / "libemf_fusion.so"
+HEADER_PATH = REPO_ROOT / "include" / "emf_fusion.h"
+
+
+class FusionParams(C.Structure):
+    """Mirror of emf_fusion_params_t."""
+
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("K", C.c_float * 9),
+                ("bg_res", C.c_int32 * 3), ("bg_voxel_size", C.c_float),
+                ("bg_rel_truncdist", C.c_float), ("volume_pose_t", C.c_float * 3),
+                ("obj_res", C.c_int32 * 3), ("obj_rel_truncdist", C.c_float),
+                ("max_tsdf_weight", C.c_float), ("assoc_sigma", C.c_float), ("alpha", C.c_float),
+                ("uni_prior", C.c_float), ("visibility_thresh", C.c_int32),
+                ("boundary", C.c_int32), ("mask_frames", C.c_int32),
+                ("materialize_gradients", C.c_int32)]
+
+
+class FrameTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("points", "estep", "raycast", "composite", "integrate",
+                                         "masks", "total")]
+
+    def as_dict(self) -> Dict[str, float]:
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
+IMG = dict(points=0, bg_assoc=1, obj_assoc=2, assoc_norm=3, raylengths=4, vertices=5, normals=6,
+           segmentation=7, bg_raylengths=8, obj_raylengths=9)
+_IMG_DTYPE = {0: ("float32", 3), 1: ("float32", 1), 2: ("float32", 1), 3: ("float32", 1),
+              4: ("float32", 1), 5: ("float32", 3), 6: ("float32", 3), 7: ("uint8", 1),
+              8: ("float32", 1), 9: ("float32", 1)}
+VOL = dict(tsdf=0, weights=1, fgprobs=2, fgmask=3)
+
+_lib = None
+
+
+class FusionError(RuntimeError):
+    def __init__(self, fn, code, msg):
+        super().__init__(f"{fn} failed with {code}: {msg}")
+        self.code = code
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", HEADER_PATH.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(emf_(?:fusion|comm|synth)_\w+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR / 'csrc'}` "
+                           "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(os.fspath(LIB_PATH))
+    lib.emf_fusion_last_error_string.restype = C.c_char_p
+    lib.emf_fusion_default_params.restype = None
+    lib.emf_fusion_destroy.restype = None
+    lib.emf_comm_destroy.restype = None
+    lib.emf_synth_destroy.restype = None
+    vp = C.c_void_p
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int32)
+    img = C.POINTER(EmfImage)
+    sigs = {
+        "emf_fusion_default_params": [C.POINTER(FusionParams)],
+        "emf_fusion_create": [C.POINTER(FusionParams), vp, C.POINTER(vp)],
+        "emf_fusion_destroy": [vp],
+        "emf_fusion_reset": [vp],
+        "emf_fusion_add_object": [vp, fp, C.c_float, ip],
+        "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
+                                     C.c_int],
+        "emf_fusion_stage_estep": [vp],
+        "emf_fusion_stage_raycast": [vp],
+        "emf_fusion_stage_integrate": [vp],
+        "emf_fusion_synchronize": [vp],
+        "emf_fusion_enable_timings": [vp, C.c_int],
+        "emf_fusion_last_timings": [vp, C.POINTER(FrameTimings)],
+        "emf_fusion_enable_raycast_stats": [vp, C.c_int],
+        "emf_fusion_raycast_stats": [vp, C.POINTER(C.c_uint64)],
+        "emf_fusion_get_image": [vp, C.c_int, C.c_int, img],
+        "emf_fusion_get_volume": [vp, C.c_int, C.c_int, C.POINTER(vp), ip],
+        "emf_fusion_visible_objects": [vp, ip, C.c_int, C.POINTER(C.c_int)],
+        "emf_fusion_frame_index": [vp],
+        "emf_fusion_owns_object": [vp, C.c_int],
+        "emf_comm_unique_id": [vp],
+        "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
+        "emf_comm_destroy": [vp],
+        "emf_synth_create": [C.c_int, C.c_int, fp, C.c_int, C.c_uint64, C.c_float, C.c_float,
+                             C.POINTER(vp)],
+        "emf_synth_destroy": [vp],
+        "emf_synth_render": [vp, C.c_int, vp, vp],
+        "emf_synth_camera_pose": [vp, C.c_int, fp, fp],
+        "emf_synth_sphere": [vp, C.c_int, C.c_int, fp, fp, fp],
+    }
+    for name, argtypes in sigs.items():
+        getattr(lib, name).argtypes = argtypes
+    lib._emf_sigs = sigs
+    _lib = lib
+    return lib
+
+
+def _check(fn: str, rc: int):
+    if rc != 0:
+        raise FusionError(fn, rc, load().emf_fusion_last_error_string().decode(errors="replace"))
+
+
+def _farr(v, n):
+    a = np.ascontiguousarray(np.asarray(v, np.float32).reshape(-1))
+    assert a.size == n
+    return (C.c_float * n)(*a.tolist())
+
+
+def default_params() -> FusionParams:
+    p = FusionParams()
+    load().emf_fusion_default_params(C.byref(p))
+    return p
+
+
+def make_params(width=640, height=480, bg_res=512, bg_voxel=0.01, obj_res=128,
+                materialize_gradients=False, **overrides) -> FusionParams:
+    """Reference defaults (config/default.cfg) with the BASELINE.json volume sizes."""
+    p = default_params()
+    p.width, p.height = width, height
+    f = 525.0 * width / 640.0
+    p.K[:] = [f, 0, width / 2 - 0.5, 0, f, height / 2 - 0.5, 0, 0, 1]
+    p.bg_res[:] = [bg_res] * 3
+    p.bg_voxel_size = bg_voxel
+    p.volume_pose_t[:] = [0, 0, bg_res * bg_voxel / 2]
+    p.obj_res[:] = [obj_res] * 3
+    p.materialize_gradients = int(materialize_gradients)
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+class Communicator:
+    """RCCL communicator (one process per GPU).  The unique id travels over torch.distributed."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, 128)
+        _check("emf_comm_create", load().emf_comm_create(buf, rank, world, C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check("emf_comm_unique_id", load().emf_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self._h:
+            load().emf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class SyntheticStream:
+    """Deterministic synthetic RGB-D stream (emf::SyntheticScene)."""
+
+    def __init__(self, width, height, K, num_spheres, seed=0xE3F5, noise=0.002, dropout=0.01):
+        self._h = C.c_void_p()
+        self.width, self.height, self.n = width, height, num_spheres
+        _check("emf_synth_create",
+               load().emf_synth_create(width, height, _farr(K, 9), num_spheres, seed, noise,
+                                       dropout, C.byref(self._h)))
+
+    def render(self, frame: int):
+        depth = np.empty((self.height, self.width), np.float32)
+        ids = np.empty((self.height, self.width), np.uint8)
+        _check("emf_synth_render",
+               load().emf_synth_render(self._h, frame, depth.ctypes.data, ids.ctypes.data))
+        return depth, ids
+
+    def camera_pose(self, frame: int):
+        R = (C.c_float * 9)()
+        t = (C.c_float * 3)()
+        _check("emf_synth_camera_pose", load().emf_synth_camera_pose(self._h, frame, R, t))
+        return np.array(R, np.float32), np.array(t, np.float32)
+
+    def sphere(self, k: int, frame: int):
+        c = (C.c_float * 3)()
+        r = C.c_float()
+        v = C.c_float()
+        _check("emf_synth_sphere",
+               load().emf_synth_sphere(self._h, k, frame, c, C.byref(r), C.byref(v)))
+        return np.array(c, np.float32), float(r.value), float(v.value)
+
+    def close(self):
+        if self._h:
+            load().emf_synth_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Fusion:
+    """One emf::EMFusion instance (background + object volumes) on the current device."""
+
+    def __init__(self, params: FusionParams, comm: Optional[Communicator] = None):
+        self._h = C.c_void_p()
+        self.params = params
+        self._comm = comm
+        _check("emf_fusion_create",
+               load().emf_fusion_create(C.byref(params), comm._h if comm else None,
+                                        C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().emf_fusion_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def reset(self):
+        _check("emf_fusion_reset", load().emf_fusion_reset(self._h))
+
+    def add_object(self, center, vol_size: float) -> int:
+        out = C.c_int32()
+        _check("emf_fusion_add_object",
+               load().emf_fusion_add_object(self._h, _farr(center, 3), vol_size, C.byref(out)))
+        return out.value
+
+    def process_frame(self, depth_view: EmfImage, cam_R, cam_t, obj_poses=None, masks=None,
+                      run_masks=False):
+        """obj_poses: {id: (R9, t3)}; masks: {id: EmfImage (device u8 0/1)}."""
+        obj_poses = obj_poses or {}
+        masks = masks or {}
+        n = len(obj_poses)
+        ids = (C.c_int32 * max(n, 1))(*obj_poses.keys())
+        Rs = (C.c_float * (9 * max(n, 1)))()
+        ts = (C.c_float * (3 * max(n, 1)))()
+        for i, (R, t) in enumerate(obj_poses.values()):
+            Rs[9 * i:9 * i + 9] = np.asarray(R, np.float32).reshape(-1).tolist()
+            ts[3 * i:3 * i + 3] = np.asarray(t, np.float32).reshape(-1).tolist()
+        m = len(masks)
+        mids = (C.c_int32 * max(m, 1))(*masks.keys())
+        mviews = (EmfImage * max(m, 1))(*masks.values())
+        _check("emf_fusion_process_frame",
+               load().emf_fusion_process_frame(self._h, C.byref(depth_view), _farr(cam_R, 9),
+                                               _farr(cam_t, 3), n, ids, Rs, ts, m, mids, mviews,
+                                               int(run_masks)))
+
+    def stage_estep(self):
+        _check("emf_fusion_stage_estep", load().emf_fusion_stage_estep(self._h))
+
+    def stage_raycast(self):
+        _check("emf_fusion_stage_raycast", load().emf_fusion_stage_raycast(self._h))
+
+    def stage_integrate(self):
+        _check("emf_fusion_stage_integrate", load().emf_fusion_stage_integrate(self._h))
+
+    def synchronize(self):
+        _check("emf_fusion_synchronize", load().emf_fusion_synchronize(self._h))
+
+    def enable_timings(self, on=True):
+        _check("emf_fusion_enable_timings", load().emf_fusion_enable_timings(self._h, int(on)))
+
+    def last_timings(self) -> Dict[str, float]:
+        t = FrameTimings()
+        _check("emf_fusion_last_timings", load().emf_fusion_last_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def enable_raycast_stats(self, on=True):
+        _check("emf_fusion_enable_raycast_stats",
+               load().emf_fusion_enable_raycast_stats(self._h, int(on)))
+
+    def raycast_stats(self):
+        c = (C.c_uint64 * 2)()
+        _check("emf_fusion_raycast_stats", load().emf_fusion_raycast_stats(self._h, c))
+        return int(c[0]), int(c[1])
+
+    def image_view(self, which: str, obj_id: int = 0) -> EmfImage:
+        v = EmfImage()
+        _check("emf_fusion_get_image",
+               load().emf_fusion_get_image(self._h, IMG[which], obj_id, C.byref(v)))
+        return v
+
+    def image(self, which: str, obj_id: int = 0) -> np.ndarray:
+        """Synchronise and copy an image of the last frame to the host."""
+        self.synchronize()
+        v = self.image_view(which, obj_id)
+        dt, ch = _IMG_DTYPE[IMG[which]]
+        out = np.empty((v.height, v.width, ch) if ch > 1 else (v.height, v.width), dt)
+        assert v.pitch == v.width * ch * out.itemsize
+        devmem.memcpy_d2h(out, v.data)
+        return out
+
+    def volume(self, which: str, obj_id: int = 0) -> np.ndarray:
+        self.synchronize()
+        ptr = C.c_void_p()
+        res = (C.c_int32 * 3)()
+        _check("emf_fusion_get_volume",
+               load().emf_fusion_get_volume(self._h, VOL[which], obj_id, C.byref(ptr), res))
+        dt = np.uint8 if which == "fgmask" else np.float32
+        out = np.empty((res[2], res[1], res[0]), dt)
+        devmem.memcpy_d2h(out, ptr.value)
+        return out
+
+    def visible_objects(self):
+        ids = (C.c_int32 * 256)()
+        n = C.c_int()
+        _check("emf_fusion_visible_objects",
+               load().emf_fusion_visible_objects(self._h, ids, 256, C.byref(n)))
+        return [ids[i] for i in range(n.value)]
+
+    def frame_index(self) -> int:
+        return load().emf_fusion_frame_index(self._h)
+
+    def owns_object(self, obj_id: int) -> bool:
+        return bool(load().emf_fusion_owns_object(self._h, obj_id))

@@ -1,0 +1,129 @@
+/*
+ * emf_fusion.h -- C handle API over the C++ host classes (emf::EMFusion / emf::TSDF / emf::ObjTSDF,
+ * emfusion_amd/csrc/core) for callers that cannot include C++ headers: the Python harness
+ * (tests/, bench.py) and FFI users.  C++ callers -- such as a port of the reference's
+ * apps/EM-Fusion.cpp main loop -- use the classes directly (see apps/emfusion_synth.cpp).
+ *
+ * The handle wraps one emf::EMFusion: one background volume + N object volumes, driven frame by
+ * frame with externally supplied poses and masks (tracking and Mask R-CNN are outside this
+ * build's scope).  Every function returns 0 on success, a negative EMF_E_* code or a positive
+ * hipError_t / ncclResult_t; emf_fusion_last_error_string() describes the last failure on the
+ * calling thread.  Nothing throws across this boundary.
+ */
+#ifndef EMF_FUSION_H
+#define EMF_FUSION_H
+
+#include "emf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct emf_fusion emf_fusion_t;
+typedef struct emf_comm emf_comm_t;
+typedef struct emf_synth emf_synth_t;
+
+/* Mirror of the fields of emf::Params / emf::TSDFParams the volumetric path reads
+ * (reference include/EMFusion/core/data.h; defaults = reference defaults). */
+typedef struct emf_fusion_params {
+    int32_t width, height;
+    float K[9];
+    int32_t bg_res[3];
+    float bg_voxel_size;
+    float bg_rel_truncdist;
+    float volume_pose_t[3]; /* background volume centre relative to the first camera */
+    int32_t obj_res[3];
+    float obj_rel_truncdist;
+    float max_tsdf_weight, assoc_sigma, alpha, uni_prior;
+    int32_t visibility_thresh, boundary, mask_frames;
+    int32_t materialize_gradients; /* 0: normals from on-the-fly differences; 1: gradient volume */
+} emf_fusion_params_t;
+
+/* per-stage GPU milliseconds of the last frame (HIP events on the main stream) */
+typedef struct emf_frame_timings {
+    float points, estep, raycast, composite, integrate, masks, total;
+} emf_frame_timings_t;
+
+enum emf_fusion_image {
+    EMF_IMG_POINTS = 0,          /* f32x3 */
+    EMF_IMG_BG_ASSOC = 1,        /* f32   normalised background association weights */
+    EMF_IMG_OBJ_ASSOC = 2,       /* f32   per object (obj_id) */
+    EMF_IMG_ASSOC_NORM = 3,      /* f32 */
+    EMF_IMG_RAYLENGTHS = 4,      /* f32   composite */
+    EMF_IMG_VERTICES = 5,        /* f32x3 composite */
+    EMF_IMG_NORMALS = 6,         /* f32x3 composite */
+    EMF_IMG_SEGMENTATION = 7,    /* u8    composite model segmentation */
+    EMF_IMG_BG_RAYLENGTHS = 8,   /* f32 */
+    EMF_IMG_OBJ_RAYLENGTHS = 9   /* f32   per object (obj_id) */
+};
+
+enum emf_fusion_volume {
+    EMF_VOL_TSDF = 0,     /* f32 */
+    EMF_VOL_WEIGHTS = 1,  /* f32 */
+    EMF_VOL_FGPROBS = 2,  /* f32, objects only */
+    EMF_VOL_FGMASK = 3    /* u8,  objects only */
+};
+
+const char* emf_fusion_last_error_string(void);
+
+void emf_fusion_default_params(emf_fusion_params_t* p);
+/* comm may be NULL (single GPU).  The handle shares ownership of comm. */
+int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion_t** out);
+void emf_fusion_destroy(emf_fusion_t* h);
+int emf_fusion_reset(emf_fusion_t* h);
+
+/* Create an object volume (edge vol_size metres, obj_res voxels) centred at `center` in world
+ * coordinates; every rank issues the same calls.  *id_out = object id (1-based). */
+int emf_fusion_add_object(emf_fusion_t* h, const float center[3], float vol_size, int32_t* id_out);
+
+/* Run one frame of the schedule (emf::EMFusion::processFrame) on a depth map resident in device
+ * memory.  obj_R / obj_t: nposes x 9 / nposes x 3 floats for the object ids in pose_ids.
+ * masks: device u8 0/1 images for the ids in mask_ids; used when run_masks != 0. */
+int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, const float cam_R[9],
+                             const float cam_t[3], int nposes, const int32_t* pose_ids,
+                             const float* obj_R, const float* obj_t, int nmasks,
+                             const int32_t* mask_ids, const emf_image_t* masks, int run_masks);
+
+/* Individual stages (emf::EMFusion::{computeAssociationWeights, raycast, integrateDepth}) acting
+ * on the state left by the last process_frame; for stage-level tests and profiling. */
+int emf_fusion_stage_estep(emf_fusion_t* h);
+int emf_fusion_stage_raycast(emf_fusion_t* h);
+int emf_fusion_stage_integrate(emf_fusion_t* h);
+
+int emf_fusion_synchronize(emf_fusion_t* h);
+int emf_fusion_enable_timings(emf_fusion_t* h, int on);
+int emf_fusion_last_timings(emf_fusion_t* h, emf_frame_timings_t* out);
+/* counters[0] = march samples, counters[1] = hits accumulated by raycast while enabled */
+int emf_fusion_enable_raycast_stats(emf_fusion_t* h, int on);
+int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]);
+
+/* Device views of per-frame images / volumes (valid until the next frame / destroy).
+ * obj_id is ignored unless the selector is per object; 0 selects the background volume. */
+int emf_fusion_get_image(emf_fusion_t* h, int which, int obj_id, emf_image_t* view);
+int emf_fusion_get_volume(emf_fusion_t* h, int which, int obj_id, void** dev_ptr, int32_t res[3]);
+/* ids of the objects classified visible by the last raycast; returns count in *n (<= cap) */
+int emf_fusion_visible_objects(emf_fusion_t* h, int32_t* ids, int cap, int* n);
+int emf_fusion_frame_index(emf_fusion_t* h);
+/* 1 if this rank holds object id's volume */
+int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);
+
+/* ---- RCCL communicator for the object-sharded multi-GPU path (one process per GPU) ---- */
+#define EMF_COMM_UNIQUE_ID_BYTES 128
+int emf_comm_unique_id(void* out128);
+int emf_comm_create(const void* unique_id128, int rank, int world, emf_comm_t** out);
+void emf_comm_destroy(emf_comm_t* c);
+
+/* ---- synthetic RGB-D stream (host side, replaces the dataset readers) ---- */
+int emf_synth_create(int width, int height, const float K[9], int num_spheres, uint64_t seed,
+                     float noise_sigma, float dropout, emf_synth_t** out);
+void emf_synth_destroy(emf_synth_t* s);
+/* depth: HOST float[w*h]; ids: HOST u8[w*h] or NULL */
+int emf_synth_render(emf_synth_t* s, int frame, float* depth, uint8_t* ids);
+int emf_synth_camera_pose(emf_synth_t* s, int frame, float R[9], float t[3]);
+int emf_synth_sphere(emf_synth_t* s, int k, int frame, float center[3], float* radius,
+                     float* volume_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMF_FUSION_H */

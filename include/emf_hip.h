@@ -147,12 +147,14 @@ int emf_hip_computeAssociation(const float* tsdf, const float* fgProbs, const em
 
 /* Replaces the normalisation half of EMFusion::computeAssociationWeights (EMFusion.cpp:653-665).
  * maps_host: HOST array of `nmaps` image views (device data), [0] = background then objects in
- * std::map (ascending ID) order; normalised in place; x/0 := 0.
- *   extraSum: NULL, or f32 W x H added LAST into the normaliser (the all-reduced sum of the
- *             association maps owned by other ranks -- the multi-GPU exchange of SURVEY 8e)
- *   norm    : NULL, or f32 W x H receiving associationNorm
- * 1 <= nmaps <= EMF_MAX_MODELS. */
-int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps,
+ * std::map (ascending ID) order; every map is divided in place by the normaliser; x/0 := 0.
+ *   nsum    : the normaliser is the sequential sum of maps[0 .. nsum-1] (single GPU: nsum = nmaps)
+ *   extraSum: NULL, or f32 W x H added LAST into the normaliser.  Multi-GPU: every rank
+ *             passes nsum = 1 (its background replica) and extraSum = the all-reduced sum of all
+ *             ranks' object maps (emf_hip_sumAssociation + RCCL all-reduce)
+ *   norm    : NULL, or f32 W x H receiving associationNorm (required when nsum > 16)
+ * 1 <= nmaps <= EMF_MAX_MODELS, 0 <= nsum <= nmaps, nsum == 0 requires extraSum. */
+int emf_hip_normalizeAssociation(const emf_image_t* maps_host, int nmaps, int nsum,
                                  const emf_image_t* extraSum, const emf_image_t* norm,
                                  emf_stream_t stream);
 

@@ -24,7 +24,9 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def dev():
-    import torch
-    if not torch.cuda.is_available():
+    """A usable MI355X through the product's own HIP runtime (no torch on the data path)."""
+    from emfusion_amd import devmem
+    if devmem.device_count() < 1:
         pytest.fail("GPU test selected but no HIP device is visible (there is no CPU fallback)")
-    return torch.device("cuda:0")
+    devmem.set_device(0)
+    return devmem

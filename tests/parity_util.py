@@ -7,23 +7,21 @@ import numpy as np
 RTOL = 1e-4
 
 
-def to_dev(a: np.ndarray, dev, pad_cols: int = 0):
-    """numpy -> device tensor.  pad_cols > 0 allocates padded rows (pitch > width * elemsize) and
-    returns a view of the valid columns, to exercise pitched images."""
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(a))
-    if pad_cols == 0:
-        return t.to(dev)
-    shape = list(t.shape)
-    shape[1] += pad_cols
-    buf = torch.full(shape, -7, dtype=t.dtype, device=dev)  # poison the padding
-    view = buf[:, : t.shape[1]]
-    view.copy_(t)
-    return view
+def to_dev(a: np.ndarray, dev=None, pad_cols: int = 0):
+    """numpy -> device array (product HIP runtime).  pad_cols > 0 allocates padded rows
+    (pitch > width * elemsize, padding poisoned) to exercise pitched images."""
+    from emfusion_amd.devmem import DeviceArray
+    return DeviceArray.from_numpy(a, pad_cols)
+
+
+def dev_full(shape, value, dtype=np.float32, pad_cols: int = 0):
+    from emfusion_amd.devmem import DeviceArray
+    return DeviceArray.full(shape, value, dtype, pad_cols)
 
 
 def to_np(t) -> np.ndarray:
-    return t.detach().cpu().numpy()
+    """Synchronise the device, then copy to the host."""
+    return t.numpy()
 
 
 def mismatch(a: np.ndarray, b: np.ndarray, rtol: float = RTOL, atol: float = 0.0) -> np.ndarray:

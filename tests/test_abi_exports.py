@@ -43,7 +43,7 @@ def test_null_and_shape_arguments_are_rejected_before_any_launch():
     ok = _lib.EmfImage(C.c_void_p(256), 32, 8, 8)
     assert lib.emf_hip_getVolumeVals(C.c_void_p(16), 4, C.byref(ok), K, K, res, 0.01, C.byref(ok),
                                      None) == -4  # EMF_E_ARG: channels
-    assert lib.emf_hip_normalizeAssociation(C.byref(ok), 0, None, None, None) == -5  # EMF_E_LIMIT
+    assert lib.emf_hip_normalizeAssociation(C.byref(ok), 0, 0, None, None, None) == -5  # EMF_E_LIMIT
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -7,7 +7,7 @@ floats, which is stronger and keeps real bugs from hiding inside an outlier budg
 import numpy as np
 import pytest
 
-from tests.parity_util import assert_parity, to_dev, to_np
+from tests.parity_util import assert_parity, dev_full, to_dev, to_np
 from tests.scenes import Pose, camera_path, intrinsics, rel_CO, rel_OC, render_depth, rot
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +39,6 @@ def alloc_vol(res_xyz, ch=1, dtype=np.float32):
 def integrate_both(oracle, ops, dev, res, vox, vol_pose, frames, assoc_fn=None, max_w=MAXW,
                    pad=0):
     """Run the same integration sequence on the oracle (numpy) and the HIP path (device)."""
-    import torch
     tsdf, wts = alloc_vol(res), alloc_vol(res)
     d_tsdf, d_wts = to_dev(tsdf, dev), to_dev(wts, dev)
     for i in frames:
@@ -49,7 +48,7 @@ def integrate_both(oracle, ops, dev, res, vox, vol_pose, frames, assoc_fn=None, 
         oracle.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, K, vox, 10 * vox, max_w)
         ops.update_tsdf(to_dev(depth, dev, pad), to_dev(assoc, dev, pad), d_tsdf, d_wts, oc.R32,
                         oc.t32, K, vox, 10 * vox, max_w)
-    torch.cuda.synchronize()
+    dev.synchronize()
     return (tsdf, wts), (d_tsdf, d_wts)
 
 
@@ -57,10 +56,9 @@ def integrate_both(oracle, ops, dev, res, vox, vol_pose, frames, assoc_fn=None, 
 
 @pytest.mark.parametrize("pad", [0, 5])
 def test_compute_points(oracle, ops, dev, pad):
-    import torch
     _, depth, _ = frame(0)
     want = oracle.compute_points(depth, K)
-    pts = torch.full((H, W + pad, 3), -7.0, device=dev)[:, :W]
+    pts = dev_full((H, W, 3), -7.0, pad_cols=pad)
     ops.compute_points(to_dev(depth, dev, pad), K, pts)
     assert_parity(to_np(pts), want, "points", exact=True)
 
@@ -105,11 +103,10 @@ def test_integrate_camera_behind_and_rotated_volume(oracle, ops, dev):
 
 @pytest.mark.parametrize("res", [(64, 64, 64), (30, 22, 18)])
 def test_tsdf_grads(oracle, ops, dev, res):
-    import torch
     rng = np.random.default_rng(4)
     tsdf = rng.uniform(-1, 1, (res[2], res[1], res[0])).astype(np.float32)
     want = oracle.compute_tsdf_grads(tsdf)
-    g = torch.full(tsdf.shape + (3,), 5.0, device=dev)  # last planes must be overwritten with 0
+    g = dev_full(tsdf.shape + (3,), 5.0)  # last planes must be overwritten with 0
     ops.compute_tsdf_grads(to_dev(tsdf, dev), g)
     assert_parity(to_np(g), want, "grads", exact=True)
 
@@ -118,7 +115,6 @@ def test_tsdf_grads(oracle, ops, dev, res):
 
 @pytest.mark.parametrize("ch", [1, 2, 3])
 def test_get_volume_vals(oracle, ops, dev, ch):
-    import torch
     rng = np.random.default_rng(20 + ch)
     n = (40, 32, 36)
     vol = rng.standard_normal((n[2], n[1], n[0]) + ((ch,) if ch > 1 else ())).astype(np.float32)
@@ -127,7 +123,7 @@ def test_get_volume_vals(oracle, ops, dev, ch):
     co = rel_CO(cam, Pose(rot([0, 1, 0], 12), [0.1, 0, 1.4]))
     want = oracle.get_volume_vals(vol, pts, co.R32, co.t32, 0.03)
     assert (want != 0).mean() > 0.05 and (want == 0).mean() > 0.01
-    vals = torch.full(want.shape, 9.0, device=dev)  # callee zero-fills
+    vals = dev_full(want.shape, 9.0)  # callee zero-fills
     ops.get_volume_vals(to_dev(vol, dev), to_dev(pts, dev), co.R32, co.t32, 0.03, vals)
     assert_parity(to_np(vals), want, f"vals ch={ch}", exact=True)
 
@@ -135,16 +131,15 @@ def test_get_volume_vals(oracle, ops, dev, ch):
 # ---- a10 / a11 -----------------------------------------------------------------------------------
 
 def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False):
-    import torch
-    ray = torch.zeros((H, W), device=dev) if ray0 is None else to_dev(ray0, dev)
-    vert = torch.zeros((H, W, 3), device=dev)
-    nrm = torch.zeros((H, W, 3), device=dev)
-    mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
-    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
+    ray = dev_full((H, W), 0.0) if ray0 is None else to_dev(ray0, dev)
+    vert = dev_full((H, W, 3), 0.0)
+    nrm = dev_full((H, W, 3), 0.0)
+    mask = dev_full((H, W), 0, np.uint8)
+    st = dev_full((2,), 0, np.uint64) if stats else None
     ops.raycast_tsdf(to_dev(tsdf, dev), None if grads is None else to_dev(grads, dev),
                      to_dev(wts, dev), None if fg is None else to_dev(fg, dev), ray, vert, nrm,
                      mask, co.R32, co.t32, K, vox, 10 * vox, st)
-    torch.cuda.synchronize()
+    dev.synchronize()
     out = [to_np(ray), to_np(vert), to_np(nrm), to_np(mask)]
     return out + [to_np(st)] if stats else out
 
@@ -192,7 +187,6 @@ def test_raycast_empty_and_unseen_volume(oracle, ops, dev):
     co = rel_CO(Pose(), Pose(t=[0, 0, 0.8]))
     want = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, co.R32, co.t32, K, 0.01, 0.1,
                                count_steps=True)
-    import torch
     got = _raycast_dev(ops, dev, tsdf, None, wts, None, co, 0.01, stats=True)
     assert not got[3].any() and not got[0].any()
     assert int(got[4][0]) == int(want[4].sum()) > 0
@@ -234,8 +228,7 @@ def test_raycast_object_with_foreground_mask(oracle, ops, dev):
     for g, w_, name in zip(got, want, ["ray", "vert", "normal", "mask"]):
         assert_parity(g, w_, name, exact=True)
     # the literal reference form (masked weights volume) gives the same image
-    import torch
-    d_masked = torch.empty_like(to_dev(wts, dev))
+    d_masked = dev_full(wts.shape, 0.0)
     ops.mask_raycast_weights(to_dev(wts, dev), to_dev(vmask, dev), d_masked)
     assert_parity(to_np(d_masked), oracle.mask_raycast_weights(wts, vmask), "raycastWeights",
                   exact=True)
@@ -248,7 +241,6 @@ def test_raycast_object_with_foreground_mask(oracle, ops, dev):
 
 @pytest.mark.parametrize("res", [(32, 32, 32), (30, 22, 18)])
 def test_fgbg_counts_and_fg_probs(oracle, ops, dev, bg_state, res):
-    import torch
     cen, r = SPHERES[0]
     vox = 0.8 / max(res)
     pose = Pose(rot([0, 0, 1], 10), cen)
@@ -268,8 +260,8 @@ def test_fgbg_counts_and_fg_probs(oracle, ops, dev, bg_state, res):
     assert fgbg[..., 0].max() >= 2 and fgbg[..., 1].max() >= 2
     assert_parity(to_np(d_fgbg), fgbg, "fgBgProbs", exact=True)
     probs, vmask = oracle.compute_fg_probs(fgbg)
-    d_probs = torch.full(probs.shape, 3.0, device=dev)
-    d_mask = torch.full(probs.shape, 7, dtype=torch.uint8, device=dev)
+    d_probs = dev_full(probs.shape, 3.0)
+    d_mask = dev_full(probs.shape, 7, np.uint8)
     ops.compute_fg_probs(d_fgbg, d_probs, d_mask)
     assert_parity(to_np(d_probs), probs, "fgProbs", exact=True)
     assert_parity(to_np(d_mask), vmask, "fgVolMask", exact=True)
@@ -294,7 +286,6 @@ def _object_state(oracle, k, res=(32, 32, 32)):
 
 
 def test_estep_background_and_objects(oracle, ops, dev, bg_state):
-    import torch
     tsdf, wts = bg_state
     objs = [_object_state(oracle, 0), _object_state(oracle, 1)]
     cam, depth, _ = frame(4)
@@ -306,7 +297,7 @@ def test_estep_background_and_objects(oracle, ops, dev, bg_state):
         co = rel_CO(cam, m["pose"])
         raw.append(oracle.compute_association(m["tsdf"], m["probs"], pts, co.R32, co.t32, m["vox"],
                                               10 * m["vox"], SIGMA, ALPHA, PRIOR))
-        out = torch.full((H, W), 9.0, device=dev)
+        out = dev_full((H, W), 9.0)
         ops.compute_association(to_dev(m["tsdf"], dev),
                                 None if m["probs"] is None else to_dev(m["probs"], dev), d_pts,
                                 co.R32, co.t32, m["vox"], 10 * m["vox"], SIGMA, ALPHA, PRIOR, out)
@@ -318,7 +309,7 @@ def test_estep_background_and_objects(oracle, ops, dev, bg_state):
     assert (raw[0] == 0).any() and (raw[1] > 0.25).any()
     want = [r.copy() for r in raw]
     norm = oracle.normalize_association(want)
-    d_norm = torch.empty((H, W), device=dev)
+    d_norm = dev_full((H, W), 0.0)
     ops.normalize_association(d_maps, norm=d_norm)
     assert_parity(to_np(d_norm), norm, "associationNorm", rtol=2e-6)
     for k, (dm, wv) in enumerate(zip(d_maps, want)):
@@ -335,14 +326,13 @@ RTOL_ASSOC = 4e-6
 def test_normalize_exact_and_chunked(oracle, ops, dev, nmaps):
     """The normalisation itself (sequential sum + x/0:=0 divide) is IEEE-exact: bit parity,
     including the multi-launch path for more than 16 models."""
-    import torch
     rng = np.random.default_rng(nmaps)
     maps = [rng.uniform(0, 3, (H, W)).astype(np.float32) for _ in range(nmaps)]
     for m in maps:
         m[:7] = 0
     d_maps = [to_dev(m, dev, 2 if i % 2 else 0) for i, m in enumerate(maps)]
     norm = oracle.normalize_association(maps)
-    d_norm = torch.empty((H, W), device=dev)
+    d_norm = dev_full((H, W), 0.0)
     ops.normalize_association(d_maps, norm=d_norm)
     assert_parity(to_np(d_norm), norm, "norm", exact=True)
     for k in range(nmaps):
@@ -350,32 +340,45 @@ def test_normalize_exact_and_chunked(oracle, ops, dev, nmaps):
 
 
 def test_sum_and_normalize_with_remote_partial(oracle, ops, dev):
-    """Multi-GPU split of the normaliser: local maps + all-reduced remote partial (extraSum)."""
-    import torch
+    """Multi-GPU split of the normaliser: each rank sums its own object maps, the
+    partials are all-reduced, and every rank normalises [background, own objects] with
+    nsum = 1 and extraSum = the reduced object sum."""
     rng = np.random.default_rng(3)
-    local = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(3)]
-    remote = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(20)]
-    d_remote = [to_dev(m, dev) for m in remote]
-    d_sum = torch.empty((H, W), device=dev)
-    ops.sum_association(d_remote, d_sum)
-    seq = remote[0].copy()
-    for m in remote[1:]:
-        seq = seq + m
-    assert_parity(to_np(d_sum), seq, "partial sum", exact=True)
-    d_local = [to_dev(m, dev) for m in local]
-    d_norm = torch.empty((H, W), device=dev)
-    ops.normalize_association(d_local, extra_sum=d_sum, norm=d_norm)
-    nrm = ((local[0] + local[1]) + local[2]) + seq
-    assert_parity(to_np(d_norm), nrm, "norm with remote partial", exact=True)
-    for k in range(3):
-        assert_parity(to_np(d_local[k]), local[k] / nrm, f"map {k}", exact=True)
+    bg = rng.uniform(0, 2, (H, W)).astype(np.float32)
+    mine = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(2)]
+    theirs = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(20)]
+    for m in [bg] + mine + theirs:
+        m[:5] = 0
+    d_sum_mine = dev_full((H, W), 0.0)
+    d_sum_theirs = dev_full((H, W), 0.0)
+    ops.sum_association([to_dev(m, dev) for m in mine], d_sum_mine)
+    ops.sum_association([to_dev(m, dev) for m in theirs], d_sum_theirs)  # 20 maps: chunked path
+    seq_mine = mine[0] + mine[1]
+    seq_theirs = theirs[0].copy()
+    for m in theirs[1:]:
+        seq_theirs = seq_theirs + m
+    assert_parity(to_np(d_sum_mine), seq_mine, "local partial", exact=True)
+    assert_parity(to_np(d_sum_theirs), seq_theirs, "remote partial", exact=True)
+    reduced = to_dev(to_np(d_sum_mine) + to_np(d_sum_theirs), dev)  # what the all-reduce delivers
+    d_maps = [to_dev(m, dev) for m in [bg] + mine]
+    d_norm = dev_full((H, W), 0.0)
+    ops.normalize_association(d_maps, extra_sum=reduced, norm=d_norm, nsum=1)
+    nrm = bg + (seq_mine + seq_theirs)
+    assert_parity(to_np(d_norm), nrm, "norm with reduced object sum", exact=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for k, m in enumerate([bg] + mine):
+            want = np.where(nrm != 0, m / nrm, 0).astype(np.float32)
+            assert_parity(to_np(d_maps[k]), want, f"map {k}", exact=True)
+    # and it stays within a few ulp of the single-GPU sequential order
+    allmaps = [bg.copy()] + [m.copy() for m in mine + theirs]
+    oracle.normalize_association(allmaps)
+    assert_parity(to_np(d_maps[1]), allmaps[1], "vs sequential order", rtol=1e-6)
 
 
 # ---- a12 -----------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("nobj", [0, 2, 19])
 def test_composite_and_visibility(oracle, ops, dev, nobj):
-    import torch
     rng = np.random.default_rng(40 + nobj)
     ids = list(range(1, nobj + 1))
     if nobj >= 2:
@@ -395,17 +398,17 @@ def test_composite_and_visibility(oracle, ops, dev, nobj):
     want = oracle.composite_raycast(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert,
                                     bg_norm, bg_mask, diff, 10)
     d = lambda a: to_dev(a, dev)
-    ray = torch.full((H, W), 5.0, device=dev)
-    vert = torch.full((H, W, 3), 5.0, device=dev)
-    nrm = torch.full((H, W, 3), 5.0, device=dev)
-    seg = torch.full((H, W), 5, dtype=torch.uint8, device=dev)
-    no_obj = torch.full((H, W), 5, dtype=torch.uint8, device=dev)
+    ray = dev_full((H, W), 5.0)
+    vert = dev_full((H, W, 3), 5.0)
+    nrm = dev_full((H, W, 3), 5.0)
+    seg = dev_full((H, W), 5, np.uint8)
+    no_obj = dev_full((H, W), 5, np.uint8)
     d_diff = d(diff0)
-    vis = torch.full((max(nobj, 1),), -1, dtype=torch.int32, device=dev)
+    vis = dev_full((max(nobj, 1),), -1, np.int32)
     ops.composite_raycast(ids, [d(a) for a in obj_ray], [d(a) for a in obj_vert],
                           [d(a) for a in obj_norm], [d(a) for a in obj_seg], d(bg_ray), d(bg_vert),
                           d(bg_norm), d(bg_mask), ray, vert, nrm, seg, d_diff, no_obj, 10, vis)
-    torch.cuda.synchronize()
+    dev.synchronize()
     names = ["ray", "vert", "norm", "seg", "noObj"]
     for g, w_, name in zip([ray, vert, nrm, seg, no_obj], want[:5], names):
         assert_parity(to_np(g), w_, name, exact=True)
@@ -416,11 +419,10 @@ def test_composite_and_visibility(oracle, ops, dev, nobj):
 
 
 def test_occluded_mask(oracle, ops, dev):
-    import torch
     rng = np.random.default_rng(6)
     obj_seg = (rng.random((H, W)) < 0.5).astype(np.uint8)
     seg = rng.integers(0, 4, (H, W)).astype(np.uint8)
-    occ = torch.full((H, W), 9, dtype=torch.uint8, device=dev)
+    occ = dev_full((H, W), 9, np.uint8)
     ops.occluded_mask(to_dev(obj_seg, dev, 1), to_dev(seg, dev), 2, occ)
     assert_parity(to_np(occ), oracle.occluded_mask(obj_seg, seg, 2), "occluded", exact=True)
 

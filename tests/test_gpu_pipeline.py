@@ -1,0 +1,136 @@
+"""End-to-end parity of the C++ host classes (emf::EMFusion schedule over the HIP kernels, driven
+through include/emf_fusion.h) against the frame-level oracle (tests/oracle_pipeline.py) on the
+same synthetic RGB-D stream: E-step x3, raycast + compositing + visibility, association-weighted
+integration and fg/bg mask integration, over several frames with moving camera and objects."""
+import numpy as np
+import pytest
+
+from tests.oracle_pipeline import Affine32, OraclePipeline
+from tests.parity_util import assert_parity, to_dev
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 120
+BG_RES, BG_VOX, OBJ_RES = 64, 0.04, 32
+NOBJ, NFRAMES, MASK_EVERY = 2, 6, 3
+
+
+@pytest.fixture(scope="module")
+def run(oracle, dev):
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+
+    # visibility threshold / boundary scaled to the small image (reference: 1600 px, 20 px @ VGA)
+    prm = pipeline.make_params(W, H, BG_RES, BG_VOX, OBJ_RES, visibility_thresh=100, boundary=5,
+                               mask_frames=MASK_EVERY)
+    K = np.array(prm.K, np.float32)
+    synth = pipeline.SyntheticStream(W, H, K, NOBJ, seed=0xE3F5)
+    fus = pipeline.Fusion(prm)
+    orc = OraclePipeline(oracle, W, H, K, BG_RES, BG_VOX, list(prm.volume_pose_t), OBJ_RES,
+                         visibility_thresh=100, boundary=5)
+    fus.enable_raycast_stats(True)
+    ids = []
+    for k in range(NOBJ):
+        c, r, vs = synth.sphere(k, 0)
+        ids.append(fus.add_object(c, vs))
+        assert orc.add_object(c, vs) == ids[-1]
+    history = []
+    for f in range(NFRAMES):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0])
+                 for i in ids}
+        run_masks = f % MASK_EVERY == 0
+        masks = {i: (sid == i).astype(np.uint8) for i in ids} if run_masks else {}
+        d_depth = to_dev(depth)
+        d_masks = {i: to_dev(m) for i, m in masks.items()}
+        fus.process_frame(image_view(d_depth), R, t, poses,
+                          {i: image_view(m) for i, m in d_masks.items()}, run_masks)
+        fus.synchronize()
+        orc.process_frame(depth, Affine32(R.reshape(3, 3), t),
+                          {i: Affine32(p[0].reshape(3, 3), p[1]) for i, p in poses.items()},
+                          masks, run_masks)
+        history.append(dict(vis=sorted(fus.visible_objects()), ovis=sorted(orc.vis)))
+    yield fus, orc, ids, history
+    fus.close()
+    synth.close()
+
+
+def test_frames_were_processed(run):
+    fus, orc, ids, history = run
+    assert fus.frame_index() == NFRAMES == orc.frame
+    assert all(fus.owns_object(i) for i in ids)
+
+
+def test_visible_sets_match_every_frame(run):
+    _, _, _, history = run
+    for f, hrec in enumerate(history):
+        assert hrec["vis"] == hrec["ovis"], f"frame {f}"
+    assert any(hrec["vis"] for hrec in history[1:]), "no object ever became visible"
+
+
+def test_background_volume(run):
+    fus, orc, _, _ = run
+    t = fus.volume("tsdf", 0)
+    w = fus.volume("weights", 0)
+    assert (orc.bg["wts"] > 0).sum() > 10000
+    # association weights pass through expf (few-ulp library differences), then through the
+    # running average: allow the north-star tolerance with a small outlier budget
+    assert_parity(w, orc.bg["wts"], "bg weights", rtol=1e-4, atol=1e-6, budget=1e-3)
+    assert_parity(t, orc.bg["tsdf"], "bg tsdf", rtol=1e-4, atol=1e-6, budget=1e-3)
+
+
+def test_object_volumes_and_foreground(run):
+    fus, orc, ids, _ = run
+    for v in orc.objects:
+        i = v["id"]
+        assert_parity(fus.volume("weights", i), v["wts"], f"obj {i} weights", rtol=1e-4, atol=1e-6,
+                      budget=1e-3)
+        assert_parity(fus.volume("tsdf", i), v["tsdf"], f"obj {i} tsdf", rtol=1e-4, atol=1e-6,
+                      budget=1e-3)
+        assert_parity(fus.volume("fgprobs", i), v["probs"], f"obj {i} fgProbs", rtol=1e-4,
+                      atol=1e-6, budget=1e-3)
+        got_mask = fus.volume("fgmask", i)
+        assert (got_mask != v["vmask"]).mean() < 1e-3
+        assert (v["vmask"] > 0).sum() > 50
+
+
+def test_association_weights(run):
+    fus, orc, ids, _ = run
+    assert_parity(fus.image("points"), orc.points, "points", exact=True)
+    assert_parity(fus.image("assoc_norm"), orc.norm, "associationNorm", rtol=1e-4, budget=1e-3)
+    assert_parity(fus.image("bg_assoc"), orc.bg_assoc, "bg association", rtol=1e-4, atol=1e-7,
+                  budget=1e-3)
+    total = fus.image("bg_assoc").astype(np.float64)
+    for v in orc.objects:
+        a = fus.image("obj_assoc", v["id"])
+        assert_parity(a, v["assoc"], f"obj {v['id']} association", rtol=1e-4, atol=1e-7,
+                      budget=1e-3)
+        total += a
+    valid = orc.norm != 0
+    assert np.allclose(total[valid], 1.0, atol=1e-5) and np.all(total[~valid] == 0)
+    assert any((v["assoc"] > 0.5).sum() > 100 for v in orc.objects), "objects never win pixels"
+
+
+def test_raycast_and_segmentation(run):
+    fus, orc, ids, _ = run
+    seg = fus.image("segmentation")
+    assert (seg != orc.seg).mean() < 2e-3
+    assert set(np.unique(orc.seg)) >= {0, 1} and (orc.seg > 0).sum() > 200
+    same = seg == orc.seg
+    ray = fus.image("raylengths")
+    assert_parity(ray[same], orc.ray[same], "composite raylengths", rtol=1e-4, budget=5e-3)
+    assert_parity(fus.image("bg_raylengths"), orc.bg_ray, "bg raylengths", rtol=1e-4, budget=5e-3)
+    for v in orc.objects:
+        assert_parity(fus.image("obj_raylengths", v["id"]), v["ray"], f"obj {v['id']} raylengths",
+                      rtol=1e-4, budget=5e-3)
+    nrm = fus.image("normals")
+    hit = (orc.ray > 0) & same
+    assert_parity(nrm[hit], orc.nrm[hit], "normals", rtol=1e-3, atol=1e-4, budget=1e-2)
+
+
+def test_march_sample_count_close_to_oracle(run):
+    fus, orc, _, _ = run
+    samples, hits = fus.raycast_stats()
+    assert hits > 0
+    assert abs(samples - orc.march_samples) <= 0.01 * orc.march_samples
