@@ -1,0 +1,344 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of EM-Fusion's per-frame volumetric hot path on MI355X.
+
+One "step" = one frame of the schedule emf::EMFusion::processFrame runs:
+compute_points + 3 x E-step (association likelihood of every model + normalisation) + raycast of
+every model + compositing/visibility + association-weighted TSDF integration of the background
+and every visible object (+ fg/bg mask integration on every 30th frame, as in the reference),
+on a deterministic synthetic RGB-D stream whose depth maps are resident in HBM before the timed
+region starts.  Poses and masks are supplied (tracking and Mask R-CNN are outside this path).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1 runs BASELINE.json configs[1]: background 512^3 @ 1 cm + 4 object volumes 128^3, 640x480.
+N > 1 (launched by torch.distributed.run, one rank per GPU) is the object-sharded layout of
+configs[3]: every rank holds a replica of the background and `--objects-per-gpu` object volumes
+of its own; ranks exchange one RCCL all-reduce per E-step (normaliser) and one per raycast
+(nearest-hit merge).  Weak scaling: per-GPU work is fixed, the scene grows with N.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
+torch is used for torch.distributed only (gloo rendezvous, barriers, max-reduce of the time); all
+device memory and streams belong to the product's own HIP runtime (emfusion_amd/devmem.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--bg-res", type=int, default=512)
+    ap.add_argument("--bg-voxel", type=float, default=0.01)
+    ap.add_argument("--obj-res", type=int, default=128)
+    ap.add_argument("--objects-per-gpu", type=int, default=4)
+    ap.add_argument("--grads", choices=["onthefly", "materialize"], default="onthefly",
+                    help="surface normals from on-the-fly TSDF differences (default) or from the "
+                         "reference's materialised gradient volume (rebuilt every frame)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target CPU time for the oracle baseline sample")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket kernel launches with HIP events in the timed region")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    """Returns (rank, world, local_rank, dist module or None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        if n_gpus != 1:
+            raise SystemExit("--gpus N > 1 needs one process per GPU: launch with "
+                             "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        return 0, 1, 0, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # gloo: host-side control plane only (rendezvous, barriers, max of the elapsed time); the
+    # data-path collectives are RCCL calls issued by the C++ communicator on its own HIP streams
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE is {world}")
+    return rank, world, int(os.environ.get("LOCAL_RANK", rank)), dist
+
+
+def main():
+    args = parse_args()
+    rank, world, local_rank, dist = dist_setup(args.gpus)
+
+    from emfusion_amd import devmem, ops, pipeline
+    from emfusion_amd.devmem import DeviceArray
+
+    if devmem.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    devmem.set_device(local_rank % devmem.device_count())
+    dev_name, arch, cus = ops.device_info()
+
+    W, H = args.width, args.height
+    P = W * H
+    nobj_total = args.objects_per_gpu * world
+    prm = pipeline.make_params(W, H, args.bg_res, args.bg_voxel, args.obj_res,
+                               materialize_gradients=(args.grads == "materialize"))
+    # visibility threshold / boundary scale with the image area (reference values are for VGA)
+    scale = (W / 640.0)
+    prm.visibility_thresh = int(round(1600 * scale * scale))
+    prm.boundary = int(round(20 * scale))
+    K = np.array(prm.K, np.float32)
+
+    comm = None
+    if world > 1:
+        import torch
+        uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = pipeline.Communicator(uid[0], rank, world)
+
+    synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, comm)
+    ids = []
+    for k in range(nobj_total):
+        c, r, vs = synth.sphere(k, 0)
+        ids.append(fus.add_object(c, vs))
+    mine = [i for i in ids if fus.owns_object(i)]
+
+    # ---- synthetic inputs, resident in HBM before anything is timed ------------------------------
+    nframes = args.warmup + args.steps
+    mask_every = prm.mask_frames
+    t_gen = time.time()
+    depth_dev, frames = [], []
+    for f in range(nframes):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0])
+                 for i in mine}
+        run_masks = f % mask_every == 0
+        d_masks = {i: DeviceArray.from_numpy((sid == i).astype(np.uint8)) for i in mine} \
+            if run_masks else {}
+        d = DeviceArray.from_numpy(depth)
+        depth_dev.append((d, d_masks))
+        frames.append(dict(view=ops.image_view(d), R=R, t=t, poses=poses,
+                           masks={i: ops.image_view(m) for i, m in d_masks.items()},
+                           run_masks=run_masks))
+    t_gen = time.time() - t_gen
+
+    def step(f):
+        fr = frames[f]
+        fus.process_frame(fr["view"], fr["R"], fr["t"], fr["poses"], fr["masks"], fr["run_masks"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warm-up (untimed): populates the volumes, saturates weights ---------------------------
+    for f in range(args.warmup):
+        step(f)
+    fus.synchronize()
+
+    # ---- timed region: exactly K frames, barrier + device sync on both sides ---------------------
+    launches_per_frame = 8 * (1 + len(mine)) + 12
+    if not args.no_kernel_events:
+        fus.kernel_timers_enable(launches_per_frame * args.steps + 64)
+    fus.enable_raycast_stats(True)
+    barrier()
+    fus.synchronize()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()  # no torch work exists; kept for the letter of the contract
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    for f in range(args.warmup, nframes):
+        step(f)
+    fus.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stats = fus.raycast_stats()
+    kern = None if args.no_kernel_events else fus.kernel_timers_collect()
+    visible = fus.visible_objects()
+
+    result = None
+    if rank == 0:
+        fps = args.steps / elapsed
+        result = {
+            "metric": "frames/sec (integrate+raycast+EM-assoc)",
+            "value": round(fps, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj_total} obj "
+                             f"{args.obj_res}^3, {W}x{H}, full EM association + weighted fusion"
+                             + (" (BASELINE.json configs[1])"
+                                if (world, nobj_total, args.bg_res, args.obj_res, W, H) ==
+                                (1, 4, 512, 128, 640, 480) else "")),
+                "objects_total": nobj_total,
+                "objects_per_gpu": args.objects_per_gpu,
+                "background": "replicated" if world > 1 else "single",
+                "gradients": args.grads,
+                "estep_per_frame": 3,
+                "mask_frames_every": mask_every,
+                "visible_objects_last_frame": len(visible),
+                "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
+            },
+        }
+        if kern is not None:
+            result["roofline"], result["kernels"] = roofline(kern, stats, P)
+        else:
+            result["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
+
+    fus.close()
+    synth.close()
+    if comm is not None:
+        comm.close()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# kernel kind -> (HIP kernel symbol for the rocprof cross-check, per-unit algorithmic bytes note)
+KERNEL_NAMES = {
+    "integrate": "k_update_tsdf",
+    "raycast": "k_raycast",
+    "assoc": "k_assoc",
+    "normalize": "k_assoc_normalize",
+    "composite": "k_composite (+k_vis_counts)",
+    "points": "k_compute_points",
+    "grads": "k_tsdf_grads",
+    "fgbg": "k_update_fgbg (+k_fg_probs)",
+}
+
+
+def algorithmic_bytes(kind, summ, stats, P):
+    """Algorithmic bytes summed over all launches of one kernel kind -- SURVEY.md section 8(d),
+    restated in DESIGN.md "Byte model".  `units` = voxels (sweeps) or pixels (image kernels)."""
+    u, n = summ["units"], max(summ["launches"], 1)
+    if kind == "integrate":   # B_int: read tsdf + weight, write tsdf + weight per voxel
+        return 16.0 * u
+    if kind == "grads":       # B_grad: 4 B read + 12 B written per voxel
+        return 16.0 * u
+    if kind == "raycast":     # B_ray: 16 gathers per march sample, gradient blend at hits, outputs
+        S, hits = stats
+        return 64.0 * S + 96.0 * hits + 29.0 * u
+    if kind == "assoc":       # B_em per model and pixel: 12 B point + 32 B tsdf gather + 4 B out
+        return 48.0 * u       # (objects add a 32 B fg gather; counted at the background's rate)
+    if kind == "normalize":   # every map read and written once
+        return 8.0 * u
+    if kind == "composite":   # 29 B per model and pixel in, 30 B per pixel out
+        return 29.0 * u
+    if kind == "points":      # 4 B in, 12 B out
+        return 16.0 * u
+    if kind == "fgbg":        # tsdf, weight, counts RMW + probability / mask out
+        return 37.0 * u
+    return 0.0
+
+
+def roofline(kern, stats, P):
+    rows = []
+    for kind, summ in kern.items():
+        if kind.startswith("_") or summ["launches"] == 0:
+            continue
+        total_b = algorithmic_bytes(kind, summ, stats, P)
+        n = summ["launches"]
+        avg_ms = summ["total_ms"] / n
+        rows.append({
+            "kernel": KERNEL_NAMES[kind], "kind": kind, "launches": n,
+            "avg_ms": round(avg_ms, 5), "total_ms": round(summ["total_ms"], 3),
+            "alg_bytes_per_launch": round(total_b / n, 1),
+            "achieved_GBs": round(total_b / n / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None,
+        })
+    rows.sort(key=lambda r: -r["total_ms"])
+    dom = rows[0]
+    roof = {
+        "kernel": dom["kernel"],
+        "bound": "hbm",
+        "achieved": dom["achieved_GBs"],
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
+        "traffic": None,  # PMC pass (rocprofv3 --pmc) is a separate run: see profiles/ + DESIGN.md
+        "avg_launch_ms": dom["avg_ms"],
+        "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+        "dropped_launches": kern.get("_dropped", 0),
+    }
+    if dom["kind"] == "raycast":
+        roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)
+    return roof, rows
+
+
+def cpu_baseline(args, prm, K, synth, ids):
+    """The oracle (our CPU restatement, kind "port") on the host cores of this box, on a bounded
+    sample of the SAME workload: frame 0 untimed (first integration), then whole frames of the
+    schedule until about --cpu-seconds of CPU time are spent."""
+    from oracle import binding as oracle
+    from tests.oracle_pipeline import Affine32, OraclePipeline
+
+    cores = oracle.set_threads(0)  # all host cores
+    W, H = args.width, args.height
+    orc = OraclePipeline(oracle, W, H, K, args.bg_res, args.bg_voxel, list(prm.volume_pose_t),
+                         args.obj_res, visibility_thresh=prm.visibility_thresh,
+                         boundary=prm.boundary)
+    for k, i in enumerate(ids):
+        c, r, vs = synth.sphere(k, 0)
+        orc.add_object(c, vs)
+
+    def run(f):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        poses = {i: Affine32(t=synth.sphere(i - 1, f)[0]) for i in ids}
+        masks = {i: (sid == i).astype(np.uint8) for i in ids} if f % prm.mask_frames == 0 else {}
+        t0 = time.perf_counter()
+        orc.process_frame(depth, Affine32(R.reshape(3, 3), t), poses, masks, bool(masks))
+        return time.perf_counter() - t0
+
+    run(0)
+    spent, n = 0.0, 0
+    while spent < args.cpu_seconds and n < 20:
+        spent += run(1 + n)
+        n += 1
+    return {
+        "value": round(n / spent, 4),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"frames 1..{n} of the same synthetic stream (frame 0 untimed), full schedule, "
+                   f"bg {args.bg_res}^3 + {len(ids)} obj {args.obj_res}^3, {W}x{H}; OpenMP over "
+                   f"{cores} host threads, {spent:.1f} s"),
+    }
+
+
+if __name__ == "__main__":
+    main()

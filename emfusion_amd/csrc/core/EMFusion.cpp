@@ -163,6 +163,8 @@ float EMFusion::stamp(int slot) {
     return 0.f;
 }
 
+double EMFusion::pixels() const { return static_cast<double>(params.frameSize.area()); }
+
 void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
 
 void EMFusion::enableRaycastStats(bool on) {
@@ -194,6 +196,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     stamp(kStart);
     {
         const emf_image_t pv = points.view();
+        auto kt = ktimers.scope(KernelTimers::Points, pixels(), main);
         emfCheck(emf_hip_computePoints(&depth, &pv, params.intr.val, main.abi()),
                  "computePoints");
     }
@@ -252,10 +255,15 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
 void EMFusion::computeAssociationWeights() {
     const emf_image_t pv = points.view();
     forkVolumeStreams();
-    background.computeAssociation(pv, pose, bg_associationWeights.view(), streamOf(0));
-    for (auto& obj : objects)
+    {
+        auto kt = ktimers.scope(KernelTimers::Assoc, pixels(), streamOf(0));
+        background.computeAssociation(pv, pose, bg_associationWeights.view(), streamOf(0));
+    }
+    for (auto& obj : objects) {
+        auto kt = ktimers.scope(KernelTimers::Assoc, pixels(), streamOf(obj.getID()));
         obj.computeAssociation(pv, pose, objImages.at(obj.getID()).associationWeights.view(),
                                streamOf(obj.getID()));
+    }
     joinVolumeStreams();
 
     // normalisation: background first, then objects in ascending id (std::map) order
@@ -263,6 +271,8 @@ void EMFusion::computeAssociationWeights() {
     maps.push_back(bg_associationWeights.view());
     for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
     const emf_image_t nv = associationNorm.view();
+    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * static_cast<double>(maps.size()),
+                            main);
     if (world == 1) {
         emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()),
                                               static_cast<int>(maps.size()), nullptr, &nv,
@@ -295,6 +305,7 @@ void EMFusion::raycast() {
         bg_vertices.setZero(s);
         bg_normals.setZero(s);
         bg_mask.setZero(s);
+        auto kt = ktimers.scope(KernelTimers::Raycast, pixels(), s);
         background.raycast(pose, params.intr, bg_raylengths.view(), bg_vertices.view(),
                            bg_normals.view(), bg_mask.view(), s, stats);
     }
@@ -305,6 +316,7 @@ void EMFusion::raycast() {
         im.vertices.setZero(s);
         im.normals.setZero(s);
         im.modelSegmentation.setZero(s);
+        auto kt = ktimers.scope(KernelTimers::Raycast, pixels(), s);
         obj.raycast(pose, params.intr, im.raylengths.view(), im.vertices.view(),
                     im.normals.view(), im.modelSegmentation.view(), s, stats);
     }
@@ -331,11 +343,14 @@ void EMFusion::raycast() {
                       v_norm = normals.view(), v_seg = modelSegmentation.view(),
                       v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
     const int nobj = static_cast<int>(ids.size());
+    {
+    auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nobj), main);
     emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(), onorm.data(),
                                       oseg.data(), &v_bgRay, &v_bgVert, &v_bgNorm, &v_bgMask,
                                       &v_ray, &v_vert, &v_norm, &v_seg, &v_diff, &v_noObj,
                                       params.boundary, visCounts.as<int32_t>(), main.abi()),
              "compositeRaycast");
+    }
     stamp(kComposite);
     if (nobj > 0) {
         hipCheck(hipMemcpyAsync(visCountsHost, visCounts.data(), sizeof(int32_t) * nobj,
@@ -349,14 +364,29 @@ void EMFusion::raycast() {
 
 void EMFusion::integrateDepth() {
     forkVolumeStreams();
-    background.integrate(depth, bg_associationWeights.view(), pose, params.intr, streamOf(0));
-    background.updateGradients(streamOf(0));
+    const bool grads = gradMode == TSDF::Gradients::Materialized;
+    {
+        auto kt = ktimers.scope(KernelTimers::Integrate,
+                                static_cast<double>(background.voxels()), streamOf(0));
+        background.integrate(depth, bg_associationWeights.view(), pose, params.intr, streamOf(0));
+    }
+    if (grads) {
+        auto kt = ktimers.scope(KernelTimers::Grads, static_cast<double>(background.voxels()),
+                                streamOf(0));
+        background.updateGradients(streamOf(0));
+    }
     for (auto& obj : objects) {
         if (!vis_objs.count(obj.getID())) continue;
         Stream& s = streamOf(obj.getID());
-        obj.integrate(depth, objImages.at(obj.getID()).associationWeights.view(), pose,
-                      params.intr, s);
-        obj.updateGradients(s);
+        {
+            auto kt = ktimers.scope(KernelTimers::Integrate, static_cast<double>(obj.voxels()), s);
+            obj.integrate(depth, objImages.at(obj.getID()).associationWeights.view(), pose,
+                          params.intr, s);
+        }
+        if (grads) {
+            auto kt = ktimers.scope(KernelTimers::Grads, static_cast<double>(obj.voxels()), s);
+            obj.updateGradients(s);
+        }
     }
     joinVolumeStreams();
 }
@@ -372,6 +402,7 @@ void EMFusion::integrateMasks(const std::map<int, emf_image_t>& matches) {
         const emf_image_t objSeg = objImages.at(obj.getID()).modelSegmentation.view();
         emfCheck(emf_hip_occludedMask(&objSeg, &segv, obj.getID(), &occv, main.abi()),
                  "occludedMask");
+        auto kt = ktimers.scope(KernelTimers::FgBg, static_cast<double>(obj.voxels()), main);
         obj.integrateMask(it->second, occv, pose, params.intr, main);
     }
 }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "Communicator.hpp"
+#include "KernelTimers.hpp"
 #include "ObjTSDF.hpp"
 #include "TSDF.hpp"
 
@@ -94,6 +95,8 @@ public:
     bool ownsObject(int id) const;
     const FrameTimings& lastTimings() const { return timings; }
     void enableTimings(bool on) { timingsOn = on; }
+    /** Per-launch HIP-event timers (see KernelTimers.hpp); maxLaunches = 0 switches them off. */
+    KernelTimers& kernelTimers() { return ktimers; }
     /** Device counters [march samples, hits] accumulated by raycast() while enabled. */
     void enableRaycastStats(bool on);
     std::array<uint64_t, 2> raycastStats();
@@ -125,6 +128,7 @@ private:
     void joinVolumeStreams();
     Stream& streamOf(int key);
     float stamp(int slot);
+    double pixels() const;
 
     Params params;
     TSDF::Gradients gradMode;
@@ -157,6 +161,7 @@ private:
     int32_t* visCountsHost = nullptr;  // pinned
     bool statsOn = false;
 
+    KernelTimers ktimers;
     bool timingsOn = false;
     FrameTimings timings;
     std::vector<hipEvent_t> stamps;

@@ -1,0 +1,70 @@
+// KernelTimers.hpp -- per-launch HIP-event timing of the path's kernels.
+//
+// Every launch site in emf::EMFusion can be bracketed by a start/stop event pair recorded on the
+// stream the kernel is launched on (so the pair measures that kernel, not the host).  Events come
+// from a pre-allocated pool; reading them happens after the timed region (collect()), so enabling
+// the timers adds two event records per launch and no synchronisation.  Each launch also reports
+// its work units (voxels or pixels) so the harness can turn durations into bytes/s.
+#pragma once
+
+#include <array>
+#include <vector>
+
+#include "types.hpp"
+
+namespace emf {
+
+class KernelTimers {
+public:
+    enum Kind {
+        Points = 0,   // computePoints
+        Assoc,        // computeAssociation (per model)
+        Normalize,    // normalizeAssociation / sumAssociation
+        Raycast,      // raycastTSDF (per model)
+        Composite,    // compositeRaycast (+ visibility)
+        Integrate,    // updateTSDF (per model)
+        Grads,        // computeTSDFGrads (materialised mode only)
+        FgBg,         // updateFgBgProbs + computeFgProbs
+        kNumKinds
+    };
+    struct Summary {
+        uint64_t launches = 0;
+        double total_ms = 0.0;
+        double units = 0.0;  // voxels (volume sweeps) or pixels (image kernels), summed
+    };
+
+    ~KernelTimers();
+    /** Allocate `maxLaunches` event pairs and start recording; 0 disables. */
+    void enable(size_t maxLaunches);
+    bool enabled() const { return !pairs.empty(); }
+    /** Drop recorded launches, keep the pool. */
+    void clear() { used = 0; dropped = 0; }
+    /** After the device is idle: per-kind launch count, summed duration and work units. */
+    std::array<Summary, kNumKinds> collect() const;
+    size_t droppedLaunches() const { return dropped; }
+
+    class Scope {
+    public:
+        Scope(KernelTimers* t, Kind k, double units, hipStream_t s);
+        ~Scope();
+        Scope(const Scope&) = delete;
+        Scope& operator=(const Scope&) = delete;
+
+    private:
+        KernelTimers* timers;
+        hipStream_t stream;
+        long slot;
+    };
+    Scope scope(Kind k, double units, const Stream& s) { return Scope(this, k, units, s.get()); }
+
+private:
+    struct Pair {
+        hipEvent_t start = nullptr, stop = nullptr;
+        Kind kind = Points;
+        double units = 0.0;
+    };
+    std::vector<Pair> pairs;
+    size_t used = 0, dropped = 0;
+};
+
+}  // namespace emf

@@ -208,6 +208,35 @@ int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]) {
     });
 }
 
+int emf_fusion_kernel_timers_enable(emf_fusion_t* h, uint64_t max_launches) {
+    REQ(h);
+    return guarded([&] {
+        h->impl->synchronize();
+        h->impl->kernelTimers().enable(static_cast<size_t>(max_launches));
+    });
+}
+
+int emf_fusion_kernel_timers_clear(emf_fusion_t* h) {
+    REQ(h);
+    h->impl->kernelTimers().clear();
+    return EMF_OK;
+}
+
+int emf_fusion_kernel_timers_collect(emf_fusion_t* h, emf_kernel_summary_t out[EMF_K_NUM_KINDS],
+                                     uint64_t* dropped) {
+    REQ(h);
+    REQ(out);
+    static_assert(static_cast<int>(EMF_K_NUM_KINDS) == static_cast<int>(KernelTimers::kNumKinds),
+                  "kernel kind enums out of sync");
+    return guarded([&] {
+        h->impl->synchronize();
+        const auto s = h->impl->kernelTimers().collect();
+        for (int k = 0; k < EMF_K_NUM_KINDS; ++k)
+            out[k] = emf_kernel_summary_t{s[k].launches, s[k].total_ms, s[k].units};
+        if (dropped) *dropped = h->impl->kernelTimers().droppedLaunches();
+    });
+}
+
 int emf_fusion_get_image(emf_fusion_t* h, int which, int obj_id, emf_image_t* view) {
     REQ(h);
     REQ(view);

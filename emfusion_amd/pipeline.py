@@ -42,6 +42,12 @@ class FrameTimings(C.Structure):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
+class KernelSummary(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("units", C.c_double)]
+
+
+KERNEL_KINDS = ("points", "assoc", "normalize", "raycast", "composite", "integrate", "grads", "fgbg")
+
 IMG = dict(points=0, bg_assoc=1, obj_assoc=2, assoc_norm=3, raylengths=4, vertices=5, normals=6,
            segmentation=7, bg_raylengths=8, obj_raylengths=9)
 _IMG_DTYPE = {0: ("float32", 3), 1: ("float32", 1), 2: ("float32", 1), 3: ("float32", 1),
@@ -96,6 +102,9 @@ def load() -> C.CDLL:
         "emf_fusion_last_timings": [vp, C.POINTER(FrameTimings)],
         "emf_fusion_enable_raycast_stats": [vp, C.c_int],
         "emf_fusion_raycast_stats": [vp, C.POINTER(C.c_uint64)],
+        "emf_fusion_kernel_timers_enable": [vp, C.c_uint64],
+        "emf_fusion_kernel_timers_clear": [vp],
+        "emf_fusion_kernel_timers_collect": [vp, C.POINTER(KernelSummary), C.POINTER(C.c_uint64)],
         "emf_fusion_get_image": [vp, C.c_int, C.c_int, img],
         "emf_fusion_get_volume": [vp, C.c_int, C.c_int, C.POINTER(vp), ip],
         "emf_fusion_visible_objects": [vp, ip, C.c_int, C.POINTER(C.c_int)],
@@ -283,6 +292,24 @@ class Fusion:
         c = (C.c_uint64 * 2)()
         _check("emf_fusion_raycast_stats", load().emf_fusion_raycast_stats(self._h, c))
         return int(c[0]), int(c[1])
+
+    def kernel_timers_enable(self, max_launches: int):
+        _check("emf_fusion_kernel_timers_enable",
+               load().emf_fusion_kernel_timers_enable(self._h, int(max_launches)))
+
+    def kernel_timers_clear(self):
+        _check("emf_fusion_kernel_timers_clear", load().emf_fusion_kernel_timers_clear(self._h))
+
+    def kernel_timers_collect(self) -> Dict[str, Dict[str, float]]:
+        """Synchronises, then returns {kind: {launches, total_ms, units}} (+ '_dropped')."""
+        arr = (KernelSummary * len(KERNEL_KINDS))()
+        dropped = C.c_uint64()
+        _check("emf_fusion_kernel_timers_collect",
+               load().emf_fusion_kernel_timers_collect(self._h, arr, C.byref(dropped)))
+        out = {k: dict(launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                       units=float(arr[i].units)) for i, k in enumerate(KERNEL_KINDS)}
+        out["_dropped"] = int(dropped.value)
+        return out
 
     def image_view(self, which: str, obj_id: int = 0) -> EmfImage:
         v = EmfImage()

@@ -97,6 +97,23 @@ int emf_fusion_last_timings(emf_fusion_t* h, emf_frame_timings_t* out);
 int emf_fusion_enable_raycast_stats(emf_fusion_t* h, int on);
 int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]);
 
+/* Per-launch HIP-event timers: every kernel launch of the schedule is bracketed by an event pair
+ * on the stream it is launched on.  enable(max_launches) allocates the pool (0 = off); collect()
+ * must be called with the device idle (after emf_fusion_synchronize). */
+enum emf_kernel_kind {
+    EMF_K_POINTS = 0, EMF_K_ASSOC, EMF_K_NORMALIZE, EMF_K_RAYCAST, EMF_K_COMPOSITE,
+    EMF_K_INTEGRATE, EMF_K_GRADS, EMF_K_FGBG, EMF_K_NUM_KINDS
+};
+typedef struct emf_kernel_summary {
+    uint64_t launches;
+    double total_ms;
+    double units; /* voxels (volume sweeps) or pixels (image kernels), summed over launches */
+} emf_kernel_summary_t;
+int emf_fusion_kernel_timers_enable(emf_fusion_t* h, uint64_t max_launches);
+int emf_fusion_kernel_timers_clear(emf_fusion_t* h);
+int emf_fusion_kernel_timers_collect(emf_fusion_t* h, emf_kernel_summary_t out[EMF_K_NUM_KINDS],
+                                     uint64_t* dropped);
+
 /* Device views of per-frame images / volumes (valid until the next frame / destroy).
  * obj_id is ignored unless the selector is per object; 0 selects the background volume. */
 int emf_fusion_get_image(emf_fusion_t* h, int which, int obj_id, emf_image_t* view);
