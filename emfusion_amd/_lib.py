@@ -41,10 +41,10 @@ SIGNATURES = {
     "emf_hip_abi_version": [],
     "emf_hip_device_info": [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     "emf_hip_computePoints": [_IMG, _IMG, _F9, _STREAM],
-    "emf_hip_updateTSDF": [_IMG, _IMG, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, C.c_float,
+    "emf_hip_updateTSDF": [_IMG, _IMG, _FP, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, C.c_float,
                            C.c_float, _STREAM],
     "emf_hip_computeTSDFGrads": [_FP, _FP, _I3, _STREAM],
-    "emf_hip_raycastTSDF": [_FP, _FP, _FP, _FP, _IMG, _IMG, _IMG, _IMG, _F9, _F9, _F9, _I3,
+    "emf_hip_raycastTSDF": [_FP, _FP, _FP, _FP, _FP, _IMG, _IMG, _IMG, _IMG, _F9, _F9, _F9, _I3,
                             C.c_float, C.c_float, _FP, _STREAM],
     "emf_hip_getVolumeVals": [_FP, C.c_int, _IMG, _F9, _F9, _I3, C.c_float, _IMG, _STREAM],
     "emf_hip_updateFgBgProbs": [_IMG, _IMG, _FP, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, _STREAM],
@@ -57,7 +57,28 @@ SIGNATURES = {
     "emf_hip_compositeRaycast": [C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG,
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
+    "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
+    "emf_hip_raycastBatched": [_FP, _FP, C.c_int, C.c_int, C.c_int, _F9, _FP, _STREAM],
+    "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _F9, _FP, _STREAM],
+    "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
+    "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
 }
+
+
+class EmfModel(C.Structure):
+    """Mirror of emf_model_t (device model table entry)."""
+
+    _fields_ = [("tsdf", C.c_void_p), ("weights", C.c_void_p), ("grads", C.c_void_p),
+                ("fgProbs", C.c_void_p), ("fgVolMask", C.c_void_p), ("brickFlags", C.c_void_p),
+                ("assoc", C.c_void_p), ("raylengths", C.c_void_p), ("vertices", C.c_void_p),
+                ("normals", C.c_void_p), ("hitMask", C.c_void_p), ("res", C.c_int32 * 3),
+                ("id", C.c_int32), ("voxelSize", C.c_float), ("truncdist", C.c_float),
+                ("maxWeight", C.c_float), ("assocC1", C.c_float), ("assocC2", C.c_float),
+                ("alpha", C.c_float), ("assocC3", C.c_float), ("reserved", C.c_int32)]
+
+
+class EmfPose(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3)]
 
 _lib = None
 

@@ -1,0 +1,317 @@
+// batched.hip -- level-3 ABI: one launch per stage for ALL models of a rank (background + objects),
+// driven by a device-resident model table (emf_model_t[]) plus per-launch poses passed by value.
+//
+// The reference fans every stage out over one CUDA stream per volume (EMFusion.h:471) and
+// synchronises the host between stages; on MI355X a frame is a handful of ~10-500 us kernels, so
+// launch latency and host round trips would dominate.  Here each stage is a single grid:
+//   k_estep             (pixel x model) lanes, likelihoods meet in LDS, normalised in the same kernel
+//   k_raycast_batched   all models' 16x16 pixel tiles in one grid, XCD-aware tile order, outputs
+//                       zero-filled by the kernel itself (no memsets)
+//   k_integrate_batched all models' 32x8x8 voxel tiles in one grid, visibility gate read on device
+// All arithmetic comes from device_core.hpp, i.e. it is the same code the per-volume kernels run.
+#include "device_core.hpp"
+
+namespace emf_hip {
+namespace {
+
+struct PoseTable {
+    emf_pose_t p[EMF_MAX_BATCH];
+};
+
+__device__ __forceinline__ M33 pose_R(const emf_pose_t& p) {
+    return M33{{p.R[0], p.R[1], p.R[2]}, {p.R[3], p.R[4], p.R[5]}, {p.R[6], p.R[7], p.R[8]}};
+}
+__device__ __forceinline__ V3 pose_t(const emf_pose_t& p) { return V3{p.t[0], p.t[1], p.t[2]}; }
+
+// ---- fused E-step ---------------------------------------------------------------------------------
+
+constexpr int kEstepPixels = 64;  // pixels per workgroup = one wave per model lane
+constexpr int kEstepLanes = 4;    // model lanes per workgroup
+
+struct EstepArgs {
+    const emf_model_t* models;
+    PoseTable poses;  // camera -> volume
+    int nmodels;
+    Img<const float> points;
+    Img<float> norm, objSum;
+    int w, h;
+    int normalize;
+};
+
+__global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const EstepArgs a) {
+    __shared__ float wl[EMF_MAX_BATCH][kEstepPixels];
+    const int tx = threadIdx.x;
+    const int x = blockIdx.x * kEstepPixels + tx, y = blockIdx.y;
+    const bool inside = x < a.w;
+    V3 pc = v3(0.f, 0.f, 0.f);
+    if (inside) {
+        const float* pp = a.points.row(y) + 3 * x;
+        pc = v3(pp[0], pp[1], pp[2]);
+    }
+    // threadIdx.y is wave-uniform (64 x-lanes = one wave): keep the model index scalar
+    for (int m = __builtin_amdgcn_readfirstlane(threadIdx.y); m < a.nmodels; m += kEstepLanes) {
+        const emf_model_t& md = a.models[m];
+        AssocModel am;
+        am.tsdf = md.tsdf;
+        am.fgProbs = md.fgProbs;
+        am.R = pose_R(a.poses.p[m]);
+        am.t = pose_t(a.poses.p[m]);
+        am.n = I3{md.res[0], md.res[1], md.res[2]};
+        am.voxelSize = md.voxelSize;
+        am.c1 = md.assocC1;
+        am.c2 = md.assocC2;
+        am.alpha = md.alpha;
+        am.c3 = md.assocC3;
+        wl[m][tx] = inside ? assoc_weight(am, pc) : 0.f;
+    }
+    __syncthreads();
+    if (!inside) return;
+    const size_t pix = static_cast<size_t>(y) * a.w + x;
+    if (a.normalize) {
+        // sequential sum: background first, then objects in table (= ascending id) order,
+        // exactly the order of the reference's add chain (EMFusion.cpp:654-657)
+        float s = wl[0][tx];
+        for (int m = 1; m < a.nmodels; ++m) s = s + wl[m][tx];
+        for (int m = threadIdx.y; m < a.nmodels; m += kEstepLanes)
+            a.models[m].assoc[pix] = (s != 0.f) ? wl[m][tx] / s : 0.f;  // x / 0 := 0 (Q7)
+        if (threadIdx.y == 0 && a.norm.data) a.norm.row(y)[x] = s;
+    } else {
+        for (int m = threadIdx.y; m < a.nmodels; m += kEstepLanes)
+            a.models[m].assoc[pix] = wl[m][tx];
+        if (threadIdx.y == 0) {
+            float s = 0.f;
+            if (a.nmodels > 1) {
+                s = wl[1][tx];
+                for (int m = 2; m < a.nmodels; ++m) s = s + wl[m][tx];
+            }
+            a.objSum.row(y)[x] = s;
+        }
+    }
+}
+
+// ---- batched raycast -------------------------------------------------------------------------------
+
+struct RaycastBatchArgs {
+    const emf_model_t* models;
+    PoseTable poses;  // camera -> volume
+    int nmodels;
+    int w, h;
+    int tilesX, tilesY;
+    int chunk;  // tiles per XCD = ceil(tilesX * tilesY / 8)
+    float fx, fy, cx, cy;
+    unsigned long long* stats;
+};
+
+__global__ __launch_bounds__(256) void k_raycast_batched(const RaycastBatchArgs a) {
+    // grid = nmodels x (8 * chunk) blocks, model-major: the background's (longest) rays start first.
+    // Block b runs on XCD b % 8 (observed dispatch order; used for L2 locality only): give each XCD
+    // a contiguous run of `chunk` tiles in raster order, i.e. a horizontal band of the image, so
+    // the voxels its rays walk stay in that XCD's 4 MiB L2.
+    const int perModel = 8 * a.chunk;
+    const int m = blockIdx.x / perModel;
+    const int i = blockIdx.x - m * perModel;
+    const int tile = (i & 7) * a.chunk + (i >> 3);
+    if (tile >= a.tilesX * a.tilesY) return;
+    const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = txx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = tyy * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const emf_model_t& md = a.models[m];
+    unsigned nsamples = 0, nhits = 0;
+    if (x < a.w && y < a.h) {
+        RayVolume v;
+        v.tsdf = md.tsdf;
+        v.grads = md.grads;
+        v.weights = md.weights;
+        v.fg = md.fgVolMask;
+        v.bricks = md.brickFlags;
+        v.R = pose_R(a.poses.p[m]);
+        v.cam = pose_t(a.poses.p[m]);
+        v.n = I3{md.res[0], md.res[1], md.res[2]};
+        v.voxelSize = md.voxelSize;
+        v.truncdist = md.truncdist;
+        // incoming raylength is zero by construction (the reference zeroes it first, Q5)
+        const RayHit r = march_ray(v, x, y, a.fx, a.fy, a.cx, a.cy, 0.f);
+        nsamples = r.samples;
+        nhits = r.hit ? 1u : 0u;
+        const size_t pix = static_cast<size_t>(y) * a.w + x;
+        md.raylengths[pix] = r.raylength;  // zeros where there is no hit
+        float* pv = md.vertices + 3 * pix;
+        float* pn = md.normals + 3 * pix;
+        pv[0] = r.vertex.x;
+        pv[1] = r.vertex.y;
+        pv[2] = r.vertex.z;
+        pn[0] = r.normal.x;
+        pn[1] = r.normal.y;
+        pn[2] = r.normal.z;
+        md.hitMask[pix] = r.hit ? 1 : 0;
+    }
+    add_ray_stats(a.stats, nsamples, nhits, lane);
+}
+
+// ---- batched integration ---------------------------------------------------------------------------
+
+struct IntegrateBatchArgs {
+    const emf_model_t* models;
+    PoseTable poses;  // volume -> camera
+    int nmodels;
+    int tileStart[EMF_MAX_BATCH + 1];  // prefix sum of tiles per model
+    const int32_t* visible;
+    unsigned long long* stats;
+    Img<const float> depth;
+    int w, h;
+    M33 K;
+};
+
+__global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchArgs a) {
+    __shared__ unsigned lds[4];
+    int m = 0;
+    while (m + 1 < a.nmodels && static_cast<int>(blockIdx.x) >= a.tileStart[m + 1]) ++m;
+    if (a.visible && a.visible[m] == 0) return;  // EMFusion.cpp:869-872, decided on the device
+    const emf_model_t& md = a.models[m];
+    IntegrateGeom g;
+    g.depth = a.depth;
+    g.assoc = Img<const float>{md.assoc, static_cast<size_t>(a.w) * sizeof(float)};
+    g.w = a.w;
+    g.h = a.h;
+    g.R = pose_R(a.poses.p[m]);
+    g.t = pose_t(a.poses.p[m]);
+    g.K = a.K;
+    g.n = I3{md.res[0], md.res[1], md.res[2]};
+    g.voxelSize = md.voxelSize;
+    g.truncdist = md.truncdist;
+    g.maxWeight = md.maxWeight;
+    const int b = blockIdx.x - a.tileStart[m];
+    if (a.stats && b == 0 && threadIdx.x == 0)
+        atomicAdd(a.stats, static_cast<unsigned long long>(g.n.x) * g.n.y * g.n.z);
+    const int ntx = (g.n.x + kTileX - 1) / kTileX, nty = (g.n.y + kTileY - 1) / kTileY;
+    const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
+    integrate_tile(g, md.tsdf, md.weights, md.brickFlags, tx * kTileX, ty * kTileY, tz * kTileZ,
+                   lds);
+}
+
+__global__ void k_vis_flags(const int32_t* __restrict__ counts, int nmodels, int thresh,
+                            int32_t* __restrict__ visible) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nmodels) return;
+    visible[s] = s == 0 ? 1 : (counts[s - 1] > thresh ? 1 : 0);
+}
+
+int check_batch(const emf_model_t* models, const emf_pose_t* poses, int nmodels, const char* fn) {
+    if (!models) return fail(EMF_E_NULL, "%s: models_dev is NULL", fn);
+    if (!poses) return fail(EMF_E_NULL, "%s: poses are NULL", fn);
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH)
+        return fail(EMF_E_LIMIT, "%s: nmodels = %d, expected 1..%d", fn, nmodels, EMF_MAX_BATCH);
+    return EMF_OK;
+}
+
+}  // namespace
+}  // namespace emf_hip
+
+using namespace emf_hip;
+
+extern "C" {
+
+int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                         const emf_image_t* points, int normalize, const emf_image_t* norm,
+                         const emf_image_t* objSum, emf_stream_t stream) {
+    EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "estepBatched"));
+    EMF_TRY(check_image(points, 12, "estepBatched: points"));
+    EstepArgs a;
+    a.models = models_dev;
+    for (int m = 0; m < nmodels; ++m) a.poses.p[m] = poseCO_host[m];
+    a.nmodels = nmodels;
+    a.points = img<const float>(points);
+    a.w = points->width;
+    a.h = points->height;
+    a.normalize = normalize ? 1 : 0;
+    a.norm = Img<float>{nullptr, 0};
+    a.objSum = Img<float>{nullptr, 0};
+    if (norm) {
+        EMF_TRY(check_image(norm, 4, "estepBatched: norm"));
+        EMF_TRY(check_same_size(norm, points, "norm", "points"));
+        a.norm = img<float>(norm);
+    }
+    if (!normalize) {
+        if (!objSum) return fail(EMF_E_NULL, "estepBatched: objSum is required when normalize == 0");
+        EMF_TRY(check_image(objSum, 4, "estepBatched: objSum"));
+        EMF_TRY(check_same_size(objSum, points, "objSum", "points"));
+        a.objSum = img<float>(objSum);
+    }
+    hipLaunchKernelGGL(k_estep, dim3(ceil_div(a.w, kEstepPixels), a.h),
+                       dim3(kEstepPixels, kEstepLanes), 0, as_stream(stream), a);
+    return launch_status("estepBatched");
+}
+
+int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                           int nmodels, int width, int height, const float K[9], uint64_t* stats,
+                           emf_stream_t stream) {
+    EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
+    EMF_REQUIRE_PTR(K);
+    if (width <= 0 || height <= 0)
+        return fail(EMF_E_SHAPE, "raycastBatched: bad image size %d x %d", width, height);
+    RaycastBatchArgs a;
+    a.models = models_dev;
+    for (int m = 0; m < nmodels; ++m) a.poses.p[m] = poseCO_host[m];
+    a.nmodels = nmodels;
+    a.w = width;
+    a.h = height;
+    a.tilesX = static_cast<int>(ceil_div(width, 16));
+    a.tilesY = static_cast<int>(ceil_div(height, 16));
+    a.chunk = static_cast<int>(ceil_div(static_cast<size_t>(a.tilesX) * a.tilesY, 8));
+    a.fx = K[0];
+    a.fy = K[4];
+    a.cx = K[2];
+    a.cy = K[5];
+    a.stats = reinterpret_cast<unsigned long long*>(stats);
+    hipLaunchKernelGGL(k_raycast_batched, dim3(static_cast<unsigned>(nmodels) * 8u * a.chunk),
+                       dim3(256), 0, as_stream(stream), a);
+    return launch_status("raycastBatched");
+}
+
+int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                             const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                             const emf_image_t* depth, const float K[9], uint64_t* stats,
+                             emf_stream_t stream) {
+    EMF_TRY(check_batch(models_dev, poseOC_host, nmodels, "integrateBatched"));
+    EMF_REQUIRE_PTR(res_host);
+    EMF_TRY(check_image(depth, 4, "integrateBatched: depth"));
+    EMF_REQUIRE_PTR(K);
+    IntegrateBatchArgs a;
+    a.models = models_dev;
+    a.nmodels = nmodels;
+    a.tileStart[0] = 0;
+    for (int m = 0; m < nmodels; ++m) {
+        const int32_t* r = res_host + 3 * m;
+        EMF_TRY(check_res(r));
+        if (r[0] % 4 != 0)
+            return fail(EMF_E_SHAPE, "integrateBatched: model %d has Nx = %d, needs Nx %% 4 == 0 "
+                        "(use emf_hip_updateTSDF)", m, r[0]);
+        a.poses.p[m] = poseOC_host[m];
+        a.tileStart[m + 1] = a.tileStart[m] + static_cast<int>(ceil_div(r[0], kTileX)) *
+                                                  static_cast<int>(ceil_div(r[1], kTileY)) *
+                                                  static_cast<int>(ceil_div(r[2], kTileZ));
+    }
+    a.visible = visible_dev;
+    a.stats = reinterpret_cast<unsigned long long*>(stats);
+    a.depth = img<const float>(depth);
+    a.w = depth->width;
+    a.h = depth->height;
+    a.K = m33_from(K);
+    hipLaunchKernelGGL(k_integrate_batched, dim3(static_cast<unsigned>(a.tileStart[nmodels])),
+                       dim3(256), 0, as_stream(stream), a);
+    return launch_status("integrateBatched");
+}
+
+int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,
+                            int32_t* visible_dev, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(visible_dev);
+    if (nmodels < 1 || nmodels > EMF_MAX_MODELS)
+        return fail(EMF_E_LIMIT, "visibilityFlags: nmodels = %d", nmodels);
+    if (nmodels > 1) EMF_REQUIRE_PTR(visCounts);
+    hipLaunchKernelGGL(k_vis_flags, dim3(ceil_div(nmodels, 64)), dim3(64), 0, as_stream(stream),
+                       visCounts, nmodels, visibilityThresh, visible_dev);
+    return launch_status("visibilityFlags");
+}
+
+}  // extern "C"

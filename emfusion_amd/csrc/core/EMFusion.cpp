@@ -1,13 +1,29 @@
 // EMFusion.cpp -- per-frame schedule (see EMFusion.hpp).  Reference: src/core/EMFusion.cpp.
+//
+// Two execution paths produce the same results:
+//   batched  (default)  one launch per stage for all models of this rank, driven by a
+//            device-resident model table; the visibility gate of integrateDepth is evaluated on
+//            the device, so a frame contains no host synchronisation at all
+//   per-volume (fallback: more than EMF_MAX_BATCH models, volumes whose Nx is not a multiple of
+//            4, materialised gradient volumes, or EMF_PER_VOLUME=1)  the reference's structure:
+//            one HIP stream per volume joined by events, host-side visibility gate
 #include "EMFusion.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace emf {
 
 namespace {
 enum Stamp { kStart = 0, kPoints, kEstep, kRaycast, kComposite, kIntegrate, kMasks, kNumStamps };
+
+emf_pose_t toPose(const Affine3f& a) {
+    emf_pose_t p;
+    for (int i = 0; i < 9; ++i) p.R[i] = a.rotation().val[i];
+    for (int i = 0; i < 3; ++i) p.t[i] = a.translation().val[i];
+    return p;
 }
+}  // namespace
 
 EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
                    std::shared_ptr<Communicator> _comm)
@@ -34,15 +50,24 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
       noObjMask(_params.frameSize),
       occludedMask(_params.frameSize),
       visCounts(sizeof(int32_t) * EMF_MAX_MODELS),
-      raycastStatsDev(2 * sizeof(uint64_t)) {
+      raycastStatsDev(2 * sizeof(uint64_t)),
+      modelTable(sizeof(emf_model_t) * EMF_MAX_BATCH),
+      visibleDev(sizeof(int32_t) * EMF_MAX_MODELS),
+      integrateStatsDev(sizeof(uint64_t)) {
     if (comm) {
         rank = comm->rank();
         world = comm->size();
         hitKeys = DeviceBuffer(params.frameSize.area() * sizeof(uint64_t));
     }
+    const char* env = std::getenv("EMF_PER_VOLUME");
+    forceLegacy = env && env[0] == '1';
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
+    hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visibleHost),
+                           sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
+             "hipHostMalloc");
+    hipCheck(hipEventCreateWithFlags(&visReady, hipEventDisableTiming), "hipEventCreate");
     stamps.resize(kNumStamps);
     for (auto& e : stamps) hipCheck(hipEventCreate(&e), "hipEventCreate");
     Stream& s = Stream::Null();
@@ -56,15 +81,22 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     raylengths.setZero(s);
     vertices.setZero(s);
     normals.setZero(s);
+    bg_raylengths.setZero(s);
     raycastStatsDev.setZero(s);
+    integrateStatsDev.setZero(s);
+    visCounts.setZero(s);
+    visibleDev.fill32(1u, s);  // background and freshly created objects integrate (Q18)
     s.waitForCompletion();
     streamOf(0);
+    rebuildModelTable();
 }
 
 EMFusion::~EMFusion() {
     (void)hipDeviceSynchronize();
     for (auto& e : stamps) (void)hipEventDestroy(e);
+    if (visReady) (void)hipEventDestroy(visReady);
     if (visCountsHost) (void)hipHostFree(visCountsHost);
+    if (visibleHost) (void)hipHostFree(visibleHost);
 }
 
 void EMFusion::reset() {
@@ -75,6 +107,7 @@ void EMFusion::reset() {
     objImages.clear();
     allIds.clear();
     vis_objs.clear();
+    visPending = false;
     for (auto it = streams.begin(); it != streams.end();)
         it = it->first == 0 ? std::next(it) : streams.erase(it);
     frameCount = 0;
@@ -83,7 +116,9 @@ void EMFusion::reset() {
     bg_associationWeights.setTo(1.f, s);
     diffRaylengths.setZero(s);
     modelSegmentation.setZero(s);
+    visibleDev.fill32(1u, s);
     s.waitForCompletion();
+    rebuildModelTable();
 }
 
 Stream& EMFusion::streamOf(int key) {
@@ -117,6 +152,8 @@ int EMFusion::addObject(const Vec3f& center, float volSize) {
 int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
     if (static_cast<int>(allIds.size()) >= EMF_MAX_MODELS - 1)
         throw HipError("EMFusion::addObject: too many objects", EMF_E_LIMIT);
+    synchronize();  // object creation is rare and changes the model table
+    refreshVisibleFromDevice();
     const int id = nextId++;
     allIds.push_back(id);
     // new objects are aligned with the world frame; only the centre matters for the pose
@@ -130,6 +167,7 @@ int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
         streamOf(id);
     }
     vis_objs.insert(id);  // a new object integrates its first frame (Q18)
+    rebuildModelTable();
     return id;
 }
 
@@ -145,8 +183,68 @@ void EMFusion::createObj(int id) {
     im.modelSegmentation.setZero(s);
     im.associationWeights.setTo(1.f, s);
     im.raylengths.setZero(s);
+    im.vertices.setZero(s);
+    im.normals.setZero(s);
     s.waitForCompletion();
     objImages.emplace(id, std::move(im));
+}
+
+// Rebuild and upload the device model table: slot 0 = background, then this rank's objects in
+// creation order.  Called with the device idle (construction, addObject, reset).
+void EMFusion::rebuildModelTable() {
+    modelsHost.clear();
+    resHost.clear();
+    emf_model_t m{};
+    background.describe(m);
+    m.assoc = bg_associationWeights.ptr();
+    m.raylengths = bg_raylengths.ptr();
+    m.vertices = bg_vertices.ptr();
+    m.normals = bg_normals.ptr();
+    m.hitMask = bg_mask.ptr();
+    modelsHost.push_back(m);
+    for (auto& obj : objects) {
+        emf_model_t o{};
+        obj.describe(o);
+        ObjImages& im = objImages.at(obj.getID());
+        o.assoc = im.associationWeights.ptr();
+        o.raylengths = im.raylengths.ptr();
+        o.vertices = im.vertices.ptr();
+        o.normals = im.normals.ptr();
+        o.hitMask = im.modelSegmentation.ptr();
+        modelsHost.push_back(o);
+    }
+    bool tileable = true;
+    for (const auto& md : modelsHost) {
+        resHost.insert(resHost.end(), md.res, md.res + 3);
+        tileable &= md.res[0] % 4 == 0;
+    }
+    batched = !forceLegacy && tileable && gradMode == TSDF::Gradients::OnTheFly &&
+              static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
+    if (batched) {
+        hipCheck(hipMemcpy(modelTable.data(), modelsHost.data(),
+                           modelsHost.size() * sizeof(emf_model_t), hipMemcpyHostToDevice),
+                 "model table upload");
+        // device gate: keep what the last raycast decided, new slots start visible
+        std::vector<int32_t> vis(modelsHost.size(), 0);
+        vis[0] = 1;
+        size_t slot = 1;
+        for (auto& obj : objects) vis[slot++] = vis_objs.count(obj.getID()) ? 1 : 0;
+        hipCheck(hipMemcpy(visibleDev.data(), vis.data(), vis.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice),
+                 "visibility upload");
+    }
+}
+
+void EMFusion::posesCO(std::vector<emf_pose_t>& out) const {
+    out.clear();
+    out.push_back(toPose(background.getPose().inv() * pose));  // reference TSDF.cpp:141,162
+    for (const auto& obj : objects) out.push_back(toPose(obj.getPose().inv() * pose));
+}
+
+void EMFusion::posesOC(std::vector<emf_pose_t>& out) const {
+    out.clear();
+    out.push_back(toPose(pose.inv() * background.getPose()));  // reference TSDF.cpp:112
+    for (const auto& obj : objects) out.push_back(toPose(pose.inv() * obj.getPose()));
 }
 
 void EMFusion::forkVolumeStreams() {
@@ -177,6 +275,31 @@ std::array<uint64_t, 2> EMFusion::raycastStats() {
     std::array<uint64_t, 2> h{};
     raycastStatsDev.download(h.data(), main);
     return h;
+}
+
+uint64_t EMFusion::takeIntegratedVoxels() {
+    synchronize();
+    uint64_t v = 0;
+    integrateStatsDev.download(&v, main);
+    integrateStatsDev.setZero(main);
+    main.waitForCompletion();
+    return v;
+}
+
+// The batched path leaves the visibility counts in pinned memory behind an event instead of
+// stalling the frame; turn them into the host-side set when somebody asks.
+void EMFusion::refreshVisibleFromDevice() {
+    if (!visPending) return;
+    hipCheck(hipEventSynchronize(visReady), "hipEventSynchronize");
+    vis_objs.clear();
+    for (size_t k = 0; k < visIds.size(); ++k)
+        if (visibleHost[k] > params.visibilityThresh) vis_objs.insert(visIds[k]);
+    visPending = false;
+}
+
+const std::set<int>& EMFusion::visibleObjects() {
+    refreshVisibleFromDevice();
+    return vis_objs;
 }
 
 void EMFusion::processFrame(const RGBD& frame) {
@@ -253,6 +376,147 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
 }
 
 void EMFusion::computeAssociationWeights() {
+    if (batched)
+        estepBatched();
+    else
+        estepPerVolume();
+}
+
+void EMFusion::raycast() {
+    if (batched)
+        raycastBatched();
+    else
+        raycastPerVolume();
+}
+
+void EMFusion::integrateDepth() {
+    if (batched)
+        integrateBatched();
+    else
+        integratePerVolume();
+}
+
+// ---- batched path ----------------------------------------------------------------------------------
+
+void EMFusion::estepBatched() {
+    std::vector<emf_pose_t> co;
+    posesCO(co);
+    const int n = static_cast<int>(co.size());
+    const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
+    const emf_model_t* table = modelTable.as<emf_model_t>();
+    if (world == 1) {
+        auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
+        emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 1, &nv, nullptr, main.abi()),
+                 "estepBatched");
+        return;
+    }
+    // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
+    // xGMI, then every rank normalises its own maps
+    {
+        auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
+        emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 0, nullptr, &sv, main.abi()),
+                 "estepBatched");
+    }
+    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), main);
+    std::vector<emf_image_t> maps;
+    maps.push_back(bg_associationWeights.view());
+    for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
+    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
+                                          main.abi()),
+             "normalizeAssociation");
+}
+
+void EMFusion::raycastBatched() {
+    std::vector<emf_pose_t> co;
+    posesCO(co);
+    const int n = static_cast<int>(co.size());
+    uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
+    {
+        auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
+        emfCheck(emf_hip_raycastBatched(modelTable.as<emf_model_t>(), co.data(), n,
+                                        params.frameSize.width, params.frameSize.height,
+                                        params.intr.val, stats, main.abi()),
+                 "raycastBatched");
+    }
+    stamp(kRaycast);
+    compositeAndVisibility(true);
+}
+
+void EMFusion::integrateBatched() {
+    std::vector<emf_pose_t> oc;
+    posesOC(oc);
+    const int n = static_cast<int>(oc.size());
+    double vox = 0;
+    for (int m = 0; m < n; ++m)
+        vox += static_cast<double>(resHost[3 * m]) * resHost[3 * m + 1] * resHost[3 * m + 2];
+    auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
+    emfCheck(emf_hip_integrateBatched(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
+                                      visibleDev.as<int32_t>(), &depth, params.intr.val,
+                                      integrateStatsDev.as<uint64_t>(), main.abi()),
+             "integrateBatched");
+}
+
+// Compositing in list (creation) order + visibility counts (reference EMFusion.cpp:760-794).
+// deviceGate: turn the counts into the integrate gate on the device and mirror them to pinned
+// memory behind an event; otherwise wait for them here (the reference's behaviour).
+void EMFusion::compositeAndVisibility(bool deviceGate) {
+    if (world > 1)
+        throw HipError("EMFusion::raycast: cross-GPU compositing is not wired up yet", EMF_E_ARG);
+    std::vector<int32_t> ids;
+    std::vector<emf_image_t> oray, overt, onorm, oseg;
+    for (auto& obj : objects) {
+        ObjImages& im = objImages.at(obj.getID());
+        ids.push_back(obj.getID());
+        oray.push_back(im.raylengths.view());
+        overt.push_back(im.vertices.view());
+        onorm.push_back(im.normals.view());
+        oseg.push_back(im.modelSegmentation.view());
+    }
+    const emf_image_t v_bgRay = bg_raylengths.view(), v_bgVert = bg_vertices.view(),
+                      v_bgNorm = bg_normals.view(), v_bgMask = bg_mask.view(),
+                      v_ray = raylengths.view(), v_vert = vertices.view(),
+                      v_norm = normals.view(), v_seg = modelSegmentation.view(),
+                      v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
+    const int nobj = static_cast<int>(ids.size());
+    {
+        auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nobj), main);
+        emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(),
+                                          onorm.data(), oseg.data(), &v_bgRay, &v_bgVert,
+                                          &v_bgNorm, &v_bgMask, &v_ray, &v_vert, &v_norm, &v_seg,
+                                          &v_diff, &v_noObj, params.boundary,
+                                          visCounts.as<int32_t>(), main.abi()),
+                 "compositeRaycast");
+        if (deviceGate)
+            emfCheck(emf_hip_visibilityFlags(visCounts.as<int32_t>(), nobj + 1,
+                                             params.visibilityThresh, visibleDev.as<int32_t>(),
+                                             main.abi()),
+                     "visibilityFlags");
+    }
+    stamp(kComposite);
+    vis_objs.clear();
+    visPending = false;
+    if (nobj == 0) return;
+    if (deviceGate) {
+        hipCheck(hipMemcpyAsync(visibleHost, visCounts.data(), sizeof(int32_t) * nobj,
+                                hipMemcpyDeviceToHost, main.get()),
+                 "visCounts D2H");
+        hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
+        visIds = ids;
+        visPending = true;
+        return;
+    }
+    hipCheck(hipMemcpyAsync(visCountsHost, visCounts.data(), sizeof(int32_t) * nobj,
+                            hipMemcpyDeviceToHost, main.get()),
+             "visCounts D2H");
+    main.waitForCompletion();  // the visible set gates integrateDepth (EMFusion.cpp:869-872)
+    for (int k = 0; k < nobj; ++k)
+        if (visCountsHost[k] > params.visibilityThresh) vis_objs.insert(ids[k]);
+}
+
+// ---- per-volume path -------------------------------------------------------------------------------
+
+void EMFusion::estepPerVolume() {
     const emf_image_t pv = points.view();
     forkVolumeStreams();
     {
@@ -280,7 +544,6 @@ void EMFusion::computeAssociationWeights() {
                  "normalizeAssociation");
         return;
     }
-    // sharded objects: local partial -> one all-reduce over xGMI -> normalise locally
     const emf_image_t sv = objPartialSum.view();
     if (maps.size() > 1) {
         emfCheck(emf_hip_sumAssociation(maps.data() + 1, static_cast<int>(maps.size()) - 1, &sv,
@@ -295,8 +558,7 @@ void EMFusion::computeAssociationWeights() {
              "normalizeAssociation");
 }
 
-void EMFusion::raycast() {
-    vis_objs.clear();
+void EMFusion::raycastPerVolume() {
     uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
     forkVolumeStreams();
     {
@@ -322,47 +584,11 @@ void EMFusion::raycast() {
     }
     joinVolumeStreams();
     stamp(kRaycast);
-
-    if (world > 1)
-        throw HipError("EMFusion::raycast: cross-GPU compositing is not wired up yet", EMF_E_ARG);
-
-    // compositing in list (creation) order + visibility counts, one fused pass
-    std::vector<int32_t> ids;
-    std::vector<emf_image_t> oray, overt, onorm, oseg;
-    for (auto& obj : objects) {
-        ObjImages& im = objImages.at(obj.getID());
-        ids.push_back(obj.getID());
-        oray.push_back(im.raylengths.view());
-        overt.push_back(im.vertices.view());
-        onorm.push_back(im.normals.view());
-        oseg.push_back(im.modelSegmentation.view());
-    }
-    const emf_image_t v_bgRay = bg_raylengths.view(), v_bgVert = bg_vertices.view(),
-                      v_bgNorm = bg_normals.view(), v_bgMask = bg_mask.view(),
-                      v_ray = raylengths.view(), v_vert = vertices.view(),
-                      v_norm = normals.view(), v_seg = modelSegmentation.view(),
-                      v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
-    const int nobj = static_cast<int>(ids.size());
-    {
-    auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nobj), main);
-    emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(), onorm.data(),
-                                      oseg.data(), &v_bgRay, &v_bgVert, &v_bgNorm, &v_bgMask,
-                                      &v_ray, &v_vert, &v_norm, &v_seg, &v_diff, &v_noObj,
-                                      params.boundary, visCounts.as<int32_t>(), main.abi()),
-             "compositeRaycast");
-    }
-    stamp(kComposite);
-    if (nobj > 0) {
-        hipCheck(hipMemcpyAsync(visCountsHost, visCounts.data(), sizeof(int32_t) * nobj,
-                                hipMemcpyDeviceToHost, main.get()),
-                 "visCounts D2H");
-        main.waitForCompletion();  // the visible set gates integrateDepth (EMFusion.cpp:869-872)
-        for (int k = 0; k < nobj; ++k)
-            if (visCountsHost[k] > params.visibilityThresh) vis_objs.insert(ids[k]);
-    }
+    compositeAndVisibility(false);
 }
 
-void EMFusion::integrateDepth() {
+void EMFusion::integratePerVolume() {
+    refreshVisibleFromDevice();
     forkVolumeStreams();
     const bool grads = gradMode == TSDF::Gradients::Materialized;
     {

@@ -90,7 +90,11 @@ public:
     TSDF& getBackground() { return background; }
     std::list<ObjTSDF>& getObjects() { return objects; }
     ObjTSDF* findObject(int id);
-    const std::set<int>& visibleObjects() const { return vis_objs; }
+    /** Objects classified visible by the last raycast (waits for the device if necessary). */
+    const std::set<int>& visibleObjects();
+    /** Voxels swept by the batched integration since the counter was last read (and reset). */
+    uint64_t takeIntegratedVoxels();
+    bool usesBatchedLaunches() const { return batched; }
     std::vector<int> objectIds() const { return allIds; }
     bool ownsObject(int id) const;
     const FrameTimings& lastTimings() const { return timings; }
@@ -124,6 +128,19 @@ private:
 
     void createObj(int id);
     void runSchedule(const emf_image_t& depthDev, const FrameInputs& in);
+    // batched (model-table) path: one launch per stage, no host synchronisation inside a frame
+    void rebuildModelTable();
+    void posesCO(std::vector<emf_pose_t>& out) const;
+    void posesOC(std::vector<emf_pose_t>& out) const;
+    void estepBatched();
+    void raycastBatched();
+    void integrateBatched();
+    void compositeAndVisibility(bool deviceGate);
+    void refreshVisibleFromDevice();
+    // legacy path: one stream per volume, host-side visibility gate (reference structure)
+    void estepPerVolume();
+    void raycastPerVolume();
+    void integratePerVolume();
     void forkVolumeStreams();
     void joinVolumeStreams();
     Stream& streamOf(int key);
@@ -160,6 +177,19 @@ private:
     DeviceBuffer raycastStatsDev;  // 2 x u64
     int32_t* visCountsHost = nullptr;  // pinned
     bool statsOn = false;
+
+    // device-resident model table for the batched launches (slot 0 = background)
+    bool batched = true;            // false: per-volume launches (see EMFusion.cpp)
+    bool forceLegacy = false;
+    DeviceBuffer modelTable;        // emf_model_t[EMF_MAX_BATCH]
+    std::vector<emf_model_t> modelsHost;
+    std::vector<int32_t> resHost;   // 3 per model
+    DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device
+    DeviceBuffer integrateStatsDev; // u64: voxels swept by integrateBatched
+    int32_t* visibleHost = nullptr; // pinned mirror of visCounts for visibleObjects()
+    hipEvent_t visReady = nullptr;
+    bool visPending = false;
+    std::vector<int32_t> visIds;    // object ids in the order of the pending counts
 
     KernelTimers ktimers;
     bool timingsOn = false;

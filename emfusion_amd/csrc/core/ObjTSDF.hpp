@@ -54,6 +54,7 @@ public:
     std::vector<uint8_t> getFgVolMask();
     std::vector<float> getFgBgCounts() const;
 
+    void describe(emf_model_t& m) const override;
     const float* fgProbsPtr() const { return fgProbs.as<float>(); }
     const uint8_t* fgVolMaskPtr() const { return fgVolMask.as<uint8_t>(); }
 

@@ -12,7 +12,9 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
       gradMode(gradients),
       frameSize(_frameSize),
       tsdfVol(voxels() * sizeof(float)),
-      tsdfWeights(voxels() * sizeof(float)) {
+      tsdfWeights(voxels() * sizeof(float)),
+      brickFlags(static_cast<size_t>((_volumeRes[0] + 7) / 8) * ((_volumeRes[1] + 7) / 8) *
+                 ((_volumeRes[2] + 7) / 8)) {
     if (gradMode == Gradients::Materialized) tsdfGrads = DeviceBuffer(voxels() * 3 * sizeof(float));
     reset(_pose);
 }
@@ -22,6 +24,8 @@ void TSDF::reset(const Affine3f& _pose) {
     tsdfVol.setZero(s);
     tsdfWeights.setZero(s);
     if (!tsdfGrads.empty()) tsdfGrads.setZero(s);
+    emfCheck(emf_hip_resetBrickFlags(brickFlags.as<uint8_t>(), volumeRes.val, s.abi()),
+             "TSDF::reset");
     s.waitForCompletion();  // per-volume streams are non-blocking: do not race the clears
     pose = _pose;
 }
@@ -45,7 +49,7 @@ void TSDF::integrate(const emf_image_t& depth, const emf_image_t& weights,
                      const Affine3f& cam_pose, const Matx33f& intr, Stream& stream) {
     const Affine3f rel_pose_OC = cam_pose.inv() * pose;  // volume -> camera
     emfCheck(emf_hip_updateTSDF(&depth, &weights, tsdfVol.as<float>(), tsdfWeights.as<float>(),
-                                rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
+                                brickFlags.as<uint8_t>(), rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
                                 intr.val, volumeRes.val, voxelSize, truncdist,
                                 params.maxTSDFWeight, stream.abi()),
              "TSDF::integrate");
@@ -63,7 +67,7 @@ void TSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_imag
                    const emf_image_t& mask, Stream& stream, uint64_t* stats) {
     const Affine3f rel_pose_CO = pose.inv() * cam_pose;  // camera -> volume
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(), nullptr,
-                                 &raylengths, &vertices, &normals, &mask,
+                                 brickFlags.as<uint8_t>(), &raylengths, &vertices, &normals, &mask,
                                  rel_pose_CO.rotation().val, rel_pose_CO.translation().val,
                                  intr.val, volumeRes.val, voxelSize, truncdist, stats,
                                  stream.abi()),
@@ -79,6 +83,27 @@ void TSDF::computeAssociation(const emf_image_t& points, const Affine3f& cam_pos
                                         truncdist, params.assocSigma, params.alpha,
                                         params.uniPrior, &associationWeights, stream.abi()),
              "TSDF::computeAssociation");
+}
+
+void TSDF::describe(emf_model_t& m) const {
+    m.tsdf = tsdfVol.as<float>();
+    m.weights = tsdfWeights.as<float>();
+    m.grads = gradsPtr();
+    m.fgProbs = nullptr;
+    m.fgVolMask = nullptr;
+    m.brickFlags = brickFlags.as<uint8_t>();
+    m.res[0] = volumeRes[0];
+    m.res[1] = volumeRes[1];
+    m.res[2] = volumeRes[2];
+    m.id = 0;
+    m.voxelSize = voxelSize;
+    m.truncdist = truncdist;
+    m.maxWeight = params.maxTSDFWeight;
+    m.assocC1 = -truncdist / params.assocSigma;         // reference TSDF.cpp:151
+    m.assocC2 = 1.f / (2.f * params.assocSigma);        // reference TSDF.cpp:154
+    m.alpha = params.alpha;
+    m.assocC3 = (1 - params.alpha) * params.uniPrior;   // reference TSDF.cpp:133
+    m.reserved = 0;
 }
 
 std::vector<float> TSDF::getTSDF() const {

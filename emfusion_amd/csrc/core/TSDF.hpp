@@ -81,7 +81,14 @@ public:
     const float* tsdfPtr() const { return tsdfVol.as<float>(); }
     const float* weightsPtr() const { return tsdfWeights.as<float>(); }
     const float* gradsPtr() const { return tsdfGrads.empty() ? nullptr : tsdfGrads.as<float>(); }
+    uint8_t* brickFlagsPtr() const { return brickFlags.as<uint8_t>(); }
     Gradients gradientMode() const { return gradMode; }
+
+    /**
+     * Static part of this volume's entry in the device model table used by the batched launches
+     * (emf_model_t, include/emf_hip.h); image pointers are filled in by the owner of the images.
+     */
+    virtual void describe(emf_model_t& m) const;
 
 protected:
     TSDFParams params;
@@ -95,6 +102,7 @@ protected:
     DeviceBuffer tsdfVol;      // N^3 f32
     DeviceBuffer tsdfWeights;  // N^3 f32
     DeviceBuffer tsdfGrads;    // N^3 x 3 f32, only in Materialized mode
+    DeviceBuffer brickFlags;   // ceil(N/8)^3 u8 uniformity flags kept by integrate(), read by raycast()
 };
 
 }  // namespace emf

@@ -1,0 +1,514 @@
+// device_core.hpp -- device functions shared by the per-volume kernels (level-1 ABI) and the
+// batched, model-table-driven kernels (native path): voxel classification / fusion for TSDF
+// integration, brick uniformity flags, and the ray march.
+//
+// Everything that decides a branch or a step is evaluated in the reference's operation order
+// (see common.hpp); the performance devices used here -- lazy weight lookups, on-the-fly
+// gradients, brick-flag short cuts, 8-byte pair loads -- never change a computed value.
+#pragma once
+
+#include "common.hpp"
+
+namespace emf_hip {
+
+// ---- brick uniformity flags ---------------------------------------------------------------------
+// One byte per 8x8x8 brick of a TSDF volume: non-zero iff EVERY voxel of the brick holds exactly
+// the same one of the three values the integration writes wholesale.
+constexpr int kBrick = 8;
+constexpr int kBrickShift = 3;
+enum : uint8_t { kBrickMixed = 0, kBrickAllZero = 1, kBrickAllOne = 2, kBrickAllNegOne = 4 };
+
+__host__ __device__ __forceinline__ int bricks_along(int n) { return (n + kBrick - 1) >> kBrickShift; }
+
+// 3-bit class of one voxel value (bit set = "equals that constant"); AND over a brick gives the flag
+__device__ __forceinline__ unsigned uniform_bits(float v) {
+    return (v == 0.f ? kBrickAllZero : 0u) | (v == 1.f ? kBrickAllOne : 0u) |
+           (v == -1.f ? kBrickAllNegOne : 0u);
+}
+__device__ __forceinline__ float brick_constant(uint8_t f) {
+    return f == kBrickAllZero ? 0.f : (f == kBrickAllOne ? 1.f : -1.f);
+}
+
+// ---- integration --------------------------------------------------------------------------------
+
+struct IntegrateGeom {
+    Img<const float> depth, assoc;
+    int w, h;
+    M33 R;  // volume -> camera
+    V3 t;
+    M33 K;
+    I3 n;
+    float voxelSize, truncdist, maxWeight;
+};
+
+enum : int { kSkip = 0, kZeroIfUnseen = 1, kNegIfUnseen = 2, kFuse = 3 };
+
+// voxel centre in the camera frame (reference TSDF.cu:345-349)
+__device__ __forceinline__ V3 voxel_in_camera(const IntegrateGeom& a, const V3& half, int x, int y,
+                                              int z) {
+    const V3 pobj = v3((static_cast<float>(x) - half.x) * a.voxelSize,
+                       (static_cast<float>(y) - half.y) * a.voxelSize,
+                       (static_cast<float>(z) - half.z) * a.voxelSize);
+    return mul(a.R, pobj) + a.t;
+}
+
+// Which branch of reference kernel_updateTSDF (TSDF.cu:327-401) a voxel takes; for the fusing
+// branch also the truncated SDF sample and its association weight.
+__device__ __forceinline__ int classify_voxel(const IntegrateGeom& a, const V3& half, int x, int y,
+                                              int z, float& tsdfSample, float& assocW) {
+    const V3 pcam = voxel_in_camera(a, half, x, y, z);
+    if (pcam.z <= 0.f) return kZeroIfUnseen;  // TSDF.cu:351-356
+    const V3 proj = mul(a.K, pcam);
+    const int px = __float2int_rn(proj.x / proj.z);  // round-half-even, TSDF.cu:360-361
+    const int py = __float2int_rn(proj.y / proj.z);
+    if (px < 0 || px >= a.w || py < 0 || py >= a.h) return kSkip;
+    const float d = a.depth.row(py)[px];
+    if (d <= 0.f) return kZeroIfUnseen;  // TSDF.cu:367-372
+    // lambda from the ROUNDED pixel (TSDF.cu:374-377)
+    const float lambda = norm(v3((static_cast<float>(px) - a.K.r0.z) / a.K.r0.x,
+                                 (static_cast<float>(py) - a.K.r1.z) / a.K.r1.y, 1.f));
+    const float sdf = d - (1.f / lambda) * norm(pcam);
+    if (sdf >= -a.truncdist) {
+        tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
+        assocW = sdf < a.truncdist ? a.assoc.row(py)[px] : 1.f;  // free space fuses with 1 (Q8)
+        return kFuse;
+    }
+    return kNegIfUnseen;  // TSDF.cu:398-400
+}
+
+// Apply the branch to (tsdf, weight); returns bit0 = tsdf changed, bit1 = weight changed.
+__device__ __forceinline__ int apply_voxel(int kind, float samp, float aw, float maxWeight,
+                                           float& tv, float& wv) {
+    const float pw = wv;
+    if (kind == kFuse) {
+        if (pw + aw > 0) {  // TSDF.cu:392-397
+            tv = (pw * tv + aw * samp) / (pw + aw);
+            wv = fminf(pw + aw, maxWeight);
+            return 3;
+        }
+    } else if (kind == kZeroIfUnseen) {
+        if (pw == 0) {
+            tv = 0.f;
+            return 1;
+        }
+    } else if (kind == kNegIfUnseen) {
+        if (pw == 0) {
+            tv = -1.f;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+// Conservative frustum test for an axis-aligned box of voxels [x0,x1] x [y0,y1] x [z0,z1]
+// (inclusive voxel indices): true only if EVERY voxel inside takes the kSkip branch, i.e.
+// projects strictly in front of the camera and outside the image.  Perspective projection maps
+// the box (convex, in front of the camera) into the convex hull of its projected corners, so if
+// all 8 corners lie beyond the same image border by more than `margin` pixels, so does every
+// voxel; the margin (1 px against a decision threshold of 0.5 px) absorbs float rounding.
+__device__ __forceinline__ bool box_outside_image(const IntegrateGeom& a, const V3& half, int x0,
+                                                  int y0, int z0, int x1, int y1, int z1) {
+    const float margin = 1.f;
+    bool left = true, right = true, top = true, bottom = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const V3 p = voxel_in_camera(a, half, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0,
+                                     (k & 4) ? z1 : z0);
+        if (!(p.z > 1e-3f)) return false;  // touches the camera plane: not cullable
+        const V3 q = mul(a.K, p);
+        const float u = q.x / q.z, v = q.y / q.z;
+        left &= u < -0.5f - margin;
+        right &= u > static_cast<float>(a.w) - 0.5f + margin;
+        top &= v < -0.5f - margin;
+        bottom &= v > static_cast<float>(a.h) - 0.5f + margin;
+    }
+    return left || right || top || bottom;
+}
+
+// ---- tiled integration: one workgroup (256 lanes) per 32 x 8 x 8 voxel tile -----------------------
+
+constexpr int kTileX = 32, kTileY = 8, kTileZ = 8;
+
+__device__ __forceinline__ bool tile_culled(const IntegrateGeom& a, const V3& half, int x0, int y0,
+                                            int z0) {
+    // Conservative test (see box_outside_image in device_core.hpp for the argument): the tile is
+    // skipped only if all 8 corner voxels are in front of the camera and beyond the SAME image
+    // border by more than a pixel.  Lane l projects corner (l & 7); the wave votes.  Every wave of
+    // the workgroup computes the same votes, so the result is block-uniform.
+    const int x1 = min(x0 + kTileX, a.n.x) - 1, y1 = min(y0 + kTileY, a.n.y) - 1,
+              z1 = min(z0 + kTileZ, a.n.z) - 1;
+    const int k = threadIdx.x & 7;
+    const V3 p = voxel_in_camera(a, half, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, (k & 4) ? z1 : z0);
+    const V3 q = mul(a.K, p);
+    const float u = q.x / q.z, v = q.y / q.z;
+    const float margin = 1.f;
+    if (!__all(p.z > 1e-3f)) return false;
+    return __all(u < -0.5f - margin) || __all(u > static_cast<float>(a.w) - 0.5f + margin) ||
+           __all(v < -0.5f - margin) || __all(v > static_cast<float>(a.h) - 0.5f + margin);
+}
+
+// Process the tile at voxel origin (x0, y0, z0) with the 256 lanes of the workgroup.
+// lds: 4 unsigned words.  All lanes of the block must call this (it contains barriers).
+__device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __restrict__ tsdf,
+                                               float* __restrict__ weights,
+                                               uint8_t* __restrict__ bricks, int x0, int y0,
+                                               int z0, unsigned* lds) {
+    const V3 half = half_extent(a.n);
+    if (tile_culled(a, half, x0, y0, z0)) return;  // block-uniform: no divergent barrier
+    const int tid = threadIdx.x;
+    if (bricks) {
+        if (tid < 4) lds[tid] = 7u;
+        __syncthreads();
+    }
+    const int xg = tid & 7, yy = (tid >> 3) & 7, zs = tid >> 6;
+    const int x = x0 + 4 * xg, y = y0 + yy;
+    unsigned bits = 7u;
+    if (x < a.n.x && y < a.n.y) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int z = z0 + zs + 4 * i;
+            if (z >= a.n.z) continue;
+            int kind[4];
+            float samp[4], aw[4];
+            bool any = false, anyFuse = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                samp[e] = 0.f;
+                aw[e] = 0.f;
+                kind[e] = classify_voxel(a, half, x + e, y, z, samp[e], aw[e]);
+                any |= kind[e] != kSkip;
+                anyFuse |= kind[e] == kFuse;
+            }
+            const size_t base = (static_cast<size_t>(z) * a.n.y + y) * a.n.x + x;
+            float tv[4], wv[4];
+            bool haveT = false;
+            if (bricks || anyFuse) {
+                const float4 tl = *reinterpret_cast<const float4*>(tsdf + base);
+                tv[0] = tl.x; tv[1] = tl.y; tv[2] = tl.z; tv[3] = tl.w;
+                haveT = true;
+            }
+            if (any) {
+                const float4 wl = *reinterpret_cast<const float4*>(weights + base);
+                wv[0] = wl.x; wv[1] = wl.y; wv[2] = wl.z; wv[3] = wl.w;
+                if (!haveT) {
+                    // Constant writes (tsdf := 0 / -1 on never-observed voxels) need no read of
+                    // the old tsdf when every voxel of the group takes one; otherwise the old
+                    // values are loaded so the vector store writes untouched voxels back bit
+                    // for bit.
+                    bool allConst = true, anyConst = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool c =
+                            (kind[e] == kZeroIfUnseen || kind[e] == kNegIfUnseen) && wv[e] == 0;
+                        allConst &= c;
+                        anyConst |= c;
+                    }
+                    if (anyConst && !allConst) {
+                        const float4 tl = *reinterpret_cast<const float4*>(tsdf + base);
+                        tv[0] = tl.x; tv[1] = tl.y; tv[2] = tl.z; tv[3] = tl.w;
+                    }
+                }
+                int changed = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    changed |= apply_voxel(kind[e], samp[e], aw[e], a.maxWeight, tv[e], wv[e]);
+                if (changed & 1)
+                    *reinterpret_cast<float4*>(tsdf + base) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                if (changed & 2)
+                    *reinterpret_cast<float4*>(weights + base) =
+                        make_float4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            if (bricks)
+                bits &= uniform_bits(tv[0]) & uniform_bits(tv[1]) & uniform_bits(tv[2]) &
+                        uniform_bits(tv[3]);
+        }
+    }
+    if (bricks) {
+        if (bits != 7u) atomicAnd(&lds[xg >> 1], bits);
+        __syncthreads();
+        if (tid < 4) {
+            const int bx = (x0 >> kBrickShift) + tid;
+            if (bx < bricks_along(a.n.x)) {
+                const int nbx = bricks_along(a.n.x), nby = bricks_along(a.n.y);
+                bricks[(static_cast<size_t>(z0 >> kBrickShift) * nby + (y0 >> kBrickShift)) * nbx +
+                       bx] = static_cast<uint8_t>(lds[tid] == 7u ? kBrickMixed : lds[tid]);
+            }
+        }
+    }
+}
+
+
+// ---- ray march ----------------------------------------------------------------------------------
+
+struct RayVolume {
+    const float* tsdf;
+    const float* grads;     // N^3 x 3 or nullptr (forward differences on the fly)
+    const float* weights;
+    const uint8_t* fg;      // foreground mask gating the weights, or nullptr
+    const uint8_t* bricks;  // brick uniformity flags of `tsdf`, or nullptr
+    M33 R;                  // camera -> volume rotation
+    V3 cam;                 // camera centre in the volume frame
+    I3 n;
+    float voxelSize, truncdist;
+};
+
+struct RayHit {
+    bool hit;
+    float raylength;
+    V3 vertex, normal;
+    unsigned samples;  // main-loop samples taken (byte-model statistic)
+};
+
+// two x-adjacent floats with one 8-byte load (only dword alignment is needed on gfx950)
+struct __attribute__((packed, aligned(4))) FloatPair {
+    float a, b;
+};
+__device__ __forceinline__ FloatPair load_pair(const float* p) {
+    return *reinterpret_cast<const FloatPair*>(p);
+}
+
+__device__ __forceinline__ float trilinear_pairs(const float* __restrict__ vol, const Cell& c,
+                                                 const I3& n) {
+    const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
+    const float* p = vol + c.base;
+    const FloatPair a = load_pair(p), b = load_pair(p + sy), d = load_pair(p + sz),
+                    e = load_pair(p + sz + sy);
+    return blend8(a.a, a.b, b.a, b.b, d.a, d.b, e.a, e.b, c.fx, c.fy, c.fz);
+}
+
+// weights as the march sees them: optionally gated by the foreground mask (ObjTSDF.cpp:209-210)
+__device__ __forceinline__ float trilinear_weights(const RayVolume& v, const Cell& c) {
+    const size_t sy = static_cast<size_t>(v.n.x), sz = sy * v.n.y;
+    const float* p = v.weights + c.base;
+    float w0 = p[0], w1 = p[1], w2 = p[sy], w3 = p[sy + 1], w4 = p[sz], w5 = p[sz + 1],
+          w6 = p[sz + sy], w7 = p[sz + sy + 1];
+    if (v.fg) {
+        const uint8_t* m = v.fg + c.base;
+        w0 = m[0] ? w0 : 0.f;
+        w1 = m[1] ? w1 : 0.f;
+        w2 = m[sy] ? w2 : 0.f;
+        w3 = m[sy + 1] ? w3 : 0.f;
+        w4 = m[sz] ? w4 : 0.f;
+        w5 = m[sz + 1] ? w5 : 0.f;
+        w6 = m[sz + sy] ? w6 : 0.f;
+        w7 = m[sz + sy + 1] ? w7 : 0.f;
+    }
+    return blend8(w0, w1, w2, w3, w4, w5, w6, w7, c.fx, c.fy, c.fz);
+}
+
+// gradient at a hit: blend of the gradient volume, or of forward differences taken on the fly
+__device__ __forceinline__ V3 gradient_at(const RayVolume& v, const Cell& c) {
+    const size_t sy = static_cast<size_t>(v.n.x), sz = sy * v.n.y;
+    float g[3][8];
+    if (v.grads) {
+        const float* p = v.grads + 3 * c.base;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t off = 3 * ((k & 1) + ((k >> 1) & 1) * sy + (k >> 2) * sz);
+            g[0][k] = p[off];
+            g[1][k] = p[off + 1];
+            g[2][k] = p[off + 2];
+        }
+    } else {
+        // a hit cell never touches the last index planes (the march requires v + 2 < N), so the
+        // "zero on the last planes" rule of the gradient volume cannot apply here
+        const float* p = v.tsdf + c.base;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t off = (k & 1) + ((k >> 1) & 1) * sy + (k >> 2) * sz;
+            const float t0 = p[off];
+            g[0][k] = p[off + 1] - t0;
+            g[1][k] = p[off + sy] - t0;
+            g[2][k] = p[off + sz] - t0;
+        }
+    }
+    V3 r;
+    r.x = blend8(g[0][0], g[0][1], g[0][2], g[0][3], g[0][4], g[0][5], g[0][6], g[0][7], c.fx,
+                 c.fy, c.fz);
+    r.y = blend8(g[1][0], g[1][1], g[1][2], g[1][3], g[1][4], g[1][5], g[1][6], g[1][7], c.fx,
+                 c.fy, c.fz);
+    r.z = blend8(g[2][0], g[2][1], g[2][2], g[2][3], g[2][4], g[2][5], g[2][6], g[2][7], c.fx,
+                 c.fy, c.fz);
+    return r;
+}
+
+// enterVolStep / exitVolStep (reference TSDF.cuh:31-63)
+__device__ __forceinline__ float enter_step(const V3& d, const V3& c, const V3& bb) {
+    const float sx = ((d.x > 0.f ? -bb.x : bb.x) - c.x) / d.x;
+    const float sy = ((d.y > 0.f ? -bb.y : bb.y) - c.y) / d.y;
+    const float sz = ((d.z > 0.f ? -bb.z : bb.z) - c.z) / d.z;
+    return fmaxf(fmaxf(sx, sy), sz);
+}
+__device__ __forceinline__ float exit_step(const V3& d, const V3& c, const V3& bb) {
+    const float sx = ((d.x > 0.f ? bb.x : -bb.x) - c.x) / d.x;
+    const float sy = ((d.y > 0.f ? bb.y : -bb.y) - c.y) / d.y;
+    const float sz = ((d.z > 0.f ? bb.z : -bb.z) - c.z) / d.z;
+    return fminf(fminf(sx, sy), sz);
+}
+
+// TSDF value at a sample cell.  When brick flags are available and every brick holding one of the
+// 8 corners is uniform with the same constant, the blend is evaluated on that constant -- exactly
+// the arithmetic the gather path performs on eight equal values -- without touching the volume.
+struct BrickCache {
+    int bx, by, bz;
+    uint8_t flag;
+};
+__device__ __forceinline__ float sample_tsdf(const RayVolume& v, const V3& idx, const Cell& c,
+                                             BrickCache& cache) {
+    if (v.bricks) {
+        const int lx = static_cast<int>(idx.x), ly = static_cast<int>(idx.y),
+                  lz = static_cast<int>(idx.z);
+        const int bx0 = lx >> kBrickShift, by0 = ly >> kBrickShift, bz0 = lz >> kBrickShift;
+        const int nbx = bricks_along(v.n.x), nby = bricks_along(v.n.y);
+        uint8_t f;
+        if (bx0 == cache.bx && by0 == cache.by && bz0 == cache.bz) {
+            f = cache.flag;
+        } else {
+            f = v.bricks[(static_cast<size_t>(bz0) * nby + by0) * nbx + bx0];
+            cache = BrickCache{bx0, by0, bz0, f};
+        }
+        if (f != kBrickMixed) {
+            const int bx1 = (lx + 1) >> kBrickShift, by1 = (ly + 1) >> kBrickShift,
+                      bz1 = (lz + 1) >> kBrickShift;
+            bool same = true;
+            if (bx1 != bx0 || by1 != by0 || bz1 != bz0) {  // cell straddles a brick boundary
+                for (int k = 1; k < 8 && same; ++k) {
+                    const int bx = (k & 1) ? bx1 : bx0, by = (k & 2) ? by1 : by0,
+                              bz = (k & 4) ? bz1 : bz0;
+                    same = v.bricks[(static_cast<size_t>(bz) * nby + by) * nbx + bx] == f;
+                }
+            }
+            if (same) {
+                const float k = brick_constant(f);
+                return blend8(k, k, k, k, k, k, k, k, c.fx, c.fy, c.fz);
+            }
+        }
+    }
+    return trilinear_pairs(v.tsdf, c, v.n);
+}
+
+// One pixel of reference kernel_raycastTSDF (TSDF.cu:466-573).  `oldRaylength` is the incoming
+// value of the raylength image (non-zero: do not search past another volume's hit).
+__device__ __forceinline__ RayHit march_ray(const RayVolume& v, int x, int y, float fx, float fy,
+                                            float cx, float cy, float oldRaylength) {
+    RayHit out;
+    out.hit = false;
+    out.samples = 0;
+    out.raylength = 0.f;
+    out.vertex = v3(0.f, 0.f, 0.f);
+    out.normal = v3(0.f, 0.f, 0.f);
+    const V3 unproj = v3((static_cast<float>(x) - cx) / fx, (static_cast<float>(y) - cy) / fy, 1.f);
+    const V3 rayv = mul(v.R, unproj);
+    const V3 dir = rayv / norm(rayv);
+    // (volSize - 1) / 2 is INTEGER division in the reference (TSDF.cu:490, Q2)
+    const V3 bb = v3(static_cast<float>((v.n.x - 1) / 2) * v.voxelSize,
+                     static_cast<float>((v.n.y - 1) / 2) * v.voxelSize,
+                     static_cast<float>((v.n.z - 1) / 2) * v.voxelSize);
+    const V3 half = half_extent(v.n);
+    float raylength = enter_step(dir, v.cam, bb);
+    float maxRay = exit_step(dir, v.cam, bb);
+    raylength += v.voxelSize;
+    maxRay -= v.voxelSize;
+    if (oldRaylength != 0) maxRay = fminf(oldRaylength, maxRay);
+    if (raylength >= maxRay) return out;  // ray misses the volume
+
+    float raystep = v.truncdist;
+    V3 p = to_voxel(v.cam + dir * raylength, v.voxelSize, half);
+    while (outside(p, 1.f, v.n) && raylength < maxRay) {  // coarse search, TSDF.cu:509-514
+        raylength += raystep;
+        p = to_voxel(v.cam + dir * raylength, v.voxelSize, half);
+    }
+    // If the search ran out (Q4) the reference reads out of bounds and then never enters the
+    // march (raylength >= maxRay): nothing is written either way.
+    if (outside(p, 1.f, v.n)) return out;
+
+    BrickCache cache{-1, -1, -1, kBrickMixed};
+    float tsdf = sample_tsdf(v, p, cell_of(p, v.n), cache);
+    if (fabsf(tsdf) < 1.f) raystep = v.voxelSize;
+    if (fabsf(tsdf) < .8f) raystep = 0.5f * v.voxelSize;
+    for (;;) {
+        raylength += raystep;
+        if (!(raylength <= maxRay)) break;
+        p = to_voxel(v.cam + dir * raylength, v.voxelSize, half);
+        if (outside(p, 2.f, v.n)) continue;
+        ++out.samples;
+        const Cell c = cell_of(p, v.n);
+        const float next = sample_tsdf(v, p, c, cache);
+        // zero crossing from behind: leave the volume's surface shell
+        if (tsdf < 0 && next > 0 && trilinear_weights(v, c) > 0.f) break;
+        if (fabsf(next) < 1.f) raystep = v.voxelSize;
+        if (fabsf(next) < .8f) raystep = 0.5f * v.voxelSize;
+        if (tsdf > 0 && next < 0) {
+            // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:542-543)
+            const float tstar = raylength - raystep * tsdf / (next - tsdf);
+            const V3 ps = to_voxel(v.cam + dir * tstar, v.voxelSize, half);
+            if (outside(ps, 2.f, v.n)) continue;  // tsdf is NOT advanced here
+            const Cell cs = cell_of(ps, v.n);
+            if (trilinear_weights(v, cs) > 0.f) {
+                const V3 g = gradient_at(v, cs);
+                const M33 Rt = transpose(v.R);
+                out.hit = true;
+                out.raylength = tstar;
+                out.vertex = mul(Rt, dir * tstar);
+                out.normal = mul(Rt, g / norm(g));  // 0/0 -> NaN like the reference
+                break;
+            }
+        }
+        tsdf = next;
+    }
+    return out;
+}
+
+// wave-level reduction of the march statistics, one atomic pair per wave
+__device__ __forceinline__ void add_ray_stats(unsigned long long* stats, unsigned samples,
+                                              unsigned hits, int lane) {
+    if (!stats) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        samples += __shfl_down(samples, off);
+        hits += __shfl_down(hits, off);
+    }
+    if (lane == 0) {
+        if (samples) atomicAdd(&stats[0], static_cast<unsigned long long>(samples));
+        if (hits) atomicAdd(&stats[1], static_cast<unsigned long long>(hits));
+    }
+}
+
+// ---- association likelihood (reference TSDF.cpp:125-156, ObjTSDF.cpp:181-201) -------------------
+
+struct AssocModel {
+    const float* tsdf;
+    const float* fgProbs;  // nullptr for the background
+    M33 R;                 // camera -> volume
+    V3 t;
+    I3 n;
+    float voxelSize;
+    float c1;  // -truncdist / sigma          (TSDF.cpp:151)
+    float c2;  // 1 / (2 sigma)               (TSDF.cpp:154)
+    float alpha;
+    float c3;  // (1 - alpha) * uniPrior      (TSDF.cpp:133)
+};
+
+// One model's un-normalised association weight at one camera-frame point.
+__device__ __forceinline__ float assoc_weight(const AssocModel& a, const V3& pc) {
+    float s = 0.f, fg = 0.f;
+    if (pc.z > 0) {
+        const V3 v = to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(a.n));
+        if (!outside(v, 1.f, a.n)) {
+            const Cell c = cell_of(v, a.n);
+            s = trilinear1(a.tsdf, c, a.n);
+            if (a.fgProbs) fg = trilinear1(a.fgProbs, c, a.n);
+        }
+    }
+    // chain of single-operator OpenCV launches, kept as separate roundings:
+    float L = fabsf(s);
+    L = L * a.c1;
+    L = expf(L);
+    L = L * a.c2;
+    if (a.fgProbs) L = L * fg;
+    float wgt = L * a.alpha;
+    wgt = wgt + a.c3;
+    return (s == 0.f) ? 0.f : wgt;  // associationMask = (lookup == 0) -> weight 0 (Q6)
+}
+
+}  // namespace emf_hip

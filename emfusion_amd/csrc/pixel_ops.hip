@@ -1,6 +1,6 @@
 // pixel_ops.hip -- per-pixel kernels: back-projection, trilinear volume lookups, the fused E-step
 // (association likelihood + normalisation) and raycast compositing.
-#include "common.hpp"
+#include "device_core.hpp"
 
 namespace emf_hip {
 namespace {
@@ -74,48 +74,17 @@ __global__ __launch_bounds__(256) void k_volume_vals(const LookupArgs a) {
 // ---- a3-a5: association likelihood (reference TSDF.cpp:125-156, ObjTSDF.cpp:181-201) --------------
 
 struct AssocArgs {
-    const float* tsdf;
-    const float* fgProbs;  // nullptr for the background
+    AssocModel m;  // device_core.hpp
     Img<const float> points;
     Img<float> out;
     int w, h;
-    M33 R;
-    V3 t;
-    I3 n;
-    float voxelSize;
-    float c1;  // -truncdist / sigma          (TSDF.cpp:151)
-    float c2;  // 1 / (2 sigma)               (TSDF.cpp:154)
-    float alpha;
-    float c3;  // (1 - alpha) * uniPrior      (TSDF.cpp:133)
 };
-
-// One model's un-normalised association weight at one camera-frame point.
-__device__ __forceinline__ float assoc_weight(const AssocArgs& a, const V3& pc) {
-    float s = 0.f, fg = 0.f;
-    if (pc.z > 0) {
-        const V3 v = to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(a.n));
-        if (!outside(v, 1.f, a.n)) {
-            const Cell c = cell_of(v, a.n);
-            s = trilinear1(a.tsdf, c, a.n);
-            if (a.fgProbs) fg = trilinear1(a.fgProbs, c, a.n);
-        }
-    }
-    // chain of single-operator OpenCV launches, kept as separate roundings:
-    float L = fabsf(s);
-    L = L * a.c1;
-    L = expf(L);
-    L = L * a.c2;
-    if (a.fgProbs) L = L * fg;
-    float wgt = L * a.alpha;
-    wgt = wgt + a.c3;
-    return (s == 0.f) ? 0.f : wgt;  // associationMask = (lookup == 0) -> weight 0 (Q6)
-}
 
 __global__ __launch_bounds__(256) void k_assoc(const AssocArgs a) {
     int x, y;
     if (!pixel_of(a.w, a.h, x, y)) return;
     const float* pp = a.points.row(y) + 3 * x;
-    a.out.row(y)[x] = assoc_weight(a, v3(pp[0], pp[1], pp[2]));
+    a.out.row(y)[x] = assoc_weight(a.m, v3(pp[0], pp[1], pp[2]));
 }
 
 // ---- a6: normalisation (reference EMFusion.cpp:653-665) ------------------------------------------
@@ -388,20 +357,20 @@ int emf_hip_computeAssociation(const float* tsdf, const float* fgProbs, const em
         return fail(EMF_E_ARG, "computeAssociation: voxelSize %g / assocSigma %g must be > 0",
                     voxelSize, assocSigma);
     AssocArgs a;
-    a.tsdf = tsdf;
-    a.fgProbs = fgProbs;
+    a.m.tsdf = tsdf;
+    a.m.fgProbs = fgProbs;
     a.points = img<const float>(points);
     a.out = img<float>(out);
     a.w = points->width;
     a.h = points->height;
-    a.R = m33_from(R_CO);
-    a.t = v3_from(t_CO);
-    a.n = i3_from(res);
-    a.voxelSize = voxelSize;
-    a.c1 = -truncdist / assocSigma;
-    a.c2 = 1.f / (2.f * assocSigma);
-    a.alpha = alpha;
-    a.c3 = (1 - alpha) * uniPrior;
+    a.m.R = m33_from(R_CO);
+    a.m.t = v3_from(t_CO);
+    a.m.n = i3_from(res);
+    a.m.voxelSize = voxelSize;
+    a.m.c1 = -truncdist / assocSigma;
+    a.m.c2 = 1.f / (2.f * assocSigma);
+    a.m.alpha = alpha;
+    a.m.c3 = (1 - alpha) * uniPrior;
     hipLaunchKernelGGL(k_assoc, pixel_grid(a.w, a.h), pixel_block(), 0, as_stream(stream), a);
     return launch_status("computeAssociation");
 }

@@ -2,7 +2,7 @@
 // counts, foreground probability.  All are HBM-streaming kernels over continuous (Nz*Ny) x Nx
 // volumes; each lane owns VEC consecutive x-voxels so the read-modify-write streams are 16-byte
 // vector accesses along the fastest axis (1 KiB per wave instruction).
-#include "common.hpp"
+#include "device_core.hpp"
 
 namespace emf_hip {
 namespace {
@@ -10,137 +10,52 @@ namespace {
 constexpr int kBlock = 256;
 
 // ---- a7: TSDF integration (reference kernel_updateTSDF, TSDF.cu:327-401) -------------------------
+//
+// Two kernels share the per-voxel code of device_core.hpp:
+//   k_update_tsdf_tiled  Nx % 4 == 0: one workgroup per 32 x 8 x 8 voxel tile (= four 8^3 bricks).
+//       Each lane owns 4 consecutive x voxels (16-byte accesses, a wave covers eight 128-byte row
+//       segments); tiles that provably project outside the image are culled with 8 corner
+//       projections instead of 2048 voxel projections; the brick uniformity flags of the tile are
+//       rebuilt from the final voxel values with an LDS AND-reduction.
+//   k_update_tsdf_linear any size: one lane per voxel, flags of touched bricks degrade to MIXED.
 
-struct IntegrateArgs {
-    Img<const float> depth, assoc;
-    int w, h;
-    float* tsdf;
-    float* weights;
-    M33 R;  // volume -> camera
-    V3 t;
-    M33 K;
-    I3 n;
-    float voxelSize, truncdist, maxWeight;
+struct TileGrid {
+    int ntx, nty, ntz;
 };
 
-enum : int { kSkip = 0, kZeroIfUnseen = 1, kNegIfUnseen = 2, kFuse = 3 };
-
-// Geometry of one voxel: which branch of the reference kernel it takes, and for the fusing branch
-// the truncated SDF sample and its association weight.
-__device__ __forceinline__ int classify_voxel(const IntegrateArgs& a, const V3& half, int x, int y,
-                                              int z, float& tsdfSample, float& assocW) {
-    const V3 pobj = v3((static_cast<float>(x) - half.x) * a.voxelSize,
-                       (static_cast<float>(y) - half.y) * a.voxelSize,
-                       (static_cast<float>(z) - half.z) * a.voxelSize);
-    const V3 pcam = mul(a.R, pobj) + a.t;
-    if (pcam.z <= 0.f) return kZeroIfUnseen;  // TSDF.cu:351-356
-    const V3 proj = mul(a.K, pcam);
-    const int px = __float2int_rn(proj.x / proj.z);  // round-half-even, TSDF.cu:360-361
-    const int py = __float2int_rn(proj.y / proj.z);
-    if (px < 0 || px >= a.w || py < 0 || py >= a.h) return kSkip;
-    const float d = a.depth.row(py)[px];
-    if (d <= 0.f) return kZeroIfUnseen;  // TSDF.cu:367-372
-    // lambda from the ROUNDED pixel (TSDF.cu:374-377)
-    const float lambda = norm(v3((static_cast<float>(px) - a.K.r0.z) / a.K.r0.x,
-                                 (static_cast<float>(py) - a.K.r1.z) / a.K.r1.y, 1.f));
-    const float sdf = d - (1.f / lambda) * norm(pcam);
-    if (sdf >= -a.truncdist) {
-        tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
-        assocW = sdf < a.truncdist ? a.assoc.row(py)[px] : 1.f;  // free space fuses with 1 (Q8)
-        return kFuse;
-    }
-    return kNegIfUnseen;  // TSDF.cu:398-400
+__global__ __launch_bounds__(kBlock) void k_update_tsdf_tiled(const IntegrateGeom a, float* tsdf,
+                                                              float* weights, uint8_t* bricks,
+                                                              const TileGrid g) {
+    __shared__ unsigned lds[4];
+    const int b = blockIdx.x;
+    const int tx = b % g.ntx, ty = (b / g.ntx) % g.nty, tz = b / (g.ntx * g.nty);
+    integrate_tile(a, tsdf, weights, bricks, tx * kTileX, ty * kTileY, tz * kTileZ, lds);
 }
 
-template <int VEC>
-struct VecT;
-template <>
-struct VecT<4> {
-    using type = float4;
-};
-template <>
-struct VecT<1> {
-    using type = float;
-};
-
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_update_tsdf(const IntegrateArgs a) {
-    using vec_t = typename VecT<VEC>::type;
-    const size_t groupsPerRow = static_cast<size_t>(a.n.x) / VEC;
-    const size_t rows = static_cast<size_t>(a.n.y) * a.n.z;
-    const size_t gid = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (gid >= rows * groupsPerRow) return;
-    const size_t row = gid / groupsPerRow;
-    const int x0 = static_cast<int>(gid - row * groupsPerRow) * VEC;
+__global__ __launch_bounds__(kBlock) void k_update_tsdf_linear(const IntegrateGeom a, float* tsdf,
+                                                               float* weights, uint8_t* bricks) {
+    const size_t total = static_cast<size_t>(a.n.x) * a.n.y * a.n.z;
+    const size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const size_t row = i / a.n.x;
+    const int x = static_cast<int>(i - row * a.n.x);
     const int y = static_cast<int>(row % a.n.y), z = static_cast<int>(row / a.n.y);
-    const V3 half = half_extent(a.n);
+    float samp = 0.f, aw = 0.f;
+    const int kind = classify_voxel(a, half_extent(a.n), x, y, z, samp, aw);
+    if (kind == kSkip) return;
+    float wv = weights[i];
+    float tv = kind == kFuse ? tsdf[i] : 0.f;
+    const int changed = apply_voxel(kind, samp, aw, a.maxWeight, tv, wv);
+    if (changed & 1) tsdf[i] = tv;
+    if (changed & 2) weights[i] = wv;
+    if (bricks && (changed & 1))  // conservative: a written brick is treated as mixed
+        bricks[(static_cast<size_t>(z >> kBrickShift) * bricks_along(a.n.y) + (y >> kBrickShift)) *
+                   bricks_along(a.n.x) + (x >> kBrickShift)] = kBrickMixed;
+}
 
-    int kind[VEC];
-    float samp[VEC], aw[VEC];
-    bool any = false, anyFuse = false;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        samp[e] = 0.f;
-        aw[e] = 0.f;
-        kind[e] = classify_voxel(a, half, x0 + e, y, z, samp[e], aw[e]);
-        any |= kind[e] != kSkip;
-        anyFuse |= kind[e] == kFuse;
-    }
-    if (!any) return;  // whole group projects outside the image: no memory touched
-
-    const size_t base = row * a.n.x + x0;
-    float wv[VEC], tv[VEC];
-    {
-        const vec_t wl = *reinterpret_cast<const vec_t*>(a.weights + base);
-        memcpy(wv, &wl, sizeof(wl));
-    }
-    // Constant writes (tsdf := 0 / -1 on never-observed voxels) need no read of the old tsdf when
-    // every voxel of the group takes one; otherwise the old values are loaded so the vector store
-    // writes back untouched voxels bit-for-bit.
-    bool allConst = true, anyConst = false;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const bool c = (kind[e] == kZeroIfUnseen || kind[e] == kNegIfUnseen) && wv[e] == 0;
-        allConst &= c;
-        anyConst |= c;
-    }
-    if (anyFuse || (anyConst && !allConst)) {
-        const vec_t tl = *reinterpret_cast<const vec_t*>(a.tsdf + base);
-        memcpy(tv, &tl, sizeof(tl));
-    }
-    bool wroteT = false, wroteW = false;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const float pw = wv[e];
-        if (kind[e] == kFuse) {
-            const float nw = aw[e];
-            if (pw + nw > 0) {  // TSDF.cu:392-397
-                tv[e] = (pw * tv[e] + nw * samp[e]) / (pw + nw);
-                wv[e] = fminf(pw + nw, a.maxWeight);
-                wroteT = wroteW = true;
-            }
-        } else if (kind[e] == kZeroIfUnseen) {
-            if (pw == 0) {
-                tv[e] = 0.f;
-                wroteT = true;
-            }
-        } else if (kind[e] == kNegIfUnseen) {
-            if (pw == 0) {
-                tv[e] = -1.f;
-                wroteT = true;
-            }
-        }
-    }
-    if (wroteT) {
-        vec_t o;
-        memcpy(&o, tv, sizeof(o));
-        *reinterpret_cast<vec_t*>(a.tsdf + base) = o;
-    }
-    if (wroteW) {
-        vec_t o;
-        memcpy(&o, wv, sizeof(o));
-        *reinterpret_cast<vec_t*>(a.weights + base) = o;
-    }
+__global__ __launch_bounds__(kBlock) void k_fill_bytes(uint8_t* p, size_t n, uint8_t v) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // ---- a8: gradient volume (reference TSDF.cpp:120-123 + kernel_computeTSDFGrads TSDF.cu:429-448) --
@@ -283,9 +198,9 @@ using namespace emf_hip;
 extern "C" {
 
 int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights, float* tsdf,
-                       float* weights, const float R_OC[9], const float t_OC[3],
-                       const float K[9], const int32_t res[3], float voxelSize, float truncdist,
-                       float maxWeight, emf_stream_t stream) {
+                       float* weights, uint8_t* brickFlags, const float R_OC[9],
+                       const float t_OC[3], const float K[9], const int32_t res[3],
+                       float voxelSize, float truncdist, float maxWeight, emf_stream_t stream) {
     EMF_TRY(check_image(depth, 4, "updateTSDF: depth"));
     EMF_TRY(check_image(assocWeights, 4, "updateTSDF: assocWeights"));
     EMF_TRY(check_same_size(depth, assocWeights, "depth", "assocWeights"));
@@ -298,13 +213,11 @@ int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights
     if (!(voxelSize > 0.f) || !(truncdist > 0.f))
         return fail(EMF_E_ARG, "updateTSDF: voxelSize %g / truncdist %g must be > 0", voxelSize,
                     truncdist);
-    IntegrateArgs a;
+    IntegrateGeom a;
     a.depth = img<const float>(depth);
     a.assoc = img<const float>(assocWeights);
     a.w = depth->width;
     a.h = depth->height;
-    a.tsdf = tsdf;
-    a.weights = weights;
     a.R = m33_from(R_OC);
     a.t = v3_from(t_OC);
     a.K = m33_from(K);
@@ -312,15 +225,27 @@ int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights
     a.voxelSize = voxelSize;
     a.truncdist = truncdist;
     a.maxWeight = maxWeight;
-    const size_t voxels = static_cast<size_t>(res[0]) * res[1] * res[2];
     if (res[0] % 4 == 0 && aligned16(tsdf) && aligned16(weights)) {
-        hipLaunchKernelGGL(k_update_tsdf<4>, dim3(ceil_div(voxels / 4, kBlock)), dim3(kBlock), 0,
-                           as_stream(stream), a);
+        TileGrid g{static_cast<int>(ceil_div(res[0], kTileX)), static_cast<int>(ceil_div(res[1], kTileY)),
+                   static_cast<int>(ceil_div(res[2], kTileZ))};
+        hipLaunchKernelGGL(k_update_tsdf_tiled, dim3(static_cast<unsigned>(g.ntx) * g.nty * g.ntz),
+                           dim3(kBlock), 0, as_stream(stream), a, tsdf, weights, brickFlags, g);
     } else {
-        hipLaunchKernelGGL(k_update_tsdf<1>, dim3(ceil_div(voxels, kBlock)), dim3(kBlock), 0,
-                           as_stream(stream), a);
+        const size_t voxels = static_cast<size_t>(res[0]) * res[1] * res[2];
+        hipLaunchKernelGGL(k_update_tsdf_linear, dim3(ceil_div(voxels, kBlock)), dim3(kBlock), 0,
+                           as_stream(stream), a, tsdf, weights, brickFlags);
     }
     return launch_status("updateTSDF");
+}
+
+int emf_hip_resetBrickFlags(uint8_t* brickFlags, const int32_t res[3], emf_stream_t stream) {
+    EMF_REQUIRE_PTR(brickFlags);
+    EMF_TRY(check_res(res));
+    const size_t n = static_cast<size_t>(bricks_along(res[0])) * bricks_along(res[1]) *
+                     bricks_along(res[2]);
+    hipLaunchKernelGGL(k_fill_bytes, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                       brickFlags, n, static_cast<uint8_t>(kBrickAllZero));
+    return launch_status("resetBrickFlags");
 }
 
 int emf_hip_computeTSDFGrads(const float* tsdf, float* grads, const int32_t res[3],

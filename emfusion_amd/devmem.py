@@ -188,3 +188,19 @@ class DeviceArray:
 def memcpy_d2h(dst: np.ndarray, src_ptr: int):
     synchronize()
     _check(_hip.hipMemcpy(dst.ctypes.data, C.c_void_p(src_ptr), dst.nbytes, _D2H), "hipMemcpy D2H")
+
+
+class DeviceView(DeviceArray):
+    """Non-owning DeviceArray over memory that belongs to someone else (e.g. a volume held by the
+    C++ host classes)."""
+
+    def __init__(self, ptr: int, shape, dtype):  # noqa: D401 - deliberately skips allocation
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        rows = self.shape[0] if self.shape else 1
+        self.pitch = self.row_bytes = self.nbytes // max(rows, 1)
+        self.ptr = ptr
+
+    def __del__(self):
+        self.ptr = None

@@ -70,13 +70,26 @@ def compute_points(depth, K, points, stream=None):
     return points
 
 
+def brick_shape(vol_shape):
+    """Shape (Bz, By, Bx) of the brick flag array of a (Nz, Ny, Nx) volume."""
+    return tuple((n + 7) // 8 for n in vol_shape[:3])
+
+
+def reset_brick_flags(tsdf_like, flags, stream=None):
+    check("emf_hip_resetBrickFlags",
+          _L.emf_hip_resetBrickFlags(_ptr(flags), _res(tsdf_like), _stream(stream)))
+    return flags
+
+
 def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdist, max_weight,
-                stream=None):
+                brick_flags=None, stream=None):
     _vol(tsdf, np.float32)
     _vol(weights, np.float32)
+    if brick_flags is not None:
+        assert brick_flags.dtype == np.dtype(np.uint8) and brick_flags.shape == brick_shape(tsdf.shape)
     check("emf_hip_updateTSDF",
           _L.emf_hip_updateTSDF(C.byref(image_view(depth)), C.byref(image_view(assoc)), _ptr(tsdf),
-                                _ptr(weights), _f(R_OC, 9), _f(t_OC, 3), _f(K, 9), _res(tsdf),
+                                _ptr(weights), _ptr(brick_flags), _f(R_OC, 9), _f(t_OC, 3), _f(K, 9), _res(tsdf),
                                 voxel_size, truncdist, max_weight, _stream(stream)))
 
 
@@ -88,7 +101,7 @@ def compute_tsdf_grads(tsdf, grads, stream=None):
 
 
 def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, mask, R_CO, t_CO, K,
-                 voxel_size, truncdist, stats=None, stream=None):
+                 voxel_size, truncdist, stats=None, brick_flags=None, stream=None):
     _vol(tsdf, np.float32)
     _vol(weights, np.float32)
     if grads is not None:
@@ -99,7 +112,7 @@ def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, m
         assert stats.dtype == np.dtype(np.uint64) and stats.shape[0] >= 2
     check("emf_hip_raycastTSDF",
           _L.emf_hip_raycastTSDF(_ptr(tsdf), _ptr(grads), _ptr(weights), _ptr(fg_mask),
-                                 C.byref(image_view(raylengths)), C.byref(image_view(vertices)),
+                                 _ptr(brick_flags), C.byref(image_view(raylengths)), C.byref(image_view(vertices)),
                                  C.byref(image_view(normals)), C.byref(image_view(mask)),
                                  _f(R_CO, 9), _f(t_CO, 3), _f(K, 9), _res(tsdf), voxel_size,
                                  truncdist, _ptr(stats), _stream(stream)))
@@ -203,3 +216,75 @@ def device_info():
     cus = C.c_int(0)
     check("emf_hip_device_info", _L.emf_hip_device_info(name, 256, arch, 256, C.byref(cus)))
     return name.value.decode(), arch.value.decode(), cus.value
+
+
+# ---- level 3: batched, model-table driven launches ----------------------------------------------
+
+def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, voxel_size,
+               truncdist, max_weight, sigma, alpha, uni_prior, model_id=0, grads=None,
+               fg_probs=None, fg_mask=None, brick_flags=None) -> "_lib.EmfModel":
+    """Fill an emf_model_t from device arrays (images must be unpadded)."""
+    f32 = np.float32
+    m = _lib.EmfModel()
+    m.tsdf, m.weights = tsdf.ptr, weights.ptr
+    m.grads = grads.ptr if grads is not None else None
+    m.fgProbs = fg_probs.ptr if fg_probs is not None else None
+    m.fgVolMask = fg_mask.ptr if fg_mask is not None else None
+    m.brickFlags = brick_flags.ptr if brick_flags is not None else None
+    for name, im in (("assoc", assoc), ("raylengths", raylengths), ("vertices", vertices),
+                     ("normals", normals), ("hitMask", hit_mask)):
+        assert not im.padded
+        setattr(m, name, im.ptr)
+    nz, ny, nx = tsdf.shape
+    m.res[:] = [nx, ny, nz]
+    m.id = model_id
+    m.voxelSize, m.truncdist, m.maxWeight = voxel_size, truncdist, max_weight
+    m.assocC1 = float(-f32(truncdist) / f32(sigma))
+    m.assocC2 = float(f32(1) / (f32(2) * f32(sigma)))
+    m.alpha = alpha
+    m.assocC3 = float((f32(1) - f32(alpha)) * f32(uni_prior))
+    return m
+
+
+def upload_models(models) -> DeviceArray:
+    arr = (_lib.EmfModel * len(models))(*models)
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    return DeviceArray.from_numpy(raw)
+
+
+def _poses(poses):
+    arr = (_lib.EmfPose * max(len(poses), 1))()
+    for i, (R, t) in enumerate(poses):
+        arr[i].R[:] = np.asarray(R, np.float32).reshape(-1).tolist()
+        arr[i].t[:] = np.asarray(t, np.float32).reshape(-1).tolist()
+    return arr
+
+
+def estep_batched(models_dev, poses_co, points, normalize=True, norm=None, obj_sum=None,
+                  stream=None):
+    check("emf_hip_estepBatched",
+          _L.emf_hip_estepBatched(_ptr(models_dev), _poses(poses_co), len(poses_co),
+                                  C.byref(image_view(points)), int(normalize),
+                                  C.byref(image_view(norm)) if norm is not None else None,
+                                  C.byref(image_view(obj_sum)) if obj_sum is not None else None,
+                                  _stream(stream)))
+
+
+def raycast_batched(models_dev, poses_co, width, height, K, stats=None, stream=None):
+    check("emf_hip_raycastBatched",
+          _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), len(poses_co), width,
+                                    height, _f(K, 9), _ptr(stats), _stream(stream)))
+
+
+def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None):
+    res = (C.c_int32 * (3 * len(poses_oc)))(*[int(v) for r in res_list for v in r])
+    check("emf_hip_integrateBatched",
+          _L.emf_hip_integrateBatched(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc),
+                                      _ptr(visible), C.byref(image_view(depth)), _f(K, 9),
+                                      _ptr(stats), _stream(stream)))
+
+
+def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):
+    check("emf_hip_visibilityFlags",
+          _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible),
+                                     _stream(stream)))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 1
+#define EMF_HIP_ABI_VERSION 2
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -58,7 +58,19 @@ typedef struct emf_image {
     int32_t height;
 } emf_image_t;
 
-#define EMF_MAX_MODELS 256 /* background + objects handled by one batched call (seg ids are u8) */
+#define EMF_MAX_MODELS 256 /* background + objects handled by one call (seg ids are u8) */
+#define EMF_MAX_BATCH 32   /* models per batched (model-table) launch */
+
+/* Brick uniformity flags: one byte per 8x8x8 brick of a TSDF volume, ceil(N/8) per axis, x fastest.
+ * 0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly 0 / +1 / -1.  Written by
+ * emf_hip_updateTSDF, consumed by emf_hip_raycastTSDF to evaluate trilinear lookups in uniform
+ * regions without gathering (bit-identical results).  A flag array must start as all 1 for a
+ * zeroed volume and be passed to EVERY integration of that volume. */
+#define EMF_BRICK 8
+#define EMF_BRICK_MIXED 0
+#define EMF_BRICK_ALL_ZERO 1
+#define EMF_BRICK_ALL_ONE 2
+#define EMF_BRICK_ALL_NEG_ONE 4
 
 int emf_hip_abi_version(void);
 /* message for the most recent non-zero return on this thread ("" if none) */
@@ -77,11 +89,12 @@ int emf_hip_computePoints(const emf_image_t* depth, const emf_image_t* points, c
                           emf_stream_t stream);
 
 /* Replaces emf::cuda::TSDF::updateTSDF (TSDF.cuh:115-122, TSDF.cu:327-427).
- * depth, assocWeights: f32 W x H (same size); tsdf, weights: N^3 f32 read-modify-write. */
+ * depth, assocWeights: f32 W x H (same size); tsdf, weights: N^3 f32 read-modify-write.
+ * brickFlags: NULL, or the volume's brick uniformity flags, kept consistent by this call. */
 int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights, float* tsdf,
-                       float* weights, const float R_OC[9], const float t_OC[3],
-                       const float K[9], const int32_t res[3], float voxelSize, float truncdist,
-                       float maxWeight, emf_stream_t stream);
+                       float* weights, uint8_t* brickFlags, const float R_OC[9],
+                       const float t_OC[3], const float K[9], const int32_t res[3],
+                       float voxelSize, float truncdist, float maxWeight, emf_stream_t stream);
 
 /* Replaces TSDF::updateGradients = tsdfGrads.setTo(0) + emf::cuda::TSDF::computeTSDFGrads
  * (TSDF.cpp:120-123, TSDF.cuh:132-134, TSDF.cu:429-464).  grads: N^3 x 3 f32; the last index
@@ -97,10 +110,13 @@ int emf_hip_computeTSDFGrads(const float* tsdf, float* grads, const int32_t res[
  *             of `tsdf` on the fly (bit-identical to a volume made by emf_hip_computeTSDFGrads)
  *   fgVolMask: NULL, or N^3 u8 -- the march then sees weights `fgVolMask ? w : 0`, which replaces
  *             ObjTSDF::raycast's per-frame raycastWeights sweep (ObjTSDF.cpp:209-210)
+ *   brickFlags: NULL, or the brick uniformity flags of `tsdf` (see EMF_BRICK): lookups whose
+ *             eight corners lie in equally-uniform bricks are computed without touching `tsdf`
  *   stats   : NULL, or 2 x u64 device counters this call ADDS to: [0] volume samples taken by the
  *             main march loop (the S of SURVEY.md section 8d), [1] hits */
 int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weights,
-                        const uint8_t* fgVolMask, const emf_image_t* raylengths,
+                        const uint8_t* fgVolMask, const uint8_t* brickFlags,
+                        const emf_image_t* raylengths,
                         const emf_image_t* vertices, const emf_image_t* normals,
                         const emf_image_t* mask, const float R_CO[9], const float t_CO[3],
                         const float K[9], const int32_t res[3], float voxelSize, float truncdist,
@@ -184,6 +200,88 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
  * occluded = saturate_u8(objSeg - (seg == id ? 255 : 0)).  All u8 W x H. */
 int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int id,
                          const emf_image_t* occluded, emf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Level 3: batched, model-table driven launches used by the host classes (emf::EMFusion).
+ * One launch covers the background and every object volume of this rank, replacing the
+ * reference's one-stream-per-volume fan-out (EMFusion.h:471, EMFusion.cpp:636-668, 727-758,
+ * 866-888).  Results are identical to calling the level-1/2 functions model by model.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Static description of one model, an array of which lives in DEVICE memory (models_dev).
+ * Slot 0 is the background, slots 1.. the objects in creation order.  Image pointers are
+ * continuous W x H buffers (pitch = width * elemsize). */
+typedef struct emf_model {
+    float* tsdf;            /* N^3 f32 */
+    float* weights;         /* N^3 f32 */
+    const float* grads;     /* N^3 x 3 f32 or NULL (on-the-fly differences) */
+    const float* fgProbs;   /* N^3 f32, objects only, else NULL */
+    const uint8_t* fgVolMask; /* N^3 u8, objects only, else NULL */
+    uint8_t* brickFlags;    /* ceil(N/8)^3 u8 or NULL */
+    float* assoc;           /* f32 association map of this model */
+    float* raylengths;      /* f32   raycast outputs of this model */
+    float* vertices;        /* f32x3 */
+    float* normals;         /* f32x3 */
+    uint8_t* hitMask;       /* u8 0/1 */
+    int32_t res[3];
+    int32_t id;             /* 0 = background */
+    float voxelSize, truncdist, maxWeight;
+    float assocC1;          /* -truncdist / assocSigma  (TSDF.cpp:151) */
+    float assocC2;          /* 1 / (2 assocSigma)       (TSDF.cpp:154) */
+    float alpha;            /*                          (TSDF.cpp:131) */
+    float assocC3;          /* (1 - alpha) * uniPrior   (TSDF.cpp:133) */
+    int32_t reserved;
+} emf_model_t;
+
+/* Rigid transform passed by value with each launch (poses change every frame). */
+typedef struct emf_pose {
+    float R[9];
+    float t[3];
+} emf_pose_t;
+
+/* E-step for all models in one launch (TSDF.cpp:125-156, ObjTSDF.cpp:181-201, EMFusion.cpp:635-670):
+ * each (pixel, model) lane computes its likelihood, partial sums meet in LDS.
+ *   poseCO_host[m]: camera -> volume m.  points: f32x3 W x H.
+ *   normalize != 0: maps are written normalised, norm (f32 W x H, may be NULL) gets the
+ *                   normaliser = sequential sum of all maps (+ nothing else): single-GPU form
+ *   normalize == 0: maps are written UN-normalised and objSum (f32 W x H, required) receives the
+ *                   sequential sum of the object maps (slots 1..): the partial a rank feeds to
+ *                   the all-reduce; finish with emf_hip_normalizeAssociation(nsum = 1, extraSum)
+ * 1 <= nmodels <= EMF_MAX_BATCH. */
+int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                         const emf_image_t* points, int normalize, const emf_image_t* norm,
+                         const emf_image_t* objSum, emf_stream_t stream);
+
+/* Raycast of all models in one launch (TSDF.cu:466-601 per model, ObjTSDF.cpp:203-216).
+ * Unlike emf_hip_raycastTSDF the outputs need no pre-zeroing: every pixel of every model's
+ * raylengths / vertices / normals / hitMask is written (zeros where there is no hit), which is
+ * what the reference's setTo(0) + kernel leave behind (EMFusion.cpp:727-758). */
+int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                           int nmodels, int width, int height, const float K[9], uint64_t* stats,
+                           emf_stream_t stream);
+
+/* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
+ *   poseOC_host[m]: volume m -> camera
+ *   res_host    : HOST int32[nmodels * 3], the resolutions stored in the table (the launch grid is
+ *                 sized from them); every model needs Nx % 4 == 0
+ *   visible_dev : NULL, or device int32[nmodels]; models with visible_dev[m] == 0 are skipped
+ *                 (EMFusion.cpp:869-872) -- evaluated on the device, no host round trip
+ * Each model's `assoc` map weights its fusion; brickFlags are kept consistent when present.
+ *   stats       : NULL, or one u64 device counter this call ADDS the voxel count of every model
+ *                 it actually sweeps to (work accounting for the byte model)
+ */
+int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                             const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                             const emf_image_t* depth, const float K[9], uint64_t* stats,
+                             emf_stream_t stream);
+
+/* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
+ * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */
+int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,
+                            int32_t* visible_dev, emf_stream_t stream);
+
+/* Fill a brick flag array for a freshly zeroed volume (all EMF_BRICK_ALL_ZERO). */
+int emf_hip_resetBrickFlags(uint8_t* brickFlags, const int32_t res[3], emf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,283 @@
+"""Parity of the level-3 (batched, model-table) launches and of the brick uniformity flags.
+
+Bars: brick flags are exactly the uniformity class of the final voxel values; a raycast that
+uses them is bit-identical to one that does not (and to the oracle); each batched launch is
+bit-identical to running the per-volume level-1/2 entry points model by model."""
+import numpy as np
+import pytest
+
+from tests.parity_util import assert_parity, dev_full, to_dev, to_np
+from tests.scenes import Pose, camera_path, intrinsics, rel_CO, rel_OC, render_depth, rot
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 120
+K = intrinsics(W, H)
+SPHERES = [((0.25, 0.05, 1.3), 0.22), ((-0.3, -0.1, 1.6), 0.18)]
+SIGMA, ALPHA, PRIOR, MAXW = 0.02, 0.8, 1.0, 64.0
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from emfusion_amd import ops as _ops
+    return _ops
+
+
+def frame(i):
+    cam = camera_path(i)
+    depth, ids = render_depth(W, H, K, cam, SPHERES, noise=0.002, dropout=0.01, seed=100 + i)
+    return cam, depth, ids
+
+
+def brick_classes(tsdf):
+    """Reference flags from voxel values: 1/2/4 where a whole 8^3 brick is exactly 0/+1/-1."""
+    nz, ny, nx = tsdf.shape
+    bz, by, bx = [(n + 7) // 8 for n in (nz, ny, nx)]
+    out = np.zeros((bz, by, bx), np.uint8)
+    for code, val in ((1, 0.0), (2, 1.0), (4, -1.0)):
+        eq = np.ones((bz * 8, by * 8, bx * 8), bool)  # padding outside the volume is neutral
+        eq[:nz, :ny, :nx] = tsdf == val
+        u = eq.reshape(bz, 8, by, 8, bx, 8).all((1, 3, 5))
+        out[u] = code
+    return out
+
+
+class Model:
+    """One volume with its device buffers, integrated identically on oracle and device."""
+
+    def __init__(self, ops, oracle, res, vox, pose, is_obj, mid):
+        self.ops, self.oracle = ops, oracle
+        self.res, self.vox, self.pose, self.id = res, np.float32(vox), pose, mid
+        nz, ny, nx = res[2], res[1], res[0]
+        self.tsdf = np.zeros((nz, ny, nx), np.float32)
+        self.wts = np.zeros((nz, ny, nx), np.float32)
+        self.d_tsdf, self.d_wts = to_dev(self.tsdf), to_dev(self.wts)
+        self.d_flags = dev_full(ops.brick_shape(self.tsdf.shape), 0, np.uint8)
+        ops.reset_brick_flags(self.d_tsdf, self.d_flags)
+        self.is_obj = is_obj
+        if is_obj:
+            self.fgbg = np.zeros((nz, ny, nx, 2), np.float32)
+            self.probs = np.zeros((nz, ny, nx), np.float32)
+            self.vmask = np.zeros((nz, ny, nx), np.uint8)
+        self.d_assoc = dev_full((H, W), 1.0)
+        self.d_ray = dev_full((H, W), 0.0)
+        self.d_vert = dev_full((H, W, 3), 0.0)
+        self.d_nrm = dev_full((H, W, 3), 0.0)
+        self.d_hit = dev_full((H, W), 0, np.uint8)
+
+    @property
+    def trunc(self):
+        return np.float32(10) * self.vox
+
+    def integrate(self, cam, depth, assoc, with_flags=True):
+        oc = rel_OC(cam, self.pose)
+        self.oracle.update_tsdf(depth, assoc, self.tsdf, self.wts, oc.R32, oc.t32, K, self.vox,
+                                self.trunc, MAXW)
+        self.ops.update_tsdf(to_dev(depth), to_dev(assoc), self.d_tsdf, self.d_wts, oc.R32, oc.t32,
+                             K, self.vox, self.trunc, MAXW,
+                             brick_flags=self.d_flags if with_flags else None)
+
+    def finish_fg(self, cam, ids):
+        oc = rel_OC(cam, self.pose)
+        self.oracle.update_fgbg_probs((ids == self.id).astype(np.uint8), np.zeros((H, W), np.uint8),
+                                      self.tsdf, self.wts, self.fgbg, oc.R32, oc.t32, K, self.vox)
+        self.probs, self.vmask = self.oracle.compute_fg_probs(self.fgbg)
+        self.d_probs, self.d_vmask = to_dev(self.probs), to_dev(self.vmask)
+
+    def table_entry(self):
+        return self.ops.make_model(
+            self.d_tsdf, self.d_wts, self.d_assoc, self.d_ray, self.d_vert, self.d_nrm, self.d_hit,
+            float(self.vox), float(self.trunc), MAXW, SIGMA, ALPHA, PRIOR, model_id=self.id,
+            fg_probs=self.d_probs if self.is_obj else None,
+            fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags)
+
+
+@pytest.fixture(scope="module")
+def scene(ops, oracle, dev):
+    models = [Model(ops, oracle, (64, 64, 64), 0.04, Pose(t=[0, 0, 1.28]), False, 0),
+              Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True, 1),
+              Model(ops, oracle, (40, 32, 24), 0.025, Pose(rot([0, 1, 0], 7), SPHERES[1][0]), True, 2)]
+    for i in range(4):
+        cam, depth, ids = frame(i)
+        for m in models:
+            m.integrate(cam, depth, np.ones((H, W), np.float32))
+            if m.is_obj:
+                m.finish_fg(cam, ids)
+    dev.synchronize()
+    return models
+
+
+# ---- brick flags ---------------------------------------------------------------------------------
+
+def test_brick_flags_are_exact_uniformity_classes(scene):
+    for m in scene:
+        assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
+        want = brick_classes(m.tsdf)
+        got = to_np(m.d_flags)
+        assert_parity(got, want, f"brick flags model {m.id}", exact=True)
+    bg = brick_classes(scene[0].tsdf)
+    assert (bg == 1).any() and (bg == 2).any() and (bg == 0).any()
+
+
+def test_brick_flags_linear_kernel_is_conservative(ops, oracle, dev):
+    # Nx % 4 != 0 takes the one-lane-per-voxel kernel: flags may only degrade to MIXED
+    res = (30, 22, 18)
+    m = Model(ops, oracle, res, 2.56 / 30, Pose(t=[0, 0, 1.28]), False, 0)
+    for i in range(2):
+        cam, depth, _ = frame(i)
+        m.integrate(cam, depth, np.ones((H, W), np.float32))
+    assert_parity(to_np(m.d_tsdf), m.tsdf, "tsdf", exact=True)
+    want, got = brick_classes(m.tsdf), to_np(m.d_flags)
+    assert np.all((got == want) | (got == 0))
+
+
+def test_culled_tiles_leave_volume_and_flags_untouched(ops, oracle, dev):
+    # camera looking away: every tile projects outside the image or behind the camera
+    m = Model(ops, oracle, (64, 64, 64), 0.04, Pose(t=[3.0, 0, 1.28]), False, 0)
+    cam, depth, _ = frame(0)
+    m.integrate(cam, depth, np.ones((H, W), np.float32))
+    assert_parity(to_np(m.d_tsdf), m.tsdf, "tsdf", exact=True)
+    assert_parity(to_np(m.d_flags), brick_classes(m.tsdf), "flags", exact=True)
+
+
+@pytest.mark.parametrize("cam_name", ["tracked", "rotated", "inside"])
+def test_raycast_with_brick_flags_is_bit_identical(ops, oracle, scene, cam_name, dev):
+    cams = {"tracked": camera_path(4), "rotated": Pose(rot([0.3, 1, 0.2], 14), [0.2, -0.1, 0.15]),
+            "inside": Pose(rot([0, 1, 0], -8), [0.0, 0.0, 0.5])}
+    for m in scene:
+        co = rel_CO(cams[cam_name], m.pose)
+        want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, co.R32,
+                                   co.t32, K, m.vox, m.trunc, count_steps=True)
+        outs = {}
+        for use in (False, True):
+            ray, vert, nrm, hit = (dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0),
+                                   dev_full((H, W, 3), 0.0), dev_full((H, W), 0, np.uint8))
+            st = dev_full((2,), 0, np.uint64)
+            ops.raycast_tsdf(m.d_tsdf, None, m.d_wts, m.d_vmask if m.is_obj else None, ray, vert,
+                             nrm, hit, co.R32, co.t32, K, m.vox, m.trunc, st,
+                             brick_flags=m.d_flags if use else None)
+            outs[use] = [to_np(ray), to_np(vert), to_np(nrm), to_np(hit), to_np(st)]
+        for k, name in enumerate(["ray", "vert", "normal", "mask"]):
+            assert_parity(outs[True][k], want[k], f"{name} with flags vs oracle (model {m.id})",
+                          exact=True)
+            assert_parity(outs[True][k], outs[False][k], f"{name} flags vs no flags", exact=True)
+        assert int(outs[True][4][0]) == int(want[4].sum()) == int(outs[False][4][0])
+
+
+# ---- batched launches ----------------------------------------------------------------------------
+
+def test_estep_batched_matches_per_model_calls(ops, oracle, scene, dev):
+    cam, depth, _ = frame(4)
+    pts = oracle.compute_points(depth, K)
+    d_pts = to_dev(pts)
+    table = ops.upload_models([m.table_entry() for m in scene])
+    poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
+    # per-model path on the device (bit reference) and the oracle (tolerance reference)
+    per, orc = [], []
+    for m, (R, t) in zip(scene, poses):
+        out = dev_full((H, W), 9.0)
+        ops.compute_association(m.d_tsdf, m.d_probs if m.is_obj else None, d_pts, R, t, m.vox,
+                                m.trunc, SIGMA, ALPHA, PRIOR, out)
+        per.append(out)
+        orc.append(oracle.compute_association(m.tsdf, m.probs if m.is_obj else None, pts, R, t,
+                                              m.vox, m.trunc, SIGMA, ALPHA, PRIOR))
+    raw = [to_np(p) for p in per]
+    # un-normalised + object partial sum (multi-GPU form)
+    d_sum = dev_full((H, W), 7.0)
+    ops.estep_batched(table, poses, d_pts, normalize=False, obj_sum=d_sum)
+    for m, r in zip(scene, raw):
+        assert_parity(to_np(m.d_assoc), r, f"un-normalised map {m.id}", exact=True)
+    assert_parity(to_np(d_sum), raw[1] + raw[2], "object partial sum", exact=True)
+    # fused normalisation (single-GPU form)
+    d_norm = dev_full((H, W), 7.0)
+    ops.estep_batched(table, poses, d_pts, normalize=True, norm=d_norm)
+    d_norm2 = dev_full((H, W), 0.0)
+    ops.normalize_association(per, norm=d_norm2)
+    assert_parity(to_np(d_norm), to_np(d_norm2), "norm", exact=True)
+    for m, p in zip(scene, per):
+        assert_parity(to_np(m.d_assoc), to_np(p), f"normalised map {m.id}", exact=True)
+    want = [o.copy() for o in orc]
+    oracle.normalize_association(want)
+    for m, wv in zip(scene, want):
+        assert_parity(to_np(m.d_assoc), wv, f"map {m.id} vs oracle", rtol=4e-6)
+
+
+def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev):
+    cam = camera_path(4)
+    table = ops.upload_models([m.table_entry() for m in scene])
+    poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
+    for m in scene:  # poison: the batched kernel must overwrite everything
+        m.d_ray.copy_from(np.full((H, W), 5, np.float32))
+        m.d_vert.copy_from(np.full((H, W, 3), 5, np.float32))
+        m.d_nrm.copy_from(np.full((H, W, 3), 5, np.float32))
+        m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
+    st = dev_full((2,), 0, np.uint64)
+    ops.raycast_batched(table, poses, W, H, K, stats=st)
+    total = 0
+    for m, (R, t) in zip(scene, poses):
+        want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t,
+                                   K, m.vox, m.trunc, count_steps=True)
+        total += int(want[4].sum())
+        assert want[3].sum() > 100
+        for got, w_, name in zip([m.d_ray, m.d_vert, m.d_nrm, m.d_hit], want,
+                                 ["ray", "vert", "normal", "mask"]):
+            assert_parity(to_np(got), w_, f"{name} model {m.id}", exact=True)
+    assert int(to_np(st)[0]) == total
+
+
+def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle, dev):
+    models = [Model(ops, oracle, (64, 64, 64), 0.04, Pose(t=[0, 0, 1.28]), False, 0),
+              Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True, 1),
+              Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[1][0]), True, 2)]
+    for m in models:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)  # unused by integrate
+    rng = np.random.default_rng(9)
+    visible = dev_full((3,), 1, np.int32)
+    stats = dev_full((1,), 0, np.uint64)
+    expect_vox = 0
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        gate = [1, 1, 0 if i == 1 else 1]  # object 2 is "not visible" on frame 1
+        visible.copy_from(np.array(gate, np.int32))
+        table = ops.upload_models([m.table_entry() for m in models])
+        d_depth = to_dev(depth)
+        poses = []
+        for m, g in zip(models, gate):
+            assoc = rng.uniform(0, 1, (H, W)).astype(np.float32)
+            m.d_assoc.copy_from(assoc)
+            oc = rel_OC(cam, m.pose)
+            poses.append((oc.R32, oc.t32))
+            if g:
+                oracle.update_tsdf(depth, assoc, m.tsdf, m.wts, oc.R32, oc.t32, K, m.vox, m.trunc,
+                                   MAXW)
+                expect_vox += m.tsdf.size
+        ops.integrate_batched(table, poses, [m.res for m in models], visible, d_depth, K, stats)
+        dev.synchronize()
+    for m in models:
+        assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
+        assert_parity(to_np(m.d_wts), m.wts, f"weights model {m.id}", exact=True)
+        assert_parity(to_np(m.d_flags), brick_classes(m.tsdf), f"flags model {m.id}", exact=True)
+    assert int(to_np(stats)[0]) == expect_vox
+
+
+def test_visibility_flags(ops, dev):
+    counts = to_dev(np.array([1601, 1600, 0, 99999], np.int32))
+    vis = dev_full((5,), -1, np.int32)
+    ops.visibility_flags(counts, 5, 1600, vis)
+    assert to_np(vis).tolist() == [1, 1, 0, 0, 1]
+
+
+def test_batched_argument_checks(ops, dev):
+    from emfusion_amd._lib import EmfHipError
+    pts = dev_full((H, W, 3), 0.0)
+    table = dev_full((64,), 0, np.uint8)
+    with pytest.raises(EmfHipError) as e:
+        ops.estep_batched(table, [(np.eye(3), np.zeros(3))] * 33, pts)
+    assert e.value.code == -5  # EMF_E_LIMIT
+    with pytest.raises(EmfHipError) as e:
+        ops.estep_batched(table, [(np.eye(3), np.zeros(3))], pts, normalize=False)
+    assert e.value.code == -1  # objSum required
+    with pytest.raises(EmfHipError) as e:
+        ops.integrate_batched(table, [(np.eye(3), np.zeros(3))], [(30, 22, 18)], None,
+                              dev_full((H, W), 1.0), K)
+    assert e.value.code == -2  # Nx % 4

@@ -15,10 +15,16 @@ BG_RES, BG_VOX, OBJ_RES = 64, 0.04, 32
 NOBJ, NFRAMES, MASK_EVERY = 2, 6, 3
 
 
-@pytest.fixture(scope="module")
-def run(oracle, dev):
+@pytest.fixture(scope="module", params=["batched", "per_volume"])
+def run(request, oracle, dev):
+    """Both execution paths of emf::EMFusion: batched model-table launches (default) and the
+    reference-shaped one-stream-per-volume path (EMF_PER_VOLUME=1)."""
+    import os
+
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
+
+    os.environ["EMF_PER_VOLUME"] = "1" if request.param == "per_volume" else "0"
 
     # visibility threshold / boundary scaled to the small image (reference: 1600 px, 20 px @ VGA)
     prm = pipeline.make_params(W, H, BG_RES, BG_VOX, OBJ_RES, visibility_thresh=100, boundary=5,
@@ -51,6 +57,7 @@ def run(oracle, dev):
                           {i: Affine32(p[0].reshape(3, 3), p[1]) for i, p in poses.items()},
                           masks, run_masks)
         history.append(dict(vis=sorted(fus.visible_objects()), ovis=sorted(orc.vis)))
+    os.environ.pop("EMF_PER_VOLUME", None)
     yield fus, orc, ids, history
     fus.close()
     synth.close()
