@@ -251,7 +251,7 @@ def algorithmic_bytes(kind, summ, stats, P):
     if kind == "grads":       # B_grad: 4 B read + 12 B written per voxel
         return 16.0 * u
     if kind == "raycast":     # B_ray: 16 gathers per march sample, gradient blend at hits, outputs
-        S, hits = stats
+        S, hits = stats[0], stats[1]
         return 64.0 * S + 96.0 * hits + 29.0 * u
     if kind == "assoc":       # B_em per model and pixel: 12 B point + 32 B tsdf gather + 4 B out
         return 48.0 * u       # (objects add a 32 B fg gather; counted at the background's rate)

@@ -102,7 +102,7 @@ struct RaycastBatchArgs {
     unsigned long long* stats;
 };
 
-__global__ __launch_bounds__(256) void k_raycast_batched(const RaycastBatchArgs a) {
+__global__ __launch_bounds__(256, 5) void k_raycast_batched(const RaycastBatchArgs a) {
     // grid = nmodels x (8 * chunk) blocks, model-major: the background's (longest) rays start first.
     // Block b runs on XCD b % 8 (observed dispatch order; used for L2 locality only): give each XCD
     // a contiguous run of `chunk` tiles in raster order, i.e. a horizontal band of the image, so
@@ -117,22 +117,24 @@ __global__ __launch_bounds__(256) void k_raycast_batched(const RaycastBatchArgs 
     const int x = txx * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = tyy * 16 + (wave >> 1) * 8 + (lane >> 3);
     const emf_model_t& md = a.models[m];
-    unsigned nsamples = 0, nhits = 0;
+    unsigned nsamples = 0, nhits = 0, ngath = 0, nskip = 0;
     if (x < a.w && y < a.h) {
         RayVolume v;
         v.tsdf = md.tsdf;
         v.grads = md.grads;
         v.weights = md.weights;
         v.fg = md.fgVolMask;
-        v.bricks = md.brickFlags;
         v.R = pose_R(a.poses.p[m]);
         v.cam = pose_t(a.poses.p[m]);
         v.n = I3{md.res[0], md.res[1], md.res[2]};
+        v.bricks = md.brickFlags ? md.brickFlags + brick_count(v.n) : nullptr;  // dilated half
         v.voxelSize = md.voxelSize;
         v.truncdist = md.truncdist;
         // incoming raylength is zero by construction (the reference zeroes it first, Q5)
         const RayHit r = march_ray(v, x, y, a.fx, a.fy, a.cx, a.cy, 0.f);
         nsamples = r.samples;
+        ngath = r.gathered;
+        nskip = r.skipped;
         nhits = r.hit ? 1u : 0u;
         const size_t pix = static_cast<size_t>(y) * a.w + x;
         md.raylengths[pix] = r.raylength;  // zeros where there is no hit
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void k_raycast_batched(const RaycastBatchArgs 
         pn[2] = r.normal.z;
         md.hitMask[pix] = r.hit ? 1 : 0;
     }
-    add_ray_stats(a.stats, nsamples, nhits, lane);
+    add_ray_stats(a.stats, nsamples, nhits, ngath, nskip, lane);
 }
 
 // ---- batched integration ---------------------------------------------------------------------------
@@ -188,6 +190,30 @@ __global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchA
     const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
     integrate_tile(g, md.tsdf, md.weights, md.brickFlags, tx * kTileX, ty * kTileY, tz * kTileZ,
                    lds);
+}
+
+// refresh the dilated flags of every model that has a flag buffer (one thread per brick)
+struct DilateBatchArgs {
+    const emf_model_t* models;
+    int nmodels;
+    int brickStart[EMF_MAX_BATCH + 1];
+    const int32_t* visible;
+};
+
+__global__ __launch_bounds__(256) void k_dilate_batched(const DilateBatchArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.brickStart[a.nmodels]) return;
+    int m = 0;
+    while (m + 1 < a.nmodels && i >= a.brickStart[m + 1]) ++m;
+    if (a.visible && a.visible[m] == 0) return;  // not integrated this frame: flags unchanged
+    const emf_model_t& md = a.models[m];
+    if (!md.brickFlags) return;
+    const int nbx = bricks_along(md.res[0]), nby = bricks_along(md.res[1]),
+              nbz = bricks_along(md.res[2]);
+    const int j = i - a.brickStart[m];
+    const int bx = j % nbx, by = (j / nbx) % nby, bz = j / (nbx * nby);
+    md.brickFlags[static_cast<size_t>(nbx) * nby * nbz + j] =
+        dilated_flag(md.brickFlags, nbx, nby, nbz, bx, by, bz);
 }
 
 __global__ void k_vis_flags(const int32_t* __restrict__ counts, int nmodels, int thresh,
@@ -300,6 +326,18 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
     a.K = m33_from(K);
     hipLaunchKernelGGL(k_integrate_batched, dim3(static_cast<unsigned>(a.tileStart[nmodels])),
                        dim3(256), 0, as_stream(stream), a);
+    DilateBatchArgs d;
+    d.models = models_dev;
+    d.nmodels = nmodels;
+    d.visible = visible_dev;
+    d.brickStart[0] = 0;
+    for (int m = 0; m < nmodels; ++m) {
+        const int32_t* r = res_host + 3 * m;
+        d.brickStart[m + 1] = d.brickStart[m] + bricks_along(r[0]) * bricks_along(r[1]) *
+                                                    bricks_along(r[2]);
+    }
+    hipLaunchKernelGGL(k_dilate_batched, dim3(ceil_div(d.brickStart[nmodels], 256)), dim3(256), 0,
+                       as_stream(stream), d);
     return launch_status("integrateBatched");
 }
 

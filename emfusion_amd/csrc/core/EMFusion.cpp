@@ -50,7 +50,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
       noObjMask(_params.frameSize),
       occludedMask(_params.frameSize),
       visCounts(sizeof(int32_t) * EMF_MAX_MODELS),
-      raycastStatsDev(2 * sizeof(uint64_t)),
+      raycastStatsDev(4 * sizeof(uint64_t)),
       modelTable(sizeof(emf_model_t) * EMF_MAX_BATCH),
       visibleDev(sizeof(int32_t) * EMF_MAX_MODELS),
       integrateStatsDev(sizeof(uint64_t)) {
@@ -270,9 +270,9 @@ void EMFusion::enableRaycastStats(bool on) {
     raycastStatsDev.setZero(main);
 }
 
-std::array<uint64_t, 2> EMFusion::raycastStats() {
+std::array<uint64_t, 4> EMFusion::raycastStats() {
     synchronize();
-    std::array<uint64_t, 2> h{};
+    std::array<uint64_t, 4> h{};
     raycastStatsDev.download(h.data(), main);
     return h;
 }

@@ -101,9 +101,10 @@ public:
     void enableTimings(bool on) { timingsOn = on; }
     /** Per-launch HIP-event timers (see KernelTimers.hpp); maxLaunches = 0 switches them off. */
     KernelTimers& kernelTimers() { return ktimers; }
-    /** Device counters [march samples, hits] accumulated by raycast() while enabled. */
+    /** Device counters [march samples, hits, gathered samples, fast-forwarded samples]
+     *  accumulated by raycast() while enabled. */
     void enableRaycastStats(bool on);
-    std::array<uint64_t, 2> raycastStats();
+    std::array<uint64_t, 4> raycastStats();
 
     // device images of the last frame (valid until the next call)
     const DeviceImage<float, 3>& getPoints() const { return points; }

@@ -13,8 +13,8 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
       frameSize(_frameSize),
       tsdfVol(voxels() * sizeof(float)),
       tsdfWeights(voxels() * sizeof(float)),
-      brickFlags(static_cast<size_t>((_volumeRes[0] + 7) / 8) * ((_volumeRes[1] + 7) / 8) *
-                 ((_volumeRes[2] + 7) / 8)) {
+      brickFlags(2 * static_cast<size_t>((_volumeRes[0] + 7) / 8) * ((_volumeRes[1] + 7) / 8) *
+                 ((_volumeRes[2] + 7) / 8)) {  // raw flags + dilated flags
     if (gradMode == Gradients::Materialized) tsdfGrads = DeviceBuffer(voxels() * 3 * sizeof(float));
     reset(_pose);
 }

@@ -198,13 +198,12 @@ int emf_fusion_enable_raycast_stats(emf_fusion_t* h, int on) {
     return guarded([&] { h->impl->enableRaycastStats(on != 0); });
 }
 
-int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]) {
+int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[4]) {
     REQ(h);
     REQ(counters);
     return guarded([&] {
         const auto c = h->impl->raycastStats();
-        counters[0] = c[0];
-        counters[1] = c[1];
+        for (int i = 0; i < 4; ++i) counters[i] = c[i];
     });
 }
 
@@ -290,6 +289,12 @@ int emf_fusion_get_volume(emf_fusion_t* h, int which, int obj_id, void** dev_ptr
     switch (which) {
         case EMF_VOL_TSDF: *dev_ptr = const_cast<float*>(vol->tsdfPtr()); return EMF_OK;
         case EMF_VOL_WEIGHTS: *dev_ptr = const_cast<float*>(vol->weightsPtr()); return EMF_OK;
+        case EMF_VOL_BRICKS:
+            *dev_ptr = vol->brickFlagsPtr();
+            res[0] = (r[0] + 7) / 8;
+            res[1] = (r[1] + 7) / 8;
+            res[2] = (r[2] + 7) / 8;
+            return EMF_OK;
         case EMF_VOL_FGPROBS:
             if (obj) {
                 *dev_ptr = const_cast<float*>(obj->fgProbsPtr());

@@ -28,6 +28,23 @@ __device__ __forceinline__ unsigned uniform_bits(float v) {
 __device__ __forceinline__ float brick_constant(uint8_t f) {
     return f == kBrickAllZero ? 0.f : (f == kBrickAllOne ? 1.f : -1.f);
 }
+__host__ __device__ __forceinline__ size_t brick_count(const I3& n) {
+    return static_cast<size_t>(bricks_along(n.x)) * bricks_along(n.y) * bricks_along(n.z);
+}
+// raw flag of brick (bx,by,bz) if it and every in-volume neighbour share that class, else MIXED
+__device__ __forceinline__ uint8_t dilated_flag(const uint8_t* __restrict__ raw, int nbx, int nby,
+                                                int nbz, int bx, int by, int bz) {
+    const uint8_t c = raw[(static_cast<size_t>(bz) * nby + by) * nbx + bx];
+    if (c == kBrickMixed) return kBrickMixed;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = bx + dx, y = by + dy, z = bz + dz;
+                if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
+                if (raw[(static_cast<size_t>(z) * nby + y) * nbx + x] != c) return kBrickMixed;
+            }
+    return c;
+}
 
 // ---- integration --------------------------------------------------------------------------------
 
@@ -245,7 +262,7 @@ struct RayVolume {
     const float* grads;     // N^3 x 3 or nullptr (forward differences on the fly)
     const float* weights;
     const uint8_t* fg;      // foreground mask gating the weights, or nullptr
-    const uint8_t* bricks;  // brick uniformity flags of `tsdf`, or nullptr
+    const uint8_t* bricks;  // DILATED brick uniformity flags of `tsdf`, or nullptr
     M33 R;                  // camera -> volume rotation
     V3 cam;                 // camera centre in the volume frame
     I3 n;
@@ -257,6 +274,8 @@ struct RayHit {
     float raylength;
     V3 vertex, normal;
     unsigned samples;  // main-loop samples taken (byte-model statistic)
+    unsigned gathered; // ... of which read the volume (not answered by the brick flags)
+    unsigned skipped;  // ... of which were fast-forwarded inside a deep-uniform brick
 };
 
 // two x-adjacent floats with one 8-byte load (only dword alignment is needed on gfx950)
@@ -346,45 +365,61 @@ __device__ __forceinline__ float exit_step(const V3& d, const V3& c, const V3& b
     return fminf(fminf(sx, sy), sz);
 }
 
-// TSDF value at a sample cell.  When brick flags are available and every brick holding one of the
-// 8 corners is uniform with the same constant, the blend is evaluated on that constant -- exactly
-// the arithmetic the gather path performs on eight equal values -- without touching the volume.
+// TSDF value at a sample cell.  `v.bricks` holds DILATED uniformity flags: non-zero only if the
+// brick AND all of its 26 neighbours are uniform with the same constant.  The 8 corners of a cell
+// whose low corner lies in such a brick are spread over that brick and its neighbours at most, so
+// all 8 voxels equal the constant and the blend is evaluated on it -- exactly the arithmetic the
+// gather path performs on eight equal values -- with one byte load and no dependence on where the
+// cell sits inside the brick (no straddling cases, hence no divergence between neighbouring rays).
 struct BrickCache {
     int bx, by, bz;
     uint8_t flag;
 };
 __device__ __forceinline__ float sample_tsdf(const RayVolume& v, const V3& idx, const Cell& c,
-                                             BrickCache& cache) {
+                                             BrickCache& cache, uint8_t& uniform) {
+    uniform = kBrickMixed;
     if (v.bricks) {
-        const int lx = static_cast<int>(idx.x), ly = static_cast<int>(idx.y),
-                  lz = static_cast<int>(idx.z);
-        const int bx0 = lx >> kBrickShift, by0 = ly >> kBrickShift, bz0 = lz >> kBrickShift;
-        const int nbx = bricks_along(v.n.x), nby = bricks_along(v.n.y);
-        uint8_t f;
-        if (bx0 == cache.bx && by0 == cache.by && bz0 == cache.bz) {
-            f = cache.flag;
-        } else {
-            f = v.bricks[(static_cast<size_t>(bz0) * nby + by0) * nbx + bx0];
-            cache = BrickCache{bx0, by0, bz0, f};
+        const int bx = static_cast<int>(idx.x) >> kBrickShift,
+                  by = static_cast<int>(idx.y) >> kBrickShift,
+                  bz = static_cast<int>(idx.z) >> kBrickShift;
+        if (bx != cache.bx || by != cache.by || bz != cache.bz) {
+            const int nbx = bricks_along(v.n.x), nby = bricks_along(v.n.y);
+            cache = BrickCache{bx, by, bz, v.bricks[(static_cast<size_t>(bz) * nby + by) * nbx + bx]};
         }
-        if (f != kBrickMixed) {
-            const int bx1 = (lx + 1) >> kBrickShift, by1 = (ly + 1) >> kBrickShift,
-                      bz1 = (lz + 1) >> kBrickShift;
-            bool same = true;
-            if (bx1 != bx0 || by1 != by0 || bz1 != bz0) {  // cell straddles a brick boundary
-                for (int k = 1; k < 8 && same; ++k) {
-                    const int bx = (k & 1) ? bx1 : bx0, by = (k & 2) ? by1 : by0,
-                              bz = (k & 4) ? bz1 : bz0;
-                    same = v.bricks[(static_cast<size_t>(bz) * nby + by) * nbx + bx] == f;
-                }
-            }
-            if (same) {
-                const float k = brick_constant(f);
-                return blend8(k, k, k, k, k, k, k, k, c.fx, c.fy, c.fz);
-            }
+        if (cache.flag != kBrickMixed) {
+            uniform = cache.flag;
+            const float k = brick_constant(cache.flag);
+            return blend8(k, k, k, k, k, k, k, k, c.fx, c.fy, c.fz);
         }
     }
-    return trilinear_pairs(v.tsdf, c, v.n);
+    return trilinear1(v.tsdf, c, v.n);
+}
+
+// How many further samples, taken `step` apart along `dir` from voxel-space position p, are
+// GUARANTEED to keep their low cell corner inside the brick (bx, by, bz) and to satisfy the
+// march's p + 2 < N condition?  Conservative by far more than any accumulated rounding (0.02
+// voxel margin + one step held back): an underestimate at worst.
+__device__ __forceinline__ int steps_inside_brick(const V3& p, const V3& dir, float step,
+                                                  float voxelSize, const I3& n, int bx, int by,
+                                                  int bz) {
+    const float eps = 0.02f;
+    const float s = step / voxelSize;  // voxels per step (approximate is fine: only a bound)
+    const float dv[3] = {dir.x * s, dir.y * s, dir.z * s};
+    const float pp[3] = {p.x, p.y, p.z};
+    const int lo[3] = {bx << kBrickShift, by << kBrickShift, bz << kBrickShift};
+    const int nn[3] = {n.x, n.y, n.z};
+    float k = 64.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int hi = min(lo[a] + kBrick, nn[a] - 2);  // exclusive bound on p
+        const float room = dv[a] > 0.f ? (static_cast<float>(hi) - eps) - pp[a]
+                                       : pp[a] - (static_cast<float>(lo[a]) + eps);
+        const float ad = fabsf(dv[a]);
+        if (ad > 1e-9f) k = fminf(k, room / ad);
+        if (!(pp[a] < static_cast<float>(hi) - eps)) k = 0.f;  // already at the volume margin
+    }
+    const int r = static_cast<int>(k) - 1;  // truncation + one step held back
+    return r > 0 ? r : 0;
 }
 
 // One pixel of reference kernel_raycastTSDF (TSDF.cu:466-573).  `oldRaylength` is the incoming
@@ -394,6 +429,8 @@ __device__ __forceinline__ RayHit march_ray(const RayVolume& v, int x, int y, fl
     RayHit out;
     out.hit = false;
     out.samples = 0;
+    out.gathered = 0;
+    out.skipped = 0;
     out.raylength = 0.f;
     out.vertex = v3(0.f, 0.f, 0.f);
     out.normal = v3(0.f, 0.f, 0.f);
@@ -423,9 +460,11 @@ __device__ __forceinline__ RayHit march_ray(const RayVolume& v, int x, int y, fl
     if (outside(p, 1.f, v.n)) return out;
 
     BrickCache cache{-1, -1, -1, kBrickMixed};
-    float tsdf = sample_tsdf(v, p, cell_of(p, v.n), cache);
+    uint8_t uni;
+    float tsdf = sample_tsdf(v, p, cell_of(p, v.n), cache, uni);
     if (fabsf(tsdf) < 1.f) raystep = v.voxelSize;
     if (fabsf(tsdf) < .8f) raystep = 0.5f * v.voxelSize;
+    const float halfVoxel = 0.5f * v.voxelSize;
     for (;;) {
         raylength += raystep;
         if (!(raylength <= maxRay)) break;
@@ -433,11 +472,12 @@ __device__ __forceinline__ RayHit march_ray(const RayVolume& v, int x, int y, fl
         if (outside(p, 2.f, v.n)) continue;
         ++out.samples;
         const Cell c = cell_of(p, v.n);
-        const float next = sample_tsdf(v, p, c, cache);
+        const float next = sample_tsdf(v, p, c, cache, uni);
+        out.gathered += uni == kBrickMixed ? 1u : 0u;
         // zero crossing from behind: leave the volume's surface shell
         if (tsdf < 0 && next > 0 && trilinear_weights(v, c) > 0.f) break;
         if (fabsf(next) < 1.f) raystep = v.voxelSize;
-        if (fabsf(next) < .8f) raystep = 0.5f * v.voxelSize;
+        if (fabsf(next) < .8f) raystep = halfVoxel;
         if (tsdf > 0 && next < 0) {
             // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:542-543)
             const float tstar = raylength - raystep * tsdf / (next - tsdf);
@@ -455,22 +495,59 @@ __device__ __forceinline__ RayHit march_ray(const RayVolume& v, int x, int y, fl
             }
         }
         tsdf = next;
+
+        // ---- fast-forward through a deep-uniform brick ------------------------------------------
+        // The sample just taken has its low corner in a brick that, like all its neighbours, holds
+        // only k in {0, +1, -1}, so `tsdf` is a blend of k.  While the following samples keep their
+        // low corner in that brick each of them is again a blend of k: no sign test above can fire
+        // (tsdf and next share k's sign, or are both 0), and the step size is at its fixed point
+        // -- blends of +-1 are +-1 or +-0.99999994, which set raystep to voxelSize or leave it;
+        // blends of 0 are 0, which set it to voxelSize/2.  Hence, when raystep already has that
+        // value, the reference loop does nothing for those samples but `raylength += raystep` and
+        // the exit test, and that is all we replay (same float additions, same order).  Only the
+        // LAST skipped sample's value is needed afterwards (it becomes `tsdf`) and is recomputed
+        // exactly.
+        if (uni != kBrickMixed && raystep == (uni == kBrickAllZero ? halfVoxel : v.voxelSize)) {
+            const int budget = steps_inside_brick(p, dir, raystep, v.voxelSize, v.n, cache.bx,
+                                                  cache.by, cache.bz);
+            int taken = 0;
+            float r = raylength;
+            for (; taken < budget; ++taken) {
+                const float rn = r + raystep;
+                if (!(rn <= maxRay)) break;
+                r = rn;
+            }
+            if (taken > 0) {
+                raylength = r;
+                out.samples += static_cast<unsigned>(taken);
+                out.skipped += static_cast<unsigned>(taken);
+                p = to_voxel(v.cam + dir * raylength, v.voxelSize, half);
+                const Cell cl = cell_of(p, v.n);
+                const float k = brick_constant(uni);
+                tsdf = blend8(k, k, k, k, k, k, k, k, cl.fx, cl.fy, cl.fz);
+            }
+        }
     }
     return out;
 }
 
 // wave-level reduction of the march statistics, one atomic pair per wave
 __device__ __forceinline__ void add_ray_stats(unsigned long long* stats, unsigned samples,
-                                              unsigned hits, int lane) {
+                                              unsigned hits, unsigned gathered, unsigned skipped,
+                                              int lane) {
     if (!stats) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         samples += __shfl_down(samples, off);
         hits += __shfl_down(hits, off);
+        gathered += __shfl_down(gathered, off);
+        skipped += __shfl_down(skipped, off);
     }
     if (lane == 0) {
         if (samples) atomicAdd(&stats[0], static_cast<unsigned long long>(samples));
         if (hits) atomicAdd(&stats[1], static_cast<unsigned long long>(hits));
+        if (gathered) atomicAdd(&stats[2], static_cast<unsigned long long>(gathered));
+        if (skipped) atomicAdd(&stats[3], static_cast<unsigned long long>(skipped));
     }
 }
 

@@ -31,16 +31,18 @@ struct RaycastArgs {
     unsigned long long* stats;
 };
 
-__global__ __launch_bounds__(256) void k_raycast(const RaycastArgs a) {
+__global__ __launch_bounds__(256, 5) void k_raycast(const RaycastArgs a) {
     // wave w of the block covers the 8x8 tile at (w & 1, w >> 1) of the block's 16x16 tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    unsigned nsamples = 0, nhits = 0;
+    unsigned nsamples = 0, nhits = 0, ngath = 0, nskip = 0;
     if (x < a.w && y < a.h) {
         // non-zero incoming raylength: do not search past another volume's hit (TSDF.cu:496-500)
         const RayHit r = march_ray(a.vol, x, y, a.fx, a.fy, a.cx, a.cy, a.ray.row(y)[x]);
         nsamples = r.samples;
+        ngath = r.gathered;
+        nskip = r.skipped;
         if (r.hit) {  // pixels without a hit are left untouched, as in the reference
             a.ray.row(y)[x] = r.raylength;
             float* pv = a.vert.row(y) + 3 * x;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void k_raycast(const RaycastArgs a) {
             nhits = 1;
         }
     }
-    add_ray_stats(a.stats, nsamples, nhits, lane);
+    add_ray_stats(a.stats, nsamples, nhits, ngath, nskip, lane);
 }
 
 }  // namespace
@@ -91,10 +93,11 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.vol.grads = grads;
     a.vol.weights = weights;
     a.vol.fg = fgVolMask;
-    a.vol.bricks = brickFlags;
     a.vol.R = m33_from(R_CO);
     a.vol.cam = v3_from(t_CO);
     a.vol.n = i3_from(res);
+    // the flag buffer holds the raw flags followed by the dilated flags; the march reads the latter
+    a.vol.bricks = brickFlags ? brickFlags + brick_count(a.vol.n) : nullptr;
     a.vol.voxelSize = voxelSize;
     a.vol.truncdist = truncdist;
     a.ray = img<float>(raylengths);

@@ -53,6 +53,17 @@ __global__ __launch_bounds__(kBlock) void k_update_tsdf_linear(const IntegrateGe
                    bricks_along(a.n.x) + (x >> kBrickShift)] = kBrickMixed;
 }
 
+// dilated[b] = raw[b] if the brick and all of its in-volume 26 neighbours share that non-zero
+// class, else MIXED (see sample_tsdf in device_core.hpp)
+__global__ __launch_bounds__(kBlock) void k_dilate_flags(const uint8_t* __restrict__ raw,
+                                                         uint8_t* __restrict__ dil, int nbx,
+                                                         int nby, int nbz) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nbx * nby * nbz) return;
+    const int bx = i % nbx, by = (i / nbx) % nby, bz = i / (nbx * nby);
+    dil[i] = dilated_flag(raw, nbx, nby, nbz, bx, by, bz);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_bytes(uint8_t* p, size_t n, uint8_t v) {
     const size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (i < n) p[i] = v;
@@ -235,6 +246,12 @@ int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights
         hipLaunchKernelGGL(k_update_tsdf_linear, dim3(ceil_div(voxels, kBlock)), dim3(kBlock), 0,
                            as_stream(stream), a, tsdf, weights, brickFlags);
     }
+    if (brickFlags) {  // refresh the dilated copy that the raycast consumes
+        const int nbx = bricks_along(res[0]), nby = bricks_along(res[1]), nbz = bricks_along(res[2]);
+        const size_t nb = static_cast<size_t>(nbx) * nby * nbz;
+        hipLaunchKernelGGL(k_dilate_flags, dim3(ceil_div(nb, kBlock)), dim3(kBlock), 0,
+                           as_stream(stream), brickFlags, brickFlags + nb, nbx, nby, nbz);
+    }
     return launch_status("updateTSDF");
 }
 
@@ -243,8 +260,9 @@ int emf_hip_resetBrickFlags(uint8_t* brickFlags, const int32_t res[3], emf_strea
     EMF_TRY(check_res(res));
     const size_t n = static_cast<size_t>(bricks_along(res[0])) * bricks_along(res[1]) *
                      bricks_along(res[2]);
-    hipLaunchKernelGGL(k_fill_bytes, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream),
-                       brickFlags, n, static_cast<uint8_t>(kBrickAllZero));
+    // raw flags followed by the dilated flags: a zeroed volume is deep-uniform everywhere
+    hipLaunchKernelGGL(k_fill_bytes, dim3(ceil_div(2 * n, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), brickFlags, 2 * n, static_cast<uint8_t>(kBrickAllZero));
     return launch_status("resetBrickFlags");
 }
 

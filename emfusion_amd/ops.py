@@ -71,8 +71,9 @@ def compute_points(depth, K, points, stream=None):
 
 
 def brick_shape(vol_shape):
-    """Shape (Bz, By, Bx) of the brick flag array of a (Nz, Ny, Nx) volume."""
-    return tuple((n + 7) // 8 for n in vol_shape[:3])
+    """Shape (2, Bz, By, Bx) of the brick flag buffer of a (Nz, Ny, Nx) volume: [0] raw flags,
+    [1] dilated flags."""
+    return (2,) + tuple((n + 7) // 8 for n in vol_shape[:3])
 
 
 def reset_brick_flags(tsdf_like, flags, stream=None):
@@ -109,7 +110,7 @@ def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, m
     if fg_mask is not None:
         _vol(fg_mask, np.uint8)
     if stats is not None:
-        assert stats.dtype == np.dtype(np.uint64) and stats.shape[0] >= 2
+        assert stats.dtype == np.dtype(np.uint64) and stats.shape[0] >= 4
     check("emf_hip_raycastTSDF",
           _L.emf_hip_raycastTSDF(_ptr(tsdf), _ptr(grads), _ptr(weights), _ptr(fg_mask),
                                  _ptr(brick_flags), C.byref(image_view(raylengths)), C.byref(image_view(vertices)),

@@ -53,7 +53,7 @@ IMG = dict(points=0, bg_assoc=1, obj_assoc=2, assoc_norm=3, raylengths=4, vertic
 _IMG_DTYPE = {0: ("float32", 3), 1: ("float32", 1), 2: ("float32", 1), 3: ("float32", 1),
               4: ("float32", 1), 5: ("float32", 3), 6: ("float32", 3), 7: ("uint8", 1),
               8: ("float32", 1), 9: ("float32", 1)}
-VOL = dict(tsdf=0, weights=1, fgprobs=2, fgmask=3)
+VOL = dict(tsdf=0, weights=1, fgprobs=2, fgmask=3, bricks=4)
 
 _lib = None
 
@@ -289,9 +289,9 @@ class Fusion:
                load().emf_fusion_enable_raycast_stats(self._h, int(on)))
 
     def raycast_stats(self):
-        c = (C.c_uint64 * 2)()
+        c = (C.c_uint64 * 4)()
         _check("emf_fusion_raycast_stats", load().emf_fusion_raycast_stats(self._h, c))
-        return int(c[0]), int(c[1])
+        return tuple(int(v) for v in c)
 
     def kernel_timers_enable(self, max_launches: int):
         _check("emf_fusion_kernel_timers_enable",
@@ -333,7 +333,7 @@ class Fusion:
         res = (C.c_int32 * 3)()
         _check("emf_fusion_get_volume",
                load().emf_fusion_get_volume(self._h, VOL[which], obj_id, C.byref(ptr), res))
-        dt = np.uint8 if which == "fgmask" else np.float32
+        dt = np.uint8 if which in ("fgmask", "bricks") else np.float32
         out = np.empty((res[2], res[1], res[0]), dt)
         devmem.memcpy_d2h(out, ptr.value)
         return out

@@ -61,7 +61,8 @@ enum emf_fusion_volume {
     EMF_VOL_TSDF = 0,     /* f32 */
     EMF_VOL_WEIGHTS = 1,  /* f32 */
     EMF_VOL_FGPROBS = 2,  /* f32, objects only */
-    EMF_VOL_FGMASK = 3    /* u8,  objects only */
+    EMF_VOL_FGMASK = 3,   /* u8,  objects only */
+    EMF_VOL_BRICKS = 4    /* u8,  brick uniformity flags, ceil(N/8) per axis (res = brick grid) */
 };
 
 const char* emf_fusion_last_error_string(void);
@@ -93,9 +94,10 @@ int emf_fusion_stage_integrate(emf_fusion_t* h);
 int emf_fusion_synchronize(emf_fusion_t* h);
 int emf_fusion_enable_timings(emf_fusion_t* h, int on);
 int emf_fusion_last_timings(emf_fusion_t* h, emf_frame_timings_t* out);
-/* counters[0] = march samples, counters[1] = hits accumulated by raycast while enabled */
+/* counters: [0] march samples, [1] hits, [2] samples that read the volume, [3] samples
+ * fast-forwarded inside uniform bricks -- accumulated by raycast while enabled */
 int emf_fusion_enable_raycast_stats(emf_fusion_t* h, int on);
-int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[2]);
+int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[4]);
 
 /* Per-launch HIP-event timers: every kernel launch of the schedule is bracketed by an event pair
  * on the stream it is launched on.  enable(max_launches) allocates the pool (0 = off); collect()

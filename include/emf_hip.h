@@ -61,11 +61,14 @@ typedef struct emf_image {
 #define EMF_MAX_MODELS 256 /* background + objects handled by one call (seg ids are u8) */
 #define EMF_MAX_BATCH 32   /* models per batched (model-table) launch */
 
-/* Brick uniformity flags: one byte per 8x8x8 brick of a TSDF volume, ceil(N/8) per axis, x fastest.
- * 0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly 0 / +1 / -1.  Written by
- * emf_hip_updateTSDF, consumed by emf_hip_raycastTSDF to evaluate trilinear lookups in uniform
- * regions without gathering (bit-identical results).  A flag array must start as all 1 for a
- * zeroed volume and be passed to EVERY integration of that volume. */
+/* Brick uniformity flags: one byte per 8x8x8 brick of a TSDF volume, B = ceil(Nx/8) * ceil(Ny/8) *
+ * ceil(Nz/8) bricks, x fastest.  0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly
+ * 0 / +1 / -1.  A flag BUFFER holds 2 * B bytes: the raw flags, then the dilated flags (a brick
+ * keeps its class only if all of its neighbours share it).  emf_hip_updateTSDF maintains both;
+ * emf_hip_raycastTSDF uses the dilated half to evaluate lookups in uniform regions without
+ * gathering and to fast-forward through them (bit-identical results).  A buffer starts as all 1
+ * for a zeroed volume (emf_hip_resetBrickFlags) and must be passed to EVERY integration of that
+ * volume. */
 #define EMF_BRICK 8
 #define EMF_BRICK_MIXED 0
 #define EMF_BRICK_ALL_ZERO 1
@@ -112,8 +115,9 @@ int emf_hip_computeTSDFGrads(const float* tsdf, float* grads, const int32_t res[
  *             ObjTSDF::raycast's per-frame raycastWeights sweep (ObjTSDF.cpp:209-210)
  *   brickFlags: NULL, or the brick uniformity flags of `tsdf` (see EMF_BRICK): lookups whose
  *             eight corners lie in equally-uniform bricks are computed without touching `tsdf`
- *   stats   : NULL, or 2 x u64 device counters this call ADDS to: [0] volume samples taken by the
- *             main march loop (the S of SURVEY.md section 8d), [1] hits */
+ *   stats   : NULL, or 4 x u64 device counters this call ADDS to: [0] volume samples taken by the
+ *             main march loop (the S of SURVEY.md section 8d), [1] hits, [2] samples that read
+ *             the volume (the rest were answered by the brick flags), [3] samples fast-forwarded */
 int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weights,
                         const uint8_t* fgVolMask, const uint8_t* brickFlags,
                         const emf_image_t* raylengths,
@@ -217,7 +221,7 @@ typedef struct emf_model {
     const float* grads;     /* N^3 x 3 f32 or NULL (on-the-fly differences) */
     const float* fgProbs;   /* N^3 f32, objects only, else NULL */
     const uint8_t* fgVolMask; /* N^3 u8, objects only, else NULL */
-    uint8_t* brickFlags;    /* ceil(N/8)^3 u8 or NULL */
+    uint8_t* brickFlags;    /* flag buffer (2 * B bytes, see EMF_BRICK) or NULL */
     float* assoc;           /* f32 association map of this model */
     float* raylengths;      /* f32   raycast outputs of this model */
     float* vertices;        /* f32x3 */

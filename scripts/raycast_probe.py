@@ -34,10 +34,10 @@ Rm = R.reshape(3, 3).astype(np.float64); tv = t.astype(np.float64)
 def rel_co(pose_t):  # volume pose = identity rotation + translation
     return Rm.astype(np.float32).reshape(-1), (tv - np.asarray(pose_t, np.float64)).astype(np.float32)
 
-def time_raycast(tsdf, wts, fg, Rco, tco, vox, reps=10):
+def time_raycast(tsdf, wts, fg, Rco, tco, vox, reps=10, flags=None):
     ray = DeviceArray.zeros((H, W)); vert = DeviceArray.zeros((H, W, 3)); nrm = DeviceArray.zeros((H, W, 3)); mask = DeviceArray.zeros((H, W), np.uint8)
-    st = DeviceArray.zeros((2,), np.uint64)
-    ops.raycast_tsdf(tsdf, None, wts, fg, ray, vert, nrm, mask, Rco, tco, K, vox, 10 * vox, st)
+    st = DeviceArray.zeros((4,), np.uint64)
+    ops.raycast_tsdf(tsdf, None, wts, fg, ray, vert, nrm, mask, Rco, tco, K, vox, 10 * vox, st, brick_flags=flags)
     devmem.synchronize()
     s = st.numpy()
     e0, e1 = Event(), Event()
@@ -45,19 +45,27 @@ def time_raycast(tsdf, wts, fg, Rco, tco, vox, reps=10):
     for _ in range(reps):
         ray.zero_(); vert.zero_(); nrm.zero_(); mask.zero_()
         devmem.synchronize()
-        e0.record(); ops.raycast_tsdf(tsdf, None, wts, fg, ray, vert, nrm, mask, Rco, tco, K, vox, 10 * vox, None); e1.record(); e1.synchronize()
+        e0.record(); ops.raycast_tsdf(tsdf, None, wts, fg, ray, vert, nrm, mask, Rco, tco, K, vox, 10 * vox, None, brick_flags=flags); e1.record(); e1.synchronize()
         times.append(e0.elapsed_ms(e1))
+    print('   stats samples=%d hits=%d gathered=%d fastfwd=%d' % tuple(int(v) for v in s))
     return np.median(times), int(s[0]), int(s[1])
 
 bg_t, bg_w = vol("tsdf", 0), vol("weights", 0)
 Rco, tco = rel_co(list(prm.volume_pose_t))
 ms, S, hits = time_raycast(bg_t, bg_w, None, Rco, tco, 0.01)
 print(f"bg raycast alone: {ms:.3f} ms  samples={S} ({S/(W*H):.1f}/ray) hits={hits}")
+bg_f = vol("bricks", 0, np.uint8)  # raw half; ops need the buffer base = same pointer
+fl = bg_f.numpy()
+print("bg brick classes: mixed %.4f zero %.4f one %.4f neg %.4f" % tuple((fl == c).mean() for c in (0, 1, 2, 4)))
+ms, S, hits = time_raycast(bg_t, bg_w, None, Rco, tco, 0.01, flags=bg_f)
+print(f"bg raycast alone WITH flags: {ms:.3f} ms")
 for i in ids:
     c, r, vs = synth.sphere(i - 1, WARM - 1)
     Rco_o, tco_o = rel_co(c)
     ms_o, S_o, h_o = time_raycast(vol("tsdf", i), vol("weights", i), vol("fgmask", i, np.uint8), Rco_o, tco_o, np.float32(vs) / np.float32(128))
-    print(f"obj {i} raycast alone: {ms_o:.3f} ms samples={S_o} hits={h_o}")
+    ms_f, _, _ = time_raycast(vol("tsdf", i), vol("weights", i), vol("fgmask", i, np.uint8), Rco_o, tco_o, np.float32(vs) / np.float32(128), flags=vol("bricks", i, np.uint8))
+    flo = vol("bricks", i, np.uint8).numpy()
+    print(f"obj {i} raycast alone: {ms_o:.3f} ms, with flags {ms_f:.3f} ms samples={S_o} hits={h_o}; bricks mixed %.3f zero %.3f one %.3f neg %.3f" % tuple((flo == c).mean() for c in (0, 1, 2, 4)))
 
 # stage timings inside the pipeline (concurrent streams)
 e0, e1 = Event(), Event()
@@ -80,3 +88,16 @@ if len(sys.argv) > 2:
     t8 = st[:H // 8 * 8, :W // 8 * 8].reshape(H // 8, 8, W // 8, 8)
     print("per-wave: mean of tile max %.1f, mean of tile mean %.1f" % (t8.max((1, 3)).mean(), t8.mean((1, 3)).mean()))
     print("tsdf==1 fraction", (tsdf == 1).mean(), "tsdf==0", (tsdf == 0).mean(), "tsdf==-1", (tsdf == -1).mean())
+
+if len(sys.argv) > 3 and sys.argv[3] == "dump":
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    ptr = C.c_void_p(); res = (C.c_int32 * 3)()
+    pipeline._check("get_volume", pipeline.load().emf_fusion_get_volume(fus._h, pipeline.VOL["bricks"], 0, C.byref(ptr), res))
+    both = DeviceView(ptr.value, (2, res[2], res[1], res[0]), np.uint8).numpy()
+    np.save("gpurun_out/bg_flags.npy", both)
+    t = bg_t.numpy()
+    # per-z-slab statistics of exact ones / near ones
+    np.save("gpurun_out/bg_tsdf_slice_y256.npy", t[:, 256, :])
+    np.save("gpurun_out/bg_tsdf_slice_z100.npy", t[100, :, :])
+    print("dumped")

@@ -42,6 +42,27 @@ def brick_classes(tsdf):
     return out
 
 
+def dilate(raw):
+    """Dilated flags: a brick keeps its class only if all in-volume neighbours share it."""
+    out = raw.copy()
+    bz, by, bx = raw.shape
+    pad = np.full((bz + 2, by + 2, bx + 2), 255, np.uint8)  # 255 = outside the volume: ignored
+    pad[1:-1, 1:-1, 1:-1] = raw
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                nb = pad[dz:dz + bz, dy:dy + by, dx:dx + bx]
+                out[(nb != raw) & (nb != 255)] = 0
+    return out
+
+
+def check_flags(got, tsdf, what):
+    want = brick_classes(tsdf)
+    assert_parity(got[0], want, f"raw brick flags {what}", exact=True)
+    assert_parity(got[1], dilate(want), f"dilated brick flags {what}", exact=True)
+    return want
+
+
 class Model:
     """One volume with its device buffers, integrated identically on oracle and device."""
 
@@ -112,9 +133,7 @@ def scene(ops, oracle, dev):
 def test_brick_flags_are_exact_uniformity_classes(scene):
     for m in scene:
         assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
-        want = brick_classes(m.tsdf)
-        got = to_np(m.d_flags)
-        assert_parity(got, want, f"brick flags model {m.id}", exact=True)
+        check_flags(to_np(m.d_flags), m.tsdf, f"model {m.id}")
     bg = brick_classes(scene[0].tsdf)
     assert (bg == 1).any() and (bg == 2).any() and (bg == 0).any()
 
@@ -128,7 +147,8 @@ def test_brick_flags_linear_kernel_is_conservative(ops, oracle, dev):
         m.integrate(cam, depth, np.ones((H, W), np.float32))
     assert_parity(to_np(m.d_tsdf), m.tsdf, "tsdf", exact=True)
     want, got = brick_classes(m.tsdf), to_np(m.d_flags)
-    assert np.all((got == want) | (got == 0))
+    assert np.all((got[0] == want) | (got[0] == 0))
+    assert_parity(got[1], dilate(got[0]), "dilated flags follow the raw flags", exact=True)
 
 
 def test_culled_tiles_leave_volume_and_flags_untouched(ops, oracle, dev):
@@ -137,7 +157,7 @@ def test_culled_tiles_leave_volume_and_flags_untouched(ops, oracle, dev):
     cam, depth, _ = frame(0)
     m.integrate(cam, depth, np.ones((H, W), np.float32))
     assert_parity(to_np(m.d_tsdf), m.tsdf, "tsdf", exact=True)
-    assert_parity(to_np(m.d_flags), brick_classes(m.tsdf), "flags", exact=True)
+    check_flags(to_np(m.d_flags), m.tsdf, "culled volume")
 
 
 @pytest.mark.parametrize("cam_name", ["tracked", "rotated", "inside"])
@@ -152,7 +172,7 @@ def test_raycast_with_brick_flags_is_bit_identical(ops, oracle, scene, cam_name,
         for use in (False, True):
             ray, vert, nrm, hit = (dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0),
                                    dev_full((H, W, 3), 0.0), dev_full((H, W), 0, np.uint8))
-            st = dev_full((2,), 0, np.uint64)
+            st = dev_full((4,), 0, np.uint64)
             ops.raycast_tsdf(m.d_tsdf, None, m.d_wts, m.d_vmask if m.is_obj else None, ray, vert,
                              nrm, hit, co.R32, co.t32, K, m.vox, m.trunc, st,
                              brick_flags=m.d_flags if use else None)
@@ -211,7 +231,7 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
         m.d_vert.copy_from(np.full((H, W, 3), 5, np.float32))
         m.d_nrm.copy_from(np.full((H, W, 3), 5, np.float32))
         m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
-    st = dev_full((2,), 0, np.uint64)
+    st = dev_full((4,), 0, np.uint64)
     ops.raycast_batched(table, poses, W, H, K, stats=st)
     total = 0
     for m, (R, t) in zip(scene, poses):
@@ -256,7 +276,7 @@ def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle,
     for m in models:
         assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
         assert_parity(to_np(m.d_wts), m.wts, f"weights model {m.id}", exact=True)
-        assert_parity(to_np(m.d_flags), brick_classes(m.tsdf), f"flags model {m.id}", exact=True)
+        check_flags(to_np(m.d_flags), m.tsdf, f"model {m.id}")
     assert int(to_np(stats)[0]) == expect_vox
 
 

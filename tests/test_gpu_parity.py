@@ -135,7 +135,7 @@ def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False
     vert = dev_full((H, W, 3), 0.0)
     nrm = dev_full((H, W, 3), 0.0)
     mask = dev_full((H, W), 0, np.uint8)
-    st = dev_full((2,), 0, np.uint64) if stats else None
+    st = dev_full((4,), 0, np.uint64) if stats else None
     ops.raycast_tsdf(to_dev(tsdf, dev), None if grads is None else to_dev(grads, dev),
                      to_dev(wts, dev), None if fg is None else to_dev(fg, dev), ray, vert, nrm,
                      mask, co.R32, co.t32, K, vox, 10 * vox, st)

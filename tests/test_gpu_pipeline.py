@@ -138,6 +138,6 @@ def test_raycast_and_segmentation(run):
 
 def test_march_sample_count_close_to_oracle(run):
     fus, orc, _, _ = run
-    samples, hits = fus.raycast_stats()
+    samples, hits, gathered, skipped = fus.raycast_stats()
     assert hits > 0
     assert abs(samples - orc.march_samples) <= 0.01 * orc.march_samples
