@@ -62,6 +62,11 @@ SIGNATURES = {
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _F9, _FP, _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
+    "emf_hip_packHitKeys": [C.c_int, _I3, _IMG, _IMG, _FP, C.c_int, C.c_int, _STREAM],
+    "emf_hip_compositeFromKeys": [_FP, C.c_int, _I3, C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG,
+                                  _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP,
+                                  _STREAM],
+    "emf_hip_visibilityFlagsIndexed": [_FP, C.c_int, _I3, C.c_int, _FP, _STREAM],
 }
 
 

@@ -61,6 +61,10 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     }
     const char* env = std::getenv("EMF_PER_VOLUME");
     forceLegacy = env && env[0] == '1';
+    // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
+    // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
+    const char* fs = std::getenv("EMF_FORCE_SHARDED");
+    sharded = comm && (world > 1 || (fs && fs[0] == '1'));
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
@@ -404,7 +408,7 @@ void EMFusion::estepBatched() {
     const int n = static_cast<int>(co.size());
     const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
     const emf_model_t* table = modelTable.as<emf_model_t>();
-    if (world == 1) {
+    if (!sharded) {
         auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
         emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 1, &nv, nullptr, main.abi()),
                  "estepBatched");
@@ -461,8 +465,10 @@ void EMFusion::integrateBatched() {
 // deviceGate: turn the counts into the integrate gate on the device and mirror them to pinned
 // memory behind an event; otherwise wait for them here (the reference's behaviour).
 void EMFusion::compositeAndVisibility(bool deviceGate) {
-    if (world > 1)
-        throw HipError("EMFusion::raycast: cross-GPU compositing is not wired up yet", EMF_E_ARG);
+    if (sharded) {
+        compositeAcrossRanks(deviceGate);
+        return;
+    }
     std::vector<int32_t> ids;
     std::vector<emf_image_t> oray, overt, onorm, oseg;
     for (auto& obj : objects) {
@@ -514,6 +520,70 @@ void EMFusion::compositeAndVisibility(bool deviceGate) {
         if (visCountsHost[k] > params.visibilityThresh) vis_objs.insert(ids[k]);
 }
 
+// Object volumes are sharded over ranks: merge the nearest hit of ALL objects with one
+// all-reduce(min) of packed (raylength, list position) keys, then finish the composite locally.
+// Every rank ends up with the same segmentation and the visibility counts of all objects.
+void EMFusion::compositeAcrossRanks(bool deviceGate) {
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    std::vector<int32_t> listPos;
+    std::vector<emf_image_t> oray, overt, onorm, oseg;
+    for (auto& obj : objects) {
+        ObjImages& im = objImages.at(obj.getID());
+        const auto it = std::find(allIds.begin(), allIds.end(), obj.getID());
+        listPos.push_back(static_cast<int32_t>(it - allIds.begin()));
+        oray.push_back(im.raylengths.view());
+        overt.push_back(im.vertices.view());
+        onorm.push_back(im.normals.view());
+        oseg.push_back(im.modelSegmentation.view());
+    }
+    const int nlocal = static_cast<int>(listPos.size());
+    const int nall = static_cast<int>(allIds.size());
+    const emf_image_t v_bgRay = bg_raylengths.view(), v_bgVert = bg_vertices.view(),
+                      v_bgNorm = bg_normals.view(), v_bgMask = bg_mask.view(),
+                      v_ray = raylengths.view(), v_vert = vertices.view(),
+                      v_norm = normals.view(), v_seg = modelSegmentation.view(),
+                      v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
+    {
+        auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nlocal), main);
+        emfCheck(emf_hip_packHitKeys(nlocal, listPos.data(), oray.data(), oseg.data(),
+                                     hitKeys.as<uint64_t>(), w, h, main.abi()),
+                 "packHitKeys");
+        comm->allReduceMinU64(hitKeys.as<uint64_t>(), params.frameSize.area(), main);
+        emfCheck(emf_hip_compositeFromKeys(hitKeys.as<uint64_t>(), nall, allIds.data(), nlocal,
+                                           listPos.data(), oray.data(), overt.data(),
+                                           onorm.data(), &v_bgRay, &v_bgVert, &v_bgNorm,
+                                           &v_bgMask, &v_ray, &v_vert, &v_norm, &v_seg, &v_diff,
+                                           &v_noObj, params.boundary, visCounts.as<int32_t>(),
+                                           main.abi()),
+                 "compositeFromKeys");
+        if (deviceGate) {
+            std::vector<int32_t> countIndex(1, 0);
+            countIndex.insert(countIndex.end(), listPos.begin(), listPos.end());
+            emfCheck(emf_hip_visibilityFlagsIndexed(visCounts.as<int32_t>(), nlocal + 1,
+                                                    countIndex.data(), params.visibilityThresh,
+                                                    visibleDev.as<int32_t>(), main.abi()),
+                     "visibilityFlagsIndexed");
+        }
+    }
+    stamp(kComposite);
+    vis_objs.clear();
+    visPending = false;
+    if (nall == 0) return;
+    int32_t* dst = deviceGate ? visibleHost : visCountsHost;
+    hipCheck(hipMemcpyAsync(dst, visCounts.data(), sizeof(int32_t) * nall, hipMemcpyDeviceToHost,
+                            main.get()),
+             "visCounts D2H");
+    if (deviceGate) {
+        hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
+        visIds = allIds;
+        visPending = true;
+        return;
+    }
+    main.waitForCompletion();
+    for (int k = 0; k < nall; ++k)
+        if (visCountsHost[k] > params.visibilityThresh) vis_objs.insert(allIds[k]);
+}
+
 // ---- per-volume path -------------------------------------------------------------------------------
 
 void EMFusion::estepPerVolume() {
@@ -537,7 +607,7 @@ void EMFusion::estepPerVolume() {
     const emf_image_t nv = associationNorm.view();
     auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * static_cast<double>(maps.size()),
                             main);
-    if (world == 1) {
+    if (!sharded) {
         emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()),
                                               static_cast<int>(maps.size()), nullptr, &nv,
                                               main.abi()),

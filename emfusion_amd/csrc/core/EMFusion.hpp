@@ -137,6 +137,7 @@ private:
     void raycastBatched();
     void integrateBatched();
     void compositeAndVisibility(bool deviceGate);
+    void compositeAcrossRanks(bool deviceGate);
     void refreshVisibleFromDevice();
     // legacy path: one stream per volume, host-side visibility gate (reference structure)
     void estepPerVolume();
@@ -182,6 +183,7 @@ private:
     // device-resident model table for the batched launches (slot 0 = background)
     bool batched = true;            // false: per-volume launches (see EMFusion.cpp)
     bool forceLegacy = false;
+    bool sharded = false;           // objects sharded over ranks: use the cross-rank exchanges
     DeviceBuffer modelTable;        // emf_model_t[EMF_MAX_BATCH]
     std::vector<emf_model_t> modelsHost;
     std::vector<int32_t> resHost;   // 3 per model

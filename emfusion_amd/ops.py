@@ -289,3 +289,41 @@ def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):
     check("emf_hip_visibilityFlags",
           _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible),
                                      _stream(stream)))
+
+
+# ---- cross-GPU compositing ------------------------------------------------------------------------
+
+def pack_hit_keys(list_pos, obj_ray, obj_seg, keys, width, height, stream=None):
+    n = len(list_pos)
+    pos = (C.c_int32 * max(n, 1))(*[int(p) for p in list_pos])
+    assert keys.dtype == np.dtype(np.uint64)
+    check("emf_hip_packHitKeys",
+          _L.emf_hip_packHitKeys(n, pos, _views(obj_ray), _views(obj_seg), _ptr(keys), width,
+                                 height, _stream(stream)))
+    return keys
+
+
+def composite_from_keys(keys, ids_all, list_pos, obj_ray, obj_vert, obj_norm, bg_ray, bg_vert,
+                        bg_norm, bg_mask, ray, vert, norm, seg, diff, no_obj, boundary, vis_counts,
+                        stream=None):
+    nall, n = len(ids_all), len(list_pos)
+    ids = (C.c_int32 * max(nall, 1))(*[int(i) for i in ids_all])
+    pos = (C.c_int32 * max(n, 1))(*[int(p) for p in list_pos])
+    check("emf_hip_compositeFromKeys",
+          _L.emf_hip_compositeFromKeys(_ptr(keys), nall, ids, n, pos, _views(obj_ray),
+                                       _views(obj_vert), _views(obj_norm),
+                                       C.byref(image_view(bg_ray)), C.byref(image_view(bg_vert)),
+                                       C.byref(image_view(bg_norm)), C.byref(image_view(bg_mask)),
+                                       C.byref(image_view(ray)), C.byref(image_view(vert)),
+                                       C.byref(image_view(norm)), C.byref(image_view(seg)),
+                                       C.byref(image_view(diff)), C.byref(image_view(no_obj)),
+                                       boundary, _ptr(vis_counts if nall else None),
+                                       _stream(stream)))
+
+
+def visibility_flags_indexed(vis_counts, count_index, thresh, visible, stream=None):
+    n = len(count_index)
+    idx = (C.c_int32 * max(n, 1))(*[int(i) for i in count_index])
+    check("emf_hip_visibilityFlagsIndexed",
+          _L.emf_hip_visibilityFlagsIndexed(_ptr(vis_counts), n, idx, thresh, _ptr(visible),
+                                            _stream(stream)))

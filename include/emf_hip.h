@@ -284,8 +284,46 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,
                             int32_t* visible_dev, emf_stream_t stream);
 
-/* Fill a brick flag array for a freshly zeroed volume (all EMF_BRICK_ALL_ZERO). */
+/* Fill a brick flag buffer (2 * B bytes) for a freshly zeroed volume (all EMF_BRICK_ALL_ZERO). */
 int emf_hip_resetBrickFlags(uint8_t* brickFlags, const int32_t res[3], emf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cross-GPU compositing (object volumes sharded over ranks).  The reference
+ * is single-GPU; these three calls bracket the ONE all-reduce(min, u64, W*H) that merges the
+ * nearest raycast hit over the objects of all ranks with the reference's tie rule (first object in
+ * creation order keeps the pixel, EMFusion.cpp:760-771):
+ *   key = (float_bits(raylength) << 32) | listPosition,   no hit = all ones.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* keys[pixel] = min key over this rank's objects.  listPos_host[k] = position of local object k in
+ * the global creation-order list; objRay / objSeg: its raycast raylengths (f32) and hit mask (u8).
+ * 0 <= nlocal <= EMF_MAX_BATCH; keys: u64 W x H, overwritten. */
+int emf_hip_packHitKeys(int nlocal, const int32_t* listPos_host, const emf_image_t* objRay_host,
+                        const emf_image_t* objSeg_host, uint64_t* keys, int width, int height,
+                        emf_stream_t stream);
+
+/* Finish the composite from all-reduced keys: segmentation id = ids_host[listPosition], raylength
+ * from the key, vertex / normal from the winner's images when it lives on this rank (zeros
+ * otherwise: they only feed rendering), then the background override, noObj mask, background
+ * vertices / normals and per-object visibility counts exactly as emf_hip_compositeRaycast
+ * (EMFusion.cpp:773-794).  ids_host: ids of ALL nall objects in creation order; visCounts: device
+ * int32[nall], overwritten. */
+int emf_hip_compositeFromKeys(const uint64_t* keys, int nall, const int32_t* ids_host, int nlocal,
+                              const int32_t* listPos_host, const emf_image_t* objRay_host,
+                              const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                              const emf_image_t* bgRay, const emf_image_t* bgVert,
+                              const emf_image_t* bgNorm, const emf_image_t* bgMask,
+                              const emf_image_t* ray, const emf_image_t* vert,
+                              const emf_image_t* norm, const emf_image_t* seg,
+                              const emf_image_t* diff, const emf_image_t* noObj, int boundary,
+                              int32_t* visCounts, emf_stream_t stream);
+
+/* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[countIndex_host[slot]] > visibilityThresh):
+ * emf_hip_visibilityFlags for a rank whose model slots map to arbitrary entries of a global count
+ * array.  1 <= nmodels <= EMF_MAX_BATCH. */
+int emf_hip_visibilityFlagsIndexed(const int32_t* visCounts, int nmodels,
+                                   const int32_t* countIndex_host, int visibilityThresh,
+                                   int32_t* visible_dev, emf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,23 +15,31 @@ BG_RES, BG_VOX, OBJ_RES = 64, 0.04, 32
 NOBJ, NFRAMES, MASK_EVERY = 2, 6, 3
 
 
-@pytest.fixture(scope="module", params=["batched", "per_volume"])
+@pytest.fixture(scope="module", params=["batched", "per_volume", "sharded_1rank",
+                                         "sharded_1rank_per_volume"])
 def run(request, oracle, dev):
-    """Both execution paths of emf::EMFusion: batched model-table launches (default) and the
-    reference-shaped one-stream-per-volume path (EMF_PER_VOLUME=1)."""
+    """Execution paths of emf::EMFusion: batched model-table launches (default), the
+    reference-shaped one-stream-per-volume path (EMF_PER_VOLUME=1), and the object-sharded
+    multi-GPU path driven through a real RCCL communicator of ONE rank (EMF_FORCE_SHARDED=1):
+    E-step partial sum -> ncclAllReduce(sum) -> normalise, hit keys -> ncclAllReduce(min) ->
+    composite from keys, indexed device-side visibility gate."""
     import os
 
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
 
-    os.environ["EMF_PER_VOLUME"] = "1" if request.param == "per_volume" else "0"
+    os.environ["EMF_PER_VOLUME"] = "1" if request.param.endswith("per_volume") else "0"
+    comm = None
+    if request.param.startswith("sharded"):
+        os.environ["EMF_FORCE_SHARDED"] = "1"
+        comm = pipeline.Communicator(pipeline.Communicator.unique_id(), 0, 1)
 
     # visibility threshold / boundary scaled to the small image (reference: 1600 px, 20 px @ VGA)
     prm = pipeline.make_params(W, H, BG_RES, BG_VOX, OBJ_RES, visibility_thresh=100, boundary=5,
                                mask_frames=MASK_EVERY)
     K = np.array(prm.K, np.float32)
     synth = pipeline.SyntheticStream(W, H, K, NOBJ, seed=0xE3F5)
-    fus = pipeline.Fusion(prm)
+    fus = pipeline.Fusion(prm, comm)
     orc = OraclePipeline(oracle, W, H, K, BG_RES, BG_VOX, list(prm.volume_pose_t), OBJ_RES,
                          visibility_thresh=100, boundary=5)
     fus.enable_raycast_stats(True)
@@ -58,8 +66,11 @@ def run(request, oracle, dev):
                           masks, run_masks)
         history.append(dict(vis=sorted(fus.visible_objects()), ovis=sorted(orc.vis)))
     os.environ.pop("EMF_PER_VOLUME", None)
+    os.environ.pop("EMF_FORCE_SHARDED", None)
     yield fus, orc, ids, history
     fus.close()
+    if comm is not None:
+        comm.close()
     synth.close()
 
 
