@@ -57,13 +57,16 @@ def parse_args():
                     help="target CPU time for the oracle baseline sample")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernel launches with HIP events in the timed region")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="debug: run the cross-rank exchange path (RCCL all-reduces) even with one "
+                         "rank, to exercise the multi-GPU code on a single GPU")
     return ap.parse_args()
 
 
 def dist_setup(n_gpus):
     """Returns (rank, world, local_rank, dist module or None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and "RANK" not in os.environ:
         if n_gpus != 1:
             raise SystemExit("--gpus N > 1 needs one process per GPU: launch with "
                              "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -81,6 +84,11 @@ def dist_setup(n_gpus):
 
 def main():
     args = parse_args()
+    # torch FIRST: its wheel bundles libamdhip64.so.7 / librccl.so.1 under the same SONAMEs as
+    # /opt/rocm, so whichever copy is loaded first serves the whole process.  Importing torch
+    # before the product libraries gives one HIP runtime (and one RCCL) for torch.distributed,
+    # the kernels and the communicator alike -- see emfusion_amd/devmem.py.
+    import torch  # noqa: F401
     rank, world, local_rank, dist = dist_setup(args.gpus)
 
     from emfusion_amd import devmem, ops, pipeline
@@ -103,10 +111,12 @@ def main():
     K = np.array(prm.K, np.float32)
 
     comm = None
-    if world > 1:
-        import torch
+    if world > 1 or args.force_sharded:
+        if args.force_sharded:
+            os.environ["EMF_FORCE_SHARDED"] = "1"
         uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)  # ncclUniqueId travels over the gloo group
         comm = pipeline.Communicator(uid[0], rank, world)
 
     synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
@@ -157,20 +167,17 @@ def main():
     fus.enable_raycast_stats(True)
     barrier()
     fus.synchronize()
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()  # no torch work exists; kept for the letter of the contract
-    except Exception:
-        pass
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()  # same HIP runtime as the product libraries (imported first)
     t0 = time.perf_counter()
     for f in range(args.warmup, nframes):
         step(f)
     fus.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -266,6 +273,22 @@ def algorithmic_bytes(kind, summ, stats, P):
     return 0.0
 
 
+def measured_traffic(kind):
+    """HBM-side bytes per launch of one kernel kind from the newest committed PMC summary
+    (profiles/*_traffic.json, produced by scripts/profile_round.sh + summarize_profile.py: sized
+    TCC_EA0 read/write request counters, collected in their own rocprofv3 --pmc passes).  The
+    counters cannot be read from inside this process, so this is the figure of the profiled run of
+    the same command and workload; None if no summary is committed."""
+    files = sorted((ROOT / "profiles").glob("*_traffic.json"))
+    if not files:
+        return None
+    try:
+        k = json.loads(files[-1].read_text())["kernels"].get(kind)
+        return None if k is None else round(k["hbm_bytes_per_launch"], 1)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline(kern, stats, P):
     rows = []
     for kind, summ in kern.items():
@@ -289,7 +312,7 @@ def roofline(kern, stats, P):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
-        "traffic": None,  # PMC pass (rocprofv3 --pmc) is a separate run: see profiles/ + DESIGN.md
+        "traffic": measured_traffic(dom["kind"]),  # bytes/launch from the committed PMC pass
         "avg_launch_ms": dom["avg_ms"],
         "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
         "dropped_launches": kern.get("_dropped", 0),

@@ -1,12 +1,17 @@
 """Device memory for the Python harness, allocated through the SAME HIP runtime the product
-libraries use (/opt/rocm/lib/libamdhip64.so.7).
+libraries are bound to.
 
-Why not torch tensors: the PyTorch wheel bundles its own libamdhip64.so (a different ROCm
-release).  Two HIP runtimes can coexist in one process, but each only synchronises its own
-streams -- torch.cuda.synchronize() does not wait for kernels that libemf_hip.so launched, and a
-torch stream handle means nothing to the other runtime.  So the harness keeps every device
-pointer, stream and synchronisation on the product's runtime, and uses torch only for
-torch.distributed (gloo) rendezvous, barriers and host-side reductions.
+The PyTorch wheel bundles its own libamdhip64.so / librccl.so (another ROCm release) that carry
+the same SONAMEs as /opt/rocm's (libamdhip64.so.7, librccl.so.1).  The dynamic loader therefore
+binds libemf_hip.so / libemf_fusion.so to whichever copy entered the process first:
+  * torch imported first (bench.py)  -> everything, torch included, runs on torch's copy;
+  * torch never imported (tests)     -> everything runs on /opt/rocm's copy;
+  * product libraries first, torch later -> torch loads its own copy by file name and the process
+    holds TWO HIP runtimes, each blind to the other's streams (torch.cuda.synchronize() would not
+    wait for our kernels, a torch stream handle would mean nothing to us).
+This module never hands torch tensors to the kernels: it resolves "libamdhip64.so.7" through the
+loader, i.e. the copy the product libraries use, and keeps every device pointer, stream, event
+and synchronisation there.  torch is used by the harness for torch.distributed only.
 """
 from __future__ import annotations
 
