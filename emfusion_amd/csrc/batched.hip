@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256, 5) void k_raycast_batched(const RaycastBatchAr
         v.R = pose_R(a.poses.p[m]);
         v.cam = pose_t(a.poses.p[m]);
         v.n = I3{md.res[0], md.res[1], md.res[2]};
-        v.bricks = md.brickFlags ? md.brickFlags + brick_count(v.n) : nullptr;  // dilated half
+        // reserved bit 1: answer uniform lookups from the flags without gathering
+        v.bricks = md.brickFlags ? md.brickFlags + brick_count(v.n) : nullptr;
+        v.blendFromFlags = (md.reserved & 2) != 0;
         v.voxelSize = md.voxelSize;
         v.truncdist = md.truncdist;
         // incoming raylength is zero by construction (the reference zeroes it first, Q5)
@@ -166,7 +168,7 @@ struct IntegrateBatchArgs {
 };
 
 __global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchArgs a) {
-    __shared__ unsigned lds[4];
+    __shared__ unsigned lds[32];
     int m = 0;
     while (m + 1 < a.nmodels && static_cast<int>(blockIdx.x) >= a.tileStart[m + 1]) ++m;
     if (a.visible && a.visible[m] == 0) return;  // EMFusion.cpp:869-872, decided on the device

@@ -60,7 +60,8 @@ void ObjTSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_i
                       const emf_image_t& mask, Stream& stream, uint64_t* stats) {
     const Affine3f rel_pose_CO = pose.inv() * cam_pose;
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(),
-                                 fgVolMask.as<uint8_t>(), brickFlags.as<uint8_t>(), &raylengths, &vertices, &normals, &mask,
+                                 fgVolMask.as<uint8_t>(),
+                                 brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr, &raylengths, &vertices, &normals, &mask,
                                  rel_pose_CO.rotation().val, rel_pose_CO.translation().val,
                                  intr.val, volumeRes.val, voxelSize, truncdist, stats,
                                  stream.abi()),

@@ -1,6 +1,8 @@
 // TSDF.cpp -- emf::TSDF over the emf_hip_* C ABI (see TSDF.hpp).
 #include "TSDF.hpp"
 
+#include <cstdlib>
+
 namespace emf {
 
 TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
@@ -13,8 +15,8 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
       frameSize(_frameSize),
       tsdfVol(voxels() * sizeof(float)),
       tsdfWeights(voxels() * sizeof(float)),
-      brickFlags(2 * static_cast<size_t>((_volumeRes[0] + 7) / 8) * ((_volumeRes[1] + 7) / 8) *
-                 ((_volumeRes[2] + 7) / 8)) {  // raw flags + dilated flags
+      brickFlags(2 * static_cast<size_t>((_volumeRes[0] + 3) / 4) * ((_volumeRes[1] + 3) / 4) *
+                 ((_volumeRes[2] + 3) / 4)) {  // raw flags + dilated flags
     if (gradMode == Gradients::Materialized) tsdfGrads = DeviceBuffer(voxels() * 3 * sizeof(float));
     reset(_pose);
 }
@@ -49,7 +51,8 @@ void TSDF::integrate(const emf_image_t& depth, const emf_image_t& weights,
                      const Affine3f& cam_pose, const Matx33f& intr, Stream& stream) {
     const Affine3f rel_pose_OC = cam_pose.inv() * pose;  // volume -> camera
     emfCheck(emf_hip_updateTSDF(&depth, &weights, tsdfVol.as<float>(), tsdfWeights.as<float>(),
-                                brickFlags.as<uint8_t>(), rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
+                                brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr,
+                                rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
                                 intr.val, volumeRes.val, voxelSize, truncdist,
                                 params.maxTSDFWeight, stream.abi()),
              "TSDF::integrate");
@@ -67,7 +70,7 @@ void TSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_imag
                    const emf_image_t& mask, Stream& stream, uint64_t* stats) {
     const Affine3f rel_pose_CO = pose.inv() * cam_pose;  // camera -> volume
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(), nullptr,
-                                 brickFlags.as<uint8_t>(), &raylengths, &vertices, &normals, &mask,
+                                 brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr, &raylengths, &vertices, &normals, &mask,
                                  rel_pose_CO.rotation().val, rel_pose_CO.translation().val,
                                  intr.val, volumeRes.val, voxelSize, truncdist, stats,
                                  stream.abi()),
@@ -85,13 +88,20 @@ void TSDF::computeAssociation(const emf_image_t& points, const Affine3f& cam_pos
              "TSDF::computeAssociation");
 }
 
+int TSDF::brickFlagMode() {
+    static const int mode = [] {
+        const char* e = std::getenv("EMF_BRICK_FLAGS");
+        return e ? (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)) : 0;
+    }();
+    return mode;
+}
+
 void TSDF::describe(emf_model_t& m) const {
     m.tsdf = tsdfVol.as<float>();
     m.weights = tsdfWeights.as<float>();
     m.grads = gradsPtr();
     m.fgProbs = nullptr;
     m.fgVolMask = nullptr;
-    m.brickFlags = brickFlags.as<uint8_t>();
     m.res[0] = volumeRes[0];
     m.res[1] = volumeRes[1];
     m.res[2] = volumeRes[2];
@@ -103,7 +113,15 @@ void TSDF::describe(emf_model_t& m) const {
     m.assocC2 = 1.f / (2.f * params.assocSigma);        // reference TSDF.cpp:154
     m.alpha = params.alpha;
     m.assocC3 = (1 - params.alpha) * params.uniPrior;   // reference TSDF.cpp:133
-    m.reserved = 0;
+    // EMF_BRICK_FLAGS selects how the brick uniformity flags are used by the class-level path:
+    //   0 (default) not maintained, not used -- on the bench scene the march time is set by a few
+    //     hundred image-border rays that graze seen/unseen space through MIXED bricks, so skipping
+    //     work elsewhere does not shorten the kernel while maintaining the flags costs ~0.2 ms
+    //   1 maintained by integrate, raycast fast-forwards through deep-uniform bricks
+    //   2 as 1, and uniform lookups are answered from the flags without gathering
+    const int mode = brickFlagMode();
+    m.brickFlags = mode ? brickFlags.as<uint8_t>() : nullptr;
+    m.reserved = mode == 2 ? 2 : 0;
 }
 
 std::vector<float> TSDF::getTSDF() const {

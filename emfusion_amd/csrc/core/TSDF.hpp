@@ -89,6 +89,8 @@ public:
      * (emf_model_t, include/emf_hip.h); image pointers are filled in by the owner of the images.
      */
     virtual void describe(emf_model_t& m) const;
+    /** 0 / 1 / 2 from the environment variable EMF_BRICK_FLAGS, see TSDF.cpp. */
+    static int brickFlagMode();
 
 protected:
     TSDFParams params;

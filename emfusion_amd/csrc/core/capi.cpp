@@ -291,9 +291,9 @@ int emf_fusion_get_volume(emf_fusion_t* h, int which, int obj_id, void** dev_ptr
         case EMF_VOL_WEIGHTS: *dev_ptr = const_cast<float*>(vol->weightsPtr()); return EMF_OK;
         case EMF_VOL_BRICKS:
             *dev_ptr = vol->brickFlagsPtr();
-            res[0] = (r[0] + 7) / 8;
-            res[1] = (r[1] + 7) / 8;
-            res[2] = (r[2] + 7) / 8;
+            res[0] = (r[0] + 3) / 4;
+            res[1] = (r[1] + 3) / 4;
+            res[2] = (r[2] + 3) / 4;
             return EMF_OK;
         case EMF_VOL_FGPROBS:
             if (obj) {

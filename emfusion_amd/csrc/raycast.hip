@@ -31,11 +31,14 @@ struct RaycastArgs {
     unsigned long long* stats;
 };
 
-__global__ __launch_bounds__(256, 5) void k_raycast(const RaycastArgs a) {
-    // wave w of the block covers the 8x8 tile at (w & 1, w >> 1) of the block's 16x16 tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+// One-wave workgroups: the march is latency-bound and a VGA frame is a single round of 4800
+// waves, so what matters is that EVERY wave is resident from the start.  With 4-wave workgroups
+// a CU holds 5 of them at 96 VGPRs (1280 slots for 1200 workgroups) and any imbalance of the
+// dispatcher sends stragglers into a second round; single waves are placed SIMD by SIMD.
+__global__ __launch_bounds__(64, 5) void k_raycast(const RaycastArgs a) {
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 8 + (lane & 7);
+    const int y = blockIdx.y * 8 + (lane >> 3);
     unsigned nsamples = 0, nhits = 0, ngath = 0, nskip = 0;
     if (x < a.w && y < a.h) {
         // non-zero incoming raylength: do not search past another volume's hit (TSDF.cu:496-500)
@@ -98,6 +101,7 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.vol.n = i3_from(res);
     // the flag buffer holds the raw flags followed by the dilated flags; the march reads the latter
     a.vol.bricks = brickFlags ? brickFlags + brick_count(a.vol.n) : nullptr;
+    a.vol.blendFromFlags = false;
     a.vol.voxelSize = voxelSize;
     a.vol.truncdist = truncdist;
     a.ray = img<float>(raylengths);
@@ -111,7 +115,7 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.cx = K[2];
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
-    hipLaunchKernelGGL(k_raycast, dim3(ceil_div(a.w, 16), ceil_div(a.h, 16)), dim3(256), 0,
+    hipLaunchKernelGGL(k_raycast, dim3(ceil_div(a.w, 8), ceil_div(a.h, 8)), dim3(64), 0,
                        as_stream(stream), a);
     return launch_status("raycastTSDF");
 }

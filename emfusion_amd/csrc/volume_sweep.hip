@@ -12,7 +12,7 @@ constexpr int kBlock = 256;
 // ---- a7: TSDF integration (reference kernel_updateTSDF, TSDF.cu:327-401) -------------------------
 //
 // Two kernels share the per-voxel code of device_core.hpp:
-//   k_update_tsdf_tiled  Nx % 4 == 0: one workgroup per 32 x 8 x 8 voxel tile (= four 8^3 bricks).
+//   k_update_tsdf_tiled  Nx % 4 == 0: one workgroup per 32 x 8 x 8 voxel tile (= 32 bricks of 4^3).
 //       Each lane owns 4 consecutive x voxels (16-byte accesses, a wave covers eight 128-byte row
 //       segments); tiles that provably project outside the image are culled with 8 corner
 //       projections instead of 2048 voxel projections; the brick uniformity flags of the tile are
@@ -26,7 +26,7 @@ struct TileGrid {
 __global__ __launch_bounds__(kBlock) void k_update_tsdf_tiled(const IntegrateGeom a, float* tsdf,
                                                               float* weights, uint8_t* bricks,
                                                               const TileGrid g) {
-    __shared__ unsigned lds[4];
+    __shared__ unsigned lds[32];
     const int b = blockIdx.x;
     const int tx = b % g.ntx, ty = (b / g.ntx) % g.nty, tz = b / (g.ntx * g.nty);
     integrate_tile(a, tsdf, weights, bricks, tx * kTileX, ty * kTileY, tz * kTileZ, lds);

@@ -73,7 +73,7 @@ def compute_points(depth, K, points, stream=None):
 def brick_shape(vol_shape):
     """Shape (2, Bz, By, Bx) of the brick flag buffer of a (Nz, Ny, Nx) volume: [0] raw flags,
     [1] dilated flags."""
-    return (2,) + tuple((n + 7) // 8 for n in vol_shape[:3])
+    return (2,) + tuple((n + 3) // 4 for n in vol_shape[:3])
 
 
 def reset_brick_flags(tsdf_like, flags, stream=None):

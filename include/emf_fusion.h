@@ -62,7 +62,7 @@ enum emf_fusion_volume {
     EMF_VOL_WEIGHTS = 1,  /* f32 */
     EMF_VOL_FGPROBS = 2,  /* f32, objects only */
     EMF_VOL_FGMASK = 3,   /* u8,  objects only */
-    EMF_VOL_BRICKS = 4    /* u8,  brick uniformity flags, ceil(N/8) per axis (res = brick grid) */
+    EMF_VOL_BRICKS = 4    /* u8,  brick uniformity flags, ceil(N/4) per axis (res = brick grid) */
 };
 
 const char* emf_fusion_last_error_string(void);

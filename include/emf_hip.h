@@ -61,15 +61,15 @@ typedef struct emf_image {
 #define EMF_MAX_MODELS 256 /* background + objects handled by one call (seg ids are u8) */
 #define EMF_MAX_BATCH 32   /* models per batched (model-table) launch */
 
-/* Brick uniformity flags: one byte per 8x8x8 brick of a TSDF volume, B = ceil(Nx/8) * ceil(Ny/8) *
- * ceil(Nz/8) bricks, x fastest.  0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly
- * 0 / +1 / -1.  A flag BUFFER holds 2 * B bytes: the raw flags, then the dilated flags (a brick
- * keeps its class only if all of its neighbours share it).  emf_hip_updateTSDF maintains both;
+/* Brick uniformity flags: one byte per 4x4x4 brick of a TSDF volume, B = ceil(Nx/4) * ceil(Ny/4) *
+ * ceil(Nz/4) bricks, x fastest.  0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly
+ * 0 / +1 / -1.  A flag BUFFER holds 2 * B bytes: the raw flags, then the dilated flags
+ * (class | D << 3, D in 1..3 = every brick within Chebyshev distance D shares the class; 0 else).  emf_hip_updateTSDF maintains both;
  * emf_hip_raycastTSDF uses the dilated half to evaluate lookups in uniform regions without
  * gathering and to fast-forward through them (bit-identical results).  A buffer starts as all 1
  * for a zeroed volume (emf_hip_resetBrickFlags) and must be passed to EVERY integration of that
  * volume. */
-#define EMF_BRICK 8
+#define EMF_BRICK 4
 #define EMF_BRICK_MIXED 0
 #define EMF_BRICK_ALL_ZERO 1
 #define EMF_BRICK_ALL_ONE 2

@@ -101,3 +101,25 @@ if len(sys.argv) > 3 and sys.argv[3] == "dump":
     np.save("gpurun_out/bg_tsdf_slice_y256.npy", t[:, 256, :])
     np.save("gpurun_out/bg_tsdf_slice_z100.npy", t[100, :, :])
     print("dumped")
+
+if len(sys.argv) > 2 and sys.argv[2] == "tail":
+    from oracle import binding as oracle
+    oracle.set_threads(0)
+    tsdf = bg_t.numpy(); wts = bg_w.numpy()
+    out = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, Rco, tco, K, np.float32(0.01), np.float32(0.1), count_steps=True)
+    st = out[4].astype(np.int64)
+    print("steps/ray: mean %.1f p50 %d p90 %d p99 %d p99.9 %d max %d" % (st.mean(), np.percentile(st, 50), np.percentile(st, 90), np.percentile(st, 99), np.percentile(st, 99.9), st.max()))
+    t8 = st.reshape(H // 8, 8, W // 8, 8)
+    wmax = t8.max((1, 3)); wmean = t8.mean((1, 3))
+    print("per-wave max steps: mean %.1f p50 %d p90 %d p99 %d max %d ; sum over waves of max = %d vs sum of all samples/64 = %d" % (wmax.mean(), np.percentile(wmax, 50), np.percentile(wmax, 90), np.percentile(wmax, 99), wmax.max(), wmax.sum(), st.sum() // 64))
+    for thr in (300, 400, 500):
+        ys, xs = np.nonzero(st > thr)
+        if len(ys):
+            print(f"rays > {thr} steps: {len(ys)}; x range {xs.min()}..{xs.max()}, y range {ys.min()}..{ys.max()}; "
+                  f"within 8 px of border: {np.mean((xs < 8) | (xs >= W - 8) | (ys < 8) | (ys >= H - 8)):.2f}; hit rate {out[3][ys, xs].mean():.2f}; "
+                  f"mean depth of hit {out[0][ys, xs][out[3][ys, xs] > 0].mean() if (out[3][ys, xs] > 0).any() else -1:.2f}")
+    # which waves are the slowest and what do their rays go through
+    iy, ix = np.unravel_index(np.argsort(wmax.ravel())[-8:], wmax.shape)
+    for a, b in zip(iy, ix):
+        tile = st[a * 8:a * 8 + 8, b * 8:b * 8 + 8]
+        print("slow wave tile (%d,%d): max %d mean %.0f min %d; ray length of hits mean %.2f" % (b * 8, a * 8, tile.max(), tile.mean(), tile.min(), out[0][a * 8:a * 8 + 8, b * 8:b * 8 + 8].mean()))

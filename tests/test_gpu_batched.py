@@ -29,31 +29,38 @@ def frame(i):
     return cam, depth, ids
 
 
+BRICK = 4  # EMF_BRICK
+
+
 def brick_classes(tsdf):
-    """Reference flags from voxel values: 1/2/4 where a whole 8^3 brick is exactly 0/+1/-1."""
+    """Reference flags from voxel values: 1/2/4 where a whole 4^3 brick is exactly 0/+1/-1."""
     nz, ny, nx = tsdf.shape
-    bz, by, bx = [(n + 7) // 8 for n in (nz, ny, nx)]
+    bz, by, bx = [(n + BRICK - 1) // BRICK for n in (nz, ny, nx)]
     out = np.zeros((bz, by, bx), np.uint8)
     for code, val in ((1, 0.0), (2, 1.0), (4, -1.0)):
-        eq = np.ones((bz * 8, by * 8, bx * 8), bool)  # padding outside the volume is neutral
+        eq = np.ones((bz * BRICK, by * BRICK, bx * BRICK), bool)  # outside the volume: neutral
         eq[:nz, :ny, :nx] = tsdf == val
-        u = eq.reshape(bz, 8, by, 8, bx, 8).all((1, 3, 5))
+        u = eq.reshape(bz, BRICK, by, BRICK, bx, BRICK).all((1, 3, 5))
         out[u] = code
     return out
 
 
-def dilate(raw):
-    """Dilated flags: a brick keeps its class only if all in-volume neighbours share it."""
-    out = raw.copy()
+def dilate(raw, max_depth=3):
+    """Dilated flags: class | D << 3, D in 1..3 the largest depth such that every in-volume brick
+    within Chebyshev distance D shares the (non-zero) class; 0 where D would be 0."""
     bz, by, bx = raw.shape
-    pad = np.full((bz + 2, by + 2, bx + 2), 255, np.uint8)  # 255 = outside the volume: ignored
-    pad[1:-1, 1:-1, 1:-1] = raw
-    for dz in range(3):
-        for dy in range(3):
-            for dx in range(3):
-                nb = pad[dz:dz + bz, dy:dy + by, dx:dx + bx]
-                out[(nb != raw) & (nb != 255)] = 0
-    return out
+    depth = np.zeros(raw.shape, np.uint8)
+    ok = raw != 0
+    for D in range(1, max_depth + 1):
+        pad = np.full((bz + 2 * D, by + 2 * D, bx + 2 * D), 255, np.uint8)  # 255 = outside: ignored
+        pad[D:-D, D:-D, D:-D] = raw
+        for dz in range(2 * D + 1):
+            for dy in range(2 * D + 1):
+                for dx in range(2 * D + 1):
+                    nb = pad[dz:dz + bz, dy:dy + by, dx:dx + bx]
+                    ok &= (nb == raw) | (nb == 255)
+        depth[ok & ((raw == 2) | (D == 1))] = D  # depth > 1 is only searched for free space (+1)
+    return np.where(depth > 0, raw | (depth << 3), 0).astype(np.uint8)
 
 
 def check_flags(got, tsdf, what):
