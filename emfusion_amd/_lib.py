@@ -58,7 +58,7 @@ SIGNATURES = {
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
-    "emf_hip_raycastBatched": [_FP, _FP, C.c_int, C.c_int, C.c_int, _F9, _FP, _STREAM],
+    "emf_hip_raycastBatched": [_FP, _FP, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _STREAM],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _F9, _FP, _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],

@@ -9,7 +9,8 @@
 //                       zero-filled by the kernel itself (no memsets)
 //   k_integrate_batched all models' 32x8x8 voxel tiles in one grid, visibility gate read on device
 // All arithmetic comes from device_core.hpp, i.e. it is the same code the per-volume kernels run.
-#include "device_core.hpp"
+#include "march_spec.hpp"
+#include "march_wave.hpp"
 
 namespace emf_hip {
 namespace {
@@ -102,7 +103,14 @@ struct RaycastBatchArgs {
     unsigned long long* stats;
 };
 
-__global__ __launch_bounds__(256, 5) void k_raycast_batched(const RaycastBatchArgs a) {
+#ifndef EMF_RB_WAVES
+#define EMF_RB_WAVES 4  // waves (8x8 pixel sub-tiles) per workgroup: 4 = 16x16 tile, 1 = 8x8 tile
+#endif
+constexpr int kRbWaves = EMF_RB_WAVES;
+constexpr int kRbTile = kRbWaves == 4 ? 16 : 8;
+
+template <bool WAVE>
+__global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
     // grid = nmodels x (8 * chunk) blocks, model-major: the background's (longest) rays start first.
     // Block b runs on XCD b % 8 (observed dispatch order; used for L2 locality only): give each XCD
     // a contiguous run of `chunk` tiles in raster order, i.e. a horizontal band of the image, so
@@ -111,33 +119,38 @@ __global__ __launch_bounds__(256, 5) void k_raycast_batched(const RaycastBatchAr
     const int m = blockIdx.x / perModel;
     const int i = blockIdx.x - m * perModel;
     const int tile = (i & 7) * a.chunk + (i >> 3);
-    if (tile >= a.tilesX * a.tilesY) return;
+    if (tile >= a.tilesX * a.tilesY) return;  // block-uniform
     const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = txx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = tyy * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int x = txx * kRbTile + (wave & 1) * 8 + (lane & 7);
+    const int y = tyy * kRbTile + (wave >> 1) * 8 + (lane >> 3);
     const emf_model_t& md = a.models[m];
-    unsigned nsamples = 0, nhits = 0, ngath = 0, nskip = 0;
-    if (x < a.w && y < a.h) {
-        RayVolume v;
-        v.tsdf = md.tsdf;
-        v.grads = md.grads;
-        v.weights = md.weights;
-        v.fg = md.fgVolMask;
-        v.R = pose_R(a.poses.p[m]);
-        v.cam = pose_t(a.poses.p[m]);
-        v.n = I3{md.res[0], md.res[1], md.res[2]};
-        // reserved bit 1: answer uniform lookups from the flags without gathering
-        v.bricks = md.brickFlags ? md.brickFlags + brick_count(v.n) : nullptr;
-        v.blendFromFlags = (md.reserved & 2) != 0;
-        v.voxelSize = md.voxelSize;
-        v.truncdist = md.truncdist;
-        // incoming raylength is zero by construction (the reference zeroes it first, Q5)
-        const RayHit r = march_ray(v, x, y, a.fx, a.fy, a.cx, a.cy, 0.f);
-        nsamples = r.samples;
-        ngath = r.gathered;
-        nskip = r.skipped;
-        nhits = r.hit ? 1u : 0u;
+    const bool valid = x < a.w && y < a.h;
+    RayVolume v;
+    v.tsdf = md.tsdf;
+    v.grads = md.grads;
+    v.weights = md.weights;
+    v.fg = md.fgVolMask;
+    v.R = pose_R(a.poses.p[m]);
+    v.cam = pose_t(a.poses.p[m]);
+    v.n = I3{md.res[0], md.res[1], md.res[2]};
+    // reserved bit 1: answer uniform lookups from the flags without gathering
+    v.bricks = (!WAVE && md.brickFlags) ? md.brickFlags + brick_count(v.n) : nullptr;
+    v.blendFromFlags = (md.reserved & 2) != 0;
+    v.voxelSize = md.voxelSize;
+    v.truncdist = md.truncdist;
+    // incoming raylength is zero by construction (the reference zeroes it first, Q5)
+    RayHit r;
+    if constexpr (WAVE) {
+        r = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, lane);  // all 64 lanes
+    } else {
+        r.hit = false;
+        r.samples = r.gathered = r.skipped = 0;
+        r.raylength = 0.f;
+        r.vertex = r.normal = v3(0.f, 0.f, 0.f);
+        if (valid) r = march_ray(v, x, y, a.fx, a.fy, a.cx, a.cy, 0.f);
+    }
+    if (valid) {
         const size_t pix = static_cast<size_t>(y) * a.w + x;
         md.raylengths[pix] = r.raylength;  // zeros where there is no hit
         float* pv = md.vertices + 3 * pix;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_batched(const RaycastBatchAr
         pn[2] = r.normal.z;
         md.hitMask[pix] = r.hit ? 1 : 0;
     }
-    add_ray_stats(a.stats, nsamples, nhits, ngath, nskip, lane);
+    add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
 }
 
 // ---- batched integration ---------------------------------------------------------------------------
@@ -272,8 +285,8 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 }
 
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
-                           int nmodels, int width, int height, const float K[9], uint64_t* stats,
-                           emf_stream_t stream) {
+                           int nmodels, int width, int height, const float K[9],
+                           int useBrickFlags, uint64_t* stats, emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
     EMF_REQUIRE_PTR(K);
     if (width <= 0 || height <= 0)
@@ -284,16 +297,24 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.nmodels = nmodels;
     a.w = width;
     a.h = height;
-    a.tilesX = static_cast<int>(ceil_div(width, 16));
-    a.tilesY = static_cast<int>(ceil_div(height, 16));
+    a.tilesX = static_cast<int>(ceil_div(width, kRbTile));
+    a.tilesY = static_cast<int>(ceil_div(height, kRbTile));
     a.chunk = static_cast<int>(ceil_div(static_cast<size_t>(a.tilesX) * a.tilesY, 8));
     a.fx = K[0];
     a.fy = K[4];
     a.cx = K[2];
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
-    hipLaunchKernelGGL(k_raycast_batched, dim3(static_cast<unsigned>(nmodels) * 8u * a.chunk),
-                       dim3(256), 0, as_stream(stream), a);
+    const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk);
+#ifdef EMF_RB_PLAIN  // experiment switch: per-lane march without flags
+    useBrickFlags = 1;
+#endif
+    if (useBrickFlags)
+        hipLaunchKernelGGL(k_raycast_batched<false>, grid, dim3(64 * kRbWaves), 0,
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(k_raycast_batched<true>, grid, dim3(64 * kRbWaves), 0,
+                           as_stream(stream), a);
     return launch_status("raycastBatched");
 }
 

@@ -440,7 +440,8 @@ void EMFusion::raycastBatched() {
         auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
         emfCheck(emf_hip_raycastBatched(modelTable.as<emf_model_t>(), co.data(), n,
                                         params.frameSize.width, params.frameSize.height,
-                                        params.intr.val, stats, main.abi()),
+                                        params.intr.val, TSDF::brickFlagMode() != 0, stats,
+                                        main.abi()),
                  "raycastBatched");
     }
     stamp(kRaycast);

@@ -17,7 +17,8 @@
 //     (fg ? w : 0) instead of materialising ObjTSDF::raycastWeights every frame
 //   * with brick uniformity flags, lookups inside uniform regions blend the constant instead of
 //     gathering eight equal values
-#include "device_core.hpp"
+#include "march_spec.hpp"
+#include "march_wave.hpp"
 
 namespace emf_hip {
 namespace {
@@ -35,32 +36,38 @@ struct RaycastArgs {
 // waves, so what matters is that EVERY wave is resident from the start.  With 4-wave workgroups
 // a CU holds 5 of them at 96 VGPRs (1280 slots for 1200 workgroups) and any imbalance of the
 // dispatcher sends stragglers into a second round; single waves are placed SIMD by SIMD.
-__global__ __launch_bounds__(64, 5) void k_raycast(const RaycastArgs a) {
+// WAVE: wave-scheduled march with cooperative tail (march_wave.hpp) -- the default; the flag-aware
+// per-lane march (device_core.hpp) is used when the caller supplies brick flags.
+
+template <bool WAVE>
+__global__ __launch_bounds__(64) void k_raycast(const RaycastArgs a) {
     const int lane = threadIdx.x;
     const int x = blockIdx.x * 8 + (lane & 7);
     const int y = blockIdx.y * 8 + (lane >> 3);
-    unsigned nsamples = 0, nhits = 0, ngath = 0, nskip = 0;
-    if (x < a.w && y < a.h) {
-        // non-zero incoming raylength: do not search past another volume's hit (TSDF.cu:496-500)
-        const RayHit r = march_ray(a.vol, x, y, a.fx, a.fy, a.cx, a.cy, a.ray.row(y)[x]);
-        nsamples = r.samples;
-        ngath = r.gathered;
-        nskip = r.skipped;
-        if (r.hit) {  // pixels without a hit are left untouched, as in the reference
-            a.ray.row(y)[x] = r.raylength;
-            float* pv = a.vert.row(y) + 3 * x;
-            float* pn = a.nrm.row(y) + 3 * x;
-            pv[0] = r.vertex.x;
-            pv[1] = r.vertex.y;
-            pv[2] = r.vertex.z;
-            pn[0] = r.normal.x;
-            pn[1] = r.normal.y;
-            pn[2] = r.normal.z;
-            a.mask.row(y)[x] = 1;
-            nhits = 1;
-        }
+    const bool valid = x < a.w && y < a.h;
+    // non-zero incoming raylength: do not search past another volume's hit (TSDF.cu:496-500)
+    const float old = valid ? a.ray.row(y)[x] : 0.f;
+    RayHit r;
+    if constexpr (WAVE) {
+        r = march_wave(a.vol, valid, x, y, a.fx, a.fy, a.cx, a.cy, old, lane);  // all lanes
+    } else {
+        r.hit = false;
+        r.samples = r.gathered = r.skipped = 0;
+        if (valid) r = march_ray(a.vol, x, y, a.fx, a.fy, a.cx, a.cy, old);
     }
-    add_ray_stats(a.stats, nsamples, nhits, ngath, nskip, lane);
+    if (valid && r.hit) {  // pixels without a hit are left untouched, as in the reference
+        a.ray.row(y)[x] = r.raylength;
+        float* pv = a.vert.row(y) + 3 * x;
+        float* pn = a.nrm.row(y) + 3 * x;
+        pv[0] = r.vertex.x;
+        pv[1] = r.vertex.y;
+        pv[2] = r.vertex.z;
+        pn[0] = r.normal.x;
+        pn[1] = r.normal.y;
+        pn[2] = r.normal.z;
+        a.mask.row(y)[x] = 1;
+    }
+    add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
 }
 
 }  // namespace
@@ -115,7 +122,11 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.cx = K[2];
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
-    hipLaunchKernelGGL(k_raycast, dim3(ceil_div(a.w, 8), ceil_div(a.h, 8)), dim3(64), 0,
-                       as_stream(stream), a);
+    if (brickFlags)
+        hipLaunchKernelGGL(k_raycast<false>, dim3(ceil_div(a.w, 8), ceil_div(a.h, 8)), dim3(64), 0,
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(k_raycast<true>, dim3(ceil_div(a.w, 8), ceil_div(a.h, 8)), dim3(64), 0,
+                           as_stream(stream), a);
     return launch_status("raycastTSDF");
 }

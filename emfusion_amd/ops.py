@@ -271,10 +271,12 @@ def estep_batched(models_dev, poses_co, points, normalize=True, norm=None, obj_s
                                   _stream(stream)))
 
 
-def raycast_batched(models_dev, poses_co, width, height, K, stats=None, stream=None):
+def raycast_batched(models_dev, poses_co, width, height, K, stats=None, use_brick_flags=False,
+                    stream=None):
     check("emf_hip_raycastBatched",
           _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), len(poses_co), width,
-                                    height, _f(K, 9), _ptr(stats), _stream(stream)))
+                                    height, _f(K, 9), int(use_brick_flags), _ptr(stats),
+                                    _stream(stream)))
 
 
 def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None):

@@ -259,10 +259,13 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 /* Raycast of all models in one launch (TSDF.cu:466-601 per model, ObjTSDF.cpp:203-216).
  * Unlike emf_hip_raycastTSDF the outputs need no pre-zeroing: every pixel of every model's
  * raylengths / vertices / normals / hitMask is written (zeros where there is no hit), which is
- * what the reference's setTo(0) + kernel leave behind (EMFusion.cpp:727-758). */
+ * what the reference's setTo(0) + kernel leave behind (EMFusion.cpp:727-758).
+ * useBrickFlags != 0: march with the models' brick flags (fast-forward through uniform bricks);
+ * 0: ignore them and march in speculative batches of 4 samples (one gather round trip per batch).
+ * Both produce the same images. */
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
-                           int nmodels, int width, int height, const float K[9], uint64_t* stats,
-                           emf_stream_t stream);
+                           int nmodels, int width, int height, const float K[9],
+                           int useBrickFlags, uint64_t* stats, emf_stream_t stream);
 
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera

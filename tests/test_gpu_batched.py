@@ -229,7 +229,8 @@ def test_estep_batched_matches_per_model_calls(ops, oracle, scene, dev):
         assert_parity(to_np(m.d_assoc), wv, f"map {m.id} vs oracle", rtol=4e-6)
 
 
-def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev):
+@pytest.mark.parametrize("use_flags", [False, True])
+def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, use_flags):
     cam = camera_path(4)
     table = ops.upload_models([m.table_entry() for m in scene])
     poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
@@ -239,7 +240,7 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
         m.d_nrm.copy_from(np.full((H, W, 3), 5, np.float32))
         m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
     st = dev_full((4,), 0, np.uint64)
-    ops.raycast_batched(table, poses, W, H, K, stats=st)
+    ops.raycast_batched(table, poses, W, H, K, stats=st, use_brick_flags=use_flags)
     total = 0
     for m, (R, t) in zip(scene, poses):
         want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t,
