@@ -42,7 +42,8 @@ SIGNATURES = {
     "emf_hip_device_info": [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     "emf_hip_computePoints": [_IMG, _IMG, _F9, _STREAM],
     "emf_hip_updateTSDF": [_IMG, _IMG, _FP, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, C.c_float,
-                           C.c_float, _STREAM],
+                           C.c_float, _IMG, _STREAM],
+    "emf_hip_computeInvLambda": [_F9, _IMG, _STREAM],
     "emf_hip_computeTSDFGrads": [_FP, _FP, _I3, _STREAM],
     "emf_hip_raycastTSDF": [_FP, _FP, _FP, _FP, _FP, _IMG, _IMG, _IMG, _IMG, _F9, _F9, _F9, _I3,
                             C.c_float, C.c_float, _FP, _STREAM],
@@ -59,7 +60,7 @@ SIGNATURES = {
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
     "emf_hip_raycastBatched": [_FP, _FP, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _STREAM],
-    "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _F9, _FP, _STREAM],
+    "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
     "emf_hip_packHitKeys": [C.c_int, _I3, _IMG, _IMG, _FP, C.c_int, C.c_int, _STREAM],

@@ -34,6 +34,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
                  _params.globalRelTruncDist * _params.globalVoxelSize, _params.volumePose,
                  _params.tsdfParams, _params.frameSize, gradients),
       depthUpload(_params.frameSize),
+      invLambda(_params.frameSize),
       points(_params.frameSize),
       raylengths(_params.frameSize),
       bg_raylengths(_params.frameSize),
@@ -61,6 +62,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     }
     const char* env = std::getenv("EMF_PER_VOLUME");
     forceLegacy = env && env[0] == '1';
+    // EMF_LAMBDA_TABLE=0: integrate with the inline 1 / lambda (A/B measurements; same results)
+    const char* lt = std::getenv("EMF_LAMBDA_TABLE");
+    useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
     // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
     const char* fs = std::getenv("EMF_FORCE_SHARDED");
@@ -90,6 +94,10 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     integrateStatsDev.setZero(s);
     visCounts.setZero(s);
     visibleDev.fill32(1u, s);  // background and freshly created objects integrate (Q18)
+    {
+        emf_image_t il = invLambda.view();
+        emfCheck(emf_hip_computeInvLambda(params.intr.val, &il, s.abi()), "computeInvLambda");
+    }
     s.waitForCompletion();
     streamOf(0);
     rebuildModelTable();
@@ -456,8 +464,10 @@ void EMFusion::integrateBatched() {
     for (int m = 0; m < n; ++m)
         vox += static_cast<double>(resHost[3 * m]) * resHost[3 * m + 1] * resHost[3 * m + 2];
     auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
+    const emf_image_t il = invLambda.view();
+    const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
     emfCheck(emf_hip_integrateBatched(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
-                                      visibleDev.as<int32_t>(), &depth, params.intr.val,
+                                      visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
                                       integrateStatsDev.as<uint64_t>(), main.abi()),
              "integrateBatched");
 }
@@ -662,10 +672,13 @@ void EMFusion::integratePerVolume() {
     refreshVisibleFromDevice();
     forkVolumeStreams();
     const bool grads = gradMode == TSDF::Gradients::Materialized;
+    const emf_image_t il = invLambda.view();
+    const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
     {
         auto kt = ktimers.scope(KernelTimers::Integrate,
                                 static_cast<double>(background.voxels()), streamOf(0));
-        background.integrate(depth, bg_associationWeights.view(), pose, params.intr, streamOf(0));
+        background.integrate(depth, bg_associationWeights.view(), pose, params.intr, streamOf(0),
+                             ilp);
     }
     if (grads) {
         auto kt = ktimers.scope(KernelTimers::Grads, static_cast<double>(background.voxels()),
@@ -678,7 +691,7 @@ void EMFusion::integratePerVolume() {
         {
             auto kt = ktimers.scope(KernelTimers::Integrate, static_cast<double>(obj.voxels()), s);
             obj.integrate(depth, objImages.at(obj.getID()).associationWeights.view(), pose,
-                          params.intr, s);
+                          params.intr, s, ilp);
         }
         if (grads) {
             auto kt = ktimers.scope(KernelTimers::Grads, static_cast<double>(obj.voxels()), s);

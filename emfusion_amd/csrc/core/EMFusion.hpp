@@ -169,6 +169,8 @@ private:
     // frame-sized device images (reference EMFusion.h:447-489)
     emf_image_t depth{};  // view of the current depth map
     DeviceImage<float> depthUpload;
+    DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
+    bool useLambdaTable = true;
     DeviceImage<float, 3> points;
     DeviceImage<float> raylengths, bg_raylengths, associationNorm, bg_associationWeights,
         diffRaylengths, objPartialSum;

@@ -48,13 +48,14 @@ Vec3f TSDF::getVolumeSize() const {
 }
 
 void TSDF::integrate(const emf_image_t& depth, const emf_image_t& weights,
-                     const Affine3f& cam_pose, const Matx33f& intr, Stream& stream) {
+                     const Affine3f& cam_pose, const Matx33f& intr, Stream& stream,
+                     const emf_image_t* invLambda) {
     const Affine3f rel_pose_OC = cam_pose.inv() * pose;  // volume -> camera
     emfCheck(emf_hip_updateTSDF(&depth, &weights, tsdfVol.as<float>(), tsdfWeights.as<float>(),
                                 brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr,
                                 rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
                                 intr.val, volumeRes.val, voxelSize, truncdist,
-                                params.maxTSDFWeight, stream.abi()),
+                                params.maxTSDFWeight, invLambda, stream.abi()),
              "TSDF::integrate");
 }
 

@@ -47,9 +47,12 @@ public:
     /**
      * Fuse one depth frame, weighted per pixel by the association weights
      * (reference TSDF::integrate, TSDF.cpp:108-118).  depth, weights: f32 W x H device images.
+     * invLambda: optional emf_hip_computeInvLambda table for `intr` (same results, fewer
+     * instructions per voxel).
      */
     void integrate(const emf_image_t& depth, const emf_image_t& weights, const Affine3f& cam_pose,
-                   const Matx33f& intr, Stream& stream = Stream::Null());
+                   const Matx33f& intr, Stream& stream = Stream::Null(),
+                   const emf_image_t* invLambda = nullptr);
 
     /**
      * Refresh the gradient volume (reference TSDF::updateGradients, TSDF.cpp:120-123).  A no-op in

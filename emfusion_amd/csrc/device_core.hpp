@@ -77,15 +77,35 @@ __device__ __forceinline__ int flag_depth(uint8_t f) { return f >> 3; }
 
 struct IntegrateGeom {
     Img<const float> depth, assoc;
+    Img<const float> invLambda;  // optional per-pixel 1 / lambda table (data == nullptr: inline)
     int w, h;
     M33 R;  // volume -> camera
     V3 t;
     M33 K;
     I3 n;
     float voxelSize, truncdist, maxWeight;
+    bool pinhole;  // K = (fx 0 cx; 0 fy cy; 0 0 1): set by is_pinhole(K) on the host
 };
 
+#ifndef EMF_INT_WPE
+#define EMF_INT_WPE 5  // waves per SIMD the tiled integration kernels are compiled for
+#endif
+
+inline bool is_pinhole(const M33& K) {
+#ifdef EMF_X_NO_PINHOLE
+    return false;
+#endif
+    return K.r0.y == 0.f && K.r1.x == 0.f && K.r2.x == 0.f && K.r2.y == 0.f && K.r2.z == 1.f;
+}
+
 enum : int { kSkip = 0, kZeroIfUnseen = 1, kNegIfUnseen = 2, kFuse = 3 };
+
+// 1 / lambda of the reference (TSDF.cu:374-377, 380): lambda = |((px - cx) / fx, (py - cy) / fy, 1)|
+__device__ __forceinline__ float inv_lambda_at(const M33& K, int px, int py) {
+    const float lambda = norm(v3((static_cast<float>(px) - K.r0.z) / K.r0.x,
+                                 (static_cast<float>(py) - K.r1.z) / K.r1.y, 1.f));
+    return 1.f / lambda;
+}
 
 // voxel centre in the camera frame (reference TSDF.cu:345-349)
 __device__ __forceinline__ V3 voxel_in_camera(const IntegrateGeom& a, const V3& half, int x, int y,
@@ -108,10 +128,10 @@ __device__ __forceinline__ int classify_voxel(const IntegrateGeom& a, const V3& 
     if (px < 0 || px >= a.w || py < 0 || py >= a.h) return kSkip;
     const float d = a.depth.row(py)[px];
     if (d <= 0.f) return kZeroIfUnseen;  // TSDF.cu:367-372
-    // lambda from the ROUNDED pixel (TSDF.cu:374-377)
-    const float lambda = norm(v3((static_cast<float>(px) - a.K.r0.z) / a.K.r0.x,
-                                 (static_cast<float>(py) - a.K.r1.z) / a.K.r1.y, 1.f));
-    const float sdf = d - (1.f / lambda) * norm(pcam);
+    // lambda from the ROUNDED pixel (TSDF.cu:374-377): a function of (px, py) and K alone, so the
+    // caller may pass it as a table of the same floats (inv_lambda_at evaluated once per pixel)
+    const float il = a.invLambda.data ? a.invLambda.row(py)[px] : inv_lambda_at(a.K, px, py);
+    const float sdf = d - il * norm(pcam);
     if (sdf >= -a.truncdist) {
         tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
         assocW = sdf < a.truncdist ? a.assoc.row(py)[px] : 1.f;  // free space fuses with 1 (Q8)
@@ -173,12 +193,12 @@ __device__ __forceinline__ bool box_outside_image(const IntegrateGeom& a, const 
 
 constexpr int kTileX = 32, kTileY = 8, kTileZ = 8;
 
+// Lane l projects corner (l & 7) of the tile; the wave votes.  Every wave of the workgroup computes
+// the same votes, so the result is block-uniform.  Conservative test (see box_outside_image for the
+// argument): the tile is skipped only if all 8 corner voxels are in front of the camera and beyond
+// the SAME image border by more than a pixel.
 __device__ __forceinline__ bool tile_culled(const IntegrateGeom& a, const V3& half, int x0, int y0,
                                             int z0) {
-    // Conservative test (see box_outside_image in device_core.hpp for the argument): the tile is
-    // skipped only if all 8 corner voxels are in front of the camera and beyond the SAME image
-    // border by more than a pixel.  Lane l projects corner (l & 7); the wave votes.  Every wave of
-    // the workgroup computes the same votes, so the result is block-uniform.
     const int x1 = min(x0 + kTileX, a.n.x) - 1, y1 = min(y0 + kTileY, a.n.y) - 1,
               z1 = min(z0 + kTileZ, a.n.z) - 1;
     const int k = threadIdx.x & 7;
@@ -186,13 +206,77 @@ __device__ __forceinline__ bool tile_culled(const IntegrateGeom& a, const V3& ha
     const V3 q = mul(a.K, p);
     const float u = q.x / q.z, v = q.y / q.z;
     const float margin = 1.f;
-    if (!__all(p.z > 1e-3f)) return false;
+    if (!__all(p.z > 1e-3f)) return false;  // touches the camera plane: not cullable
     return __all(u < -0.5f - margin) || __all(u > static_cast<float>(a.w) - 0.5f + margin) ||
            __all(v < -0.5f - margin) || __all(v > static_cast<float>(a.h) - 0.5f + margin);
 }
 
+// K * p for the projection.  For a pinhole matrix (fx 0 cx; 0 fy cy; 0 0 1) the general product
+// (k00 x + k01 y) + k02 z adds 0 * y = +-0 to k00 x, which changes nothing unless k00 x is itself a
+// zero of the other sign -- and then the following + cx z (or the comparison / division that
+// consumes the value) does not see the sign.  So the short form gives the same pixel; p is finite.
+__device__ __forceinline__ V3 project(const IntegrateGeom& a, const V3& p) {
+    if (a.pinhole)  // kernel-argument uniform
+        return v3(a.K.r0.x * p.x + a.K.r0.z * p.z, a.K.r1.y * p.y + a.K.r1.z * p.z, p.z);
+    return mul(a.K, p);
+}
+
+// Where a voxel lands in the image: everything of classify_voxel that needs no memory.
+struct VoxelShot {
+    int px, py;    // rounded pixel (valid only if inImage)
+    bool behind;   // p_cam.z <= 0  (TSDF.cu:351)
+    bool inImage;  // in front of the camera and inside the image (TSDF.cu:362-365)
+    float n2;      // |p_cam|^2 summed in norm()'s order; the sqrt is taken where it is needed
+};
+__device__ __forceinline__ VoxelShot shoot_voxel(const IntegrateGeom& a, const V3& half, int x,
+                                                 int y, int z) {
+    VoxelShot s;
+    const V3 pcam = voxel_in_camera(a, half, x, y, z);
+    s.behind = pcam.z <= 0.f;
+    const V3 proj = project(a, pcam);
+    // for `behind` voxels the quotients are never used (the reference returns before dividing)
+    s.px = __float2int_rn(proj.x / proj.z);  // round-half-even, TSDF.cu:360-361
+    s.py = __float2int_rn(proj.y / proj.z);
+    s.inImage = !s.behind && s.px >= 0 && s.px < a.w && s.py >= 0 && s.py < a.h;
+    s.n2 = pcam.x * pcam.x + pcam.y * pcam.y + pcam.z * pcam.z;
+    return s;
+}
+
+// The branch of kernel_updateTSDF a voxel takes, from its shot, the depth at its pixel and
+// 1 / lambda (same decisions and arithmetic as classify_voxel, which the one-voxel-per-lane
+// kernel uses).  For the fusing branch: the truncated SDF sample, and whether the association
+// weight of the pixel applies (inside the truncation band) or the constant 1 (free space, Q8).
+__device__ __forceinline__ int classify_shot(const IntegrateGeom& a, const VoxelShot& s, float d,
+                                             float il, float& tsdfSample, bool& bandVoxel) {
+    bandVoxel = false;
+    if (s.behind) return kZeroIfUnseen;
+    if (!s.inImage) return kSkip;
+    if (d <= 0.f) return kZeroIfUnseen;
+    const float sdf = d - il * sqrtf(s.n2);
+    if (sdf >= -a.truncdist) {
+        tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
+        bandVoxel = sdf < a.truncdist;
+        return kFuse;
+    }
+    return kNegIfUnseen;
+}
+
 // Process the tile at voxel origin (x0, y0, z0) with the 256 lanes of the workgroup.
 // lds: 32 unsigned words.  All lanes of the block must call this (it contains barriers).
+//
+// Each lane owns two groups of 4 consecutive x voxels (z and z + 4).  The reference kernel is a
+// chain per voxel: project -> depth -> association weight -> volume read -> write.  Here
+//   A. the 8 projections of the lane are computed first (pure arithmetic, shoot_voxel);
+//   B. every load that does not depend on a loaded value is issued together: depth and 1 / lambda
+//      at the 8 pixels, and the two 16-byte volume reads, predicated on "some voxel of the group
+//      is behind the camera or lands in the image" (a property of the projection, not of depth);
+//   C. the voxels are classified and fused; the association weight is read only by voxels inside
+//      the truncation band (about one tile in ten touches it).
+// What bounds it (scripts/probes/integrate_trace.hip): arithmetic.  ~70 VALU
+// instructions per voxel -- two IEEE divisions to project, a square root, up to two more divisions
+// to fuse -- put the VALU floor of the bench workload at ~0.30 ms; removing the load dependencies,
+// staging the pixel window in LDS, persistent tile scheduling were all measured and gave nothing
+// or lost, the 1 / lambda table and 6 waves per SIMD gave 9 %.
 __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __restrict__ tsdf,
                                                float* __restrict__ weights,
                                                uint8_t* __restrict__ bricks, int x0, int y0,
@@ -200,6 +284,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
     const V3 half = half_extent(a.n);
     if (tile_culled(a, half, x0, y0, z0)) return;  // block-uniform: no divergent barrier
     const int tid = threadIdx.x;
+    const bool haveIl = a.invLambda.data != nullptr;
     // 32 x 8 x 8 voxels = 8 x 2 x 2 bricks of 4^3: lds[bx + 8 * (by + 2 * bz)]
     if (bricks) {
         if (tid < 32) lds[tid] = 7u;
@@ -209,63 +294,80 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
     const int x = x0 + 4 * xg, y = y0 + yy;
     unsigned bits[2] = {7u, 7u};  // one per z half of the tile = one per brick this lane touches
     if (x < a.n.x && y < a.n.y) {
+        // ---- phase A: arithmetic only ------------------------------------------------------------
+        // kept per voxel: packed pixel (py << 16 | px) and |p_cam|^2; per lane: two 8-bit masks
+        unsigned pix[2][4], inMask = 0, behindMask = 0;
+        float n2[2][4];
+        bool live[2], touch[2];
+        size_t base[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int z = z0 + zs + 4 * i;
-            if (z >= a.n.z) continue;
-            int kind[4];
-            float samp[4], aw[4];
-            bool any = false, anyFuse = false;
+            live[i] = z < a.n.z;
+            const int zc = live[i] ? z : a.n.z - 1;
+            base[i] = (static_cast<size_t>(zc) * a.n.y + y) * a.n.x + x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                samp[e] = 0.f;
-                aw[e] = 0.f;
-                kind[e] = classify_voxel(a, half, x + e, y, z, samp[e], aw[e]);
-                any |= kind[e] != kSkip;
-                anyFuse |= kind[e] == kFuse;
+                const VoxelShot s = shoot_voxel(a, half, x + e, y, zc);
+                pix[i][e] = s.inImage ? (static_cast<unsigned>(s.py) << 16) | static_cast<unsigned>(s.px) : 0u;
+                n2[i][e] = s.n2;
+                if (s.inImage && live[i]) inMask |= 1u << (4 * i + e);
+                if (s.behind && live[i]) behindMask |= 1u << (4 * i + e);
             }
-            const size_t base = (static_cast<size_t>(z) * a.n.y + y) * a.n.x + x;
-            float tv[4], wv[4];
-            bool haveT = false;
-            if (bricks || anyFuse) {
-                const float4 tl = *reinterpret_cast<const float4*>(tsdf + base);
-                tv[0] = tl.x; tv[1] = tl.y; tv[2] = tl.z; tv[3] = tl.w;
-                haveT = true;
-            }
-            if (any) {
-                const float4 wl = *reinterpret_cast<const float4*>(weights + base);
-                wv[0] = wl.x; wv[1] = wl.y; wv[2] = wl.z; wv[3] = wl.w;
-                if (!haveT) {
-                    // Constant writes (tsdf := 0 / -1 on never-observed voxels) need no read of
-                    // the old tsdf when every voxel of the group takes one; otherwise the old
-                    // values are loaded so the vector store writes untouched voxels back bit
-                    // for bit.
-                    bool allConst = true, anyConst = false;
+            touch[i] = (((inMask | behindMask) >> (4 * i)) & 15u) != 0;
+        }
+        // ---- phase B: all independent loads in flight together -------------------------------------
+        float d[2][4], il[2][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool c =
-                            (kind[e] == kZeroIfUnseen || kind[e] == kNegIfUnseen) && wv[e] == 0;
-                        allConst &= c;
-                        anyConst |= c;
-                    }
-                    if (anyConst && !allConst) {
-                        const float4 tl = *reinterpret_cast<const float4*>(tsdf + base);
-                        tv[0] = tl.x; tv[1] = tl.y; tv[2] = tl.z; tv[3] = tl.w;
-                    }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d[i][e] = il[i][e] = 0.f;
+                if (inMask & (1u << (4 * i + e))) {
+                    const int px = pix[i][e] & 0xffffu, py = pix[i][e] >> 16;
+                    d[i][e] = a.depth.row(py)[px];
+                    if (haveIl) il[i][e] = a.invLambda.row(py)[px];
                 }
+            }
+        float tv[2][4], wv[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 tl = make_float4(0.f, 0.f, 0.f, 0.f), wl = tl;
+            if ((bricks && live[i]) || touch[i]) tl = *reinterpret_cast<const float4*>(tsdf + base[i]);
+            if (touch[i]) wl = *reinterpret_cast<const float4*>(weights + base[i]);
+            tv[i][0] = tl.x; tv[i][1] = tl.y; tv[i][2] = tl.z; tv[i][3] = tl.w;
+            wv[i][0] = wl.x; wv[i][1] = wl.y; wv[i][2] = wl.z; wv[i][3] = wl.w;
+        }
+        // ---- phase C: classify, fuse, store ---------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (touch[i]) {
                 int changed = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    changed |= apply_voxel(kind[e], samp[e], aw[e], a.maxWeight, tv[e], wv[e]);
+                for (int e = 0; e < 4; ++e) {
+                    VoxelShot s;
+                    s.px = pix[i][e] & 0xffffu;
+                    s.py = pix[i][e] >> 16;
+                    s.inImage = (inMask >> (4 * i + e)) & 1u;
+                    s.behind = (behindMask >> (4 * i + e)) & 1u;
+                    s.n2 = n2[i][e];
+                    const float ile = haveIl ? il[i][e] : inv_lambda_at(a.K, s.px, s.py);
+                    float samp = 0.f;
+                    bool band;
+                    const int kind = classify_shot(a, s, d[i][e], ile, samp, band);
+                    const float aw = band ? a.assoc.row(s.py)[s.px] : 1.f;
+                    changed |= apply_voxel(kind, samp, aw, a.maxWeight, tv[i][e], wv[i][e]);
+                }
                 if (changed & 1)
-                    *reinterpret_cast<float4*>(tsdf + base) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                    *reinterpret_cast<float4*>(tsdf + base[i]) =
+                        make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]);
                 if (changed & 2)
-                    *reinterpret_cast<float4*>(weights + base) =
-                        make_float4(wv[0], wv[1], wv[2], wv[3]);
+                    *reinterpret_cast<float4*>(weights + base[i]) =
+                        make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
             }
-            if (bricks)  // the lane's 4 voxels are one x-row of brick (xg, yy >> 2, i)
-                bits[i] = uniform_bits(tv[0]) & uniform_bits(tv[1]) & uniform_bits(tv[2]) &
-                          uniform_bits(tv[3]);
+            if (bricks && live[i])  // the lane's 4 voxels are one x-row of brick (xg, yy >> 2, i)
+                bits[i] = uniform_bits(tv[i][0]) & uniform_bits(tv[i][1]) &
+                          uniform_bits(tv[i][2]) & uniform_bits(tv[i][3]);
         }
     }
     if (bricks) {

@@ -93,26 +93,58 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, int x, int y, floa
     r.active = true;
 }
 
+#ifdef EMF_X_FASTDIV
+__device__ __forceinline__ float xdiv(float x, float d, float rcp) {
+    const float q = x * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, x), rcp, q);
+}
+__device__ __forceinline__ V3 to_voxel_x(const V3& p, float d, float rcp, const V3& half) {
+    return v3(xdiv(p.x, d, rcp) + half.x, xdiv(p.y, d, rcp) + half.y, xdiv(p.z, d, rcp) + half.z);
+}
+#else
+__device__ __forceinline__ V3 to_voxel_x(const V3& p, float d, float, const V3& half) {
+    return to_voxel(p, d, half);
+}
+#endif
+#ifdef EMF_X_OFF32
+__device__ __forceinline__ float trilinear1_x(const float* __restrict__ vol, const V3& idx, const I3& n) {
+    const int lx = static_cast<int>(idx.x), ly = static_cast<int>(idx.y), lz = static_cast<int>(idx.z);
+    const float fx = idx.x - static_cast<float>(lx), fy = idx.y - static_cast<float>(ly),
+                fz = idx.z - static_cast<float>(lz);
+    const unsigned sy = 4u * static_cast<unsigned>(n.x), sz = sy * static_cast<unsigned>(n.y);
+    const unsigned o = (static_cast<unsigned>(lz) * static_cast<unsigned>(n.y) + static_cast<unsigned>(ly)) * sy + 4u * static_cast<unsigned>(lx);
+    const char* b = reinterpret_cast<const char*>(vol);
+    const float c0 = *reinterpret_cast<const float*>(b + o), c1 = *reinterpret_cast<const float*>(b + o + 4u);
+    const unsigned o1 = o + sy, o2 = o + sz, o3 = o2 + sy;
+    const float c2 = *reinterpret_cast<const float*>(b + o1), c3 = *reinterpret_cast<const float*>(b + o1 + 4u);
+    const float c4 = *reinterpret_cast<const float*>(b + o2), c5 = *reinterpret_cast<const float*>(b + o2 + 4u);
+    const float c6 = *reinterpret_cast<const float*>(b + o3), c7 = *reinterpret_cast<const float*>(b + o3 + 4u);
+    return blend8(c0, c1, c2, c3, c4, c5, c6, c7, fx, fy, fz);
+}
+#endif
+
 // One iteration of `while ((raylength += raystep) <= maxRaylength)` (TSDF.cu:523-572) for the
 // calling lane.  Clears r.active when the march ends (range exhausted, back-side crossing, hit).
-__device__ __forceinline__ void ray_step(const RayVolume& v, RayState& r, RayHit& out) {
+__device__ __forceinline__ void ray_step(const RayVolume& v, RayState& r, RayHit& out, float rcp = 0.f) {
     const V3 half = half_extent(v.n);
     r.raylength += r.raystep;
     if (!(r.raylength <= r.maxRay)) {
         r.active = false;
         return;
     }
-    const V3 p = to_voxel(v.cam + r.dir * r.raylength, v.voxelSize, half);
+    const V3 p = to_voxel_x(v.cam + r.dir * r.raylength, v.voxelSize, rcp, half);
     if (outside(p, 2.f, v.n)) {
         ++r.plainRun;
         return;
     }
     ++out.samples;
-    ++out.gathered;
-    const Cell c = cell_of(p, v.n);
-    const float next = trilinear1(v.tsdf, c, v.n);
+#ifdef EMF_X_OFF32
+    const float next = trilinear1_x(v.tsdf, p, v.n);
+#else
+    const float next = trilinear1(v.tsdf, cell_of(p, v.n), v.n);
+#endif
     // zero crossing from behind: leave the volume's surface shell
-    if (r.tsdf < 0 && next > 0 && trilinear_weights(v, c) > 0.f) {
+    if (r.tsdf < 0 && next > 0 && trilinear_weights(v, cell_of(p, v.n)) > 0.f) {
         r.active = false;
         return;
     }
@@ -212,6 +244,7 @@ __device__ __forceinline__ RayHit march_wave(const RayVolume& v, bool valid, int
     r.plainRun = 0;
     r.active = false;
     if (valid) ray_setup(v, x, y, fx, fy, cx, cy, oldRaylength, r);
+    const float rcp = 1.0f / v.voxelSize;
     for (;;) {
         const unsigned long long act = __ballot(r.active);
         if (act == 0) break;
@@ -219,11 +252,12 @@ __device__ __forceinline__ RayHit march_wave(const RayVolume& v, bool valid, int
         const unsigned long long cand =
             __popcll(act) <= kCoopMaxRays ? __ballot(r.active && r.plainRun >= kCoopMinRun) : 0ull;
         if (cand == 0) {
-            if (r.active) ray_step(v, r, out);
+            if (r.active) ray_step(v, r, out, rcp);
         } else {
             coop_advance(v, __ffsll(static_cast<long long>(cand)) - 1, lane, r, out);
         }
     }
+    out.gathered = out.samples;
     return out;
 }
 

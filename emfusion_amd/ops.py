@@ -82,8 +82,18 @@ def reset_brick_flags(tsdf_like, flags, stream=None):
     return flags
 
 
+def compute_inv_lambda(K, inv_lambda, stream=None):
+    """inv_lambda: f32 H x W DeviceArray, written with the per-pixel 1 / lambda table."""
+    check("emf_hip_computeInvLambda",
+          _L.emf_hip_computeInvLambda(_f(K, 9), C.byref(image_view(inv_lambda)), _stream(stream)))
+
+
+def _opt_view(img):
+    return C.byref(image_view(img)) if img is not None else None
+
+
 def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdist, max_weight,
-                brick_flags=None, stream=None):
+                brick_flags=None, stream=None, inv_lambda=None):
     _vol(tsdf, np.float32)
     _vol(weights, np.float32)
     if brick_flags is not None:
@@ -91,7 +101,8 @@ def update_tsdf(depth, assoc, tsdf, weights, R_OC, t_OC, K, voxel_size, truncdis
     check("emf_hip_updateTSDF",
           _L.emf_hip_updateTSDF(C.byref(image_view(depth)), C.byref(image_view(assoc)), _ptr(tsdf),
                                 _ptr(weights), _ptr(brick_flags), _f(R_OC, 9), _f(t_OC, 3), _f(K, 9), _res(tsdf),
-                                voxel_size, truncdist, max_weight, _stream(stream)))
+                                voxel_size, truncdist, max_weight, _opt_view(inv_lambda),
+                                _stream(stream)))
 
 
 def compute_tsdf_grads(tsdf, grads, stream=None):
@@ -279,12 +290,14 @@ def raycast_batched(models_dev, poses_co, width, height, K, stats=None, use_bric
                                     _stream(stream)))
 
 
-def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None):
+def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None,
+                      inv_lambda=None):
     res = (C.c_int32 * (3 * len(poses_oc)))(*[int(v) for r in res_list for v in r])
     check("emf_hip_integrateBatched",
           _L.emf_hip_integrateBatched(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc),
-                                      _ptr(visible), C.byref(image_view(depth)), _f(K, 9),
-                                      _ptr(stats), _stream(stream)))
+                                      _ptr(visible), C.byref(image_view(depth)),
+                                      _opt_view(inv_lambda), _f(K, 9), _ptr(stats),
+                                      _stream(stream)))
 
 
 def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):

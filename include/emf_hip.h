@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 2
+#define EMF_HIP_ABI_VERSION 3
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -93,11 +93,19 @@ int emf_hip_computePoints(const emf_image_t* depth, const emf_image_t* points, c
 
 /* Replaces emf::cuda::TSDF::updateTSDF (TSDF.cuh:115-122, TSDF.cu:327-427).
  * depth, assocWeights: f32 W x H (same size); tsdf, weights: N^3 f32 read-modify-write.
- * brickFlags: NULL, or the volume's brick uniformity flags, kept consistent by this call. */
+ * brickFlags: NULL, or the volume's brick uniformity flags, kept consistent by this call.
+ * invLambda : NULL, or the table written by emf_hip_computeInvLambda for the same K and image size;
+ *             identical results, about a quarter fewer instructions per fused voxel. */
 int emf_hip_updateTSDF(const emf_image_t* depth, const emf_image_t* assocWeights, float* tsdf,
                        float* weights, uint8_t* brickFlags, const float R_OC[9],
                        const float t_OC[3], const float K[9], const int32_t res[3],
-                       float voxelSize, float truncdist, float maxWeight, emf_stream_t stream);
+                       float voxelSize, float truncdist, float maxWeight,
+                       const emf_image_t* invLambda, emf_stream_t stream);
+
+/* The pixel-only factor of the integration (TSDF.cu:374-380): invLambda(x, y) =
+ * 1 / |((x - cx) / fx, (y - cy) / fy, 1)|, f32 W x H, the very floats updateTSDF computes inline
+ * per voxel from the rounded pixel.  Depends on K and the image size only: compute once. */
+int emf_hip_computeInvLambda(const float K[9], emf_image_t* invLambda, emf_stream_t stream);
 
 /* Replaces TSDF::updateGradients = tsdfGrads.setTo(0) + emf::cuda::TSDF::computeTSDFGrads
  * (TSDF.cpp:120-123, TSDF.cuh:132-134, TSDF.cu:429-464).  grads: N^3 x 3 f32; the last index
@@ -274,13 +282,14 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
  *   visible_dev : NULL, or device int32[nmodels]; models with visible_dev[m] == 0 are skipped
  *                 (EMFusion.cpp:869-872) -- evaluated on the device, no host round trip
  * Each model's `assoc` map weights its fusion; brickFlags are kept consistent when present.
+ *   invLambda   : NULL, or emf_hip_computeInvLambda's table for K and the depth size
  *   stats       : NULL, or one u64 device counter this call ADDS the voxel count of every model
  *                 it actually sweeps to (work accounting for the byte model)
  */
 int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                              const int32_t* res_host, int nmodels, const int32_t* visible_dev,
-                             const emf_image_t* depth, const float K[9], uint64_t* stats,
-                             emf_stream_t stream);
+                             const emf_image_t* depth, const emf_image_t* invLambda,
+                             const float K[9], uint64_t* stats, emf_stream_t stream);
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */

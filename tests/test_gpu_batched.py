@@ -253,7 +253,12 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
     assert int(to_np(st)[0]) == total
 
 
-def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle, dev):
+@pytest.mark.parametrize("table", [False, True], ids=["inline", "table"])
+def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle, dev, table):
+    il = None
+    if table:
+        il = dev_full((H, W), -3.0)
+        ops.compute_inv_lambda(K, il)
     models = [Model(ops, oracle, (64, 64, 64), 0.04, Pose(t=[0, 0, 1.28]), False, 0),
               Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True, 1),
               Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[1][0]), True, 2)]
@@ -267,7 +272,7 @@ def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle,
         cam, depth, ids = frame(i)
         gate = [1, 1, 0 if i == 1 else 1]  # object 2 is "not visible" on frame 1
         visible.copy_from(np.array(gate, np.int32))
-        table = ops.upload_models([m.table_entry() for m in models])
+        mtab = ops.upload_models([m.table_entry() for m in models])
         d_depth = to_dev(depth)
         poses = []
         for m, g in zip(models, gate):
@@ -279,7 +284,8 @@ def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle,
                 oracle.update_tsdf(depth, assoc, m.tsdf, m.wts, oc.R32, oc.t32, K, m.vox, m.trunc,
                                    MAXW)
                 expect_vox += m.tsdf.size
-        ops.integrate_batched(table, poses, [m.res for m in models], visible, d_depth, K, stats)
+        ops.integrate_batched(mtab, poses, [m.res for m in models], visible, d_depth, K, stats,
+                              inv_lambda=il)
         dev.synchronize()
     for m in models:
         assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)

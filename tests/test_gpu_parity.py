@@ -36,18 +36,26 @@ def alloc_vol(res_xyz, ch=1, dtype=np.float32):
     return np.zeros((nz, ny, nx) if ch == 1 else (nz, ny, nx, ch), dtype)
 
 
+def inv_lambda_table(ops, pad=0):
+    """The per-pixel 1 / lambda table of emf_hip_computeInvLambda for the test intrinsics."""
+    tab = dev_full((H, W), -3.0, pad_cols=pad)
+    ops.compute_inv_lambda(K, tab)
+    return tab
+
+
 def integrate_both(oracle, ops, dev, res, vox, vol_pose, frames, assoc_fn=None, max_w=MAXW,
-                   pad=0):
+                   pad=0, table=False):
     """Run the same integration sequence on the oracle (numpy) and the HIP path (device)."""
     tsdf, wts = alloc_vol(res), alloc_vol(res)
     d_tsdf, d_wts = to_dev(tsdf, dev), to_dev(wts, dev)
+    il = inv_lambda_table(ops, pad) if table else None
     for i in frames:
         cam, depth, ids = frame(i)
         assoc = np.ones((H, W), np.float32) if assoc_fn is None else assoc_fn(i, ids)
         oc = rel_OC(cam, vol_pose)
         oracle.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, K, vox, 10 * vox, max_w)
         ops.update_tsdf(to_dev(depth, dev, pad), to_dev(assoc, dev, pad), d_tsdf, d_wts, oc.R32,
-                        oc.t32, K, vox, 10 * vox, max_w)
+                        oc.t32, K, vox, 10 * vox, max_w, inv_lambda=il)
     dev.synchronize()
     return (tsdf, wts), (d_tsdf, d_wts)
 
@@ -65,12 +73,25 @@ def test_compute_points(oracle, ops, dev, pad):
 
 # ---- a7 ------------------------------------------------------------------------------------------
 
+def test_inv_lambda_table_is_the_inline_expression(ops, dev):
+    """1 / |((x - cx) / fx, (y - cy) / fy, 1)| in float32, operation by operation (TSDF.cu:374-380)."""
+    f32 = np.float32
+    k = np.asarray(K, f32).reshape(-1)
+    xs = (np.arange(W, dtype=f32) - k[2]) / k[0]
+    ys = (np.arange(H, dtype=f32) - k[5]) / k[4]
+    xx, yy = xs[None, :] * xs[None, :], ys[:, None] * ys[:, None]
+    want = f32(1) / np.sqrt((xx + yy) + f32(1), dtype=f32)
+    got = to_np(inv_lambda_table(ops, pad=3))
+    assert_parity(got, want.astype(f32), "invLambda", exact=True)
+
+
+@pytest.mark.parametrize("table", [False, True], ids=["inline", "table"])
 @pytest.mark.parametrize("res,pad", [((64, 64, 64), 0), ((64, 64, 64), 3), ((30, 22, 18), 0),
                                      ((36, 20, 28), 0)])
-def test_integrate_sequence(oracle, ops, dev, res, pad):
+def test_integrate_sequence(oracle, ops, dev, res, pad, table):
     vox = 2.56 / max(res)
     (tsdf, wts), (d_t, d_w) = integrate_both(oracle, ops, dev, res, vox, BG["pose"], range(3),
-                                             pad=pad)
+                                             pad=pad, table=table)
     assert (wts > 0).sum() > 1000 and (tsdf == -1).sum() > 10
     assert_parity(to_np(d_t), tsdf, f"tsdf {res}", exact=True)
     assert_parity(to_np(d_w), wts, f"weights {res}", exact=True)
