@@ -46,7 +46,7 @@ SIGNATURES = {
     "emf_hip_computeInvLambda": [_F9, _IMG, _STREAM],
     "emf_hip_computeTSDFGrads": [_FP, _FP, _I3, _STREAM],
     "emf_hip_raycastTSDF": [_FP, _FP, _FP, _FP, _FP, _IMG, _IMG, _IMG, _IMG, _F9, _F9, _F9, _I3,
-                            C.c_float, C.c_float, _FP, _STREAM],
+                            C.c_float, C.c_float, C.c_float, _FP, _STREAM],
     "emf_hip_getVolumeVals": [_FP, C.c_int, _IMG, _F9, _F9, _I3, C.c_float, _IMG, _STREAM],
     "emf_hip_updateFgBgProbs": [_IMG, _IMG, _FP, _FP, _FP, _F9, _F9, _F9, _I3, C.c_float, _STREAM],
     "emf_hip_computeFgProbs": [_FP, _FP, _FP, _I3, _STREAM],
@@ -59,7 +59,9 @@ SIGNATURES = {
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
-    "emf_hip_raycastBatched": [_FP, _FP, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _STREAM],
+    "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP,
+                               _STREAM],
+    "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
@@ -80,7 +82,8 @@ class EmfModel(C.Structure):
                 ("normals", C.c_void_p), ("hitMask", C.c_void_p), ("res", C.c_int32 * 3),
                 ("id", C.c_int32), ("voxelSize", C.c_float), ("truncdist", C.c_float),
                 ("maxWeight", C.c_float), ("assocC1", C.c_float), ("assocC2", C.c_float),
-                ("alpha", C.c_float), ("assocC3", C.c_float), ("reserved", C.c_int32)]
+                ("alpha", C.c_float), ("assocC3", C.c_float), ("reserved", C.c_int32),
+                ("rcpVoxel", C.c_float), ("pad_", C.c_int32)]
 
 
 class EmfPose(C.Structure):

@@ -63,9 +63,51 @@ int launch_status(const char* what) {
     return EMF_OK;
 }
 
+// Exhaustive comparison of x / d with its reciprocal form (march_wave.hpp div_voxel) over all 2^32
+// float bit patterns; counts disagreements inside the range the march can produce.
+__global__ __launch_bounds__(256) void k_check_reciprocal(float d, float rcp,
+                                                          unsigned long long* mismatches) {
+    const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    unsigned bad = 0;
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+         i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float(static_cast<unsigned>(i));
+        const float ax = fabsf(x);
+        if (!(ax >= 1e-30f && ax <= 1e30f)) continue;  // also skips NaN
+        const float q0 = x * rcp;
+        const float q = __builtin_fmaf(__builtin_fmaf(-q0, d, x), rcp, q0);
+        bad += __float_as_uint(q) != __float_as_uint(x / d);
+    }
+    if (bad) atomicAdd(mismatches, static_cast<unsigned long long>(bad));
+}
+
 }  // namespace emf_hip
 
 extern "C" {
+
+int emf_hip_voxelReciprocal(float voxelSize, float* rcp) {
+    using namespace emf_hip;
+    if (!rcp) return fail(EMF_E_NULL, "voxelReciprocal: rcp is NULL");
+    *rcp = 0.f;
+    if (!(voxelSize >= 1e-6f && voxelSize <= 1e3f))  // quotients of the checked range stay finite
+        return fail(EMF_E_ARG, "voxelReciprocal: voxelSize %g outside [1e-6, 1e3]", voxelSize);
+    unsigned long long* dev = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(dev, 0, sizeof(unsigned long long));
+    unsigned long long bad = 1;
+    if (e == hipSuccess) {
+        const float r = 1.0f / voxelSize;
+        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, nullptr, voxelSize, r, dev);
+        e = hipMemcpy(&bad, dev, sizeof(bad), hipMemcpyDeviceToHost);  // synchronises
+        if (e == hipSuccess && bad == 0) *rcp = r;
+    }
+    if (dev) (void)hipFree(dev);
+    if (e != hipSuccess) {
+        set_error("voxelReciprocal: %s", hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    return EMF_OK;
+}
 
 int emf_hip_abi_version(void) { return EMF_HIP_ABI_VERSION; }
 

@@ -9,7 +9,6 @@
 //                       zero-filled by the kernel itself (no memsets)
 //   k_integrate_batched all models' 32x8x8 voxel tiles in one grid, visibility gate read on device
 // All arithmetic comes from device_core.hpp, i.e. it is the same code the per-volume kernels run.
-#include "march_spec.hpp"
 #include "march_wave.hpp"
 
 namespace emf_hip {
@@ -100,6 +99,7 @@ struct RaycastBatchArgs {
     int tilesX, tilesY;
     int chunk;  // tiles per XCD = ceil(tilesX * tilesY / 8)
     float fx, fy, cx, cy;
+    unsigned divideMask;  // bit m: model m must divide by voxelSize (pose out of the checked range)
     unsigned long long* stats;
 };
 
@@ -109,8 +109,50 @@ struct RaycastBatchArgs {
 constexpr int kRbWaves = EMF_RB_WAVES;
 constexpr int kRbTile = kRbWaves == 4 ? 16 : 8;
 
+#ifdef EMF_RAY_TRACE  // timeline instrumentation, trace builds only (scripts/raycast_timeline.py)
+struct RayTraceRec {
+    unsigned long long t0, t1;
+    unsigned hw, xcc, model, tile, wave, samplesMax, samplesSum, activeLanes;
+};
+__device__ RayTraceRec g_rayTrace[32768];
+__device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned samples, int m, int tile,
+                                           int wave, int lane) {
+    unsigned mx = samples, sm = samples;
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, static_cast<unsigned>(__shfl_xor(static_cast<int>(mx), o)));
+        sm += static_cast<unsigned>(__shfl_xor(static_cast<int>(sm), o));
+    }
+    const unsigned long long lanes = __ballot(samples > 0);
+    const unsigned slot = blockIdx.x * EMF_RB_WAVES + wave;
+    if (lane == 0 && slot < 32768u) {
+        RayTraceRec t;
+        t.t0 = t0;
+        t.t1 = wall_clock64();
+        t.hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        t.xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        t.model = m;
+        t.tile = tile;
+        t.wave = wave;
+        t.samplesMax = mx;
+        t.samplesSum = sm;
+        t.activeLanes = __popcll(lanes);
+        g_rayTrace[slot] = t;
+    }
+}
+#else
+__device__ __forceinline__ void trace_wave(unsigned long long, unsigned, int, int, int, int) {}
+#endif
+
 template <bool WAVE>
+#ifdef EMF_RB_WPE
+__attribute__((amdgpu_waves_per_eu(EMF_RB_WPE, EMF_RB_WPE)))
+#endif
 __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
+#ifdef EMF_RAY_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#else
+    const unsigned long long trace_t0 = 0;
+#endif
     // grid = nmodels x (8 * chunk) blocks, model-major: the background's (longest) rays start first.
     // Block b runs on XCD b % 8 (observed dispatch order; used for L2 locality only): give each XCD
     // a contiguous run of `chunk` tiles in raster order, i.e. a horizontal band of the image, so
@@ -139,10 +181,35 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     v.blendFromFlags = (md.reserved & 2) != 0;
     v.voxelSize = md.voxelSize;
     v.truncdist = md.truncdist;
+    v.rcpVoxel = ((a.divideMask >> m) & 1u) ? 0.f : md.rcpVoxel;
     // incoming raylength is zero by construction (the reference zeroes it first, Q5)
     RayHit r;
     if constexpr (WAVE) {
-        r = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, lane);  // all 64 lanes
+        const size_t pix = static_cast<size_t>(y) * a.w + x;
+        auto sink = [&](float raylength, const V3& vertex, const V3& normal) {
+            md.raylengths[pix] = raylength;
+            float* pv = md.vertices + 3 * pix;
+            float* pn = md.normals + 3 * pix;
+            pv[0] = vertex.x;
+            pv[1] = vertex.y;
+            pv[2] = vertex.z;
+            pn[0] = normal.x;
+            pn[1] = normal.y;
+            pn[2] = normal.z;
+            md.hitMask[pix] = 1;
+        };
+        const MarchCount c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink);
+        if (valid && !c.hit) {  // zeros where there is no hit
+            md.raylengths[pix] = 0.f;
+            float* pv = md.vertices + 3 * pix;
+            float* pn = md.normals + 3 * pix;
+            pv[0] = pv[1] = pv[2] = 0.f;
+            pn[0] = pn[1] = pn[2] = 0.f;
+            md.hitMask[pix] = 0;
+        }
+        add_ray_stats(a.stats, c.samples, c.hit ? 1u : 0u, c.samples, 0u, lane);
+        trace_wave(trace_t0, c.samples, m, tile, wave, lane);
+        return;
     } else {
         r.hit = false;
         r.samples = r.gathered = r.skipped = 0;
@@ -164,6 +231,7 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
         md.hitMask[pix] = r.hit ? 1 : 0;
     }
     add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
+    trace_wave(trace_t0, r.samples, m, tile, wave, lane);
 }
 
 // ---- batched integration ---------------------------------------------------------------------------
@@ -290,15 +358,24 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 }
 
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
-                           int nmodels, int width, int height, const float K[9],
-                           int useBrickFlags, uint64_t* stats, emf_stream_t stream) {
+                           const int32_t* res_host, int nmodels, int width, int height,
+                           const float K[9], int useBrickFlags, uint64_t* stats,
+                           emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
+    EMF_REQUIRE_PTR(res_host);
     EMF_REQUIRE_PTR(K);
     if (width <= 0 || height <= 0)
         return fail(EMF_E_SHAPE, "raycastBatched: bad image size %d x %d", width, height);
     RaycastBatchArgs a;
     a.models = models_dev;
-    for (int m = 0; m < nmodels; ++m) a.poses.p[m] = poseCO_host[m];
+    a.divideMask = 0;
+    bool offsets32 = true;
+    for (int m = 0; m < nmodels; ++m) {
+        a.poses.p[m] = poseCO_host[m];
+        EMF_TRY(check_res(res_host + 3 * m));
+        offsets32 = offsets32 && fits_offsets32(res_host + 3 * m);
+        if (usable_reciprocal(1.f, poseCO_host[m].t) == 0.f) a.divideMask |= 1u << m;
+    }
     a.nmodels = nmodels;
     a.w = width;
     a.h = height;
@@ -311,10 +388,7 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
     const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk);
-#ifdef EMF_RB_PLAIN  // experiment switch: per-lane march without flags
-    useBrickFlags = 1;
-#endif
-    if (useBrickFlags)
+    if (useBrickFlags || !offsets32)  // the wave march addresses with 32-bit byte offsets
         hipLaunchKernelGGL(k_raycast_batched<false>, grid, dim3(64 * kRbWaves), 0,
                            as_stream(stream), a);
     else
@@ -322,6 +396,14 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
                            as_stream(stream), a);
     return launch_status("raycastBatched");
 }
+
+#ifdef EMF_RAY_TRACE
+int emf_hip_debugFetchRayTrace(void* host, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rayTrace),
+                                                bytes < sizeof(g_rayTrace) ? bytes : sizeof(g_rayTrace)));
+}
+#endif
 
 int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                              const int32_t* res_host, int nmodels, const int32_t* visible_dev,

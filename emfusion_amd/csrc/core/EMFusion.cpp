@@ -446,10 +446,14 @@ void EMFusion::raycastBatched() {
     uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
     {
         auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
-        emfCheck(emf_hip_raycastBatched(modelTable.as<emf_model_t>(), co.data(), n,
-                                        params.frameSize.width, params.frameSize.height,
-                                        params.intr.val, TSDF::brickFlagMode() != 0, stats,
-                                        main.abi()),
+        const emf_model_t* table = modelTable.as<emf_model_t>();
+        const int w = params.frameSize.width, h = params.frameSize.height;
+        const int flags = TSDF::brickFlagMode() != 0;
+        // One grid for all models.  (Measured alternative: the objects' grid on a second stream so
+        // that their waves need not queue behind the resident background -- 3 % slower, the two
+        // queues did not interleave usefully; scripts/raycast_timeline.py shows the queueing.)
+        emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
+                                        flags, stats, main.abi()),
                  "raycastBatched");
     }
     stamp(kRaycast);

@@ -63,7 +63,7 @@ void ObjTSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_i
                                  fgVolMask.as<uint8_t>(),
                                  brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr, &raylengths, &vertices, &normals, &mask,
                                  rel_pose_CO.rotation().val, rel_pose_CO.translation().val,
-                                 intr.val, volumeRes.val, voxelSize, truncdist, stats,
+                                 intr.val, volumeRes.val, voxelSize, truncdist, rcpVoxel, stats,
                                  stream.abi()),
              "ObjTSDF::raycast");
 }

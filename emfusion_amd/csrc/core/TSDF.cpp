@@ -18,6 +18,11 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
       brickFlags(2 * static_cast<size_t>((_volumeRes[0] + 3) / 4) * ((_volumeRes[1] + 3) / 4) *
                  ((_volumeRes[2] + 3) / 4)) {  // raw flags + dilated flags
     if (gradMode == Gradients::Materialized) tsdfGrads = DeviceBuffer(voxels() * 3 * sizeof(float));
+    // once per volume: is 1 / voxelSize usable in place of the march's divisions?  (exhaustive
+    // device check, ~3 ms; EMF_VOXEL_RCP=0 keeps the divisions for A/B measurements)
+    const char* vr = std::getenv("EMF_VOXEL_RCP");
+    if (!(vr && vr[0] == '0'))
+        emfCheck(emf_hip_voxelReciprocal(voxelSize, &rcpVoxel), "TSDF: voxelReciprocal");
     reset(_pose);
 }
 
@@ -73,7 +78,7 @@ void TSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_imag
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(), nullptr,
                                  brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr, &raylengths, &vertices, &normals, &mask,
                                  rel_pose_CO.rotation().val, rel_pose_CO.translation().val,
-                                 intr.val, volumeRes.val, voxelSize, truncdist, stats,
+                                 intr.val, volumeRes.val, voxelSize, truncdist, rcpVoxel, stats,
                                  stream.abi()),
              "TSDF::raycast");
 }
@@ -123,6 +128,8 @@ void TSDF::describe(emf_model_t& m) const {
     const int mode = brickFlagMode();
     m.brickFlags = mode ? brickFlags.as<uint8_t>() : nullptr;
     m.reserved = mode == 2 ? 2 : 0;
+    m.rcpVoxel = rcpVoxel;
+    m.pad_ = 0;
 }
 
 std::vector<float> TSDF::getTSDF() const {

@@ -100,6 +100,7 @@ protected:
     Vec3i volumeRes;
     float voxelSize;
     float truncdist;
+    float rcpVoxel = 0.f;  // emf_hip_voxelReciprocal(voxelSize): checked stand-in for x / voxelSize
     Affine3f pose;  // volume-centre frame -> world
     Gradients gradMode;
     Size frameSize;

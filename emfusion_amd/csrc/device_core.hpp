@@ -401,7 +401,19 @@ struct RayVolume {
     V3 cam;                 // camera centre in the volume frame
     I3 n;
     float voxelSize, truncdist;
+    float rcpVoxel;         // 1 / voxelSize checked by emf_hip_voxelReciprocal, or 0 = divide
 };
+
+// Host: may the march use `rcp` for this pose?  (march_wave.hpp: positions must stay below 1e30;
+// with |t| <= 1e15 the slab test bounds |raylength| by ~2e15.)  NaN fails the comparison.
+inline float usable_reciprocal(float rcp, const float t[3]) {
+    const bool ok = fabsf(t[0]) <= 1e15f && fabsf(t[1]) <= 1e15f && fabsf(t[2]) <= 1e15f;
+    return ok ? rcp : 0.f;
+}
+// Host: does the volume fit the 32-bit byte offsets of march_wave.hpp?
+inline bool fits_offsets32(const int32_t res[3]) {
+    return static_cast<unsigned long long>(res[0]) * res[1] * res[2] <= (1ull << 30);
+}
 
 struct RayHit {
     bool hit;

@@ -1,66 +1,145 @@
-// march_wave.hpp -- the ray march of reference kernel_raycastTSDF (TSDF.cu:466-573) scheduled per
-// WAVE instead of per lane.
+// march_wave.hpp -- the ray march of reference kernel_raycastTSDF (TSDF.cu:466-573), scheduled per
+// wave and trimmed to the instructions the arithmetic needs.
 //
-// Why: one VGA raycast is a single round of 4800 waves and the march is a chain of dependent steps
-// (~200 instructions + one gather round trip each), so the kernel lasts as long as its longest
-// rays.  On the bench scene the median ray takes ~240 steps but a few hundred image-border rays
-// graze the seen/unseen boundary at half-voxel steps for 500-800 steps, and object volumes leave
-// most waves with a handful of rays that actually cross the box (scripts/raycast_probe.py tail).
-// A lane that marches alone keeps its wave alive while 63 lanes idle.
+// What bounds the raycast on MI355X (scripts/raycast_timeline.py): instructions
+// per step, twice over.  A VGA raycast of the 512^3 background is 4800 waves, all resident at once.
+// While they are, ~5 waves share each SIMD and a step costs ~1.2 us: the VALU is saturated.  Then
+// the waves with the longest rays run on alone (image-border rays grazing the seen / unseen
+// boundary: 400-1100 half-voxel steps against a median of 240) -- a lone wave issues in order, so
+// a step costs (instructions x 4-5 cycles) + one memory round trip, ~0.8 us, and that tail is up
+// to half the kernel.  Either way time is proportional to the instruction count of one step.
 //
-// MEASURED OUTCOME: the wave-level loop below (ordinary mode only, one
-// scalar ballot per iteration) is the fastest variant, 0.53 ms for the 512^3 bench background
-// against 0.57-0.65 ms for per-lane loops.  The cooperative mode is exact and 20x faster on long
-// plain runs, but the rays that form the tail of this workload are NOT plain -- they graze the
-// seen/unseen boundary, their 0/1 blends keep crossing the 0.8 / 1.0 thresholds and flip the step
-// size every few samples -- so it fires on 0.1 % of the samples while its code costs 30 % in
-// registers and scheduling.  It is therefore compiled out by default (EMF_COOP_MAX_RAYS = 0) and
-// kept for scenes with long uniform stretches.
-//
-// Two modes, chosen per wave iteration by a ballot:
-//   * many rays active: every active lane takes one ordinary step (ray_step = one iteration of
-//     the reference loop);
-//   * at most kCoopMaxRays rays active: the wave works for ONE of them.  Lane j evaluates the
-//     sample j + 1 steps ahead -- its raylength by the same j + 1 sequential float additions the
-//     reference would perform -- gathers and blends it; a prefix over the ballot of in-volume
-//     samples gives each lane the TSDF value that would precede it; the first sample that could
-//     change the march state (step size change, sign change, end of range) is found with a
-//     ballot + ffs.  All samples before it are "plain": the reference loop would only advance
-//     `raylength`, count them and carry the last value in `tsdf`, which is what the leader lane
-//     does in one go.  The event sample itself is then taken through ray_step on the leader, so
-//     every state-changing decision is made by exactly the code of the ordinary path.
-// Results are bit-identical to the per-lane march (tests/test_gpu_parity.py).
+// The step below does the reference's arithmetic, operation for operation, in fewer instructions:
+//   * loop control per wave: one ballot per iteration instead of per-lane loop bookkeeping;
+//   * p / voxelSize: a constant divisor.  q = x * r, q' = fma(fma(-q, d, x), r, q) with
+//     r = 1 / d equals the IEEE quotient for every float x with 1e-30 <= |x| <= 1e30 -- not
+//     argued but CHECKED: emf_hip_voxelReciprocal runs all 2^32 inputs through both forms for the
+//     given d and hands out r only if none differs.  Outside that range: |x| < 1e-30 gives
+//     |q| < 1e-24 either way and the following "+ (N - 1) / 2" absorbs it (N = 1: the sample is
+//     outside the volume either way); |x| > 1e30 cannot occur because the host refuses r for poses
+//     with |t| > 1e15 and the march keeps |raylength| below that.  3 instructions instead of 11;
+//   * the 8 corners are read with GLOBAL loads at a 32-bit byte offset from a scalar base (the
+//     model table hands out generic pointers, for which the compiler emits flat loads and 64-bit
+//     address arithmetic); volumes above 4 GiB take the 64-bit march_ray instead (host decision);
+//   * the bounds test is one predicate, not five nested exec-mask branches.
+// Variants that were measured and dropped (kept in git history, numbers in DESIGN.md 5.3):
+// speculative batching of K samples (+8 % at K = 2, register-bound beyond), a cooperative mode in
+// which the 64 lanes evaluate 64 consecutive samples of one ray (exact, but the tail rays change
+// their step size every few samples, so it almost never applies), brick-flag fast-forward.
 #pragma once
 
 #include "device_core.hpp"
 
 namespace emf_hip {
 
-#ifndef EMF_COOP_MAX_RAYS
-#define EMF_COOP_MAX_RAYS 0
-#endif
-constexpr int kCoopMaxRays = EMF_COOP_MAX_RAYS;
+typedef const __attribute__((address_space(1))) char* gchar_p;
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+typedef const __attribute__((address_space(1))) uint8_t* gbyte_p;
+typedef float pair_f __attribute__((ext_vector_type(2), aligned(4)));  // two x-adjacent voxels
+typedef const __attribute__((address_space(1))) pair_f* gpair_p;
 
-#ifndef EMF_COOP_MIN_RUN
-#define EMF_COOP_MIN_RUN 24
-#endif
-// Cooperative mode advances ONE ray by up to 64 samples for the price of a few ordinary steps,
-// whereas an ordinary iteration advances EVERY active ray by one: it pays only on long runs of
-// plain samples.  A ray qualifies once its last kCoopMinRun samples were plain (image-border rays
-// grazing seen/unseen space, rays crossing unseen or free space of an object volume); rays in the
-// near-surface band, where the step size changes and the crossing is imminent, never do.
-constexpr int kCoopMinRun = EMF_COOP_MIN_RUN;
+// global (not flat) load of base[byteOff / 4]; base is wave-uniform, the offset 32 bits
+__device__ __forceinline__ float gload(const float* base, unsigned byteOff) {
+    return *(gfloat_p)((gchar_p)base + byteOff);
+}
+__device__ __forceinline__ uint8_t gload(const uint8_t* base, unsigned off) {
+    return *(gbyte_p)((gchar_p)base + off);
+}
+// base[byteOff / 4] and its x neighbour with one 8-byte load (dword alignment suffices on gfx950)
+__device__ __forceinline__ pair_f gload2(const float* base, unsigned byteOff) {
+    return *(gpair_p)((gchar_p)base + byteOff);
+}
+
+// x / voxelSize: IEEE division, or its checked 3-instruction equal (rcp != 0, see the header)
+__device__ __forceinline__ float div_voxel(float x, float d, float rcp) {
+    if (rcp != 0.f) {  // wave-uniform
+        const float q = x * rcp;
+        return __builtin_fmaf(__builtin_fmaf(-q, d, x), rcp, q);
+    }
+    return x / d;
+}
+__device__ __forceinline__ V3 to_voxel(const V3& p, const RayVolume& v, const V3& half) {
+    V3 q;
+    if (v.rcpVoxel != 0.f) {  // wave-uniform: one branch for the three coordinates
+        q = v3(div_voxel(p.x, v.voxelSize, v.rcpVoxel), div_voxel(p.y, v.voxelSize, v.rcpVoxel),
+               div_voxel(p.z, v.voxelSize, v.rcpVoxel));
+    } else {
+        q = p / v.voxelSize;
+    }
+    return q + half;
+}
+
+// outside(): the same six comparisons, evaluated without short-circuit branches
+__device__ __forceinline__ bool outside_flat(const V3& p, float pad, const V3& nf) {
+    return (p.x < 0.f) | (p.x + pad >= nf.x) | (p.y < 0.f) | (p.y + pad >= nf.y) | (p.z < 0.f) |
+           (p.z + pad >= nf.z);
+}
+
+// corner addressing with a 32-bit byte offset (volumes up to 4 GiB per channel)
+struct Cell32 {
+    unsigned off;  // 4 * (((lz * Ny) + ly) * Nx + lx)
+    float fx, fy, fz;
+};
+__device__ __forceinline__ Cell32 cell32_of(const V3& idx, const I3& n) {
+    const int lx = static_cast<int>(idx.x), ly = static_cast<int>(idx.y),
+              lz = static_cast<int>(idx.z);
+    Cell32 c;
+    c.off = ((static_cast<unsigned>(lz) * static_cast<unsigned>(n.y) + static_cast<unsigned>(ly)) *
+                 static_cast<unsigned>(n.x) +
+             static_cast<unsigned>(lx)) *
+            4u;
+    c.fx = idx.x - static_cast<float>(lx);
+    c.fy = idx.y - static_cast<float>(ly);
+    c.fz = idx.z - static_cast<float>(lz);
+    return c;
+}
+__device__ __forceinline__ Cell widen(const Cell32& c) {
+    return Cell{static_cast<size_t>(c.off >> 2), c.fx, c.fy, c.fz};
+}
+
+__device__ __forceinline__ float trilinear1_g(const float* vol, const Cell32& c, const I3& n) {
+    const unsigned sy = 4u * static_cast<unsigned>(n.x), sz = sy * static_cast<unsigned>(n.y);
+    const pair_f a = gload2(vol, c.off), b = gload2(vol, c.off + sy), d = gload2(vol, c.off + sz),
+                 e = gload2(vol, c.off + sz + sy);
+    return blend8(a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, c.fx, c.fy, c.fz);
+}
+
+// weights as the march sees them: optionally gated by the foreground mask (ObjTSDF.cpp:209-210)
+__device__ __forceinline__ float trilinear_weights_g(const RayVolume& v, const Cell32& c) {
+    const unsigned sy = 4u * static_cast<unsigned>(v.n.x), sz = sy * static_cast<unsigned>(v.n.y);
+    const unsigned o[4] = {c.off, c.off + sy, c.off + sz, c.off + sz + sy};
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const pair_f p = gload2(v.weights, o[k]);
+        w[2 * k] = p.x;
+        w[2 * k + 1] = p.y;
+    }
+    if (v.fg) {  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[2 * k] = gload(v.fg, o[k] >> 2) ? w[2 * k] : 0.f;
+            w[2 * k + 1] = gload(v.fg, (o[k] >> 2) + 1u) ? w[2 * k + 1] : 0.f;
+        }
+    }
+    return blend8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], c.fx, c.fy, c.fz);
+}
+
+struct MarchCount {
+    bool hit;
+    unsigned samples;  // main-loop samples taken (byte-model statistic)
+};
 
 struct RayState {
     V3 dir;
     float raylength, maxRay, raystep, tsdf;
-    int plainRun;  // consecutive samples that changed nothing but raylength / tsdf
     bool active;
 };
 
 // Everything before the main loop of the reference kernel (TSDF.cu:476-521).
-__device__ __forceinline__ void ray_setup(const RayVolume& v, int x, int y, float fx, float fy,
-                                          float cx, float cy, float oldRaylength, RayState& r) {
+__device__ __forceinline__ void ray_setup(const RayVolume& v, const V3& half, const V3& nf, int x,
+                                          int y, float fx, float fy, float cx, float cy,
+                                          float oldRaylength, RayState& r) {
     r.active = false;
     const V3 unproj = v3((static_cast<float>(x) - cx) / fx, (static_cast<float>(y) - cy) / fy, 1.f);
     const V3 rayv = mul(v.R, unproj);
@@ -69,7 +148,6 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, int x, int y, floa
     const V3 bb = v3(static_cast<float>((v.n.x - 1) / 2) * v.voxelSize,
                      static_cast<float>((v.n.y - 1) / 2) * v.voxelSize,
                      static_cast<float>((v.n.z - 1) / 2) * v.voxelSize);
-    const V3 half = half_extent(v.n);
     r.raylength = enter_step(r.dir, v.cam, bb);
     r.maxRay = exit_step(r.dir, v.cam, bb);
     r.raylength += v.voxelSize;
@@ -77,96 +155,56 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, int x, int y, floa
     if (oldRaylength != 0) r.maxRay = fminf(oldRaylength, r.maxRay);
     r.raystep = v.truncdist;
     r.tsdf = 0.f;
-    r.plainRun = 0;
     if (r.raylength >= r.maxRay) return;  // ray misses the volume
-    V3 p = to_voxel(v.cam + r.dir * r.raylength, v.voxelSize, half);
-    while (outside(p, 1.f, v.n) && r.raylength < r.maxRay) {  // coarse search, TSDF.cu:509-514
+    V3 p = to_voxel(v.cam + r.dir * r.raylength, v, half);
+    while (outside_flat(p, 1.f, nf) && r.raylength < r.maxRay) {  // coarse search, TSDF.cu:509-514
         r.raylength += r.raystep;
-        p = to_voxel(v.cam + r.dir * r.raylength, v.voxelSize, half);
+        p = to_voxel(v.cam + r.dir * r.raylength, v, half);
     }
     // If the search ran out (Q4) the reference reads out of bounds and then never enters the
     // march (raylength >= maxRay): nothing is written either way.
-    if (outside(p, 1.f, v.n)) return;
-    r.tsdf = trilinear1(v.tsdf, cell_of(p, v.n), v.n);
+    if (outside_flat(p, 1.f, nf)) return;
+    r.tsdf = trilinear1_g(v.tsdf, cell32_of(p, v.n), v.n);
     if (fabsf(r.tsdf) < 1.f) r.raystep = v.voxelSize;
     if (fabsf(r.tsdf) < .8f) r.raystep = 0.5f * v.voxelSize;
     r.active = true;
 }
 
-#ifdef EMF_X_FASTDIV
-__device__ __forceinline__ float xdiv(float x, float d, float rcp) {
-    const float q = x * rcp;
-    return __builtin_fmaf(__builtin_fmaf(-q, d, x), rcp, q);
-}
-__device__ __forceinline__ V3 to_voxel_x(const V3& p, float d, float rcp, const V3& half) {
-    return v3(xdiv(p.x, d, rcp) + half.x, xdiv(p.y, d, rcp) + half.y, xdiv(p.z, d, rcp) + half.z);
-}
-#else
-__device__ __forceinline__ V3 to_voxel_x(const V3& p, float d, float, const V3& half) {
-    return to_voxel(p, d, half);
-}
-#endif
-#ifdef EMF_X_OFF32
-__device__ __forceinline__ float trilinear1_x(const float* __restrict__ vol, const V3& idx, const I3& n) {
-    const int lx = static_cast<int>(idx.x), ly = static_cast<int>(idx.y), lz = static_cast<int>(idx.z);
-    const float fx = idx.x - static_cast<float>(lx), fy = idx.y - static_cast<float>(ly),
-                fz = idx.z - static_cast<float>(lz);
-    const unsigned sy = 4u * static_cast<unsigned>(n.x), sz = sy * static_cast<unsigned>(n.y);
-    const unsigned o = (static_cast<unsigned>(lz) * static_cast<unsigned>(n.y) + static_cast<unsigned>(ly)) * sy + 4u * static_cast<unsigned>(lx);
-    const char* b = reinterpret_cast<const char*>(vol);
-    const float c0 = *reinterpret_cast<const float*>(b + o), c1 = *reinterpret_cast<const float*>(b + o + 4u);
-    const unsigned o1 = o + sy, o2 = o + sz, o3 = o2 + sy;
-    const float c2 = *reinterpret_cast<const float*>(b + o1), c3 = *reinterpret_cast<const float*>(b + o1 + 4u);
-    const float c4 = *reinterpret_cast<const float*>(b + o2), c5 = *reinterpret_cast<const float*>(b + o2 + 4u);
-    const float c6 = *reinterpret_cast<const float*>(b + o3), c7 = *reinterpret_cast<const float*>(b + o3 + 4u);
-    return blend8(c0, c1, c2, c3, c4, c5, c6, c7, fx, fy, fz);
-}
-#endif
-
 // One iteration of `while ((raylength += raystep) <= maxRaylength)` (TSDF.cu:523-572) for the
 // calling lane.  Clears r.active when the march ends (range exhausted, back-side crossing, hit).
-__device__ __forceinline__ void ray_step(const RayVolume& v, RayState& r, RayHit& out, float rcp = 0.f) {
-    const V3 half = half_extent(v.n);
+// A hit is handed to `sink(raylength, vertex, normal)` at once instead of being carried through
+// the loop in registers (7 loop-carried values cost ~25 register moves per iteration).
+template <class Sink>
+__device__ __forceinline__ void ray_step(const RayVolume& v, const V3& half, const V3& nf,
+                                         RayState& r, MarchCount& out, Sink& sink) {
     r.raylength += r.raystep;
     if (!(r.raylength <= r.maxRay)) {
         r.active = false;
         return;
     }
-    const V3 p = to_voxel_x(v.cam + r.dir * r.raylength, v.voxelSize, rcp, half);
-    if (outside(p, 2.f, v.n)) {
-        ++r.plainRun;
-        return;
-    }
+    const V3 p = to_voxel(v.cam + r.dir * r.raylength, v, half);
+    if (outside_flat(p, 2.f, nf)) return;
     ++out.samples;
-#ifdef EMF_X_OFF32
-    const float next = trilinear1_x(v.tsdf, p, v.n);
-#else
-    const float next = trilinear1(v.tsdf, cell_of(p, v.n), v.n);
-#endif
+    const Cell32 c = cell32_of(p, v.n);
+    const float next = trilinear1_g(v.tsdf, c, v.n);
     // zero crossing from behind: leave the volume's surface shell
-    if (r.tsdf < 0 && next > 0 && trilinear_weights(v, cell_of(p, v.n)) > 0.f) {
+    if (r.tsdf < 0 && next > 0 && trilinear_weights_g(v, c) > 0.f) {
         r.active = false;
         return;
     }
-    const float stepBefore = r.raystep;
     if (fabsf(next) < 1.f) r.raystep = v.voxelSize;
     if (fabsf(next) < .8f) r.raystep = 0.5f * v.voxelSize;
-    // same classification as coop_advance: plain = nothing but raylength / tsdf moves
-    const bool plain = r.raystep == stepBefore && !(r.tsdf < 0 && next > 0) && !(r.tsdf > 0 && next < 0);
-    r.plainRun = plain ? r.plainRun + 1 : 0;
     if (r.tsdf > 0 && next < 0) {
         // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:542-543)
         const float tstar = r.raylength - r.raystep * r.tsdf / (next - r.tsdf);
-        const V3 ps = to_voxel(v.cam + r.dir * tstar, v.voxelSize, half);
-        if (outside(ps, 2.f, v.n)) return;  // reference `continue`: tsdf is NOT advanced
-        const Cell cs = cell_of(ps, v.n);
-        if (trilinear_weights(v, cs) > 0.f) {
-            const V3 g = gradient_at(v, cs);
+        const V3 ps = to_voxel(v.cam + r.dir * tstar, v, half);
+        if (outside_flat(ps, 2.f, nf)) return;  // reference `continue`: tsdf is NOT advanced
+        const Cell32 cs = cell32_of(ps, v.n);
+        if (trilinear_weights_g(v, cs) > 0.f) {
+            const V3 g = gradient_at(v, widen(cs));
             const M33 Rt = transpose(v.R);
             out.hit = true;
-            out.raylength = tstar;
-            out.vertex = mul(Rt, r.dir * tstar);
-            out.normal = mul(Rt, g / norm(g));  // 0/0 -> NaN like the reference
+            sink(tstar, mul(Rt, r.dir * tstar), mul(Rt, g / norm(g)));  // 0/0 -> NaN like the reference
             r.active = false;
             return;
         }
@@ -174,90 +212,25 @@ __device__ __forceinline__ void ray_step(const RayVolume& v, RayState& r, RayHit
     r.tsdf = next;
 }
 
-// The whole wave works on the ray of lane `leader`: returns through `r` / `out` of that lane.
-// Must be called by all 64 lanes (wave-uniform control flow).
-__device__ __forceinline__ void coop_advance(const RayVolume& v, int leader, int lane, RayState& r,
-                                             RayHit& out) {
-    const V3 half = half_extent(v.n);
-    const float r0 = __shfl(r.raylength, leader), mx = __shfl(r.maxRay, leader),
-                st = __shfl(r.raystep, leader), ts = __shfl(r.tsdf, leader);
-    const V3 d = v3(__shfl(r.dir.x, leader), __shfl(r.dir.y, leader), __shfl(r.dir.z, leader));
-    // sample j + 1 of the leader's ray: raylength after j + 1 executions of `raylength += raystep`
-    float rj = r0;
-    for (int i = 0; i <= lane; ++i) rj = rj + st;
-    const bool inRange = rj <= mx;
-    const V3 pj = to_voxel(v.cam + d * rj, v.voxelSize, half);
-    const bool ins = inRange && !outside(pj, 2.f, v.n);
-    float nx = 0.f;
-    if (ins) nx = trilinear1(v.tsdf, cell_of(pj, v.n), v.n);
-    const unsigned long long M = __ballot(ins);
-    // value the reference's `tsdf` would hold when it reaches this sample, provided every earlier
-    // sample of the batch is plain: the blend of the nearest earlier in-volume sample, else `ts`
-    const unsigned long long below = M & ((1ull << lane) - 1ull);
-    const int prevLane = below ? 63 - __clzll(static_cast<long long>(below)) : 0;
-    const float prevVal = __shfl(nx, prevLane);
-    const float prev = below ? prevVal : ts;
-    float ns = st;
-    if (fabsf(nx) < 1.f) ns = v.voxelSize;
-    if (fabsf(nx) < .8f) ns = 0.5f * v.voxelSize;
-    // anything but "advance raylength / count / carry the value" is an event
-    const bool event = !inRange || (ins && (ns != st || (prev < 0 && nx > 0) || (prev > 0 && nx < 0)));
-    const unsigned long long E = __ballot(event);
-    const int e = E ? __ffsll(static_cast<long long>(E)) - 1 : 64;  // samples [0, e) are plain
-    const unsigned long long plain = e >= 64 ? ~0ull : ((1ull << e) - 1ull);
-    const unsigned long long Mp = M & plain;
-    const float rLast = __shfl(rj, e > 0 ? e - 1 : 0);
-    const float tLast = __shfl(nx, Mp ? 63 - __clzll(static_cast<long long>(Mp)) : 0);
-    if (lane == leader) {
-        if (e > 0) {
-            r.raylength = rLast;
-            r.plainRun += e;
-            const unsigned cnt = static_cast<unsigned>(__popcll(Mp));
-            out.samples += cnt;
-            out.gathered += cnt;
-            out.skipped += cnt;  // statistic: samples consumed cooperatively
-            if (Mp) r.tsdf = tLast;
-        }
-#ifdef EMF_COOP_DEBUG_CALLS
-        out.gathered += 1000000u;  // diagnostic build only: count cooperative calls
-#endif
-        // the sample that may change the march state goes through the ordinary step
-        if (e < 64) ray_step(v, r, out);
-    }
-}
-
 // March the ray of pixel (x, y); `valid` = the pixel exists.  All 64 lanes of the wave call this.
-__device__ __forceinline__ RayHit march_wave(const RayVolume& v, bool valid, int x, int y, float fx,
-                                             float fy, float cx, float cy, float oldRaylength,
-                                             int lane) {
-    RayHit out;
+// The volume must fit 32-bit byte offsets (Nx Ny Nz <= 2^30): the caller checks.
+template <class Sink>
+__device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid, int x, int y,
+                                                 float fx, float fy, float cx, float cy,
+                                                 float oldRaylength, Sink& sink) {
+    MarchCount out;
     out.hit = false;
     out.samples = 0;
-    out.gathered = 0;
-    out.skipped = 0;
-    out.raylength = 0.f;
-    out.vertex = v3(0.f, 0.f, 0.f);
-    out.normal = v3(0.f, 0.f, 0.f);
+    const V3 half = half_extent(v.n);
+    const V3 nf = v3(static_cast<float>(v.n.x), static_cast<float>(v.n.y), static_cast<float>(v.n.z));
     RayState r;
     r.dir = v3(0.f, 0.f, 1.f);
     r.raylength = r.maxRay = r.raystep = r.tsdf = 0.f;
-    r.plainRun = 0;
     r.active = false;
-    if (valid) ray_setup(v, x, y, fx, fy, cx, cy, oldRaylength, r);
-    const float rcp = 1.0f / v.voxelSize;
-    for (;;) {
-        const unsigned long long act = __ballot(r.active);
-        if (act == 0) break;
-        // rays that have just shown a long plain run are worth the whole wave's attention
-        const unsigned long long cand =
-            __popcll(act) <= kCoopMaxRays ? __ballot(r.active && r.plainRun >= kCoopMinRun) : 0ull;
-        if (cand == 0) {
-            if (r.active) ray_step(v, r, out, rcp);
-        } else {
-            coop_advance(v, __ffsll(static_cast<long long>(cand)) - 1, lane, r, out);
-        }
+    if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, r);
+    while (__ballot(r.active) != 0) {
+        if (r.active) ray_step(v, half, nf, r, out, sink);
     }
-    out.gathered = out.samples;
     return out;
 }
 

@@ -17,7 +17,6 @@
 //     (fg ? w : 0) instead of materialising ObjTSDF::raycastWeights every frame
 //   * with brick uniformity flags, lookups inside uniform regions blend the constant instead of
 //     gathering eight equal values
-#include "march_spec.hpp"
 #include "march_wave.hpp"
 
 namespace emf_hip {
@@ -36,8 +35,8 @@ struct RaycastArgs {
 // waves, so what matters is that EVERY wave is resident from the start.  With 4-wave workgroups
 // a CU holds 5 of them at 96 VGPRs (1280 slots for 1200 workgroups) and any imbalance of the
 // dispatcher sends stragglers into a second round; single waves are placed SIMD by SIMD.
-// WAVE: wave-scheduled march with cooperative tail (march_wave.hpp) -- the default; the flag-aware
-// per-lane march (device_core.hpp) is used when the caller supplies brick flags.
+// WAVE: wave-scheduled march (march_wave.hpp) -- the default; the flag-aware per-lane march
+// (device_core.hpp) is used when the caller supplies brick flags or the volume exceeds 4 GiB.
 
 template <bool WAVE>
 __global__ __launch_bounds__(64) void k_raycast(const RaycastArgs a) {
@@ -49,7 +48,22 @@ __global__ __launch_bounds__(64) void k_raycast(const RaycastArgs a) {
     const float old = valid ? a.ray.row(y)[x] : 0.f;
     RayHit r;
     if constexpr (WAVE) {
-        r = march_wave(a.vol, valid, x, y, a.fx, a.fy, a.cx, a.cy, old, lane);  // all lanes
+        // pixels without a hit are left untouched, as in the reference
+        auto sink = [&](float raylength, const V3& vertex, const V3& normal) {
+            a.ray.row(y)[x] = raylength;
+            float* pv = a.vert.row(y) + 3 * x;
+            float* pn = a.nrm.row(y) + 3 * x;
+            pv[0] = vertex.x;
+            pv[1] = vertex.y;
+            pv[2] = vertex.z;
+            pn[0] = normal.x;
+            pn[1] = normal.y;
+            pn[2] = normal.z;
+            a.mask.row(y)[x] = 1;
+        };
+        const MarchCount c = march_wave(a.vol, valid, x, y, a.fx, a.fy, a.cx, a.cy, old, sink);
+        add_ray_stats(a.stats, c.samples, c.hit ? 1u : 0u, c.samples, 0u, lane);
+        return;
     } else {
         r.hit = false;
         r.samples = r.gathered = r.skipped = 0;
@@ -81,7 +95,7 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
                                    const emf_image_t* normals, const emf_image_t* mask,
                                    const float R_CO[9], const float t_CO[3], const float K[9],
                                    const int32_t res[3], float voxelSize, float truncdist,
-                                   uint64_t* stats, emf_stream_t stream) {
+                                   float rcpVoxel, uint64_t* stats, emf_stream_t stream) {
     EMF_REQUIRE_PTR(tsdf);
     EMF_REQUIRE_PTR(weights);
     EMF_TRY(check_image(raylengths, 4, "raycastTSDF: raylengths"));
@@ -111,6 +125,7 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.vol.blendFromFlags = false;
     a.vol.voxelSize = voxelSize;
     a.vol.truncdist = truncdist;
+    a.vol.rcpVoxel = usable_reciprocal(rcpVoxel, t_CO);
     a.ray = img<float>(raylengths);
     a.vert = img<float>(vertices);
     a.nrm = img<float>(normals);
@@ -122,7 +137,7 @@ extern "C" int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const 
     a.cx = K[2];
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
-    if (brickFlags)
+    if (brickFlags || !fits_offsets32(res))
         hipLaunchKernelGGL(k_raycast<false>, dim3(ceil_div(a.w, 8), ceil_div(a.h, 8)), dim3(64), 0,
                            as_stream(stream), a);
     else

@@ -113,7 +113,7 @@ def compute_tsdf_grads(tsdf, grads, stream=None):
 
 
 def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, mask, R_CO, t_CO, K,
-                 voxel_size, truncdist, stats=None, brick_flags=None, stream=None):
+                 voxel_size, truncdist, stats=None, brick_flags=None, stream=None, rcp_voxel=0.0):
     _vol(tsdf, np.float32)
     _vol(weights, np.float32)
     if grads is not None:
@@ -127,7 +127,7 @@ def raycast_tsdf(tsdf, grads, weights, fg_mask, raylengths, vertices, normals, m
                                  _ptr(brick_flags), C.byref(image_view(raylengths)), C.byref(image_view(vertices)),
                                  C.byref(image_view(normals)), C.byref(image_view(mask)),
                                  _f(R_CO, 9), _f(t_CO, 3), _f(K, 9), _res(tsdf), voxel_size,
-                                 truncdist, _ptr(stats), _stream(stream)))
+                                 truncdist, float(rcp_voxel), _ptr(stats), _stream(stream)))
 
 
 def get_volume_vals(vol, points, R_CO, t_CO, voxel_size, vals, stream=None):
@@ -234,7 +234,7 @@ def device_info():
 
 def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, voxel_size,
                truncdist, max_weight, sigma, alpha, uni_prior, model_id=0, grads=None,
-               fg_probs=None, fg_mask=None, brick_flags=None) -> "_lib.EmfModel":
+               fg_probs=None, fg_mask=None, brick_flags=None, rcp_voxel=0.0) -> "_lib.EmfModel":
     """Fill an emf_model_t from device arrays (images must be unpadded)."""
     f32 = np.float32
     m = _lib.EmfModel()
@@ -255,6 +255,7 @@ def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, vo
     m.assocC2 = float(f32(1) / (f32(2) * f32(sigma)))
     m.alpha = alpha
     m.assocC3 = float((f32(1) - f32(alpha)) * f32(uni_prior))
+    m.rcpVoxel = rcp_voxel  # 0, or ops.voxel_reciprocal(voxel_size)
     return m
 
 
@@ -282,10 +283,18 @@ def estep_batched(models_dev, poses_co, points, normalize=True, norm=None, obj_s
                                   _stream(stream)))
 
 
-def raycast_batched(models_dev, poses_co, width, height, K, stats=None, use_brick_flags=False,
-                    stream=None):
+def voxel_reciprocal(voxel_size) -> float:
+    """1 / voxel_size if the device check finds it usable in place of x / voxel_size, else 0."""
+    r = C.c_float(0.0)
+    check("emf_hip_voxelReciprocal", _L.emf_hip_voxelReciprocal(float(voxel_size), C.byref(r)))
+    return float(r.value)
+
+
+def raycast_batched(models_dev, poses_co, res_list, width, height, K, stats=None,
+                    use_brick_flags=False, stream=None):
+    res = (C.c_int32 * (3 * len(poses_co)))(*[int(v) for r in res_list for v in r])
     check("emf_hip_raycastBatched",
-          _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), len(poses_co), width,
+          _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width,
                                     height, _f(K, 9), int(use_brick_flags), _ptr(stats),
                                     _stream(stream)))
 

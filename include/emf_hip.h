@@ -123,6 +123,8 @@ int emf_hip_computeTSDFGrads(const float* tsdf, float* grads, const int32_t res[
  *             ObjTSDF::raycast's per-frame raycastWeights sweep (ObjTSDF.cpp:209-210)
  *   brickFlags: NULL, or the brick uniformity flags of `tsdf` (see EMF_BRICK): lookups whose
  *             eight corners lie in equally-uniform bricks are computed without touching `tsdf`
+ *   rcpVoxel: 0, or the value emf_hip_voxelReciprocal returned for `voxelSize`: the march then
+ *             divides by the voxel size in 3 instructions instead of 11, same results
  *   stats   : NULL, or 4 x u64 device counters this call ADDS to: [0] volume samples taken by the
  *             main march loop (the S of SURVEY.md section 8d), [1] hits, [2] samples that read
  *             the volume (the rest were answered by the brick flags), [3] samples fast-forwarded */
@@ -132,7 +134,15 @@ int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weig
                         const emf_image_t* vertices, const emf_image_t* normals,
                         const emf_image_t* mask, const float R_CO[9], const float t_CO[3],
                         const float K[9], const int32_t res[3], float voxelSize, float truncdist,
-                        uint64_t* stats, emf_stream_t stream);
+                        float rcpVoxel, uint64_t* stats, emf_stream_t stream);
+
+/* Reciprocal of a voxel size, CHECKED for use in place of the division x / voxelSize:
+ * runs every one of the 2^32 float bit patterns x through  q = x * r; q = fma(fma(-q, d, x), r, q)
+ * (r = 1 / d) and through the IEEE division on the device, and stores r in *rcp only if the two
+ * agree bit for bit for all x with 1e-30 <= |x| <= 1e30 (0 otherwise; the march keeps its
+ * arguments inside that range, see march_wave.hpp).  SYNCHRONOUS (about 3 ms): call it once per
+ * volume, at creation. */
+int emf_hip_voxelReciprocal(float voxelSize, float* rcp);
 
 /* Replaces emf::cuda::TSDF::getVolumeVals (TSDF.cuh:197-203, TSDF.cu:662-726).
  * vol: N^3 x channels f32 (channels 1..3, interleaved); points f32x3; vals f32 x channels.
@@ -243,6 +253,8 @@ typedef struct emf_model {
     float alpha;            /*                          (TSDF.cpp:131) */
     float assocC3;          /* (1 - alpha) * uniPrior   (TSDF.cpp:133) */
     int32_t reserved;
+    float rcpVoxel;         /* emf_hip_voxelReciprocal(voxelSize), or 0 = divide */
+    int32_t pad_;
 } emf_model_t;
 
 /* Rigid transform passed by value with each launch (poses change every frame). */
@@ -268,12 +280,15 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
  * Unlike emf_hip_raycastTSDF the outputs need no pre-zeroing: every pixel of every model's
  * raylengths / vertices / normals / hitMask is written (zeros where there is no hit), which is
  * what the reference's setTo(0) + kernel leave behind (EMFusion.cpp:727-758).
- * useBrickFlags != 0: march with the models' brick flags (fast-forward through uniform bricks);
- * 0: ignore them and march in speculative batches of 4 samples (one gather round trip per batch).
- * Both produce the same images. */
+ *   res_host: HOST int32[nmodels * 3], the resolutions stored in the table
+ *   useBrickFlags != 0: march with the models' brick flags (fast-forward through uniform bricks);
+ *   0: ignore them and use the wave-scheduled march (default; faster on the bench scene).
+ * Both produce the same images.  Models whose table entry carries rcpVoxel != 0 divide by the
+ * voxel size with the checked reciprocal (emf_hip_voxelReciprocal), same results. */
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
-                           int nmodels, int width, int height, const float K[9],
-                           int useBrickFlags, uint64_t* stats, emf_stream_t stream);
+                           const int32_t* res_host, int nmodels, int width, int height,
+                           const float K[9], int useBrickFlags, uint64_t* stats,
+                           emf_stream_t stream);
 
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera

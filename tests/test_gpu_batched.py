@@ -117,7 +117,8 @@ class Model:
             self.d_tsdf, self.d_wts, self.d_assoc, self.d_ray, self.d_vert, self.d_nrm, self.d_hit,
             float(self.vox), float(self.trunc), MAXW, SIGMA, ALPHA, PRIOR, model_id=self.id,
             fg_probs=self.d_probs if self.is_obj else None,
-            fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags)
+            fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags,
+            rcp_voxel=self.ops.voxel_reciprocal(self.vox))
 
 
 @pytest.fixture(scope="module")
@@ -240,7 +241,8 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
         m.d_nrm.copy_from(np.full((H, W, 3), 5, np.float32))
         m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
     st = dev_full((4,), 0, np.uint64)
-    ops.raycast_batched(table, poses, W, H, K, stats=st, use_brick_flags=use_flags)
+    ops.raycast_batched(table, poses, [m.res for m in scene], W, H, K, stats=st,
+                        use_brick_flags=use_flags)
     total = 0
     for m, (R, t) in zip(scene, poses):
         want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t,

@@ -151,7 +151,29 @@ def test_get_volume_vals(oracle, ops, dev, ch):
 
 # ---- a10 / a11 -----------------------------------------------------------------------------------
 
-def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False):
+_RCP = {}
+
+
+def checked_reciprocal(ops, vox):
+    """emf_hip_voxelReciprocal, once per voxel size (it sweeps all 2^32 floats on the device)."""
+    key = float(np.float32(vox))
+    if key not in _RCP:
+        _RCP[key] = ops.voxel_reciprocal(key)
+    return _RCP[key]
+
+
+def test_voxel_reciprocal_is_checked_and_exact(ops, dev):
+    for vox in (0.01, 0.02, 0.04, 2 * 0.3 / 128, 0.0123456):
+        r = checked_reciprocal(ops, vox)
+        assert r == float(np.float32(1) / np.float32(vox)), vox  # accepted: the plain reciprocal
+    from emfusion_amd._lib import EmfHipError
+    with pytest.raises(EmfHipError):
+        ops.voxel_reciprocal(0.0)
+
+
+def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False, divide=False):
+    """divide=False: the march uses the checked reciprocal of the voxel size (the default of the
+    class-level path); True: IEEE divisions.  Both must equal the oracle bit for bit."""
     ray = dev_full((H, W), 0.0) if ray0 is None else to_dev(ray0, dev)
     vert = dev_full((H, W, 3), 0.0)
     nrm = dev_full((H, W, 3), 0.0)
@@ -159,7 +181,8 @@ def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False
     st = dev_full((4,), 0, np.uint64) if stats else None
     ops.raycast_tsdf(to_dev(tsdf, dev), None if grads is None else to_dev(grads, dev),
                      to_dev(wts, dev), None if fg is None else to_dev(fg, dev), ray, vert, nrm,
-                     mask, co.R32, co.t32, K, vox, 10 * vox, st)
+                     mask, co.R32, co.t32, K, vox, 10 * vox, st,
+                     rcp_voxel=0.0 if divide else checked_reciprocal(ops, vox))
     dev.synchronize()
     out = [to_np(ray), to_np(vert), to_np(nrm), to_np(mask)]
     return out + [to_np(st)] if stats else out
@@ -184,15 +207,16 @@ CAMS = {
 }
 
 
+@pytest.mark.parametrize("divide", [False, True], ids=["reciprocal", "divide"])
 @pytest.mark.parametrize("cam_name", list(CAMS))
 @pytest.mark.parametrize("use_grad_volume", [False, True])
-def test_raycast_background(oracle, ops, dev, bg_state, cam_name, use_grad_volume):
+def test_raycast_background(oracle, ops, dev, bg_state, cam_name, use_grad_volume, divide):
     tsdf, wts = bg_state
     grads = oracle.compute_tsdf_grads(tsdf) if use_grad_volume else None
     co = rel_CO(CAMS[cam_name], BG["pose"])
     want = oracle.raycast_tsdf(tsdf, grads, wts, None, W, H, co.R32, co.t32, K, BG["vox"],
                                10 * BG["vox"], count_steps=True)
-    got = _raycast_dev(ops, dev, tsdf, grads, wts, None, co, BG["vox"], stats=True)
+    got = _raycast_dev(ops, dev, tsdf, grads, wts, None, co, BG["vox"], stats=True, divide=divide)
     if cam_name != "outside_oblique":
         assert want[3].sum() > 2000
     assert_parity(got[3], want[3], "mask", exact=True)
