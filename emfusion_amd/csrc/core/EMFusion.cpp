@@ -90,6 +90,8 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     vertices.setZero(s);
     normals.setZero(s);
     bg_raylengths.setZero(s);
+    associationNorm.setZero(s);  // read by getters before the first E-step (frame 0 has none)
+    objPartialSum.setZero(s);
     raycastStatsDev.setZero(s);
     integrateStatsDev.setZero(s);
     visCounts.setZero(s);
