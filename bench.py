@@ -218,10 +218,14 @@ def main():
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
         }
+        copy_gbs = copy_bandwidth(devmem, ops)
         if kern is not None:
-            result["roofline"], result["kernels"] = roofline(kern, stats, P)
+            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs)
         else:
             result["roofline"] = None
+        result["hbm_copy_GBs"] = copy_gbs  # attainable D2D stream bandwidth of THIS box (read + write)
+        # work aggregate for the scaling curves: every rank's volumes advance one frame per step
+        result["volume_frames_per_s"] = round(fps * (world + nobj_total), 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
 
@@ -289,7 +293,26 @@ def measured_traffic(kind):
         return None
 
 
-def roofline(kern, stats, P):
+def copy_bandwidth(devmem, ops, mib=1024, reps=10):
+    """GB/s (bytes read + bytes written) of the plain 16-byte-per-lane copy kernel between two
+    `mib` MiB buffers: what this box's HBM sustains for a pure stream."""
+    from emfusion_amd.devmem import DeviceArray, Event
+    n = mib * 1024 * 1024 // 4
+    src, dst = DeviceArray.zeros((n,), np.float32), DeviceArray.zeros((n,), np.float32)
+    for _ in range(3):
+        ops.stream_copy(dst, src)
+    e0, e1 = Event(), Event()
+    e0.record()
+    for _ in range(reps):
+        ops.stream_copy(dst, src)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_ms(e1) / reps
+    del src, dst
+    return round(2.0 * n * 4 / (ms * 1e-3) / 1e9, 1)
+
+
+def roofline(kern, stats, P, copy_gbs=None):
     rows = []
     for kind, summ in kern.items():
         if kind.startswith("_") or summ["launches"] == 0:
@@ -317,6 +340,18 @@ def roofline(kern, stats, P):
         "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
         "dropped_launches": kern.get("_dropped", 0),
     }
+    if copy_gbs:
+        roof["frac_of_copy"] = round(dom["achieved_GBs"] / copy_gbs, 4)
+    # SURVEY 8(d) headline for the streaming part: algorithmic integrate bytes over integrate time
+    integ = next((r for r in rows if r["kind"] == "integrate"), None)
+    if integ:
+        roof["integrate_stream"] = {
+            "achieved": integ["achieved_GBs"], "unit": "GB/s",
+            "frac": round(integ["achieved_GBs"] / HBM_PEAK_GBS, 4),
+            "frac_of_copy": round(integ["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
+            "avg_launch_ms": integ["avg_ms"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"],
+            "traffic": measured_traffic("integrate"),
+        }
     if dom["kind"] == "raycast":
         roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)
     return roof, rows

@@ -62,7 +62,9 @@ SIGNATURES = {
     "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP,
                                _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
-    "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, _STREAM],
+    "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
+    "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_int, _FP,
+                                 _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
     "emf_hip_packHitKeys": [C.c_int, _I3, _IMG, _IMG, _FP, C.c_int, C.c_int, _STREAM],

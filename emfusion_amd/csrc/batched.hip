@@ -408,7 +408,8 @@ int emf_hip_debugFetchRayTrace(void* host, size_t bytes) {
 int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                              const int32_t* res_host, int nmodels, const int32_t* visible_dev,
                              const emf_image_t* depth, const emf_image_t* invLambda,
-                             const float K[9], uint64_t* stats, emf_stream_t stream) {
+                             const float K[9], int maintainBrickFlags, uint64_t* stats,
+                             emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseOC_host, nmodels, "integrateBatched"));
     EMF_REQUIRE_PTR(res_host);
     EMF_TRY(check_image(depth, 4, "integrateBatched: depth"));
@@ -442,6 +443,7 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
     a.pinhole = is_pinhole(a.K);
     hipLaunchKernelGGL(k_integrate_batched, dim3(static_cast<unsigned>(a.tileStart[nmodels])),
                        dim3(256), 0, as_stream(stream), a);
+    if (!maintainBrickFlags) return launch_status("integrateBatched");
     DilateBatchArgs d;
     d.models = models_dev;
     d.nmodels = nmodels;

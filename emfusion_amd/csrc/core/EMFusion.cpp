@@ -474,6 +474,7 @@ void EMFusion::integrateBatched() {
     const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
     emfCheck(emf_hip_integrateBatched(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
                                       visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
+                                      TSDF::brickFlagMode() != 0,
                                       integrateStatsDev.as<uint64_t>(), main.abi()),
              "integrateBatched");
 }

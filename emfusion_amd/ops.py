@@ -222,6 +222,12 @@ def occluded_mask(obj_seg, seg, obj_id, occluded, stream=None):
     return occluded
 
 
+def stream_copy(dst, src, stream=None):
+    """dst <- src with the plain copy kernel (both DeviceArrays of equal byte size)."""
+    assert dst.nbytes == src.nbytes
+    check("emf_hip_streamCopy", _L.emf_hip_streamCopy(_ptr(dst), _ptr(src), dst.nbytes, _stream(stream)))
+
+
 def device_info():
     name = C.create_string_buffer(256)
     arch = C.create_string_buffer(256)
@@ -305,7 +311,7 @@ def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=N
     check("emf_hip_integrateBatched",
           _L.emf_hip_integrateBatched(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc),
                                       _ptr(visible), C.byref(image_view(depth)),
-                                      _opt_view(inv_lambda), _f(K, 9), _ptr(stats),
+                                      _opt_view(inv_lambda), _f(K, 9), 1, _ptr(stats),
                                       _stream(stream)))
 
 

@@ -136,6 +136,10 @@ int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weig
                         const float K[9], const int32_t res[3], float voxelSize, float truncdist,
                         float rcpVoxel, uint64_t* stats, emf_stream_t stream);
 
+/* Plain device-to-device copy kernel (16 B per lane per iteration): the "attainable HBM bandwidth"
+ * yardstick bench.py times beside the hot path.  16-byte aligned. */
+int emf_hip_streamCopy(void* dst, const void* src, size_t bytes, emf_stream_t stream);
+
 /* Reciprocal of a voxel size, CHECKED for use in place of the division x / voxelSize:
  * runs every one of the 2^32 float bit patterns x through  q = x * r; q = fma(fma(-q, d, x), r, q)
  * (r = 1 / d) and through the IEEE division on the device, and stores r in *rcp only if the two
@@ -298,13 +302,16 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
  *                 (EMFusion.cpp:869-872) -- evaluated on the device, no host round trip
  * Each model's `assoc` map weights its fusion; brickFlags are kept consistent when present.
  *   invLambda   : NULL, or emf_hip_computeInvLambda's table for K and the depth size
+ *   maintainBrickFlags: 0 if no model of the table carries brick flags (skips the launch that
+ *                 refreshes the dilated flags); non-zero otherwise
  *   stats       : NULL, or one u64 device counter this call ADDS the voxel count of every model
  *                 it actually sweeps to (work accounting for the byte model)
  */
 int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                              const int32_t* res_host, int nmodels, const int32_t* visible_dev,
                              const emf_image_t* depth, const emf_image_t* invLambda,
-                             const float K[9], uint64_t* stats, emf_stream_t stream);
+                             const float K[9], int maintainBrickFlags, uint64_t* stats,
+                             emf_stream_t stream);
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */
