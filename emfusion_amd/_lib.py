@@ -63,6 +63,11 @@ SIGNATURES = {
                                _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
+    "emf_hip_trackScratchBytes": [C.c_int, C.c_int],
+    "emf_hip_trackPrepare": [_FP, _FP, C.c_int, C.c_float, _STREAM],
+    "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
+                             C.c_int, _STREAM],
+    "emf_hip_computePoseGradients": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, _FP, _STREAM],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_int, _FP,
                                  _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
@@ -91,6 +96,29 @@ class EmfModel(C.Structure):
 class EmfPose(C.Structure):
     _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3)]
 
+
+class EmfTrackParams(C.Structure):
+    """Mirror of emf_track_params_t (reference defaults, data.h:36-43)."""
+
+    _fields_ = [("huberThresh", C.c_float), ("maxWeight", C.c_float), ("tau", C.c_float),
+                ("eps1", C.c_float), ("eps2", C.c_float), ("nuInit", C.c_float)]
+
+    @classmethod
+    def defaults(cls):
+        return cls(0.2, 64.0, 1e3, 1e-8, 1e-8, 2.0)
+
+
+class EmfTrackState(C.Structure):
+    """Mirror of emf_track_state_t (device-resident Levenberg-Marquardt state of one model)."""
+
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("Rtrial", C.c_float * 9),
+                ("ttrial", C.c_float * 3), ("A", C.c_float * 36), ("b", C.c_float * 6),
+                ("x", C.c_float * 6), ("mu", C.c_float), ("nu", C.c_float), ("rho", C.c_float),
+                ("err", C.c_float), ("errNew", C.c_float), ("maxIwBits", C.c_uint32),
+                ("converged", C.c_int32), ("firstIteration", C.c_int32),
+                ("evaluateGradient", C.c_int32), ("haveTrial", C.c_int32),
+                ("iterations", C.c_int32), ("accepted", C.c_int32), ("pad_", C.c_int32)]
+
 _lib = None
 
 
@@ -116,6 +144,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.emf_hip_trackScratchBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

@@ -1,0 +1,582 @@
+// tracking.hip -- weighted Levenberg-Marquardt ICP on the TSDF.
+//
+// Reference: TSDF::prepareTracking ... computePoseUpdate (TSDF.cpp:170-344, 375-395), driven by
+// EMFusion::performTracking (EMFusion.cpp:672-724); kernels computePoseGradients, getVolumeVals,
+// computeAb, multSingletonCol (TSDF.cu:603-660, 662-726, 729-766, 821-853).  One LM iteration
+// there is ~15 single-operator launches on 4 streams, a 44 MB (W*H x 36) `As` buffer that is
+// written, re-read, scaled and column-reduced, two device->host copies with stream syncs, a 6x6
+// solve on the host and -- on every trial step -- another lookup pass and a third sync.
+//
+// Here an iteration is five small launches and NO host round trip; all Levenberg-Marquardt state
+// lives in device memory (emf_track_state_t), so a frame's iterations are enqueued back to back
+// (or replayed from a hipGraph) and the host reads the final pose once:
+//   k_track_maxw    per pixel: the clamped integration-weight lookup; its image maximum (the
+//                   NORM_INF of cv::cuda::normalize) via wave max + one atomicMax per workgroup
+//   k_track_accum   per pixel: pose gradient (6), residual, Huber x normalised-weight x
+//                   association weight; the 21 + 6 unique sums of A = sum w g g^T, b = sum w r g
+//                   and the error sum r^2 w are reduced in registers (wave shuffles), through LDS,
+//                   to one row of partials per workgroup -- `As` is never materialised
+//   k_track_solve   one wave per model: adds the partials in a fixed order, convergence test,
+//                   mu initialisation, (A + mu I) x = b by LU with partial pivoting, step-size
+//                   test, trial pose exp(-x) * pose
+//   k_track_error   per pixel: residual at the trial pose, partial sums of r^2 w
+//   k_track_update  one wave per model: gain ratio, accept / reject, damping update
+// Kernels of a converged model, or of an iteration that may not re-evaluate the gradient
+// (TSDF.cpp `evaluateGradient`), return at once on a device-side flag.
+//
+// Parity: per-pixel quantities follow the reference's operations one by one (the pose gradient
+// is bit-identical to the oracle; tests/test_gpu_tracking.py).  Sums are formed in a different --
+// but fixed, run-to-run deterministic -- order than cv::cuda::reduce's unspecified one, and the
+// SE(3) exponential / QR re-orthonormalisation restate Sophus / Eigen (absent from the reference
+// tree, versions unpinned): these agree with the oracle to float rounding, not bit for bit.
+#include "device_core.hpp"
+
+namespace emf_hip {
+namespace {
+
+constexpr int kTrackBlock = 256;   // pixels per workgroup
+constexpr int kSums = 28;          // 21 (upper triangle of A) + 6 (b) + 1 (error)
+
+struct TrackFrame {
+    const emf_model_t* models;
+    emf_track_state_t* states;
+    int nmodels;
+    Img<const float> points;
+    int w, h, nblocks;
+    emf_track_params_t prm;
+    char* scratch;          // per model: [w image W*H][iw image W*H][partials nblocks * 28][err nblocks]
+    size_t scratchStride;   // bytes per model
+};
+
+__device__ __forceinline__ float* scratch_w(const TrackFrame& f, int m) {
+    return reinterpret_cast<float*>(f.scratch + f.scratchStride * m);
+}
+__device__ __forceinline__ float* scratch_iw(const TrackFrame& f, int m) {
+    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h;
+}
+__device__ __forceinline__ float* scratch_partials(const TrackFrame& f, int m) {
+    return scratch_iw(f, m) + static_cast<size_t>(f.w) * f.h;
+}
+__device__ __forceinline__ float* scratch_err(const TrackFrame& f, int m) {
+    return scratch_partials(f, m) + static_cast<size_t>(f.nblocks) * kSums;
+}
+
+__device__ __forceinline__ M33 state_R(const float* R) {
+    return M33{{R[0], R[1], R[2]}, {R[3], R[4], R[5]}, {R[6], R[7], R[8]}};
+}
+
+// pixel of this lane: blockIdx.x covers the image in runs of kTrackBlock pixels, blockIdx.y = model
+__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc) {
+    pix = static_cast<size_t>(blockIdx.x) * kTrackBlock + threadIdx.x;
+    pc = v3(0.f, 0.f, 0.f);
+    if (pix >= static_cast<size_t>(f.w) * f.h) return false;
+    const int y = static_cast<int>(pix / f.w), x = static_cast<int>(pix - static_cast<size_t>(y) * f.w);
+    const float* p = f.points.row(y) + 3 * x;
+    pc = v3(p[0], p[1], p[2]);
+    return true;
+}
+
+// getVolumeVals of one channel at one point (TSDF.cu:662-688): 0 outside [0, N - 1)
+__device__ __forceinline__ float lookup1(const float* vol, const M33& R, const V3& t, const V3& pc,
+                                         const I3& n, float voxelSize) {
+    if (!(pc.z > 0)) return 0.f;
+    const V3 v = to_voxel(mul(R, pc) + t, voxelSize, half_extent(n));
+    if (outside(v, 1.f, n)) return 0.f;
+    return trilinear1(vol, cell_of(v, n), n);
+}
+
+// kernel_computePoseGradients for one point (TSDF.cu:603-637): g[0..2] = trilinear(gradient) /
+// voxelSize, g[3..5] = skew(p) * g[0..2]; zeros where the reference returns without writing
+__device__ __forceinline__ void pose_gradient(const float* tsdf, const float* grads, const M33& R,
+                                              const V3& t, const V3& pc, const I3& n,
+                                              float voxelSize, float g[6]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[k] = 0.f;
+    if (!(pc.z > 0)) return;
+    const V3 p = mul(R, pc) + t;
+    const V3 v = to_voxel(p, voxelSize, half_extent(n));
+    if (outside(v, 2.f, n)) return;
+    RayVolume rv;
+    rv.tsdf = tsdf;
+    rv.grads = grads;
+    rv.n = n;
+    const V3 gt = gradient_at(rv, cell_of(v, n)) / voxelSize;
+    // make_float33(0,-p.z,p.y, p.z,0,-p.x, -p.y,p.x,0) * grad_tsdf, evaluated as the full
+    // matrix-vector product of the reference (products with the literal zeros included)
+    const M33 S{{0.f, -p.z, p.y}, {p.z, 0.f, -p.x}, {-p.y, p.x, 0.f}};
+    const V3 gr = mul(S, gt);
+    g[0] = gt.x; g[1] = gt.y; g[2] = gt.z;
+    g[3] = gr.x; g[4] = gr.y; g[5] = gr.z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- per-pixel kernels ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) {
+    const int m = blockIdx.y;
+    emf_track_state_t& st = f.states[m];
+    if (st.converged || !st.evaluateGradient) return;  // TSDF.cpp:212-214
+    const emf_model_t& md = f.models[m];
+    size_t pix;
+    V3 pc;
+    float iw = 0.f;
+    if (load_point(f, pix, pc)) {
+        iw = lookup1(md.weights, state_R(st.R), v3(st.t[0], st.t[1], st.t[2]), pc,
+                     I3{md.res[0], md.res[1], md.res[2]}, md.voxelSize);
+        iw = fminf(iw, f.prm.maxWeight);  // cv::cuda::min(intWeights, maxTSDFWeight), TSDF.cpp:234
+        scratch_iw(f, m)[pix] = iw;
+    }
+    const float mx = wave_max(fabsf(iw));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&st.maxIwBits, __float_as_uint(mx));
+}
+
+__global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f) {
+    __shared__ float red[kTrackBlock / 64][kSums];
+    const int m = blockIdx.y;
+    emf_track_state_t& st = f.states[m];
+    if (st.converged || !st.evaluateGradient) return;
+    const emf_model_t& md = f.models[m];
+    const M33 R = state_R(st.R);
+    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
+    const I3 n{md.res[0], md.res[1], md.res[2]};
+    // cv::cuda::normalize(NORM_INF, alpha = 1): scale = norm > DBL_EPSILON ? 1 / norm : 0
+    const float mx = __uint_as_float(st.maxIwBits);
+    const float scale = static_cast<double>(mx) > 2.220446049250313e-16
+                            ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f;
+    size_t pix;
+    V3 pc;
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f;
+    if (load_point(f, pix, pc)) {
+        pose_gradient(md.tsdf, md.grads, R, t, pc, n, md.voxelSize, g);
+        r = lookup1(md.tsdf, R, t, pc, n, md.voxelSize);
+        const float a = fabsf(r);
+        float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
+        tw = fminf(tw, 1.0f);
+        w = scratch_iw(f, m)[pix] * scale;
+        w = tw * w;               // multiply(trackWeights, intWeights)
+        w = w * md.assoc[pix];    // multiply(intWeights, associationWeights)
+        scratch_w(f, m)[pix] = w;
+    }
+    // As = (g_j * g_k) * w, bs = (r * g_j) * w: the products of computeAb / multSingletonCol
+    float s[kSums];
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = j; k < 6; ++k) s[q++] = (g[j] * g[k]) * w;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
+    s[27] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) {
+        const float v = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        float v = red[0][threadIdx.x];
+        for (int i = 1; i < kTrackBlock / 64; ++i) v += red[i][threadIdx.x];
+        scratch_partials(f, m)[static_cast<size_t>(blockIdx.x) * kSums + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(kTrackBlock) void k_track_error(const TrackFrame f) {
+    __shared__ float red[kTrackBlock / 64];
+    const int m = blockIdx.y;
+    const emf_track_state_t& st = f.states[m];
+    if (st.converged || !st.haveTrial) return;
+    const emf_model_t& md = f.models[m];
+    size_t pix;
+    V3 pc;
+    float e = 0.f;
+    if (load_point(f, pix, pc)) {
+        const float r = lookup1(md.tsdf, state_R(st.Rtrial), v3(st.ttrial[0], st.ttrial[1], st.ttrial[2]),
+                                pc, I3{md.res[0], md.res[1], md.res[2]}, md.voxelSize);
+        e = (r * r) * scratch_w(f, m)[pix];
+    }
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = red[0];
+        for (int i = 1; i < kTrackBlock / 64; ++i) v += red[i];
+        scratch_err(f, m)[blockIdx.x] = v;
+    }
+}
+
+// ---- SE(3) helpers (float; restating Sophus::SE3f::exp / log used at TSDF.cpp:300-313) -----------
+
+struct Se3 {
+    M33 R;
+    V3 t;
+};
+
+__host__ __device__ inline M33 mat_mul(const M33& a, const M33& b) {
+    const M33 bt = transpose(b);
+    return M33{{dot(a.r0, bt.r0), dot(a.r0, bt.r1), dot(a.r0, bt.r2)},
+               {dot(a.r1, bt.r0), dot(a.r1, bt.r1), dot(a.r1, bt.r2)},
+               {dot(a.r2, bt.r0), dot(a.r2, bt.r1), dot(a.r2, bt.r2)}};
+}
+
+// exp of the twist (upsilon, omega) -- translation part first, as Sophus orders it
+__host__ __device__ inline Se3 se3_exp(const float x[6]) {
+    const V3 u = v3(x[0], x[1], x[2]), o = v3(x[3], x[4], x[5]);
+    const float th2 = dot(o, o), th = sqrtf(th2);
+    float A, B, C;
+    if (th < 1e-4f) {
+        A = 1.f - th2 / 6.f;
+        B = 0.5f - th2 / 24.f;
+        C = 1.f / 6.f - th2 / 120.f;
+    } else {
+        A = sinf(th) / th;
+        B = (1.f - cosf(th)) / th2;
+        C = (th - sinf(th)) / (th2 * th);
+    }
+    const M33 O{{0.f, -o.z, o.y}, {o.z, 0.f, -o.x}, {-o.y, o.x, 0.f}};
+    const M33 O2 = mat_mul(O, O);
+    auto comb = [](float a, const M33& X, float b, const M33& Y) {
+        return M33{{(X.r0.x * a + Y.r0.x * b) + 1.f, X.r0.y * a + Y.r0.y * b, X.r0.z * a + Y.r0.z * b},
+                   {X.r1.x * a + Y.r1.x * b, (X.r1.y * a + Y.r1.y * b) + 1.f, X.r1.z * a + Y.r1.z * b},
+                   {X.r2.x * a + Y.r2.x * b, X.r2.y * a + Y.r2.y * b, (X.r2.z * a + Y.r2.z * b) + 1.f}};
+    };
+    Se3 e;
+    e.R = comb(A, O, B, O2);          // I + A O + B O^2
+    e.t = mul(comb(B, O, C, O2), u);  // V u,  V = I + B O + C O^2
+    return e;
+}
+
+// |log(R, t)| -- only the norm enters the step-size test (TSDF.cpp:292-296)
+__host__ __device__ inline float se3_log_norm(const M33& R, const V3& t) {
+    const float tr = R.r0.x + R.r1.y + R.r2.z;
+    const float c = fminf(1.f, fmaxf(-1.f, (tr - 1.f) * 0.5f));
+    const float th = acosf(c);
+    const V3 a = v3(R.r2.y - R.r1.z, R.r0.z - R.r2.x, R.r1.x - R.r0.y);  // 2 sin(th) * axis
+    V3 o;
+    if (th < 1e-4f) o = a * (0.5f * (1.f + th * th / 6.f));
+    else o = a * (th / (2.f * sinf(th)));
+    const float th2 = dot(o, o);
+    // V^-1 = I - O / 2 + D O^2,  D = (1 - (th / 2) cot(th / 2)) / th^2
+    float D;
+    if (th2 < 1e-8f) D = 1.f / 12.f;
+    else {
+        const float thn = sqrtf(th2), hf = 0.5f * thn;
+        D = (1.f - hf * cosf(hf) / sinf(hf)) / th2;
+    }
+    const M33 O{{0.f, -o.z, o.y}, {o.z, 0.f, -o.x}, {-o.y, o.x, 0.f}};
+    const V3 Ot = mul(O, t), OOt = mul(O, Ot);
+    const V3 u = t + Ot * (-0.5f) + OOt * D;
+    return sqrtf(dot(u, u) + th2);
+}
+
+// Solve M x = b (6 x 6) by LU with partial pivoting, float -- cv::solve(DECOMP_LU) on CV_32F.
+// Returns false for a singular system (cv::solve then returns x = 0).
+__host__ __device__ inline bool solve6(float M[6][6], float rhs[6], float x[6]) {
+    for (int c = 0; c < 6; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 6; ++r)
+            if (fabsf(M[r][c]) > fabsf(M[p][c])) p = r;
+        if (fabsf(M[p][c]) < 1.1920929e-06f) {  // FLT_EPSILON * 10, the threshold of cv::hal::LU32f
+            for (int i = 0; i < 6; ++i) x[i] = 0.f;
+            return false;
+        }
+        if (p != c) {
+            for (int k = c; k < 6; ++k) {
+                const float tmp = M[c][k];
+                M[c][k] = M[p][k];
+                M[p][k] = tmp;
+            }
+            const float tmp = rhs[c];
+            rhs[c] = rhs[p];
+            rhs[p] = tmp;
+        }
+        const float d = -1.f / M[c][c];
+        for (int r = c + 1; r < 6; ++r) {
+            const float alpha = M[r][c] * d;
+            for (int k = c + 1; k < 6; ++k) M[r][k] += alpha * M[c][k];
+            rhs[r] += alpha * rhs[c];
+        }
+    }
+    for (int r = 5; r >= 0; --r) {
+        float s = rhs[r];
+        for (int k = r + 1; k < 6; ++k) s -= M[r][k] * x[k];
+        x[r] = s / M[r][r];
+    }
+    return true;
+}
+
+// ---- per-model kernels (one wave each) -----------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_track_solve(const TrackFrame f) {
+    __shared__ double sums[kSums];
+    const int m = blockIdx.x, lane = threadIdx.x;
+    emf_track_state_t& st = f.states[m];
+    if (st.converged) return;
+    if (st.evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); otherwise A, b, err are kept
+        if (lane < kSums) {
+            const float* p = scratch_partials(f, m) + lane;
+            double acc = 0.0;  // fixed order: workgroup 0, 1, 2, ...
+            for (int b = 0; b < f.nblocks; ++b) acc += static_cast<double>(p[static_cast<size_t>(b) * kSums]);
+            sums[lane] = acc;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int q = 0;
+            for (int j = 0; j < 6; ++j)
+                for (int k = j; k < 6; ++k) {
+                    const float v = static_cast<float>(sums[q++]);
+                    st.A[6 * j + k] = v;
+                    st.A[6 * k + j] = v;
+                }
+            float maxB = 0.f;
+            for (int j = 0; j < 6; ++j) {
+                st.b[j] = static_cast<float>(sums[21 + j]);
+                maxB = fmaxf(maxB, fabsf(st.b[j]));
+            }
+            st.err = static_cast<float>(sums[27]);
+            if (maxB < f.prm.eps1) st.converged = 1;  // TSDF.cpp:276-278
+        }
+    }
+    __syncthreads();
+    if (lane != 0 || st.converged) return;
+    // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
+    if (st.firstIteration) {
+        float maxA = st.A[0];
+        for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
+        st.mu = f.prm.tau * maxA;
+        st.firstIteration = 0;
+    }
+    float M[6][6], rhs[6], x[6];
+    for (int j = 0; j < 6; ++j) {
+        for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
+        rhs[j] = st.b[j];
+    }
+    solve6(M, rhs, x);
+    float nx = 0.f;
+    for (int j = 0; j < 6; ++j) {
+        st.x[j] = x[j];
+        nx += x[j] * x[j];
+    }
+    nx = sqrtf(nx);
+    const M33 R = state_R(st.R);
+    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
+    if (nx < f.prm.eps2 * (se3_log_norm(R, t) + f.prm.eps2)) {
+        st.converged = 1;
+        return;
+    }
+    float mx[6];
+    for (int j = 0; j < 6; ++j) mx[j] = -x[j];
+    const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
+    const M33 Rn = mat_mul(inc.R, R);
+    const V3 tn = mul(inc.R, t) + inc.t;
+    st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
+    st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
+    st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
+    st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
+    st.haveTrial = 1;
+}
+
+__global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
+    __shared__ double total;
+    const int m = blockIdx.x, lane = threadIdx.x;
+    emf_track_state_t& st = f.states[m];
+    if (st.converged || !st.haveTrial) return;
+    if (lane == 0) {
+        const float* p = scratch_err(f, m);
+        double acc = 0.0;
+        for (int b = 0; b < f.nblocks; ++b) acc += static_cast<double>(p[b]);
+        total = acc;
+        const float errNew = static_cast<float>(total);
+        st.errNew = errNew;
+        // gain = 0.5 * -x^T (mu * -x - b)  (TSDF.cpp:319)
+        float gain = 0.f;
+        for (int j = 0; j < 6; ++j) gain += -st.x[j] * (st.mu * -st.x[j] - st.b[j]);
+        gain = 0.5f * gain;
+        const float rho = (st.err - errNew) / gain;
+        st.rho = rho;
+        st.iterations += 1;
+        if (rho > 0) {  // accept (TSDF.cpp:322-327)
+            for (int k = 0; k < 9; ++k) st.R[k] = st.Rtrial[k];
+            for (int k = 0; k < 3; ++k) st.t[k] = st.ttrial[k];
+            const float c = 2.f * rho - 1.f;
+            const float rhoFac = 1.f - c * c * c;
+            st.mu *= fmaxf(1.f / 3.f, rhoFac);
+            st.nu = f.prm.nuInit;
+            st.evaluateGradient = 1;
+            st.accepted += 1;
+            st.maxIwBits = 0u;  // the next iteration recomputes the weight maximum
+        } else {  // reject (TSDF.cpp:328-336)
+            st.mu *= st.nu;
+            st.nu *= f.prm.nuInit;
+            st.evaluateGradient = 0;
+        }
+        st.haveTrial = 0;
+    }
+}
+
+struct PrepareArgs {
+    emf_track_state_t* states;
+    emf_pose_t poses[EMF_MAX_BATCH];
+    int nmodels;
+    float nuInit;
+};
+
+__global__ void k_track_prepare(const PrepareArgs a) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.nmodels) return;
+    emf_track_state_t st;
+    for (int k = 0; k < 9; ++k) st.R[k] = st.Rtrial[k] = a.poses[m].R[k];
+    for (int k = 0; k < 3; ++k) st.t[k] = st.ttrial[k] = a.poses[m].t[k];
+    for (int k = 0; k < 36; ++k) st.A[k] = 0.f;
+    for (int k = 0; k < 6; ++k) st.b[k] = st.x[k] = 0.f;
+    st.mu = 0.f;
+    st.nu = a.nuInit;  // TSDF.cpp:188-191
+    st.rho = st.err = st.errNew = 0.f;
+    st.maxIwBits = 0u;
+    st.converged = 0;
+    st.firstIteration = 1;
+    st.evaluateGradient = 1;
+    st.haveTrial = 0;
+    st.iterations = 0;
+    st.accepted = 0;
+    a.states[m] = st;
+}
+
+// level 1: kernel_computePoseGradients as an image (TSDF.cu:603-660)
+struct PoseGradArgs {
+    const float* tsdf;
+    const float* grads;
+    Img<const float> points;
+    float* out;  // (W*H) x 6
+    M33 R;
+    V3 t;
+    I3 n;
+    float voxelSize;
+    int w, h;
+};
+
+__global__ __launch_bounds__(kTrackBlock) void k_pose_gradients(const PoseGradArgs a) {
+    const size_t pix = static_cast<size_t>(blockIdx.x) * kTrackBlock + threadIdx.x;
+    if (pix >= static_cast<size_t>(a.w) * a.h) return;
+    const int y = static_cast<int>(pix / a.w), x = static_cast<int>(pix - static_cast<size_t>(y) * a.w);
+    const float* p = a.points.row(y) + 3 * x;
+    float g[6];
+    pose_gradient(a.tsdf, a.grads, a.R, a.t, v3(p[0], p[1], p[2]), a.n, a.voxelSize, g);
+    float* o = a.out + 6 * pix;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = g[k];  // every pixel written: the setTo(0) is folded in
+}
+
+int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* states_dev,
+               int nmodels, const emf_image_t* points, const emf_track_params_t* prm,
+               void* scratch_dev, size_t scratchBytesPerModel, const char* fn) {
+    if (!models_dev || !states_dev || !prm || !scratch_dev) return fail(EMF_E_NULL, "%s: NULL argument", fn);
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH)
+        return fail(EMF_E_LIMIT, "%s: nmodels = %d, expected 1..%d", fn, nmodels, EMF_MAX_BATCH);
+    EMF_TRY(check_image(points, 12, fn));
+    f.models = models_dev;
+    f.states = states_dev;
+    f.nmodels = nmodels;
+    f.points = img<const float>(points);
+    f.w = points->width;
+    f.h = points->height;
+    f.nblocks = static_cast<int>(ceil_div(static_cast<size_t>(f.w) * f.h, kTrackBlock));
+    f.prm = *prm;
+    f.scratch = static_cast<char*>(scratch_dev);
+    f.scratchStride = scratchBytesPerModel;
+    if (scratchBytesPerModel < emf_hip_trackScratchBytes(f.w, f.h) || scratchBytesPerModel % 16)
+        return fail(EMF_E_ARG, "%s: scratch of %zu bytes per model, need %zu (multiple of 16)", fn,
+                    scratchBytesPerModel, emf_hip_trackScratchBytes(f.w, f.h));
+    return EMF_OK;
+}
+
+}  // namespace
+}  // namespace emf_hip
+
+using namespace emf_hip;
+
+extern "C" {
+
+size_t emf_hip_trackScratchBytes(int width, int height) {
+    const size_t px = static_cast<size_t>(width) * height;
+    const size_t nblocks = ceil_div(px, kTrackBlock);
+    const size_t bytes = (2 * px + nblocks * (kSums + 1)) * sizeof(float);
+    return (bytes + 255) / 256 * 256;
+}
+
+int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO_host, int nmodels,
+                         float nuInit, emf_stream_t stream) {
+    if (!states_dev || !poseCO_host) return fail(EMF_E_NULL, "trackPrepare: NULL argument");
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH)
+        return fail(EMF_E_LIMIT, "trackPrepare: nmodels = %d, expected 1..%d", nmodels, EMF_MAX_BATCH);
+    PrepareArgs a;
+    a.states = states_dev;
+    for (int m = 0; m < nmodels; ++m) a.poses[m] = poseCO_host[m];
+    a.nmodels = nmodels;
+    a.nuInit = nuInit;
+    hipLaunchKernelGGL(k_track_prepare, dim3(1), dim3(64), 0, as_stream(stream), a);
+    return launch_status("trackPrepare");
+}
+
+int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
+                         const emf_image_t* points, const emf_track_params_t* params,
+                         void* scratch_dev, size_t scratchBytesPerModel, int iterations,
+                         emf_stream_t stream) {
+    TrackFrame f;
+    EMF_TRY(fill_frame(f, models_dev, states_dev, nmodels, points, params, scratch_dev,
+                       scratchBytesPerModel, "trackIterate"));
+    if (iterations < 0) return fail(EMF_E_ARG, "trackIterate: iterations = %d", iterations);
+    const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
+    hipStream_t s = as_stream(stream);
+    for (int i = 0; i < iterations; ++i) {
+        hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
+        hipLaunchKernelGGL(k_track_accum, px, dim3(kTrackBlock), 0, s, f);
+        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(k_track_error, px, dim3(kTrackBlock), 0, s, f);
+        hipLaunchKernelGGL(k_track_update, dim3(nmodels), dim3(64), 0, s, f);
+    }
+    return launch_status("trackIterate");
+}
+
+int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const emf_image_t* points,
+                                 const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                                 float voxelSize, float* grads6, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(tsdf);
+    EMF_REQUIRE_PTR(grads6);
+    EMF_REQUIRE_PTR(R_CO);
+    EMF_REQUIRE_PTR(t_CO);
+    EMF_TRY(check_image(points, 12, "computePoseGradients: points"));
+    EMF_TRY(check_res(res));
+    if (!(voxelSize > 0.f)) return fail(EMF_E_ARG, "computePoseGradients: voxelSize %g", voxelSize);
+    PoseGradArgs a;
+    a.tsdf = tsdf;
+    a.grads = grads;
+    a.points = img<const float>(points);
+    a.out = grads6;
+    a.R = m33_from(R_CO);
+    a.t = v3_from(t_CO);
+    a.n = i3_from(res);
+    a.voxelSize = voxelSize;
+    a.w = points->width;
+    a.h = points->height;
+    hipLaunchKernelGGL(k_pose_gradients,
+                       dim3(static_cast<unsigned>(ceil_div(static_cast<size_t>(a.w) * a.h, kTrackBlock))),
+                       dim3(kTrackBlock), 0, as_stream(stream), a);
+    return launch_status("computePoseGradients");
+}
+
+}  // extern "C"
+
+static_assert(sizeof(emf_track_state_t) == 340, "emf_track_state_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_model_t) == 144, "emf_model_t layout is mirrored in _lib.py");

@@ -357,3 +357,40 @@ def visibility_flags_indexed(vis_counts, count_index, thresh, visible, stream=No
     check("emf_hip_visibilityFlagsIndexed",
           _L.emf_hip_visibilityFlagsIndexed(_ptr(vis_counts), n, idx, thresh, _ptr(visible),
                                             _stream(stream)))
+
+
+# ---- tracking (SURVEY f-1) ----------------------------------------------------------------------
+
+def compute_pose_gradients(tsdf, grads, points, R_CO, t_CO, voxel_size, out, stream=None):
+    """out: float32 DeviceArray (H * W, 6); grads: gradient volume or None (on the fly)."""
+    _vol(tsdf, np.float32)
+    check("emf_hip_computePoseGradients",
+          _L.emf_hip_computePoseGradients(_ptr(tsdf), _ptr(grads), C.byref(image_view(points)),
+                                          _f(R_CO, 9), _f(t_CO, 3), _res(tsdf), voxel_size,
+                                          _ptr(out), _stream(stream)))
+
+
+def track_scratch_bytes(width, height) -> int:
+    return int(_L.emf_hip_trackScratchBytes(int(width), int(height)))
+
+
+def track_prepare(states_dev, poses_co, nu_init=2.0, stream=None):
+    """states_dev: uint8 DeviceArray of len(poses_co) * sizeof(EmfTrackState) bytes."""
+    check("emf_hip_trackPrepare",
+          _L.emf_hip_trackPrepare(_ptr(states_dev), _poses(poses_co), len(poses_co), nu_init,
+                                  _stream(stream)))
+
+
+def track_iterate(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model,
+                  iterations=1, stream=None):
+    check("emf_hip_trackIterate",
+          _L.emf_hip_trackIterate(_ptr(models_dev), _ptr(states_dev), nmodels,
+                                  C.byref(image_view(points)), C.byref(params), _ptr(scratch),
+                                  scratch_per_model, iterations, _stream(stream)))
+
+
+def read_track_states(states_dev, nmodels):
+    """Synchronise and return the device LM states as a list of EmfTrackState."""
+    raw = states_dev.numpy().tobytes()
+    n = C.sizeof(_lib.EmfTrackState)
+    return [_lib.EmfTrackState.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(nmodels)]

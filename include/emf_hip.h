@@ -359,6 +359,65 @@ int emf_hip_visibilityFlagsIndexed(const int32_t* visCounts, int nmodels,
                                    const int32_t* countIndex_host, int visibilityThresh,
                                    int32_t* visible_dev, emf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tracking: weighted Levenberg-Marquardt ICP on the TSDF
+ * (TSDF.cpp:170-344, 375-395; EMFusion.cpp:672-724).  All LM state lives in device memory.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* TSDFParams fields of the tracker (data.h:32-66) */
+typedef struct emf_track_params {
+    float huberThresh; /* 0.2  */
+    float maxWeight;   /* maxTSDFWeight, 64 */
+    float tau;         /* 1e3  */
+    float eps1;        /* 1e-8 */
+    float eps2;        /* 1e-8 */
+    float nuInit;      /* 2    */
+} emf_track_params_t;
+
+/* Per-model Levenberg-Marquardt state (device memory; read it back after synchronising).
+ * R, t = rel_pose_CO (camera -> volume), the quantity TSDF::prepareTracking sets up and
+ * TSDF::syncTrack converts back: cam_pose = pose * rel_pose_CO. */
+typedef struct emf_track_state {
+    float R[9], t[3];
+    float Rtrial[9], ttrial[3];
+    float A[36], b[6], x[6];
+    float mu, nu, rho, err, errNew;
+    uint32_t maxIwBits;        /* float bits of max |min(intWeights, maxWeight)| */
+    int32_t converged;         /* trackingConverged */
+    int32_t firstIteration;
+    int32_t evaluateGradient;
+    int32_t haveTrial;
+    int32_t iterations;        /* trial steps evaluated */
+    int32_t accepted;          /* ... of which accepted (rho > 0) */
+    int32_t pad_;
+} emf_track_state_t;
+
+/* bytes of scratch per model for emf_hip_trackIterate on a width x height image */
+size_t emf_hip_trackScratchBytes(int width, int height);
+
+/* TSDF::prepareTracking for all models (TSDF.cpp:170-191): states[m] <- initial LM state with
+ * rel_pose_CO = poseCO_host[m], which the caller has re-orthonormalised (the reference runs a
+ * Householder QR of the rotation block on the host). */
+int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO_host, int nmodels,
+                         float nuInit, emf_stream_t stream);
+
+/* `iterations` LM iterations of every model in lock-step, as EMFusion::performTracking runs them
+ * (EMFusion.cpp:673-684, 692-720): five launches per iteration, no host synchronisation; models
+ * that have converged, and iterations that must not re-evaluate the gradient, are skipped on
+ * device-side flags.  Each model's `assoc` map supplies the association weights.
+ * scratch_dev: nmodels * scratchBytesPerModel bytes (>= emf_hip_trackScratchBytes). */
+int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
+                         const emf_image_t* points, const emf_track_params_t* params,
+                         void* scratch_dev, size_t scratchBytesPerModel, int iterations,
+                         emf_stream_t stream);
+
+/* Level 1: replaces emf::cuda::TSDF::computePoseGradients (TSDF.cuh, TSDF.cu:603-660).
+ * grads6: (W*H) x 6 f32, every row written (zeros where the reference leaves its setTo(0));
+ * grads: N^3 x 3 gradient volume or NULL (forward differences blended on the fly, same values). */
+int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const emf_image_t* points,
+                                 const float R_CO[9], const float t_CO[3], const int32_t res[3],
+                                 float voxelSize, float* grads6, emf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

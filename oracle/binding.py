@@ -200,3 +200,38 @@ def occluded_mask(obj_seg, seg, obj_id, fma=False):
     occ = np.empty((h, w), np.uint8)
     lib(fma).orc_occludedMask(_p(obj_seg), _p(seg), int(obj_id), _p(occ), w, h)
     return occ
+
+
+# ---- f-1: tracking ------------------------------------------------------------------------------
+
+def compute_pose_gradients(tsdf, grads_vol, points, R_CO, t_CO, voxel_size, fma=False):
+    tsdf, points = _c(tsdf), _c(points)
+    h, w = points.shape[:2]
+    out = np.empty((h * w, 6), np.float32)
+    gv = _c(grads_vol) if grads_vol is not None else None
+    lib(fma).orc_computePoseGradients(_p(tsdf), _p(gv) if gv is not None else None, _p(points), w, h,
+                                      _farr(R_CO, 9), _farr(t_CO, 3), _res(tsdf),
+                                      C.c_float(voxel_size), _p(out))
+    return out
+
+
+def tracking_weights(tsdf_vals, int_weights_raw, assoc, huber, max_weight, fma=False):
+    tv, iw, a = _c(tsdf_vals), _c(int_weights_raw), _c(assoc)
+    tw, out = np.empty_like(tv), np.empty_like(tv)
+    lib(fma).orc_trackingWeights(_p(tv), _p(iw), _p(a), tv.size, C.c_float(huber),
+                                 C.c_float(max_weight), _p(tw), _p(out))
+    return tw, out
+
+
+def reduce_ab(grads6, tsdf_vals, int_weights, fma=False):
+    g, tv, iw = _c(grads6), _c(tsdf_vals), _c(int_weights)
+    A, b = np.empty(36, np.float32), np.empty(6, np.float32)
+    lib(fma).orc_reduceAb(_p(g), _p(tv), _p(iw), tv.size, _p(A), _p(b))
+    return A.reshape(6, 6), b
+
+
+def tracking_error(tsdf_vals, int_weights, fma=False):
+    tv, iw = _c(tsdf_vals), _c(int_weights)
+    f = lib(fma).orc_trackingError
+    f.restype = C.c_double
+    return float(f(_p(tv), _p(iw), tv.size))

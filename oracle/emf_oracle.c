@@ -492,3 +492,105 @@ void orc_occludedMask(const uint8_t* objSeg, const uint8_t* seg, int id, uint8_t
         occluded[i] = sat_u8((int)objSeg[i] - own);      /* saturating u8 subtract */
     }
 }
+
+/* ==== f-1: weighted LM-ICP tracking ================================= */
+
+/* cuda::TSDF::computePoseGradients / kernel_computePoseGradients (TSDF.cu:603-660).
+ * grads6: (W*H) x 6, zero-filled first (TSDF.cu:655); per pixel with p_cam.z > 0 and the sample
+ * inside [0, N-2): [ grad_tsdf (3), skew(p) * grad_tsdf (3) ], grad_tsdf = trilinear(tsdfGrads) /
+ * voxelSize.  gradsVol: the N^3 x 3 gradient volume, or NULL = forward differences of `tsdf`
+ * blended on the fly (the same values, see trilinear_grad). */
+void orc_computePoseGradients(const float* tsdf, const float* gradsVol, const float* points, int w,
+                              int h, const float R_CO[9], const float t_CO[3], const int res[3],
+                              float voxelSize, float* grads6) {
+    const m33 R = mk33(R_CO);
+    const v3 t = mk(t_CO[0], t_CO[1], t_CO[2]);
+    memset(grads6, 0, (size_t)w * h * 6 * sizeof(float));
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t pi = (size_t)y * w + x;
+            const v3 pc = mk(points[3 * pi], points[3 * pi + 1], points[3 * pi + 2]);
+            if (pc.z <= 0) continue;
+            const v3 p = add3(mulmv(R, pc), t);
+            const v3 v = to_voxel(p, voxelSize, res);
+            if (out_of(v, 2.f, res)) continue;  /* TSDF.cu:623-626 */
+            v3 g;
+            if (gradsVol)
+                g = mk(trilinear(gradsVol, 3, 0, v, res), trilinear(gradsVol, 3, 1, v, res),
+                       trilinear(gradsVol, 3, 2, v, res));
+            else
+                g = mk(trilinear_grad(tsdf, 0, v, res), trilinear_grad(tsdf, 1, v, res),
+                       trilinear_grad(tsdf, 2, v, res));
+            g = div3(g, voxelSize);
+            /* make_float33(0,-p.z,p.y, p.z,0,-p.x, -p.y,p.x,0) * grad_tsdf (TSDF.cu:630-632) */
+            const v3 r0 = mk(0.f, -p.z, p.y), r1 = mk(p.z, 0.f, -p.x), r2 = mk(-p.y, p.x, 0.f);
+            const v3 gr = mk(dot3(r0, g), dot3(r1, g), dot3(r2, g));
+            float* o = grads6 + 6 * pi;
+            o[0] = g.x; o[1] = g.y; o[2] = g.z;
+            o[3] = gr.x; o[4] = gr.y; o[5] = gr.z;
+        }
+}
+
+/* TSDF::computeHuberWeights + normalizeTSDFWeights + combineWeights (TSDF.cpp:218-252).
+ * tsdfVals, intWeightsRaw: the two getVolumeVals lookups; assoc: association weights.
+ * trackWeights = min(huber / |tsdfVals|, 1) with OpenCV's x / 0 := 0 (Q7);
+ * intWeights   = min(raw, maxWeight) scaled by 1 / max (cv::cuda::normalize, NORM_INF, alpha 1:
+ *                scale = norm > DBL_EPSILON ? 1 / norm : 0, applied in float), then
+ *                trackWeights * intWeights, then * assoc (two separate multiplies). */
+void orc_trackingWeights(const float* tsdfVals, const float* intWeightsRaw, const float* assoc,
+                         int n, float huberThresh, float maxWeight, float* trackWeights,
+                         float* intWeights) {
+    float mx = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float a = fabsf(tsdfVals[i]);
+        float tw = a != 0.f ? huberThresh / a : 0.f;
+        trackWeights[i] = fminf(tw, 1.0f);
+        const float c = fminf(intWeightsRaw[i], maxWeight);
+        intWeights[i] = c;
+        if (fabsf(c) > mx) mx = fabsf(c);
+    }
+    const float scale = (double)mx > 2.220446049250313e-16 ? (float)(1.0 / (double)mx) : 0.f;
+    for (int i = 0; i < n; ++i) {
+        float v = intWeights[i] * scale;
+        v = trackWeights[i] * v;
+        v = v * assoc[i];
+        intWeights[i] = v;
+    }
+}
+
+/* computeAb + multSingletonCol + column reduce (TSDF.cu:729-766, 821-853, TSDF.cpp:254-262,
+ * 375-388): A = sum_i w_i g_i g_i^T (all 36 entries, row-major), b = sum_i w_i r_i g_i.
+ * Each product is formed in float exactly as the kernels do -- (g_j * g_k) * w, (r * g_j) * w --
+ * the SUM is accumulated in double and rounded once: cv::cuda::reduce's order is unspecified,
+ * so this is the reference value any order approximates. */
+void orc_reduceAb(const float* grads6, const float* tsdfVals, const float* intWeights, int n,
+                  float A[36], float b[6]) {
+    double As[36] = {0}, bs[6] = {0};
+    for (int i = 0; i < n; ++i) {
+        const float* g = grads6 + 6 * (size_t)i;
+        const float w = intWeights[i], r = tsdfVals[i];
+        for (int j = 0; j < 6; ++j) {
+            for (int k = 0; k < 6; ++k) {
+                const float a = g[j] * g[k];
+                As[6 * j + k] += (double)(a * w);
+            }
+            const float bb = r * g[j];
+            bs[j] += (double)(bb * w);
+        }
+    }
+    for (int j = 0; j < 36; ++j) A[j] = (float)As[j];
+    for (int j = 0; j < 6; ++j) b[j] = (float)bs[j];
+}
+
+/* TSDF::computeError (TSDF.cpp:390-394): sum(tsdfVals^2 * intWeights), double accumulation of
+ * float products (cv::cuda::sum accumulates in double). */
+double orc_trackingError(const float* tsdfVals, const float* intWeights, int n) {
+    double e = 0;
+    for (int i = 0; i < n; ++i) {
+        float v = tsdfVals[i] * tsdfVals[i];
+        v = v * intWeights[i];
+        e += (double)v;
+    }
+    return e;
+}

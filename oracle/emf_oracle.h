@@ -106,6 +106,22 @@ void orc_compositeRaycast(int nobj, const int* ids, const float* const* objRay,
 void orc_occludedMask(const uint8_t* objSeg, const uint8_t* seg, int id, uint8_t* occluded, int w,
                       int h);
 
+/* ---- f-1: weighted LM-ICP tracking --------------------------------------------------------- */
+
+/* kernel_computePoseGradients (TSDF.cu:603-660).  grads6: (W*H) x 6.  gradsVol may be NULL. */
+void orc_computePoseGradients(const float* tsdf, const float* gradsVol, const float* points, int w,
+                              int h, const float R_CO[9], const float t_CO[3], const int res[3],
+                              float voxelSize, float* grads6);
+/* Huber weights, max-normalised integration weights, association (TSDF.cpp:218-252). */
+void orc_trackingWeights(const float* tsdfVals, const float* intWeightsRaw, const float* assoc,
+                         int n, float huberThresh, float maxWeight, float* trackWeights,
+                         float* intWeights);
+/* computeAb + weighting + column sums (TSDF.cu:729-766, TSDF.cpp:254-262, 375-388). */
+void orc_reduceAb(const float* grads6, const float* tsdfVals, const float* intWeights, int n,
+                  float A[36], float b[6]);
+/* TSDF::computeError (TSDF.cpp:390-394). */
+double orc_trackingError(const float* tsdfVals, const float* intWeights, int n);
+
 #ifdef __cplusplus
 }
 #endif

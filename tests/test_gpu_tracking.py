@@ -1,0 +1,181 @@
+"""Tracking: the device-resident weighted Levenberg-Marquardt ICP against
+the oracle restatement of TSDF.cpp:170-344 (tests/oracle_tracking.py) on the same inputs.
+
+Per-pixel quantities are bit-exact (pose gradients).  The Hessian sums are formed in a different,
+fixed order than the oracle's double accumulation and the SE(3) / solver arithmetic is restated on
+both sides, so LM states are compared within float-rounding tolerances, and the converged poses
+within the north-star 1e-4.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.oracle_tracking import OracleTracker, orthonormalise
+from tests.parity_util import assert_parity, dev_full, to_dev, to_np
+from tests.scenes import Pose, camera_path, intrinsics, rel_CO, rel_OC, render_depth, rot
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 120
+K = intrinsics(W, H)
+SPHERES = [((0.25, 0.05, 1.3), 0.22), ((-0.3, -0.1, 1.6), 0.18)]
+BG = dict(n=(64, 64, 64), vox=0.04, pose=Pose(t=[0, 0, 1.28]))
+OBJ = dict(n=(32, 32, 32), vox=0.02, pose=Pose(t=SPHERES[0][0]))
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from emfusion_amd import ops as _ops
+    return _ops
+
+
+def _integrate(oracle, vol, frames):
+    n = vol["n"]
+    tsdf, wts = np.zeros((n[2], n[1], n[0]), np.float32), np.zeros((n[2], n[1], n[0]), np.float32)
+    for i in frames:
+        cam = camera_path(i)
+        depth, _ = render_depth(W, H, K, cam, SPHERES, noise=0.002, dropout=0.01, seed=100 + i)
+        oc = rel_OC(cam, vol["pose"])
+        oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K, vol["vox"],
+                           10 * vol["vox"], 64.0)
+    return tsdf, wts
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    vols = []
+    for v in (BG, OBJ):
+        tsdf, wts = _integrate(oracle, v, range(4))
+        vols.append(dict(v, tsdf=tsdf, wts=wts))
+    cam = camera_path(5)
+    depth, _ = render_depth(W, H, K, cam, SPHERES, noise=0.002, dropout=0.01, seed=105)
+    points = oracle.compute_points(depth, K)
+    rng = np.random.default_rng(3)
+    assoc = [np.ones((H, W), np.float32), rng.uniform(0.2, 1.0, (H, W)).astype(np.float32)]
+    # the tracker starts from a pose that is off by ~1.5 cm and ~0.6 degrees
+    guess = cam * Pose(rot([0.2, 1.0, 0.3], 0.6), [0.012, -0.006, 0.008])
+    return dict(vols=vols, cam=cam, guess=guess, points=points, assoc=assoc)
+
+
+def _models(ops, world, which):
+    keep, entries = [], []
+    for k in which:
+        v = world["vols"][k]
+        d = dict(tsdf=to_dev(v["tsdf"]), wts=to_dev(v["wts"]), assoc=to_dev(world["assoc"][k]),
+                 ray=dev_full((H, W), 0.0), vert=dev_full((H, W, 3), 0.0), nrm=dev_full((H, W, 3), 0.0),
+                 hit=dev_full((H, W), 0, np.uint8))
+        keep.append(d)
+        entries.append(ops.make_model(d["tsdf"], d["wts"], d["assoc"], d["ray"], d["vert"], d["nrm"],
+                                      d["hit"], float(np.float32(v["vox"])), float(np.float32(10 * v["vox"])),
+                                      64.0, 0.02, 0.8, 1.0, model_id=k))
+    return ops.upload_models(entries), keep
+
+
+def _start_pose(world, k):
+    co = rel_CO(world["guess"], world["vols"][k]["pose"])
+    return orthonormalise(co.R32.reshape(3, 3)).reshape(-1), co.t32
+
+
+class DeviceTracker:
+    def __init__(self, ops, world, which):
+        from emfusion_amd import _lib
+        self.ops, self.n = ops, len(which)
+        self.table, self.keep = _models(ops, world, which)
+        self.states = dev_full((self.n * C.sizeof(_lib.EmfTrackState),), 0, np.uint8)
+        self.per_model = ops.track_scratch_bytes(W, H)
+        self.scratch = dev_full((self.n * self.per_model,), 0, np.uint8)
+        self.points = to_dev(world["points"])
+        self.params = _lib.EmfTrackParams.defaults()
+        ops.track_prepare(self.states, [_start_pose(world, k) for k in which])
+
+    def iterate(self, iterations=1):
+        self.ops.track_iterate(self.table, self.states, self.n, self.points, self.params, self.scratch,
+                               self.per_model, iterations)
+        return self.ops.read_track_states(self.states, self.n)
+
+
+def _oracle_tracker(oracle, world, k):
+    v = world["vols"][k]
+    t = OracleTracker(oracle, v["tsdf"], v["wts"], v["vox"])
+    R, tt = _start_pose(world, k)
+    t.prepare(R, tt)
+    return t
+
+
+@pytest.mark.parametrize("use_grad_volume", [False, True])
+def test_pose_gradients_bit_exact(oracle, ops, dev, world, use_grad_volume):
+    v = world["vols"][0]
+    R, t = _start_pose(world, 0)
+    grads = oracle.compute_tsdf_grads(v["tsdf"]) if use_grad_volume else None
+    want = oracle.compute_pose_gradients(v["tsdf"], grads, world["points"], R, t, v["vox"])
+    out = dev_full((H * W, 6), 9.0)
+    ops.compute_pose_gradients(to_dev(v["tsdf"]), None if grads is None else to_dev(grads),
+                               to_dev(world["points"]), R, t, float(np.float32(v["vox"])), out)
+    assert (np.abs(want).sum(1) > 0).sum() > 5000
+    assert_parity(to_np(out), want, "pose gradients", exact=True)
+
+
+@pytest.mark.parametrize("k", [0, 1], ids=["background", "object"])
+def test_first_iteration_matches_oracle(oracle, ops, dev, world, k):
+    dt = DeviceTracker(ops, world, [k])
+    st = dt.iterate(1)[0]
+    ot = _oracle_tracker(oracle, world, k)
+    ot.iterate(world["points"], world["assoc"][k])
+    h = ot.history[0]
+    A, b = np.array(st.A, np.float32).reshape(6, 6), np.array(st.b, np.float32)
+    assert np.abs(h["A"]).max() > 1.0
+    assert np.abs(A - h["A"]).max() <= 2e-5 * np.abs(h["A"]).max(), "Hessian"
+    assert np.abs(b - h["b"]).max() <= 2e-5 * max(np.abs(h["b"]).max(), 1e-3), "gradient"
+    assert abs(st.err - h["err"]) <= 1e-5 * h["err"], "error at the current pose"
+    x = np.array(st.x, np.float32)
+    assert np.abs(x - h["x"]).max() <= 1e-4 * np.abs(h["x"]).max(), "LM step"
+    assert abs(st.errNew - h["err_new"]) <= 1e-5 * h["err_new"], "error at the trial pose"
+    assert (st.rho > 0) == (h["rho"] > 0) and abs(st.rho - h["rho"]) <= 1e-2 * abs(h["rho"]) + 1e-3
+    assert st.iterations == 1 and st.accepted == ot.accepted
+    assert np.allclose(np.array(st.R, np.float32).reshape(3, 3), ot.R, atol=1e-6)
+    assert np.allclose(np.array(st.t, np.float32), ot.t, atol=1e-6)
+    assert abs(st.mu - float(ot.mu)) <= 1e-4 * float(ot.mu)
+
+
+def _pose_error(R, t, world, k):
+    """Distance of a rel_pose_CO estimate from the true one (rotation angle in rad, metres)."""
+    true = rel_CO(world["cam"], world["vols"][k]["pose"])
+    dR = np.asarray(R, np.float64).reshape(3, 3) @ true.R.T
+    ang = np.arccos(min(1.0, max(-1.0, (np.trace(dR) - 1) / 2)))
+    return ang, float(np.linalg.norm(np.asarray(t, np.float64) - true.t))
+
+
+def test_tracking_converges_like_the_oracle(oracle, ops, dev, world):
+    iters = 100  # params.maxTrackingIter: the damping starts at 1e3 * max diag(A) and shrinks slowly
+    dt = DeviceTracker(ops, world, [0])
+    st = dt.iterate(iters)[0]
+    ot = _oracle_tracker(oracle, world, 0)
+    for _ in range(iters):
+        ot.iterate(world["points"], world["assoc"][0])
+    a0, d0 = _pose_error(*_start_pose(world, 0), world, 0)
+    a1, d1 = _pose_error(st.R, st.t, world, 0)
+    a2, d2 = _pose_error(ot.R, ot.t, world, 0)
+    assert st.accepted >= 5 and ot.accepted >= 5
+    assert d1 < 0.5 * d0 and a1 < 0.5 * a0, (a0, d0, a1, d1)       # it tracks
+    # both minimise the same objective from the same start: the poses agree to the tolerance
+    assert np.abs(np.array(st.R, np.float32).reshape(3, 3) - ot.R).max() < 1e-4, (a1, d1, a2, d2)
+    assert np.abs(np.array(st.t, np.float32) - ot.t).max() < 1e-4, (a1, d1, a2, d2)
+
+
+def test_models_in_lockstep_equal_single_runs(ops, dev, world):
+    both = DeviceTracker(ops, world, [0, 1]).iterate(12)
+    for k in (0, 1):
+        one = DeviceTracker(ops, world, [k]).iterate(12)[0]
+        for name in ("R", "t", "A", "b", "x"):
+            assert list(getattr(both[k], name)) == list(getattr(one, name)), (k, name)  # deterministic
+        assert (both[k].mu, both[k].accepted, both[k].iterations) == (one.mu, one.accepted, one.iterations)
+
+
+def test_converged_models_do_nothing(ops, dev, world):
+    from emfusion_amd import _lib
+    dt = DeviceTracker(ops, world, [0])
+    dt.params = _lib.EmfTrackParams(0.2, 64.0, 1e3, 1e30, 1e-8, 2.0)  # eps1 huge: converged at once
+    st = dt.iterate(3)[0]
+    assert st.converged == 1 and st.iterations == 0 and st.accepted == 0
+    assert list(st.R) == list(dt.iterate(1)[0].R)
