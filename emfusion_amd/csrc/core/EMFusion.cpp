@@ -10,6 +10,8 @@
 #include "EMFusion.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cmath>
 #include <cstdlib>
 
 namespace emf {
@@ -63,6 +65,8 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     const char* env = std::getenv("EMF_PER_VOLUME");
     forceLegacy = env && env[0] == '1';
     // EMF_LAMBDA_TABLE=0: integrate with the inline 1 / lambda (A/B measurements; same results)
+    // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
+    if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -111,6 +115,7 @@ EMFusion::~EMFusion() {
     if (visReady) (void)hipEventDestroy(visReady);
     if (visCountsHost) (void)hipHostFree(visCountsHost);
     if (visibleHost) (void)hipHostFree(visibleHost);
+    if (trackStatesHost) (void)hipHostFree(trackStatesHost);
 }
 
 void EMFusion::reset() {
@@ -351,9 +356,11 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         // (reference EMFusion.cpp:79, 687, 87).  Tracking itself is outside this build; its
         // results arrive as in.cam_pose / in.obj_poses at the points where it would update them.
         computeAssociationWeights();
-        pose = in.cam_pose;  // background (camera) tracking result
+        if (in.trackCamera) trackCamera();  // EMFusion.cpp:673-685
+        else pose = in.cam_pose;            // ... or its result, supplied
         computeAssociationWeights();
-        applyObjectPoses();  // object tracking results
+        if (in.trackObjects) trackObjects();  // EMFusion.cpp:689-723
+        else applyObjectPoses();
         computeAssociationWeights();
         stamp(kEstep);
         raycast();
@@ -387,6 +394,131 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         timings.total = ms(kStart, kMasks);
     }
     ++frameCount;
+}
+
+// ---- tracking -------------------------------------------------------------------------------------
+
+namespace {
+// Q of the QR decomposition of M with a positive diagonal of R -- what TSDF::prepareTracking's
+// Householder QR + sign fix computes (TSDF.cpp:176-183) -- by Gram-Schmidt in double.
+Matx33f orthonormalised(const Matx33f& M) {
+    double c[3][3], q[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[j][i] = M(i, j);  // c[j] = column j
+    for (int j = 0; j < 3; ++j) {
+        double v[3] = {c[j][0], c[j][1], c[j][2]};
+        for (int k = 0; k < j; ++k) {
+            const double d = q[k][0] * c[j][0] + q[k][1] * c[j][1] + q[k][2] * c[j][2];
+            for (int i = 0; i < 3; ++i) v[i] -= d * q[k][i];
+        }
+        const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int i = 0; i < 3; ++i) q[j][i] = v[i] / n;
+    }
+    Matx33f Q;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Q(i, j) = static_cast<float>(q[j][i]);
+    return Q;
+}
+}  // namespace
+
+void EMFusion::trackModels(int first, int count) {
+    if (count <= 0) return;
+    if (!batched)
+        throw HipError("EMFusion: tracking needs the batched path (<= 32 models, Nx % 4 == 0)",
+                       EMF_E_LIMIT);
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    const size_t per = emf_hip_trackScratchBytes(w, h);
+    if (trackStates.empty()) {
+        trackStates = DeviceBuffer(sizeof(emf_track_state_t) * EMF_MAX_BATCH);
+        trackScratch = DeviceBuffer(per * EMF_MAX_BATCH);
+        hipCheck(hipHostMalloc(reinterpret_cast<void**>(&trackStatesHost),
+                               sizeof(emf_track_state_t) * EMF_MAX_BATCH, hipHostMallocDefault),
+                 "hipHostMalloc");
+    }
+    std::vector<emf_pose_t> co;
+    posesCO(co);
+    for (int m = first; m < first + count; ++m) {  // prepareTracking: re-orthonormalised rel_pose_CO
+        const Matx33f Q = orthonormalised(Matx33f(co[m].R));
+        for (int k = 0; k < 9; ++k) co[m].R[k] = Q.val[k];
+    }
+    emf_track_params_t tp;
+    tp.huberThresh = params.tsdfParams.huberThresh;
+    tp.maxWeight = params.tsdfParams.maxTSDFWeight;
+    tp.tau = params.tsdfParams.tau;
+    tp.eps1 = params.tsdfParams.eps1;
+    tp.eps2 = params.tsdfParams.eps2;
+    tp.nuInit = params.tsdfParams.nu_init;
+    emf_track_state_t* states = trackStates.as<emf_track_state_t>() + first;
+    const emf_image_t pv = points.view();
+    {
+        auto kt = ktimers.scope(KernelTimers::Track,
+                                pixels() * count * params.maxTrackingIter, main);
+        emfCheck(emf_hip_trackPrepare(states, co.data() + first, count, tp.nuInit, main.abi()),
+                 "trackPrepare");
+        // The loop itself needs no host: iterations are enqueued in chunks and the device-side
+        // `converged` flags are polled once per chunk, only to stop enqueuing launches that would
+        // return at once (LM converges in 20-40 of the 100 iterations; a no-op iteration still
+        // costs five launches).  The states come back with the last poll: the E-step and raycast
+        // that follow take the poses by value.
+        const int chunk = trackChunk > 0 ? trackChunk : params.maxTrackingIter;
+        for (int done = 0; done < params.maxTrackingIter;) {
+            const int n = std::min(chunk, params.maxTrackingIter - done);
+            emfCheck(emf_hip_trackIterate(modelTable.as<emf_model_t>() + first, states, count, &pv,
+                                          &tp, static_cast<char*>(trackScratch.data()) + per * first,
+                                          per, n, main.abi()),
+                     "trackIterate");
+            done += n;
+            hipCheck(hipMemcpyAsync(trackStatesHost + first, states,
+                                    sizeof(emf_track_state_t) * count, hipMemcpyDeviceToHost,
+                                    main.get()),
+                     "hipMemcpyAsync");
+            main.waitForCompletion();
+            bool all = true;
+            for (int m = first; m < first + count; ++m) all = all && trackStatesHost[m].converged;
+            if (all) break;
+        }
+    }
+}
+
+void EMFusion::trackCamera() {
+    trackModels(0, 1);
+    const emf_track_state_t& st = trackStatesHost[0];
+    const Affine3f rel(Matx33f(st.R), Vec3f(st.t[0], st.t[1], st.t[2]));
+    pose = background.getPose() * rel;  // TSDF::syncTrack (TSDF.cpp:339-345)
+    TrackResult r;
+    r.iterations = st.iterations;
+    r.accepted = st.accepted;
+    r.converged = st.converged != 0;
+    r.error = st.err;
+    trackResults[0] = r;
+}
+
+void EMFusion::trackObjects() {
+    const int n = static_cast<int>(objects.size());
+    trackModels(1, n);
+    int m = 1;
+    for (auto& obj : objects) {
+        const emf_track_state_t& st = trackStatesHost[m++];
+        const Affine3f rel(Matx33f(st.R), Vec3f(st.t[0], st.t[1], st.t[2]));
+        obj.setPose(pose * rel.inv());  // ObjTSDF::syncTrack (ObjTSDF.cpp:228-235)
+        TrackResult r;
+        r.iterations = st.iterations;
+        r.accepted = st.accepted;
+        r.converged = st.converged != 0;
+        r.error = st.err;
+        trackResults[obj.getID()] = r;
+    }
+}
+
+const TrackResult* EMFusion::getTrackResult(int id) const {
+    auto it = trackResults.find(id);
+    return it == trackResults.end() ? nullptr : &it->second;
+}
+
+const ObjTSDF* EMFusion::getObject(int id) const {
+    for (const auto& o : objects)
+        if (o.getID() == id) return &o;
+    return nullptr;
 }
 
 void EMFusion::computeAssociationWeights() {

@@ -38,6 +38,19 @@ struct FrameInputs {
     std::map<int, Affine3f> obj_poses;       // object id -> volume-centre -> world
     std::map<int, emf_image_t> masks;        // object id -> u8 0/1 mask (device), mask frames only
     bool runMasks = false;                   // this frame is a mask frame (frame % maskRCNNFrames)
+    // Tracking (reference EMFusion::performTracking, EMFusion.cpp:672-724).  When set, the
+    // corresponding supplied pose(s) are ignored: the camera pose is tracked against the
+    // background from the previous frame's pose, then every object's pose against its volume.
+    bool trackCamera = false;
+    bool trackObjects = false;
+};
+
+/** Outcome of the last tracking run of one model (0 = camera against the background). */
+struct TrackResult {
+    int iterations = 0;  // LM trial steps evaluated
+    int accepted = 0;    // ... of which accepted
+    bool converged = false;
+    float error = 0.f;   // weighted squared residual sum at the final pose
 };
 
 /** Per-stage GPU time of the last processed frame (milliseconds, from HIP events). */
@@ -53,6 +66,19 @@ public:
 
     /** Drop all objects and clear the background (reference EMFusion.cpp:58-68). */
     void reset();
+
+    /**
+     * Track the camera against the background volume (reference EMFusion.cpp:673-685) or all
+     * objects against the camera (EMFusion.cpp:689-723) with the current association weights.
+     * Device-resident Levenberg-Marquardt (emf_hip_trackIterate): params.maxTrackingIter
+     * iterations are enqueued without host round trips; the poses are read back once.
+     */
+    void trackCamera();
+    void trackObjects();
+    /** Result of the last tracking run of model `id` (0 = camera), or nullptr. */
+    const TrackResult* getTrackResult(int id) const;
+    Affine3f getCameraPose() const { return pose; }
+    const ObjTSDF* getObject(int id) const;
 
     /**
      * Create an object volume centred at `center` (world) with edge length `volSize` metres --
@@ -171,6 +197,14 @@ private:
     DeviceImage<float> depthUpload;
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
+
+    // ---- tracking (SURVEY f-1) ----
+    void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)
+    int trackChunk = 8;                        // iterations per convergence poll (0: never poll)
+    DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_BATCH]
+    DeviceBuffer trackScratch;                 // EMF_MAX_BATCH x emf_hip_trackScratchBytes
+    emf_track_state_t* trackStatesHost = nullptr;  // pinned mirror
+    std::map<int, TrackResult> trackResults;   // by model id
     DeviceImage<float, 3> points;
     DeviceImage<float> raylengths, bg_raylengths, associationNorm, bg_associationWeights,
         diffRaylengths, objPartialSum;

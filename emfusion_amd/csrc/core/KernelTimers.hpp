@@ -25,6 +25,7 @@ public:
         Integrate,    // updateTSDF (per model)
         Grads,        // computeTSDFGrads (materialised mode only)
         FgBg,         // updateFgBgProbs + computeFgProbs
+        Track,        // one tracking stage (prepare + maxTrackingIter LM iterations)
         kNumKinds
     };
     struct Summary {

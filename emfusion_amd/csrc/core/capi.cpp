@@ -15,6 +15,7 @@ struct emf_comm {
 };
 struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
+    bool trackCamera = false, trackObjects = false;
 };
 struct emf_synth {
     std::unique_ptr<SyntheticScene> impl;
@@ -83,6 +84,7 @@ void emf_fusion_default_params(emf_fusion_params_t* p) {
     p->boundary = d.boundary;
     p->mask_frames = d.maskRCNNFrames;
     p->materialize_gradients = 0;
+    p->max_tracking_iter = d.maxTrackingIter;
 }
 
 int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion_t** out) {
@@ -106,6 +108,7 @@ int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion
         q.visibilityThresh = p->visibility_thresh;
         q.boundary = p->boundary;
         q.maskRCNNFrames = p->mask_frames;
+        if (p->max_tracking_iter > 0) q.maxTrackingIter = p->max_tracking_iter;
         auto h = std::make_unique<emf_fusion>();
         h->impl = std::make_unique<EMFusion>(
             q, p->materialize_gradients ? TSDF::Gradients::Materialized : TSDF::Gradients::OnTheFly,
@@ -156,7 +159,47 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
                 m33(obj_R + 9 * i), Vec3f(obj_t[3 * i], obj_t[3 * i + 1], obj_t[3 * i + 2]));
         for (int i = 0; i < nmasks; ++i) in.masks[mask_ids[i]] = masks[i];
         in.runMasks = run_masks != 0;
+        in.trackCamera = h->trackCamera;
+        in.trackObjects = h->trackObjects;
         h->impl->processFrame(*depth_dev, in);
+    });
+}
+
+int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects) {
+    REQ(h);
+    h->trackCamera = track_camera != 0;
+    h->trackObjects = track_objects != 0;
+    return EMF_OK;
+}
+
+int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]) {
+    REQ(h);
+    REQ(R);
+    REQ(t);
+    return guarded([&] {
+        Affine3f p;
+        if (id == 0) {
+            p = h->impl->getCameraPose();
+        } else {
+            const ObjTSDF* o = h->impl->getObject(id);
+            if (!o) throw HipError("emf_fusion_get_pose: no such object on this rank", EMF_E_ARG);
+            p = o->getPose();
+        }
+        for (int k = 0; k < 9; ++k) R[k] = p.rotation().val[k];
+        for (int k = 0; k < 3; ++k) t[k] = p.translation()[k];
+    });
+}
+
+int emf_fusion_track_result(emf_fusion_t* h, int id, int32_t* iterations, int32_t* accepted,
+                            int32_t* converged, float* error) {
+    REQ(h);
+    return guarded([&] {
+        const TrackResult* r = h->impl->getTrackResult(id);
+        if (!r) throw HipError("emf_fusion_track_result: model was never tracked", EMF_E_ARG);
+        if (iterations) *iterations = r->iterations;
+        if (accepted) *accepted = r->accepted;
+        if (converged) *converged = r->converged ? 1 : 0;
+        if (error) *error = r->error;
     });
 }
 

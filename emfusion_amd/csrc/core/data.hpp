@@ -69,7 +69,7 @@ public:
     Affine3f volumePose;
 
     float volPad = 2.f;
-    int maxTrackingIter = 100;  // unused here
+    int maxTrackingIter = 100;
     /** Mask frames: fg/bg probabilities are integrated every maskRCNNFrames-th frame. */
     int maskRCNNFrames = 30;
     float existenceThresh = 0.1f;  // unused here (object lifecycle)

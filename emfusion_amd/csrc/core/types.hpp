@@ -51,6 +51,7 @@ struct Matx33f {
     Matx33f() = default;
     Matx33f(float a, float b, float c, float d, float e, float f, float g, float h, float i)
         : val{a, b, c, d, e, f, g, h, i} {}
+    explicit Matx33f(const float* p) : val{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]} {}
     static Matx33f eye() { return Matx33f(); }
     float operator()(int r, int c) const { return val[3 * r + c]; }
     float& operator()(int r, int c) { return val[3 * r + c]; }

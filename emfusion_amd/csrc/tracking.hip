@@ -114,6 +114,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// sum of p[i * stride], i < n, over the 64 lanes of the calling wave: lane-strided partial sums in
+// double, then a fixed xor tree -- the same order on every run
+__device__ __forceinline__ double wave_strided_sum(const float* p, int n, int stride, int lane) {
+    double acc = 0.0;
+    for (int i = lane; i < n; i += 64) acc += static_cast<double>(p[static_cast<size_t>(i) * stride]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -318,20 +327,18 @@ __host__ __device__ inline bool solve6(float M[6][6], float rhs[6], float x[6]) 
 
 // ---- per-model kernels (one wave each) -----------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_track_solve(const TrackFrame f) {
+__global__ __launch_bounds__(256) void k_track_solve(const TrackFrame f) {
     __shared__ double sums[kSums];
-    const int m = blockIdx.x, lane = threadIdx.x;
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     emf_track_state_t& st = f.states[m];
     if (st.converged) return;
     if (st.evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); otherwise A, b, err are kept
-        if (lane < kSums) {
-            const float* p = scratch_partials(f, m) + lane;
-            double acc = 0.0;  // fixed order: workgroup 0, 1, 2, ...
-            for (int b = 0; b < f.nblocks; ++b) acc += static_cast<double>(p[static_cast<size_t>(b) * kSums]);
-            sums[lane] = acc;
+        for (int c = wave; c < kSums; c += 4) {  // 4 waves x 7 columns of the partials
+            const double v = wave_strided_sum(scratch_partials(f, m) + c, f.nblocks, kSums, lane);
+            if (lane == 0) sums[c] = v;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             int q = 0;
             for (int j = 0; j < 6; ++j)
                 for (int k = j; k < 6; ++k) {
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(64) void k_track_solve(const TrackFrame f) {
         }
     }
     __syncthreads();
-    if (lane != 0 || st.converged) return;
+    if (threadIdx.x != 0 || st.converged) return;
     // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
     if (st.firstIteration) {
         float maxA = st.A[0];
@@ -388,15 +395,11 @@ __global__ __launch_bounds__(64) void k_track_solve(const TrackFrame f) {
 }
 
 __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
-    __shared__ double total;
     const int m = blockIdx.x, lane = threadIdx.x;
     emf_track_state_t& st = f.states[m];
     if (st.converged || !st.haveTrial) return;
+    const double total = wave_strided_sum(scratch_err(f, m), f.nblocks, 1, lane);
     if (lane == 0) {
-        const float* p = scratch_err(f, m);
-        double acc = 0.0;
-        for (int b = 0; b < f.nblocks; ++b) acc += static_cast<double>(p[b]);
-        total = acc;
         const float errNew = static_cast<float>(total);
         st.errNew = errNew;
         // gain = 0.5 * -x^T (mu * -x - b)  (TSDF.cpp:319)
@@ -542,7 +545,7 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     for (int i = 0; i < iterations; ++i) {
         hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_accum, px, dim3(kTrackBlock), 0, s, f);
-        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(64), 0, s, f);
+        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(256), 0, s, f);
         hipLaunchKernelGGL(k_track_error, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_update, dim3(nmodels), dim3(64), 0, s, f);
     }

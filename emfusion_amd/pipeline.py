@@ -31,7 +31,7 @@ class FusionParams(C.Structure):
                 ("max_tsdf_weight", C.c_float), ("assoc_sigma", C.c_float), ("alpha", C.c_float),
                 ("uni_prior", C.c_float), ("visibility_thresh", C.c_int32),
                 ("boundary", C.c_int32), ("mask_frames", C.c_int32),
-                ("materialize_gradients", C.c_int32)]
+                ("materialize_gradients", C.c_int32), ("max_tracking_iter", C.c_int32)]
 
 
 class FrameTimings(C.Structure):
@@ -46,7 +46,8 @@ class KernelSummary(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("units", C.c_double)]
 
 
-KERNEL_KINDS = ("points", "assoc", "normalize", "raycast", "composite", "integrate", "grads", "fgbg")
+KERNEL_KINDS = ("points", "assoc", "normalize", "raycast", "composite", "integrate", "grads", "fgbg",
+                "track")
 
 IMG = dict(points=0, bg_assoc=1, obj_assoc=2, assoc_norm=3, raylengths=4, vertices=5, normals=6,
            segmentation=7, bg_raylengths=8, obj_raylengths=9)
@@ -94,6 +95,9 @@ def load() -> C.CDLL:
         "emf_fusion_add_object": [vp, fp, C.c_float, ip],
         "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
                                      C.c_int],
+        "emf_fusion_set_tracking": [vp, C.c_int, C.c_int],
+        "emf_fusion_get_pose": [vp, C.c_int, fp, fp],
+        "emf_fusion_track_result": [vp, C.c_int, ip, ip, ip, fp],
         "emf_fusion_stage_estep": [vp],
         "emf_fusion_stage_raycast": [vp],
         "emf_fusion_stage_integrate": [vp],
@@ -263,6 +267,23 @@ class Fusion:
                load().emf_fusion_process_frame(self._h, C.byref(depth_view), _farr(cam_R, 9),
                                                _farr(cam_t, 3), n, ids, Rs, ts, m, mids, mviews,
                                                int(run_masks)))
+
+    def set_tracking(self, camera=True, objects=True):
+        """From the next frame on, track the camera / object poses instead of taking them as inputs."""
+        _check("emf_fusion_set_tracking", load().emf_fusion_set_tracking(self._h, int(camera), int(objects)))
+
+    def pose(self, obj_id: int = 0):
+        """(R 3x3, t 3): camera -> world for id 0, object volume -> world otherwise."""
+        R, t = (C.c_float * 9)(), (C.c_float * 3)()
+        _check("emf_fusion_get_pose", load().emf_fusion_get_pose(self._h, int(obj_id), R, t))
+        return np.array(R, np.float32).reshape(3, 3), np.array(t, np.float32)
+
+    def track_result(self, obj_id: int = 0) -> Dict[str, float]:
+        it, acc, conv, err = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        _check("emf_fusion_track_result",
+               load().emf_fusion_track_result(self._h, int(obj_id), C.byref(it), C.byref(acc),
+                                              C.byref(conv), C.byref(err)))
+        return dict(iterations=it.value, accepted=acc.value, converged=bool(conv.value), error=err.value)
 
     def stage_estep(self):
         _check("emf_fusion_stage_estep", load().emf_fusion_stage_estep(self._h))

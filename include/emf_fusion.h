@@ -37,6 +37,7 @@ typedef struct emf_fusion_params {
     float max_tsdf_weight, assoc_sigma, alpha, uni_prior;
     int32_t visibility_thresh, boundary, mask_frames;
     int32_t materialize_gradients; /* 0: normals from on-the-fly differences; 1: gradient volume */
+    int32_t max_tracking_iter;     /* LM iterations per tracking stage (data.h:106: 100) */
 } emf_fusion_params_t;
 
 /* per-stage GPU milliseconds of the last frame (HIP events on the main stream) */
@@ -85,6 +86,15 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
                              const float* obj_R, const float* obj_t, int nmasks,
                              const int32_t* mask_ids, const emf_image_t* masks, int run_masks);
 
+/* Tracking (SURVEY f-1).  set_tracking: from the next frame on, process_frame ignores the supplied
+ * camera pose / object poses and tracks them instead (EMFusion::performTracking); frame 0 always
+ * takes the supplied poses.  get_pose: id 0 = camera -> world, else object volume -> world.
+ * track_result: iterations / accepted / converged / error of the last run of model id. */
+int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects);
+int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);
+int emf_fusion_track_result(emf_fusion_t* h, int id, int32_t* iterations, int32_t* accepted,
+                            int32_t* converged, float* error);
+
 /* Individual stages (emf::EMFusion::{computeAssociationWeights, raycast, integrateDepth}) acting
  * on the state left by the last process_frame; for stage-level tests and profiling. */
 int emf_fusion_stage_estep(emf_fusion_t* h);
@@ -104,7 +114,7 @@ int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[4]);
  * must be called with the device idle (after emf_fusion_synchronize). */
 enum emf_kernel_kind {
     EMF_K_POINTS = 0, EMF_K_ASSOC, EMF_K_NORMALIZE, EMF_K_RAYCAST, EMF_K_COMPOSITE,
-    EMF_K_INTEGRATE, EMF_K_GRADS, EMF_K_FGBG, EMF_K_NUM_KINDS
+    EMF_K_INTEGRATE, EMF_K_GRADS, EMF_K_FGBG, EMF_K_TRACK, EMF_K_NUM_KINDS
 };
 typedef struct emf_kernel_summary {
     uint64_t launches;

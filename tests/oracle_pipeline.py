@@ -146,8 +146,22 @@ class OraclePipeline:
             v["probs"], v["vmask"] = self.o.compute_fg_probs(v["fgbg"])
 
     # ---- the schedule -------------------------------------------------------------------------
+    def _track(self, vols, assoc_of, iters):
+        """Lock-step LM of `vols` (EMFusion.cpp:673-684 / 692-720); returns their rel_pose_CO."""
+        from tests.oracle_tracking import OracleTracker
+        trackers = []
+        for v in vols:
+            t = OracleTracker(self.o, v["tsdf"], v["wts"], v["vox"], max_weight=self.p["max_weight"])
+            co = v["pose"].inv() * self.pose
+            t.prepare(co.R, co.t)
+            trackers.append(t)
+        for _ in range(iters):
+            for v, t in zip(vols, trackers):
+                t.iterate(self.points, assoc_of(v))
+        return trackers
+
     def process_frame(self, depth, cam_pose: Affine32, obj_poses=None, masks=None,
-                      run_masks=False):
+                      run_masks=False, track_camera=False, track_objects=False, track_iters=100):
         obj_poses = obj_poses or {}
         self.points = self.o.compute_points(depth, self.K)
 
@@ -158,9 +172,20 @@ class OraclePipeline:
 
         if self.frame > 0:
             self._estep()
-            self.pose = cam_pose
+            if track_camera:
+                t = self._track([self.bg], lambda v: self.bg_assoc, track_iters)[0]
+                self.pose = self.bg["pose"] * Affine32(t.R, t.t)  # TSDF::syncTrack
+                self.track = {0: t}
+            else:
+                self.pose = cam_pose
             self._estep()
-            apply_obj()
+            if track_objects:
+                objs = sorted(self.objects, key=lambda v: v["id"])
+                for v, t in zip(objs, self._track(objs, lambda v: v["assoc"], track_iters)):
+                    v["pose"] = self.pose * Affine32(t.R, t.t).inv()  # ObjTSDF::syncTrack
+                    self.track[v["id"]] = t
+            else:
+                apply_obj()
             self._estep()
             self._raycast()
         else:
