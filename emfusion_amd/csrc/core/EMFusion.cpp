@@ -353,8 +353,8 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
 
     if (frameCount > 0) {
         // Q17: the E-step runs three times per frame around the two tracking stages
-        // (reference EMFusion.cpp:79, 687, 87).  Tracking itself is outside this build; its
-        // results arrive as in.cam_pose / in.obj_poses at the points where it would update them.
+        // (reference EMFusion.cpp:79, 687, 87).  The stages either run here (trackCamera /
+        // trackObjects) or their results arrive as in.cam_pose / in.obj_poses.
         computeAssociationWeights();
         if (in.trackCamera) trackCamera();  // EMFusion.cpp:673-685
         else pose = in.cam_pose;            // ... or its result, supplied

@@ -145,9 +145,18 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) 
         iw = fminf(iw, f.prm.maxWeight);  // cv::cuda::min(intWeights, maxTSDFWeight), TSDF.cpp:234
         scratch_iw(f, m)[pix] = iw;
     }
-    const float mx = wave_max(fabsf(iw));
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&st.maxIwBits, __float_as_uint(mx));
+    __shared__ float red[kTrackBlock / 64];
+    const float wmx = wave_max(fabsf(iw));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = red[0];
+        for (int i = 1; i < kTrackBlock / 64; ++i) mx = fmaxf(mx, red[i]);
+        // non-negative floats order like their bit patterns; most workgroups find the maximum
+        // (the weight cap, after a few frames) already there and skip the same-address atomic
+        const unsigned bits = __float_as_uint(mx);
+        if (bits > __atomic_load_n(&st.maxIwBits, __ATOMIC_RELAXED)) atomicMax(&st.maxIwBits, bits);
+    }
 }
 
 __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f) {
@@ -197,7 +206,8 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f)
     if (threadIdx.x < kSums) {
         float v = red[0][threadIdx.x];
         for (int i = 1; i < kTrackBlock / 64; ++i) v += red[i][threadIdx.x];
-        scratch_partials(f, m)[static_cast<size_t>(blockIdx.x) * kSums + threadIdx.x] = v;
+        // component-major: the final reduction reads each component contiguously
+        scratch_partials(f, m)[static_cast<size_t>(threadIdx.x) * f.nblocks + blockIdx.x] = v;
     }
 }
 
@@ -327,14 +337,17 @@ __host__ __device__ inline bool solve6(float M[6][6], float rhs[6], float x[6]) 
 
 // ---- per-model kernels (one wave each) -----------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_track_solve(const TrackFrame f) {
+constexpr int kSolveWaves = 8;
+
+__global__ __launch_bounds__(64 * kSolveWaves) void k_track_solve(const TrackFrame f) {
     __shared__ double sums[kSums];
     const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     emf_track_state_t& st = f.states[m];
     if (st.converged) return;
     if (st.evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); otherwise A, b, err are kept
-        for (int c = wave; c < kSums; c += 4) {  // 4 waves x 7 columns of the partials
-            const double v = wave_strided_sum(scratch_partials(f, m) + c, f.nblocks, kSums, lane);
+        for (int c = wave; c < kSums; c += kSolveWaves) {
+            const double v = wave_strided_sum(scratch_partials(f, m) + static_cast<size_t>(c) * f.nblocks,
+                                              f.nblocks, 1, lane);
             if (lane == 0) sums[c] = v;
         }
         __syncthreads();
@@ -545,7 +558,7 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     for (int i = 0; i < iterations; ++i) {
         hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_accum, px, dim3(kTrackBlock), 0, s, f);
-        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(64 * kSolveWaves), 0, s, f);
         hipLaunchKernelGGL(k_track_error, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_update, dim3(nmodels), dim3(64), 0, s, f);
     }
