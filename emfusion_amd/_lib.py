@@ -63,6 +63,7 @@ SIGNATURES = {
                                _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
+    "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],
     "emf_hip_trackScratchBytes": [C.c_int, C.c_int],
     "emf_hip_trackPrepare": [_FP, _FP, C.c_int, C.c_float, _STREAM],
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,

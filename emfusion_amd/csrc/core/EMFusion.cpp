@@ -36,6 +36,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
                  _params.globalRelTruncDist * _params.globalVoxelSize, _params.volumePose,
                  _params.tsdfParams, _params.frameSize, gradients),
       depthUpload(_params.frameSize),
+      depthFiltered(_params.frameSize),
       invLambda(_params.frameSize),
       points(_params.frameSize),
       raylengths(_params.frameSize),
@@ -326,16 +327,29 @@ void EMFusion::processFrame(const RGBD& frame) {
         throw HipError("EMFusion::processFrame: frame size differs from Params::frameSize",
                        EMF_E_SHAPE);
     depthUpload.upload(frame.depth, main);  // reference EMFusion.cpp:72
-    runSchedule(depthUpload.view(), pending);
+    FrameInputs in = pending;
+    in.preprocessDepth = true;              // reference EMFusion.cpp:74
+    runSchedule(depthUpload.view(), in);
 }
 
 void EMFusion::processFrame(const emf_image_t& depthDev, const FrameInputs& in) {
     runSchedule(depthDev, in);
 }
 
+void EMFusion::preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& depthOut) {
+    emfCheck(emf_hip_preprocessDepth(&depthRaw, &depthOut, params.bilateral_kernel_size,
+                                     params.bilateral_sigma_depth, params.bilateral_sigma_spatial,
+                                     main.abi()),
+             "preprocessDepth");
+}
+
 void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     depth = depthDev;
     stamp(kStart);
+    if (in.preprocessDepth) {
+        preprocessDepth(depthDev, depthFiltered.view());
+        depth = depthFiltered.view();
+    }
     {
         const emf_image_t pv = points.view();
         auto kt = ktimers.scope(KernelTimers::Points, pixels(), main);

@@ -43,6 +43,10 @@ struct FrameInputs {
     // background from the previous frame's pose, then every object's pose against its volume.
     bool trackCamera = false;
     bool trackObjects = false;
+    // EMFusion::preprocessDepth (EMFusion.cpp:294-305): bilateral filter + NaN / zero patches on
+    // the incoming depth.  The reference always runs it; off by default here so that the hot-path
+    // frame keeps SURVEY 8(d)'s definition.  processFrame(const RGBD&) always filters.
+    bool preprocessDepth = false;
 };
 
 /** Outcome of the last tracking run of one model (0 = camera against the background). */
@@ -75,6 +79,8 @@ public:
      */
     void trackCamera();
     void trackObjects();
+    /** Reference EMFusion::preprocessDepth (EMFusion.cpp:294-305), one launch. */
+    void preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& depthOut);
     /** Result of the last tracking run of model `id` (0 = camera), or nullptr. */
     const TrackResult* getTrackResult(int id) const;
     Affine3f getCameraPose() const { return pose; }
@@ -195,6 +201,7 @@ private:
     // frame-sized device images (reference EMFusion.h:447-489)
     emf_image_t depth{};  // view of the current depth map
     DeviceImage<float> depthUpload;
+    DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
 

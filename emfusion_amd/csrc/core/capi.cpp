@@ -15,7 +15,7 @@ struct emf_comm {
 };
 struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
-    bool trackCamera = false, trackObjects = false;
+    bool trackCamera = false, trackObjects = false, preprocess = false;
 };
 struct emf_synth {
     std::unique_ptr<SyntheticScene> impl;
@@ -161,6 +161,7 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.runMasks = run_masks != 0;
         in.trackCamera = h->trackCamera;
         in.trackObjects = h->trackObjects;
+        in.preprocessDepth = h->preprocess;
         h->impl->processFrame(*depth_dev, in);
     });
 }
@@ -169,6 +170,12 @@ int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects
     REQ(h);
     h->trackCamera = track_camera != 0;
     h->trackObjects = track_objects != 0;
+    return EMF_OK;
+}
+
+int emf_fusion_set_preprocess(emf_fusion_t* h, int on) {
+    REQ(h);
+    h->preprocess = on != 0;
     return EMF_OK;
 }
 

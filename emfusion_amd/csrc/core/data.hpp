@@ -52,7 +52,7 @@ public:
     Size frameSize;
     Matx33f intr;
 
-    // depth pre-processing (bilateral filter) -- unused here (next scope row)
+    // depth pre-processing (bilateral filter), EMFusion::preprocessDepth
     float bilateral_sigma_depth = 0.04f;
     float bilateral_sigma_spatial = 4.5f;
     int bilateral_kernel_size = 7;

@@ -278,6 +278,58 @@ __global__ __launch_bounds__(256) void k_occluded(Img<const uint8_t> objSeg, Img
     occ.row(y)[x] = static_cast<uint8_t>(v < 0 ? 0 : v);
 }
 
+
+// ---- f-2: depth pre-processing (EMFusion::preprocessDepth, EMFusion.cpp:294-305) ----------------
+// cv::cuda::bilateralFilter (OpenCV, third-party; restated, parity unpinned) + the reference's two
+// patches (NaN -> 0, raw == 0 -> 0) in one pass.  A 32 x 8 pixel workgroup stages its tile plus the
+// ksz / 2 halo in LDS (borders reflected, BORDER_REFLECT_101), so each depth value is read from
+// memory once instead of up to 37 times.
+constexpr int kBfX = 32, kBfY = 8, kBfMaxR = 7;  // kernel sizes up to 15
+
+struct BilateralArgs {
+    Img<const float> raw;
+    Img<float> out;
+    int w, h, ksz;
+    float ss, sc;  // -0.5 / sigma_spatial^2, -0.5 / sigma_depth^2
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+__global__ __launch_bounds__(kBfX* kBfY) void k_preprocess_depth(const BilateralArgs a) {
+    __shared__ float tile[kBfY + 2 * kBfMaxR][kBfX + 2 * kBfMaxR + 1];
+    const int r = a.ksz / 2;
+    const int x0 = blockIdx.x * kBfX, y0 = blockIdx.y * kBfY;
+    const int tw = kBfX + 2 * r, th = kBfY + 2 * r;
+    for (int i = threadIdx.y * kBfX + threadIdx.x; i < tw * th; i += kBfX * kBfY) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tile[ty][tx] = a.raw.row(reflect101(y0 + ty - r, a.h))[reflect101(x0 + tx - r, a.w)];
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+    if (x >= a.w || y >= a.h) return;
+    const float center = tile[threadIdx.y + r][threadIdx.x + r];
+    const float r2 = static_cast<float>(r * r);
+    float sum1 = 0.f, sum2 = 0.f;
+    for (int dy = 0; dy < a.ksz; ++dy)
+        for (int dx = 0; dx < a.ksz; ++dx) {
+            const float space2 = static_cast<float>((dx - r) * (dx - r) + (dy - r) * (dy - r));
+            if (space2 > r2) continue;
+            const float v = tile[threadIdx.y + dy][threadIdx.x + dx];
+            const float d = fabsf(v - center);
+            const float wgt = expf(space2 * a.ss + (d * d) * a.sc);
+            sum1 = sum1 + wgt * v;
+            sum2 = sum2 + wgt;
+        }
+    float o = sum1 / sum2;
+    if (o != o) o = 0.f;         // compare(depth, depth, NE) -> setTo(0)
+    if (center == 0.f) o = 0.f;  // compare(depth_raw, 0, EQ) -> setTo(0)
+    a.out.row(y)[x] = o;
+}
+
 }  // namespace
 }  // namespace emf_hip
 
@@ -561,6 +613,31 @@ int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int 
                        as_stream(stream), img<const uint8_t>(objSeg), img<const uint8_t>(seg), id,
                        img<uint8_t>(occluded), seg->width, seg->height);
     return launch_status("occludedMask");
+}
+
+int emf_hip_preprocessDepth(const emf_image_t* depthRaw, const emf_image_t* depth, int kernelSize,
+                            float sigmaDepth, float sigmaSpatial, emf_stream_t stream) {
+    EMF_TRY(check_image(depthRaw, 4, "preprocessDepth: depthRaw"));
+    EMF_TRY(check_image(depth, 4, "preprocessDepth: depth"));
+    EMF_TRY(check_same_size(depthRaw, depth, "depthRaw", "depth"));
+    if (depthRaw->data == depth->data) return fail(EMF_E_ARG, "preprocessDepth: in place is not supported");
+    if (kernelSize < 1 || kernelSize > 2 * kBfMaxR + 1 || kernelSize % 2 == 0)
+        return fail(EMF_E_ARG, "preprocessDepth: kernel size %d, expected odd and <= %d", kernelSize,
+                    2 * kBfMaxR + 1);
+    if (!(sigmaDepth > 0.f) || !(sigmaSpatial > 0.f))
+        return fail(EMF_E_ARG, "preprocessDepth: sigmas must be > 0");
+    BilateralArgs a;
+    a.raw = img<const float>(depthRaw);
+    a.out = img<float>(depth);
+    a.w = depthRaw->width;
+    a.h = depthRaw->height;
+    a.ksz = kernelSize;
+    a.ss = -0.5f / (sigmaSpatial * sigmaSpatial);
+    a.sc = -0.5f / (sigmaDepth * sigmaDepth);
+    hipLaunchKernelGGL(k_preprocess_depth,
+                       dim3(static_cast<unsigned>(ceil_div(a.w, kBfX)), static_cast<unsigned>(ceil_div(a.h, kBfY))),
+                       dim3(kBfX, kBfY), 0, as_stream(stream), a);
+    return launch_status("preprocessDepth");
 }
 
 }  // extern "C"

@@ -394,3 +394,11 @@ def read_track_states(states_dev, nmodels):
     raw = states_dev.numpy().tobytes()
     n = C.sizeof(_lib.EmfTrackState)
     return [_lib.EmfTrackState.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(nmodels)]
+
+
+# ---- depth pre-processing (SURVEY f-2) -----------------------------------------------------------
+
+def preprocess_depth(raw, out, ksz=7, sigma_depth=0.04, sigma_spatial=4.5, stream=None):
+    check("emf_hip_preprocessDepth",
+          _L.emf_hip_preprocessDepth(C.byref(image_view(raw)), C.byref(image_view(out)), int(ksz),
+                                     sigma_depth, sigma_spatial, _stream(stream)))

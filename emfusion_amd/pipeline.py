@@ -96,6 +96,7 @@ def load() -> C.CDLL:
         "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
                                      C.c_int],
         "emf_fusion_set_tracking": [vp, C.c_int, C.c_int],
+        "emf_fusion_set_preprocess": [vp, C.c_int],
         "emf_fusion_get_pose": [vp, C.c_int, fp, fp],
         "emf_fusion_track_result": [vp, C.c_int, ip, ip, ip, fp],
         "emf_fusion_stage_estep": [vp],
@@ -271,6 +272,10 @@ class Fusion:
     def set_tracking(self, camera=True, objects=True):
         """From the next frame on, track the camera / object poses instead of taking them as inputs."""
         _check("emf_fusion_set_tracking", load().emf_fusion_set_tracking(self._h, int(camera), int(objects)))
+
+    def set_preprocess(self, on=True):
+        """Filter incoming depth maps as the reference's preprocessDepth does (bilateral + patches)."""
+        _check("emf_fusion_set_preprocess", load().emf_fusion_set_preprocess(self._h, int(on)))
 
     def pose(self, obj_id: int = 0):
         """(R 3x3, t 3): camera -> world for id 0, object volume -> world otherwise."""

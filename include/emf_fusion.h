@@ -91,6 +91,8 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
  * takes the supplied poses.  get_pose: id 0 = camera -> world, else object volume -> world.
  * track_result: iterations / accepted / converged / error of the last run of model id. */
 int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects);
+/* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
+int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);
 int emf_fusion_track_result(emf_fusion_t* h, int id, int32_t* iterations, int32_t* accepted,
                             int32_t* converged, float* error);

@@ -359,6 +359,13 @@ int emf_hip_visibilityFlagsIndexed(const int32_t* visCounts, int nmodels,
                                    const int32_t* countIndex_host, int visibilityThresh,
                                    int32_t* visible_dev, emf_stream_t stream);
 
+/* Depth pre-processing: replaces EMFusion::preprocessDepth
+ * (EMFusion.cpp:294-305) = cv::cuda::bilateralFilter(kernelSize, sigmaDepth [m], sigmaSpatial [px],
+ * reflected borders) + NaN -> 0 + "0 wherever the raw depth is 0", one launch.  f32 W x H images,
+ * not in place; kernelSize odd, <= 15. */
+int emf_hip_preprocessDepth(const emf_image_t* depthRaw, const emf_image_t* depth, int kernelSize,
+                            float sigmaDepth, float sigmaSpatial, emf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tracking: weighted Levenberg-Marquardt ICP on the TSDF
  * (TSDF.cpp:170-344, 375-395; EMFusion.cpp:672-724).  All LM state lives in device memory.

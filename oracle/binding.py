@@ -235,3 +235,14 @@ def tracking_error(tsdf_vals, int_weights, fma=False):
     f = lib(fma).orc_trackingError
     f.restype = C.c_double
     return float(f(_p(tv), _p(iw), tv.size))
+
+
+# ---- f-2: depth pre-processing ------------------------------------------------------------------
+
+def preprocess_depth(raw, ksz=7, sigma_depth=0.04, sigma_spatial=4.5, fma=False):
+    raw = _c(raw)
+    h, w = raw.shape
+    out = np.empty_like(raw)
+    lib(fma).orc_preprocessDepth(_p(raw), w, h, int(ksz), C.c_float(sigma_depth),
+                                 C.c_float(sigma_spatial), _p(out))
+    return out

@@ -594,3 +594,44 @@ double orc_trackingError(const float* tsdfVals, const float* intWeights, int n) 
     }
     return e;
 }
+
+/* ==== f-2: depth pre-processing (EMFusion::preprocessDepth, EMFusion.cpp:294-305) ============== */
+
+static inline int reflect101(int i, int n) { /* cv::BORDER_REFLECT_101, the BORDER_DEFAULT */
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+/* cv::cuda::bilateralFilter (third-party, OpenCV cudaimgproc bilateral_filter.cu -- not in the
+ * reference tree; restated from its published algorithm, parity unpinned): window ksz x ksz
+ * clipped to the disc of radius ksz / 2, weight = exp(space2 * (-0.5 / sigma_spatial^2) +
+ * (value - centre)^2 * (-0.5 / sigma_color^2)), out = sum(weight * value) / sum(weight), borders
+ * reflected.  Then the two patches of the reference: NaN -> 0, and 0 wherever the raw depth is 0. */
+void orc_preprocessDepth(const float* raw, int w, int h, int ksz, float sigmaDepth,
+                         float sigmaSpatial, float* out) {
+    const int r = ksz / 2;
+    const float r2 = (float)(r * r);
+    const float ss = -0.5f / (sigmaSpatial * sigmaSpatial);
+    const float sc = -0.5f / (sigmaDepth * sigmaDepth);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float center = raw[(size_t)y * w + x];
+            float sum1 = 0.f, sum2 = 0.f;
+            for (int cy = y - r; cy < y - r + ksz; ++cy)
+                for (int cx = x - r; cx < x - r + ksz; ++cx) {
+                    const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+                    if (space2 > r2) continue;
+                    const float v = raw[(size_t)reflect101(cy, h) * w + reflect101(cx, w)];
+                    const float d = fabsf(v - center);
+                    const float wgt = expf(space2 * ss + (d * d) * sc);
+                    sum1 = sum1 + wgt * v;
+                    sum2 = sum2 + wgt;
+                }
+            float o = sum1 / sum2;
+            if (o != o) o = 0.f;         /* compare(depth, depth, NE) -> setTo(0) */
+            if (center == 0.f) o = 0.f;  /* compare(depth_raw, 0, EQ) -> setTo(0) */
+            out[(size_t)y * w + x] = o;
+        }
+}

@@ -122,6 +122,10 @@ void orc_reduceAb(const float* grads6, const float* tsdfVals, const float* intWe
 /* TSDF::computeError (TSDF.cpp:390-394). */
 double orc_trackingError(const float* tsdfVals, const float* intWeights, int n);
 
+/* ---- f-2: EMFusion::preprocessDepth (EMFusion.cpp:294-305): bilateral filter + patches ------ */
+void orc_preprocessDepth(const float* raw, int w, int h, int ksz, float sigmaDepth,
+                         float sigmaSpatial, float* out);
+
 #ifdef __cplusplus
 }
 #endif
