@@ -64,6 +64,9 @@ SIGNATURES = {
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
     "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],
+    "emf_hip_pointStatsScratchBytes": [],
+    "emf_hip_maskedPointStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _STREAM],
+    "emf_hip_maskOverlap": [_IMG, _IMG, _FP, _STREAM],
     "emf_hip_trackScratchBytes": [C.c_int, C.c_int],
     "emf_hip_trackPrepare": [_FP, _FP, C.c_int, C.c_float, _STREAM],
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
@@ -146,6 +149,7 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.emf_hip_trackScratchBytes.restype = C.c_size_t
+    lib.emf_hip_pointStatsScratchBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

@@ -117,6 +117,7 @@ EMFusion::~EMFusion() {
     if (visCountsHost) (void)hipHostFree(visCountsHost);
     if (visibleHost) (void)hipHostFree(visibleHost);
     if (trackStatesHost) (void)hipHostFree(trackStatesHost);
+    if (lifecycleHost) (void)hipHostFree(lifecycleHost);
 }
 
 void EMFusion::reset() {
@@ -386,10 +387,20 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         stamp(kComposite);
     }
 
+    // object creation from unmatched masks happens between raycast and integration, so that a new
+    // (empty, hence invisible to the raycast) volume still integrates its first frame (Q18)
+    lastCreated.clear();
+    std::map<int, emf_image_t> masks = in.masks;
+    for (const emf_image_t& m : in.newObjectMasks) {
+        const int id = initNewObjVolume(m);
+        lastCreated.push_back(id);
+        if (id >= 0) masks[id] = m;
+    }
+
     integrateDepth();
     stamp(kIntegrate);
 
-    if (in.runMasks && !in.masks.empty()) integrateMasks(in.masks);
+    if ((in.runMasks || !in.newObjectMasks.empty()) && !masks.empty()) integrateMasks(masks);
     stamp(kMasks);
 
     if (timingsOn) {
@@ -408,6 +419,97 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         timings.total = ms(kStart, kMasks);
     }
     ++frameCount;
+}
+
+// ---- object creation / matching from masks ---------------------------------------------------------
+
+emf_point_stats_t EMFusion::maskedStats(const emf_image_t& mask, const Affine3f& frame) {
+    if (statsScratch.empty()) {
+        statsScratch = DeviceBuffer(emf_hip_pointStatsScratchBytes());
+        statsDev = DeviceBuffer(sizeof(emf_point_stats_t));
+        overlapDev = DeviceBuffer(513 * sizeof(uint32_t));
+        hipCheck(hipHostMalloc(&lifecycleHost, 513 * sizeof(uint32_t), hipHostMallocDefault),
+                 "hipHostMalloc");
+    }
+    const emf_image_t pv = points.view();
+    emfCheck(emf_hip_maskedPointStats(&pv, &mask, frame.rotation().val, frame.translation().val,
+                                      statsScratch.data(), statsDev.as<emf_point_stats_t>(),
+                                      main.abi()),
+             "maskedPointStats");
+    hipCheck(hipMemcpyAsync(lifecycleHost, statsDev.data(), sizeof(emf_point_stats_t),
+                            hipMemcpyDeviceToHost, main.get()),
+             "hipMemcpyAsync");
+    main.waitForCompletion();
+    return *static_cast<emf_point_stats_t*>(lifecycleHost);
+}
+
+float EMFusion::volumeIOU(const ObjTSDF& obj, const Vec3f& p10, const Vec3f& p90) const {
+    const Vec3f center = (p10 + p90) / 2.f;
+    const Vec3f dims = p90 - p10;
+    const float volSize = params.volPad * std::max(dims[0], std::max(dims[1], dims[2]));
+    const Vec3f hv(volSize / 2, volSize / 2, volSize / 2);
+    const Vec3f low_new = center - hv, high_new = center + hv;
+    Vec3f low, high;
+    obj.getCorners(low, high);
+    const Vec3f prev = obj.getVolumeSize();
+    const float vol = 1.f * prev[0] * prev[1] * prev[2];
+    const float vol_new = std::pow(volSize, 3.f);
+    float vol_int = 1.f;
+    for (int k = 0; k < 3; ++k) {
+        const float d = std::min(high[k], high_new[k]) - std::max(low[k], low_new[k]);
+        if (d < 0) return 0.f;  // no overlap
+        vol_int = vol_int * d;
+    }
+    return vol_int / (vol_new + vol - vol_int);
+}
+
+int EMFusion::initNewObjVolume(const emf_image_t& mask) {
+    if (sharded)
+        throw HipError("EMFusion::initNewObjVolume: not available on the sharded path (an overlap "
+                       "test needs every object's geometry on every rank)", EMF_E_ARG);
+    // world frame first: the count decides whether anything else is needed (EMFusion.cpp:501-503)
+    const emf_point_stats_t world_stats = maskedStats(mask, pose);
+    if (static_cast<int>(world_stats.count) < params.visibilityThresh) return -1;
+    for (const auto& obj : objects) {  // EMFusion.cpp:508-524
+        const emf_point_stats_t s = maskedStats(mask, obj.getPose().inv() * pose);
+        const float iou = volumeIOU(obj, Vec3f(s.p10[0], s.p10[1], s.p10[2]),
+                                    Vec3f(s.p90[0], s.p90[1], s.p90[2]));
+        if (iou > params.volIOUThresh) return -1;
+    }
+    const Vec3f p10(world_stats.p10[0], world_stats.p10[1], world_stats.p10[2]);
+    const Vec3f p90(world_stats.p90[0], world_stats.p90[1], world_stats.p90[2]);
+    const Vec3f center = (p10 + p90) / 2.f;
+    const Vec3f off = center - pose.translation();
+    if (std::sqrt(off[0] * off[0] + off[1] * off[1] + off[2] * off[2]) > params.distanceThresh)
+        return -1;  // EMFusion.cpp:531-533
+    const Vec3f dims = p90 - p10;
+    const float volSize = params.volPad * std::max(dims[0], std::max(dims[1], dims[2]));
+    return addObject(center, volSize);
+}
+
+int EMFusion::matchSegmentation(const emf_image_t& mask, float& match_iou) {
+    refreshVisibleFromDevice();
+    if (statsScratch.empty()) (void)maskedStats(mask, Affine3f());  // allocates the buffers
+    const emf_image_t seg = modelSegmentation.view();
+    emfCheck(emf_hip_maskOverlap(&mask, &seg, overlapDev.as<uint32_t>(), main.abi()), "maskOverlap");
+    hipCheck(hipMemcpyAsync(lifecycleHost, overlapDev.data(), 513 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, main.get()),
+             "hipMemcpyAsync");
+    main.waitForCompletion();
+    const uint32_t* c = static_cast<const uint32_t*>(lifecycleHost);
+    int match_id = -1;
+    for (const auto& obj : objects) {
+        const int id = obj.getID();
+        if (!vis_objs.count(id) || id > 255) continue;
+        const float inter = static_cast<float>(c[1 + id]);
+        const float uni = static_cast<float>(c[0] + c[257 + id] - c[1 + id]);
+        const float iou = inter / uni;  // 0 / 0 = NaN never exceeds match_iou, as in the reference
+        if (iou > match_iou) {
+            match_iou = iou;
+            match_id = id;
+        }
+    }
+    return match_iou > params.matchIOUThresh ? match_id : -1;
 }
 
 // ---- tracking -------------------------------------------------------------------------------------

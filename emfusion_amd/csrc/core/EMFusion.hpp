@@ -47,6 +47,10 @@ struct FrameInputs {
     // the incoming depth.  The reference always runs it; off by default here so that the hot-path
     // frame keeps SURVEY 8(d)'s definition.  processFrame(const RGBD&) always filters.
     bool preprocessDepth = false;
+    // Instance masks (device u8 W x H) that matched no existing object: after the raycast and
+    // before the integration each one runs through initNewObjVolume (EMFusion.cpp:446-494, 104-109
+    // of processFrame); a created object integrates this frame's depth and this mask.
+    std::vector<emf_image_t> newObjectMasks;
 };
 
 /** Outcome of the last tracking run of one model (0 = camera against the background). */
@@ -79,10 +83,27 @@ public:
      */
     void trackCamera();
     void trackObjects();
+    /**
+     * Reference EMFusion::initNewObjVolume (EMFusion.cpp:498-557): spawn an object volume from an
+     * instance mask (device u8 W x H, non-zero = inside) of the CURRENT frame's points.  Returns
+     * the new object id, or -1 if the mask has too few valid points (visibilityThresh), overlaps an
+     * existing volume too much (volIOUThresh) or lies too far away (distanceThresh).
+     */
+    int initNewObjVolume(const emf_image_t& mask);
+    /** Reference EMFusion::volumeIOU (EMFusion.cpp:559-611). */
+    float volumeIOU(const ObjTSDF& obj, const Vec3f& p10, const Vec3f& p90) const;
+    /**
+     * Reference EMFusion::matchSegmentation (EMFusion.cpp:797-825): the visible object whose
+     * raycast segmentation overlaps `mask` best; its id if the IoU exceeds matchIOUThresh, else
+     * -1.  match_iou is updated as in the reference (in/out).
+     */
+    int matchSegmentation(const emf_image_t& mask, float& match_iou);
     /** Reference EMFusion::preprocessDepth (EMFusion.cpp:294-305), one launch. */
     void preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& depthOut);
     /** Result of the last tracking run of model `id` (0 = camera), or nullptr. */
     const TrackResult* getTrackResult(int id) const;
+    /** Ids returned by initNewObjVolume for FrameInputs::newObjectMasks of the last frame (-1: none). */
+    const std::vector<int>& lastCreatedObjects() const { return lastCreated; }
     Affine3f getCameraPose() const { return pose; }
     const ObjTSDF* getObject(int id) const;
 
@@ -204,6 +225,12 @@ private:
     DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
+
+    // ---- object creation / matching (SURVEY f-3) ----
+    emf_point_stats_t maskedStats(const emf_image_t& mask, const Affine3f& frame);  // synchronises
+    DeviceBuffer statsScratch, statsDev, overlapDev;
+    std::vector<int> lastCreated;
+    void* lifecycleHost = nullptr;  // pinned: emf_point_stats_t / 513 x u32
 
     // ---- tracking (SURVEY f-1) ----
     void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)

@@ -16,6 +16,7 @@ struct emf_comm {
 struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
     bool trackCamera = false, trackObjects = false, preprocess = false;
+    std::vector<emf_image_t> queuedMasks;
 };
 struct emf_synth {
     std::unique_ptr<SyntheticScene> impl;
@@ -162,6 +163,7 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.trackCamera = h->trackCamera;
         in.trackObjects = h->trackObjects;
         in.preprocessDepth = h->preprocess;
+        in.newObjectMasks.swap(h->queuedMasks);
         h->impl->processFrame(*depth_dev, in);
     });
 }
@@ -171,6 +173,37 @@ int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects
     h->trackCamera = track_camera != 0;
     h->trackObjects = track_objects != 0;
     return EMF_OK;
+}
+
+int emf_fusion_create_object_from_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id) {
+    REQ(h);
+    REQ(mask);
+    REQ(id);
+    return guarded([&] { *id = h->impl->initNewObjVolume(*mask); });
+}
+
+int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t* masks) {
+    REQ(h);
+    if (n > 0) REQ(masks);
+    return guarded([&] { h->queuedMasks.assign(masks, masks + (n > 0 ? n : 0)); });
+}
+
+int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count) {
+    REQ(h);
+    REQ(count);
+    return guarded([&] {
+        const auto& v = h->impl->lastCreatedObjects();
+        *count = static_cast<int32_t>(v.size());
+        for (int i = 0; ids && i < capacity && i < static_cast<int>(v.size()); ++i) ids[i] = v[i];
+    });
+}
+
+int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou) {
+    REQ(h);
+    REQ(mask);
+    REQ(id);
+    REQ(iou);
+    return guarded([&] { *id = h->impl->matchSegmentation(*mask, *iou); });
 }
 
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on) {

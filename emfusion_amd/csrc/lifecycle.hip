@@ -1,0 +1,230 @@
+// lifecycle.hip -- device primitives of object creation / matching from instance masks
+// (the part that needs no mesh): EMFusion::initNewObjVolume,
+// computeValidPoints, filterPoints + transformPoints + computePercentiles, matchSegmentation
+// (reference EMFusion.cpp:329-540, 797-825; EMFusion.cu:63-98).
+//
+// The reference compacts the masked points with thrust::copy_if (per channel), transforms them
+// with cv::cuda::transformPoints, splits the channels, runs three full device-wide thrust::sort
+// passes and downloads two columns -- to read two order statistics per axis.  An order statistic
+// does not need the order: here the k-th smallest value of each axis is found by a radix SELECT
+// over the float keys (4 passes of 8 bits, LDS histograms, a few hundred bytes of scratch), fused
+// with the mask test, the validity test and the rigid transform, with no compaction and no
+// sorted copy.  The selected values are elements of the data, so the result is bit-identical to
+// sorting.  matchSegmentation's per-object compare / and / or / countNonZero chain (two host
+// round trips per object) is one kernel that counts intersection and union for all objects.
+#include "common.hpp"
+
+namespace emf_hip {
+namespace {
+
+constexpr int kLcBlock = 256;
+
+// order-preserving map float -> uint32 (negative floats reversed, positive offset)
+__device__ __forceinline__ unsigned order_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct StatsArgs {
+    Img<const float> points;   // camera-frame points, f32x3
+    Img<const uint8_t> mask;   // instance mask, non-zero = inside
+    int w, h;
+    M33 R;                     // target frame <- camera
+    V3 t;
+    emf_point_stats_t* out;    // result (device)
+    unsigned* scratch;         // [0] count, [1..6] selected prefixes, [7..12] residual ranks,
+                               // [16 .. 16 + 6 * 256) histograms
+    int pass;                  // 0..3: which byte of the key, from the top
+};
+
+constexpr int kHistBase = 16;
+
+// transformed point of pixel i if it is inside the mask and valid (computeValidPoints: any
+// coordinate non-zero, EMFusion.cpp:397-406)
+__device__ __forceinline__ bool masked_point(const StatsArgs& a, size_t i, V3& p) {
+    const int y = static_cast<int>(i / a.w), x = static_cast<int>(i - static_cast<size_t>(y) * a.w);
+    if (a.mask.row(y)[x] == 0) return false;
+    const float* q = a.points.row(y) + 3 * x;
+    const V3 pc = v3(q[0], q[1], q[2]);
+    if (pc.x == 0.f && pc.y == 0.f && pc.z == 0.f) return false;
+    p = mul(a.R, pc) + a.t;  // cv::cuda::transformPoints (EMFusion.cpp:408-415)
+    return true;
+}
+
+// pass 0 also counts the points; every pass histograms one key byte of the points whose higher
+// bytes equal the selected prefix, separately for the 6 (axis, rank) selections
+__global__ __launch_bounds__(kLcBlock) void k_stats_hist(const StatsArgs a) {
+    __shared__ unsigned hist[6][256];
+    for (int i = threadIdx.x; i < 6 * 256; i += kLcBlock) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    const int shift = 24 - 8 * a.pass;
+    unsigned local = 0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kLcBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kLcBlock) {
+        V3 p;
+        if (!masked_point(a, i, p)) continue;
+        ++local;
+        const unsigned key[3] = {order_key(p.x), order_key(p.y), order_key(p.z)};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {  // s = 2 * axis + (0: p10, 1: p90)
+            const unsigned k = key[s >> 1];
+            const bool match = a.pass == 0 || (k >> (shift + 8)) == a.scratch[1 + s];
+            if (match) atomicAdd(&hist[s][(k >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * 256; i += kLcBlock) {
+        const unsigned v = (&hist[0][0])[i];
+        if (v) atomicAdd(&a.scratch[kHistBase + i], v);
+    }
+    if (a.pass == 0 && local) atomicAdd(&a.scratch[0], local);
+}
+
+// one wave: pick, for each of the 6 selections, the bucket that holds the wanted rank; extend the
+// prefix, reduce the rank, clear the histograms for the next pass; after the last pass write the
+// result
+__global__ __launch_bounds__(64) void k_stats_pick(const StatsArgs a) {
+    const int s = threadIdx.x;
+    const unsigned count = a.scratch[0];
+    if (s < 6 && count > 0) {
+        unsigned rank;
+        if (a.pass == 0) {
+            // sorted.col(static_cast<int>(points.cols * .1f)) / (.9f)  (EMFusion.cu:90-91)
+            const float frac = (s & 1) ? .9f : .1f;
+            rank = static_cast<unsigned>(static_cast<int>(static_cast<float>(count) * frac));
+            if (rank >= count) rank = count - 1;
+        } else {
+            rank = a.scratch[7 + s];
+        }
+        const unsigned* h = a.scratch + kHistBase + 256 * s;
+        unsigned acc = 0, b = 0;
+        for (; b < 255u; ++b) {
+            if (acc + h[b] > rank) break;
+            acc += h[b];
+        }
+        const unsigned prefix = a.pass == 0 ? b : ((a.scratch[1 + s] << 8) | b);
+        a.scratch[1 + s] = prefix;
+        a.scratch[7 + s] = rank - acc;
+        if (a.pass == 3) {
+            const float v = key_value(prefix);
+            if (s & 1) a.out->p90[s >> 1] = v;
+            else a.out->p10[s >> 1] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * 256; i += 64) a.scratch[kHistBase + i] = 0u;
+    if (threadIdx.x == 0 && a.pass == 3) {
+        a.out->count = count;
+        if (count == 0)
+            for (int k = 0; k < 3; ++k) a.out->p10[k] = a.out->p90[k] = 0.f;
+    }
+}
+
+__global__ void k_stats_clear(unsigned* scratch) {
+    for (int i = threadIdx.x; i < kHistBase + 6 * 256; i += blockDim.x) scratch[i] = 0u;
+}
+
+// ---- mask / model-segmentation overlap (matchSegmentation, EMFusion.cpp:797-825) -------------------
+
+struct IouArgs {
+    Img<const uint8_t> seg;       // new instance mask (non-zero = inside)
+    Img<const uint8_t> modelSeg;  // composite model segmentation (object ids, 0 = background)
+    int w, h;
+    unsigned* counts;             // [0] pixels of the mask; [1 + id] intersection with model id;
+                                  // [257 + id] pixels of model id  (id 1..255)
+};
+
+__global__ __launch_bounds__(kLcBlock) void k_mask_overlap(const IouArgs a) {
+    __shared__ unsigned inter[256], area[256], maskPx;
+    for (int i = threadIdx.x; i < 256; i += kLcBlock) inter[i] = area[i] = 0u;
+    if (threadIdx.x == 0) maskPx = 0u;
+    __syncthreads();
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kLcBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kLcBlock) {
+        const int y = static_cast<int>(i / a.w), x = static_cast<int>(i - static_cast<size_t>(y) * a.w);
+        const bool in = a.seg.row(y)[x] != 0;
+        const unsigned id = a.modelSeg.row(y)[x];
+        if (in) atomicAdd(&maskPx, 1u);
+        if (id) {
+            atomicAdd(&area[id], 1u);
+            if (in) atomicAdd(&inter[id], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kLcBlock) {
+        if (inter[i]) atomicAdd(&a.counts[1 + i], inter[i]);
+        if (area[i]) atomicAdd(&a.counts[257 + i], area[i]);
+    }
+    if (threadIdx.x == 0 && maskPx) atomicAdd(&a.counts[0], maskPx);
+}
+
+__global__ void k_clear_u32(unsigned* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+}  // namespace
+}  // namespace emf_hip
+
+using namespace emf_hip;
+
+extern "C" {
+
+size_t emf_hip_pointStatsScratchBytes(void) { return (kHistBase + 6 * 256) * sizeof(unsigned); }
+
+int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask, const float R[9],
+                             const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
+                             emf_stream_t stream) {
+    EMF_TRY(check_image(points, 12, "maskedPointStats: points"));
+    EMF_TRY(check_image(mask, 1, "maskedPointStats: mask"));
+    EMF_TRY(check_same_size(points, mask, "points", "mask"));
+    EMF_REQUIRE_PTR(R);
+    EMF_REQUIRE_PTR(t);
+    EMF_REQUIRE_PTR(scratch_dev);
+    EMF_REQUIRE_PTR(stats_dev);
+    StatsArgs a;
+    a.points = img<const float>(points);
+    a.mask = img<const uint8_t>(mask);
+    a.w = points->width;
+    a.h = points->height;
+    a.R = m33_from(R);
+    a.t = v3_from(t);
+    a.out = stats_dev;
+    a.scratch = static_cast<unsigned*>(scratch_dev);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_stats_clear, dim3(1), dim3(256), 0, s, a.scratch);
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n, kLcBlock * 4));
+    for (int pass = 0; pass < 4; ++pass) {
+        a.pass = pass;
+        hipLaunchKernelGGL(k_stats_hist, dim3(blocks), dim3(kLcBlock), 0, s, a);
+        hipLaunchKernelGGL(k_stats_pick, dim3(1), dim3(64), 0, s, a);
+    }
+    return launch_status("maskedPointStats");
+}
+
+int emf_hip_maskOverlap(const emf_image_t* seg, const emf_image_t* modelSeg, uint32_t* counts_dev,
+                        emf_stream_t stream) {
+    EMF_TRY(check_image(seg, 1, "maskOverlap: seg"));
+    EMF_TRY(check_image(modelSeg, 1, "maskOverlap: modelSeg"));
+    EMF_TRY(check_same_size(seg, modelSeg, "seg", "modelSeg"));
+    EMF_REQUIRE_PTR(counts_dev);
+    IouArgs a;
+    a.seg = img<const uint8_t>(seg);
+    a.modelSeg = img<const uint8_t>(modelSeg);
+    a.w = seg->width;
+    a.h = seg->height;
+    a.counts = counts_dev;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_clear_u32, dim3(1), dim3(256), 0, s, counts_dev, 513);
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    hipLaunchKernelGGL(k_mask_overlap, dim3(static_cast<unsigned>(ceil_div(n, kLcBlock * 4))),
+                       dim3(kLcBlock), 0, s, a);
+    return launch_status("maskOverlap");
+}
+
+}  // extern "C"

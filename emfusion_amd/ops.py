@@ -402,3 +402,26 @@ def preprocess_depth(raw, out, ksz=7, sigma_depth=0.04, sigma_spatial=4.5, strea
     check("emf_hip_preprocessDepth",
           _L.emf_hip_preprocessDepth(C.byref(image_view(raw)), C.byref(image_view(out)), int(ksz),
                                      sigma_depth, sigma_spatial, _stream(stream)))
+
+
+# ---- object creation / matching from masks (SURVEY f-3) ------------------------------------------
+
+def masked_point_stats(points, mask, R, t, stream=None):
+    """(count, p10[3], p90[3]) of the valid masked points after x' = R x + t (synchronises)."""
+    scratch = DeviceArray.zeros((int(_L.emf_hip_pointStatsScratchBytes()) // 4,), np.uint32)
+    out = DeviceArray.zeros((7,), np.float32)
+    check("emf_hip_maskedPointStats",
+          _L.emf_hip_maskedPointStats(C.byref(image_view(points)), C.byref(image_view(mask)), _f(R, 9),
+                                      _f(t, 3), _ptr(scratch), _ptr(out), _stream(stream)))
+    raw = out.numpy()
+    return int(raw.view(np.uint32)[0]), raw[1:4].copy(), raw[4:7].copy()
+
+
+def mask_overlap(seg, model_seg, stream=None):
+    """(mask pixels, intersection[256], area[256]) against every id of the model segmentation."""
+    counts = DeviceArray.zeros((513,), np.uint32)
+    check("emf_hip_maskOverlap",
+          _L.emf_hip_maskOverlap(C.byref(image_view(seg)), C.byref(image_view(model_seg)),
+                                 _ptr(counts), _stream(stream)))
+    c = counts.numpy()
+    return int(c[0]), c[1:257].copy(), c[257:513].copy()

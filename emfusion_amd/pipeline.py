@@ -97,6 +97,10 @@ def load() -> C.CDLL:
                                      C.c_int],
         "emf_fusion_set_tracking": [vp, C.c_int, C.c_int],
         "emf_fusion_set_preprocess": [vp, C.c_int],
+        "emf_fusion_create_object_from_mask": [vp, img, ip],
+        "emf_fusion_match_mask": [vp, img, ip, fp],
+        "emf_fusion_queue_new_object_masks": [vp, C.c_int, img],
+        "emf_fusion_last_created": [vp, ip, C.c_int, ip],
         "emf_fusion_get_pose": [vp, C.c_int, fp, fp],
         "emf_fusion_track_result": [vp, C.c_int, ip, ip, ip, fp],
         "emf_fusion_stage_estep": [vp],
@@ -272,6 +276,31 @@ class Fusion:
     def set_tracking(self, camera=True, objects=True):
         """From the next frame on, track the camera / object poses instead of taking them as inputs."""
         _check("emf_fusion_set_tracking", load().emf_fusion_set_tracking(self._h, int(camera), int(objects)))
+
+    def create_object_from_mask(self, mask_view: EmfImage) -> int:
+        """EMFusion::initNewObjVolume on the current frame's points; -1 if no object is created."""
+        i = C.c_int32(-1)
+        _check("emf_fusion_create_object_from_mask",
+               load().emf_fusion_create_object_from_mask(self._h, C.byref(mask_view), C.byref(i)))
+        return i.value
+
+    def queue_new_object_masks(self, mask_views):
+        """Masks for in-frame object creation by the next process_frame (initOrMatchObjs)."""
+        arr = (EmfImage * max(len(mask_views), 1))(*mask_views)
+        _check("emf_fusion_queue_new_object_masks",
+               load().emf_fusion_queue_new_object_masks(self._h, len(mask_views), arr))
+
+    def last_created(self):
+        ids, n = (C.c_int32 * 64)(), C.c_int32(0)
+        _check("emf_fusion_last_created", load().emf_fusion_last_created(self._h, ids, 64, C.byref(n)))
+        return [ids[i] for i in range(min(n.value, 64))]
+
+    def match_mask(self, mask_view: EmfImage):
+        """EMFusion::matchSegmentation: (object id or -1, best IoU)."""
+        i, iou = C.c_int32(-1), C.c_float(0.0)
+        _check("emf_fusion_match_mask",
+               load().emf_fusion_match_mask(self._h, C.byref(mask_view), C.byref(i), C.byref(iou)))
+        return i.value, iou.value
 
     def set_preprocess(self, on=True):
         """Filter incoming depth maps as the reference's preprocessDepth does (bilateral + patches)."""

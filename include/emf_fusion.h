@@ -91,6 +91,16 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
  * takes the supplied poses.  get_pose: id 0 = camera -> world, else object volume -> world.
  * track_result: iterations / accepted / converged / error of the last run of model id. */
 int emf_fusion_set_tracking(emf_fusion_t* h, int track_camera, int track_objects);
+/* Object creation / matching from a device instance mask (u8 W x H, non-zero = inside) of the
+ * current frame (EMFusion::initNewObjVolume / matchSegmentation, SURVEY f-3).  *id = new / matched
+ * object id, or -1.  *iou is in/out for match (start it at 0). */
+int emf_fusion_create_object_from_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id);
+/* In-frame creation, as the reference does it (initOrMatchObjs before integrateDepth): the masks
+ * queued here are run through initNewObjVolume by the NEXT process_frame, after its raycast and
+ * before its integration; last_created returns the ids (-1 = rejected), in queue order. */
+int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t* masks);
+int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
+int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);

@@ -367,6 +367,36 @@ int emf_hip_preprocessDepth(const emf_image_t* depthRaw, const emf_image_t* dept
                             float sigmaDepth, float sigmaSpatial, emf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Object creation / matching from instance masks (mesh-free part)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* What EMFusion::initNewObjVolume needs of the masked points (EMFusion.cpp:498-535):
+ * count = pixels with mask != 0 and a valid point (computeValidPoints: any coordinate != 0);
+ * p10 / p90 = per axis, the elements at index int(count * .1f) and int(count * .9f) of the sorted
+ * coordinates of those points after x' = R x + t (computePercentiles, EMFusion.cu:77-98). */
+typedef struct emf_point_stats {
+    uint32_t count;
+    float p10[3];
+    float p90[3];
+} emf_point_stats_t;
+
+size_t emf_hip_pointStatsScratchBytes(void);
+
+/* filterPoints + transformPoints + computePercentiles (EMFusion.cu:63-98, EMFusion.cpp:408-415)
+ * fused into a masked radix select: no compaction, no sort, bit-identical order statistics.
+ * points f32x3, mask u8 (W x H); stats_dev and scratch_dev in device memory; 9 small launches. */
+int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask, const float R[9],
+                             const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
+                             emf_stream_t stream);
+
+/* The counts behind EMFusion::matchSegmentation (EMFusion.cpp:797-825) for ALL objects at once:
+ * counts_dev[0] = pixels of `seg`; counts_dev[1 + id] = |seg AND (modelSeg == id)|;
+ * counts_dev[257 + id] = |modelSeg == id|, id = 1..255 (513 uint32, cleared by the call).
+ * IoU(id) = inter / (counts[0] + area - inter). */
+int emf_hip_maskOverlap(const emf_image_t* seg, const emf_image_t* modelSeg, uint32_t* counts_dev,
+                        emf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Tracking: weighted Levenberg-Marquardt ICP on the TSDF
  * (TSDF.cpp:170-344, 375-395; EMFusion.cpp:672-724).  All LM state lives in device memory.
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,154 @@
+"""Object creation / matching primitives (SURVEY f-3): masked radix-select point statistics against
+sorting (reference filterPoints + transformPoints + computePercentiles, EMFusion.cu:63-98), and the
+all-objects overlap counts against the compare / and / or / countNonZero chain of
+EMFusion::matchSegmentation (EMFusion.cpp:797-825)."""
+import numpy as np
+import pytest
+
+from tests.parity_util import dev_full, to_dev
+from tests.scenes import Pose, camera_path, intrinsics, render_depth, rot
+
+pytestmark = pytest.mark.gpu
+W, H = 160, 120
+K = intrinsics(W, H)
+SPHERES = [((0.25, 0.05, 1.3), 0.22), ((-0.3, -0.1, 1.6), 0.18)]
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from emfusion_amd import ops as _ops
+    return _ops
+
+
+def sorted_stats(points, mask, R, t):
+    """The reference's way: compact, transform, sort each channel, take two columns."""
+    f32 = np.float32
+    valid = (mask != 0) & np.any(points != 0, axis=2)
+    p = points[valid].astype(f32)
+    n = len(p)
+    if n == 0:
+        return 0, np.zeros(3, f32), np.zeros(3, f32)
+    R = np.asarray(R, f32).reshape(3, 3)
+    q = np.empty_like(p)
+    for i in range(3):  # (r0 x + r1 y) + r2 z, then + t: the product's operation order
+        q[:, i] = f32(f32(f32(R[i, 0] * p[:, 0]) + f32(R[i, 1] * p[:, 1])) + f32(R[i, 2] * p[:, 2])) + f32(t[i])
+    s = np.sort(q, axis=0)
+    return n, s[int(f32(n) * f32(.1))], s[int(f32(n) * f32(.9))]
+
+
+@pytest.mark.parametrize("case", ["sphere", "rotated", "empty", "single", "negative", "padded"])
+def test_masked_point_stats_equal_sorting(oracle, ops, dev, case):
+    cam = camera_path(3)
+    depth, ids = render_depth(W, H, K, cam, SPHERES, noise=0.003, dropout=0.02, seed=11)
+    points = oracle.compute_points(depth, K)
+    mask = (ids == 1).astype(np.uint8)
+    R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    pad = 0
+    if case == "rotated":
+        R, t = rot([0.3, 1, 0.1], 25).astype(np.float32), np.array([0.4, -2.0, 0.3], np.float32)
+    elif case == "empty":
+        mask[:] = 0
+    elif case == "single":
+        mask[:] = 0
+        mask[60, 80] = 7
+    elif case == "negative":
+        mask = ((ids > 0) * 255).astype(np.uint8)
+        t = np.array([-0.1, 0.0, -1.45], np.float32)  # coordinates of both signs, zeros nearby
+    elif case == "padded":
+        pad = 5
+        mask = np.ones((H, W), np.uint8)  # everything valid: the dropout pixels must be skipped
+    n, p10, p90 = sorted_stats(points, mask, R, t)
+    got_n, g10, g90 = ops.masked_point_stats(to_dev(points, dev, pad), to_dev(mask, dev, pad), R, t)
+    assert got_n == n
+    if case in ("sphere", "rotated", "negative", "padded"):
+        assert n > 500 and np.all(p90 > p10)
+    assert g10.tobytes() == p10.astype(np.float32).tobytes(), (g10, p10)
+    assert g90.tobytes() == p90.astype(np.float32).tobytes(), (g90, p90)
+
+
+def test_mask_overlap_counts(ops, dev):
+    rng = np.random.default_rng(5)
+    model = np.zeros((H, W), np.uint8)
+    model[20:70, 30:90] = 1
+    model[50:110, 70:150] = 2
+    model[0:5, 0:5] = 255
+    seg = np.zeros((H, W), np.uint8)
+    seg[40:100, 60:120] = 1
+    seg[rng.uniform(size=(H, W)) < 0.02] = 200
+    n, inter, area = ops.mask_overlap(to_dev(seg, dev, 3), to_dev(model, dev))
+    assert n == int((seg != 0).sum())
+    for i in (1, 2, 255, 9):
+        assert inter[i] == int(((seg != 0) & (model == i)).sum()), i
+        assert area[i] == int((model == i).sum()), i
+    iou1 = inter[1] / (n + area[1] - inter[1])
+    want = ((seg != 0) & (model == 1)).sum() / ((seg != 0) | (model == 1)).sum()
+    assert abs(iou1 - want) < 1e-12
+
+
+# ---- host logic on top: EMFusion::initNewObjVolume / volumeIOU / matchSegmentation ----------------
+
+def volume_iou(low, high, prev_size, p10, p90, vol_pad=2.0):
+    """EMFusion::volumeIOU (EMFusion.cpp:559-611) in float32."""
+    f32 = np.float32
+    center = (p10 + p90) / f32(2)
+    vs = f32(vol_pad) * (p90 - p10).max()
+    low_n, high_n = center - vs / f32(2), center + vs / f32(2)
+    d = np.minimum(high, high_n) - np.maximum(low, low_n)
+    if (d < 0).any():
+        return 0.0
+    vi = f32(np.prod(d.astype(f32)))
+    return float(vi / (f32(vs) ** 3 + f32(np.prod(prev_size)) - vi))
+
+
+def test_objects_are_created_and_matched_from_masks(oracle, dev):
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    Wf, Hf = 320, 240
+    prm = pipeline.make_params(Wf, Hf, 128, 0.04, 32, visibility_thresh=400, boundary=10)
+    Kf = np.array(prm.K, np.float32)
+    synth = pipeline.SyntheticStream(Wf, Hf, Kf, 2, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    keep, centers = [], {}
+    for f in range(4):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        d = to_dev(depth)
+        masks = {i: to_dev((sid == i).astype(np.uint8)) for i in centers}
+        keep += [d, masks]
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), c) for i, c in centers.items()}
+        if f == 0:  # both instance masks are "unmatched": created inside the frame, like the reference
+            new = [to_dev((sid == k).astype(np.uint8)) for k in (1, 2)]
+            tiny = np.zeros((Hf, Wf), np.uint8)
+            tiny[100:110, 100:110] = 1
+            new.append(to_dev(tiny))  # fewer than visibilityThresh valid points
+            new.append(new[0])        # the first mask again: the volume would coincide (volume IoU)
+            keep.append(new)
+            fus.queue_new_object_masks([image_view(m) for m in new])
+        fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, True)
+        fus.synchronize()
+        if f == 0:
+            assert fus.last_created() == [1, 2, -1, -1]
+            pts = oracle.compute_points(depth, Kf)
+            for k in (1, 2):
+                n, p10, p90 = sorted_stats(pts, (sid == k).astype(np.uint8), R.reshape(3, 3), t)
+                Ro, to = fus.pose(k)
+                assert n >= 400 and np.allclose(Ro, np.eye(3))
+                assert np.allclose(to, (p10 + p90) / np.float32(2), atol=1e-6)
+                centers[k] = to
+            assert fus.create_object_from_mask(image_view(new[1])) == -1  # also between frames
+    # after a few frames the raycast segmentation shows the objects: masks match them
+    seg = fus.image("segmentation")
+    assert set(np.unique(seg)) >= {0, 1, 2}
+    depth, sid = synth.render(3)
+    for k in (1, 2):
+        m = (sid == k).astype(np.uint8)
+        got_id, iou = fus.match_mask(image_view(to_dev(m)))
+        want = ((m != 0) & (seg == k)).sum() / ((m != 0) | (seg == k)).sum()
+        assert got_id == k and abs(iou - want) < 1e-6 and iou > 0.2
+    empty = np.zeros((Hf, Wf), np.uint8)
+    empty[0:3, 0:3] = 1
+    assert fus.match_mask(image_view(to_dev(empty)))[0] == -1
+    assert volume_iou(np.full(3, -1, np.float32), np.full(3, 1, np.float32), np.full(3, 2, np.float32),
+                      np.full(3, -.5, np.float32), np.full(3, .5, np.float32)) == pytest.approx(1.0)
+    fus.close()
+    synth.close()
