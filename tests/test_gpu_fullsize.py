@@ -1,0 +1,171 @@
+"""BASELINE.json's full sizes (configs[0]: background 256^3; configs[1]: background 512^3 + 4 objects
+128^3; 640 x 480).  The small-size tests compare every output with the oracle; here the same code
+paths are checked where the oracle is slow, through known answers and size-independent properties:
+
+  * a fronto-parallel wall: closed-form TSDF, hit depth D + voxel / 2 (Q1), normal (0, 0, -1)
+  * one direct comparison with the oracle at 512^3 (two integrations + a raycast, all host threads)
+  * batched launches == per-volume launches, bit for bit; reciprocal march == dividing march
+  * repeatability (same inputs -> same bits), weight cap, normalisation identity, compositing
+    consistency on the 5-model frame
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.parity_util import assert_parity, dev_full, to_dev, to_np
+from tests.scenes import Pose, intrinsics, rel_CO, rel_OC
+
+pytestmark = pytest.mark.gpu
+W, H = 640, 480
+K = intrinsics(W, H)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from emfusion_amd import ops as _ops
+    return _ops
+
+
+def _vol(n):
+    return np.zeros((n, n, n), np.float32)
+
+
+@pytest.mark.parametrize("n,vox", [(256, 0.02), (512, 0.01)], ids=["config0_256", "config1_512"])
+def test_wall_known_answers(ops, dev, n, vox):
+    D = 2.0
+    depth = np.full((H, W), D, np.float32)
+    pose = Pose(t=[0, 0, n * vox / 2])
+    cam = Pose()
+    oc, co = rel_OC(cam, pose), rel_CO(cam, pose)
+    d_t, d_w = to_dev(_vol(n)), to_dev(_vol(n))
+    il = dev_full((H, W), 0.0)
+    ops.compute_inv_lambda(K, il)
+    ones = to_dev(np.ones((H, W), np.float32))
+    for _ in range(2):
+        ops.update_tsdf(to_dev(depth), ones, d_t, d_w, oc.R32, oc.t32, K, vox, 10 * vox, 64.0, inv_lambda=il)
+    tsdf, wts = to_np(d_t), to_np(d_w)
+    # voxel column on the optical axis: projective SDF of a plane = (D - z_voxel) / truncdist
+    c = n // 2
+    z = (np.arange(n, dtype=np.float32) - np.float32((n - 1) / 2)) * np.float32(vox) + np.float32(n * vox / 2)
+    x = (np.float32(c) - np.float32((n - 1) / 2)) * np.float32(vox)
+    col_t, col_w = tsdf[:, c, c], wts[:, c, c]
+    lam = np.sqrt(1 + 2 * (x / z) ** 2)  # |(u, v, 1)| of the voxel's own ray, before pixel rounding
+    sdf = D - np.sqrt(z * z + 2 * x * x) / lam
+    near = np.abs(sdf) < 8 * vox
+    assert near.sum() >= 10
+    assert np.abs(col_t[near] - sdf[near] / (10 * vox)).max() < 0.06  # pixel rounding of lambda only
+    seen = z > 0.3  # nearer voxels of this off-axis column project outside the image
+    assert (col_w[seen & (sdf > -10 * vox + vox)] == 2).all() and (col_t[seen & (sdf > 11 * vox)] == 1).all()
+    assert (col_t[sdf < -11 * vox] == -1).all() and (col_w[sdf < -11 * vox] == 0).all()
+    ray, vert, nrm = dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0), dev_full((H, W, 3), 0.0)
+    hit, st = dev_full((H, W), 0, np.uint8), dev_full((4,), 0, np.uint64)
+    ops.raycast_tsdf(d_t, None, d_w, None, ray, vert, nrm, hit, co.R32, co.t32, K, vox, 10 * vox, st,
+                     rcp_voxel=ops.voxel_reciprocal(vox))
+    hit, vert, nrm = to_np(hit), to_np(vert), to_np(nrm)
+    inner = np.zeros((H, W), bool)
+    inner[40:-40, 40:-40] = True
+    assert hit[inner].all()
+    # Q1: the interpolated crossing lies one (half-voxel) step behind the surface
+    assert np.abs(vert[inner][:, 2] - (D + vox / 2)).max() < 0.25 * vox
+    # the projective SDF (lambda of the rounded pixel) is planar only up to a few degrees
+    dev_n = np.abs(nrm[inner] - np.array([0, 0, -1], np.float32))
+    assert dev_n.max() < 0.15 and dev_n.mean() < 0.02
+    assert int(to_np(st)[1]) == int(hit.sum())
+
+
+@pytest.fixture(scope="module")
+def bench_scene(dev):
+    """configs[1] through the host classes: 6 frames of the bench's synthetic stream."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    prm = pipeline.make_params(W, H, 512, 0.01, 128)
+    Kp = np.array(prm.K, np.float32)
+    synth = pipeline.SyntheticStream(W, H, Kp, 4, seed=0xE3F5)
+
+    def run(env=None):
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        fus = pipeline.Fusion(prm, None)
+        ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(4)]
+        for f in range(6):
+            depth, sid = synth.render(f)
+            R, t = synth.camera_pose(f)
+            poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
+            masks = {i: to_dev((sid == i).astype(np.uint8)) for i in ids} if f == 0 else {}
+            d = to_dev(depth)
+            fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, f == 0)
+            fus.synchronize()
+        out = dict(bg_t=fus.volume("tsdf", 0), bg_w=fus.volume("weights", 0),
+                   obj_t={i: fus.volume("tsdf", i) for i in ids}, ray=fus.image("raylengths"),
+                   seg=fus.image("segmentation"), norm=fus.image("assoc_norm"), bg_a=fus.image("bg_assoc"),
+                   obj_a={i: fus.image("obj_assoc", i) for i in ids},
+                   obj_ray={i: fus.image("obj_raylengths", i) for i in ids}, ids=ids)
+        fus.close()
+        for k in (env or {}):
+            os.environ.pop(k, None)
+        return out
+    base = run()
+    yield dict(run=run, base=base, synth=synth, prm=prm)
+    synth.close()
+
+
+def test_full_size_frame_is_repeatable_and_path_independent(bench_scene):
+    base = bench_scene["base"]
+    again = bench_scene["run"]()
+    per_volume = bench_scene["run"]({"EMF_PER_VOLUME": "1"})
+    divide = bench_scene["run"]({"EMF_VOXEL_RCP": "0", "EMF_LAMBDA_TABLE": "0"})
+    for other, what in ((again, "second run"), (per_volume, "per-volume launches"),
+                        (divide, "IEEE divisions, inline 1/lambda")):
+        for key in ("bg_t", "bg_w", "ray", "seg"):
+            assert base[key].tobytes() == other[key].tobytes(), (what, key)
+        for i in base["ids"]:
+            assert base["obj_t"][i].tobytes() == other["obj_t"][i].tobytes(), (what, i)
+
+
+def test_full_size_frame_invariants(bench_scene):
+    b = bench_scene["base"]
+    assert b["bg_w"].max() <= 64 and (b["bg_w"] > 0).sum() > 3e6 and (b["bg_t"] == -1).sum() > 1e6
+    total = b["bg_a"].astype(np.float64) + sum(a.astype(np.float64) for a in b["obj_a"].values())
+    valid = b["norm"] != 0
+    assert valid.mean() > 0.9
+    assert np.abs(total[valid] - 1).max() < 1e-5 and (total[~valid] == 0).all()
+    assert set(np.unique(b["seg"])) <= {0, 1, 2, 3, 4} and (b["seg"] > 0).sum() > 2000
+    for i in b["ids"]:  # where an object owns the pixel, the composite carries that object's ray
+        own = b["seg"] == i
+        assert (b["ray"][own] == b["obj_ray"][i][own]).all()
+
+
+def test_full_size_against_the_oracle(oracle, ops, dev):
+    """Two integrations and a raycast of the 512^3 background, HIP vs oracle, every voxel / pixel."""
+    from emfusion_amd import pipeline
+    oracle.set_threads(os.cpu_count() or 8)
+    n, vox = 512, 0.01
+    prm = pipeline.make_params(W, H, n, vox, 128)
+    Kp = np.array(prm.K, np.float32).reshape(3, 3)
+    synth = pipeline.SyntheticStream(W, H, Kp.reshape(-1), 2, seed=0xE3F5)
+    pose = Pose(t=list(prm.volume_pose_t))
+    tsdf, wts = _vol(n), _vol(n)
+    d_t, d_w = to_dev(tsdf), to_dev(wts)
+    rng = np.random.default_rng(1)
+    for f in range(2):
+        depth, _ = synth.render(f)
+        R, t = synth.camera_pose(f)
+        cam = Pose(R.reshape(3, 3).astype(np.float64), t.astype(np.float64))
+        oc = rel_OC(cam, pose)
+        assoc = rng.uniform(0.3, 1.0, (H, W)).astype(np.float32)
+        oracle.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, Kp, vox, 10 * vox, 64.0)
+        ops.update_tsdf(to_dev(depth), to_dev(assoc), d_t, d_w, oc.R32, oc.t32, Kp, vox, 10 * vox, 64.0)
+    assert_parity(to_np(d_t), tsdf, "tsdf 512^3", exact=True)
+    assert_parity(to_np(d_w), wts, "weights 512^3", exact=True)
+    co = rel_CO(cam, pose)
+    want = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, co.R32, co.t32, Kp, vox, 10 * vox, count_steps=True)
+    ray, vert, nrm = dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0), dev_full((H, W, 3), 0.0)
+    hit, st = dev_full((H, W), 0, np.uint8), dev_full((4,), 0, np.uint64)
+    ops.raycast_tsdf(d_t, None, d_w, None, ray, vert, nrm, hit, co.R32, co.t32, Kp, vox, 10 * vox, st,
+                     rcp_voxel=ops.voxel_reciprocal(vox))
+    for got, w_, name in zip((ray, vert, nrm, hit), want, ("ray", "vert", "normal", "mask")):
+        assert_parity(to_np(got), w_, f"{name} 640x480 / 512^3", exact=True)
+    assert int(to_np(st)[0]) == int(want[4].sum()) and want[3].sum() > 250000
+    synth.close()
+    oracle.set_threads(min(8, os.cpu_count() or 1))
