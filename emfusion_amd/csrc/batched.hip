@@ -103,11 +103,9 @@ struct RaycastBatchArgs {
     unsigned long long* stats;
 };
 
-#ifndef EMF_RB_WAVES
-#define EMF_RB_WAVES 4  // waves (8x8 pixel sub-tiles) per workgroup: 4 = 16x16 tile, 1 = 8x8 tile
-#endif
-constexpr int kRbWaves = EMF_RB_WAVES;
-constexpr int kRbTile = kRbWaves == 4 ? 16 : 8;
+// 4 waves (8x8-pixel sub-tiles) per workgroup = a 16x16 tile; 1-wave workgroups measured the same
+constexpr int kRbWaves = 4;
+constexpr int kRbTile = 16;
 
 #ifdef EMF_RAY_TRACE  // timeline instrumentation, trace builds only (scripts/raycast_timeline.py)
 struct RayTraceRec {
@@ -123,7 +121,7 @@ __device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned sampl
         sm += static_cast<unsigned>(__shfl_xor(static_cast<int>(sm), o));
     }
     const unsigned long long lanes = __ballot(samples > 0);
-    const unsigned slot = blockIdx.x * EMF_RB_WAVES + wave;
+    const unsigned slot = blockIdx.x * 4 + wave;
     if (lane == 0 && slot < 32768u) {
         RayTraceRec t;
         t.t0 = t0;
@@ -144,9 +142,6 @@ __device__ __forceinline__ void trace_wave(unsigned long long, unsigned, int, in
 #endif
 
 template <bool WAVE>
-#ifdef EMF_RB_WPE
-__attribute__((amdgpu_waves_per_eu(EMF_RB_WPE, EMF_RB_WPE)))
-#endif
 __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
 #ifdef EMF_RAY_TRACE
     const unsigned long long trace_t0 = wall_clock64();

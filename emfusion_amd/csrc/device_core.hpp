@@ -92,9 +92,6 @@ struct IntegrateGeom {
 #endif
 
 inline bool is_pinhole(const M33& K) {
-#ifdef EMF_X_NO_PINHOLE
-    return false;
-#endif
     return K.r0.y == 0.f && K.r1.x == 0.f && K.r2.x == 0.f && K.r2.y == 0.f && K.r2.z == 1.f;
 }
 
