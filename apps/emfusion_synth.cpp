@@ -3,8 +3,13 @@
 // stream instead of a dataset reader.  Prints frames/s and per-stage GPU milliseconds.
 //
 //   emfusion_synth [--frames N] [--objects K] [--bg-res R] [--obj-res R] [--width W --height H]
-//                  [--materialize-gradients]
+//                  [--materialize-gradients] [--autonomous]
+// --autonomous: nothing but depth and instance masks go in, as in the reference's own loop -- objects
+// are spawned from the masks of frame 0 (initNewObjVolume), camera and object poses are tracked
+// (performTracking), later masks are matched to the models (matchSegmentation); the ground-truth
+// poses of the stream are only used to report the tracking error at the end.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +21,7 @@
 
 int main(int argc, char** argv) {
     int frames = 120, objects = 4, bgRes = 512, objRes = 128, width = 640, height = 480;
-    bool materialize = false;
+    bool materialize = false, autonomous = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? std::atoi(argv[++i]) : 0; };
@@ -27,6 +32,7 @@ int main(int argc, char** argv) {
         else if (a == "--width") width = next();
         else if (a == "--height") height = next();
         else if (a == "--materialize-gradients") materialize = true;
+        else if (a == "--autonomous") autonomous = true;
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
@@ -47,8 +53,9 @@ int main(int argc, char** argv) {
         emf::EMFusion emf(params, materialize ? emf::TSDF::Gradients::Materialized
                                               : emf::TSDF::Gradients::OnTheFly);
         std::vector<int> ids;
-        for (int k = 0; k < objects; ++k)
-            ids.push_back(emf.addObject(scene.sphereCenter(k, 0), scene.objectVolumeSize(k)));
+        if (!autonomous)
+            for (int k = 0; k < objects; ++k)
+                ids.push_back(emf.addObject(scene.sphereCenter(k, 0), scene.objectVolumeSize(k)));
 
         const size_t P = params.frameSize.area();
         std::vector<float> depth(P);
@@ -58,29 +65,56 @@ int main(int argc, char** argv) {
         emf.enableTimings(true);
 
         double gpuMs = 0;
+        int spawned = 0;
         const auto t0 = std::chrono::steady_clock::now();
         for (int f = 0; f < frames; ++f) {  // while (reader->moreFrames())
             scene.render(f, depth.data(), sid.data());  // frame = reader->getNextFrame()
             emf::FrameInputs in;
             in.cam_pose = scene.cameraPose(f);
-            for (int k = 0; k < objects; ++k)
-                in.obj_poses[ids[k]] = emf::Affine3f(emf::Matx33f::eye(), scene.sphereCenter(k, f));
             in.runMasks = f % params.maskRCNNFrames == 0;
             if (in.runMasks)
                 for (int k = 0; k < objects; ++k) {
                     for (size_t i = 0; i < P; ++i) mask[i] = sid[i] == k + 1 ? 1 : 0;
                     maskDev[k].upload(mask.data(), emf.mainStream());
                     emf.mainStream().waitForCompletion();  // host buffer is reused
-                    in.masks[ids[k]] = maskDev[k].view();
                 }
+            if (!autonomous) {
+                for (int k = 0; k < objects; ++k)
+                    in.obj_poses[ids[k]] = emf::Affine3f(emf::Matx33f::eye(), scene.sphereCenter(k, f));
+                if (in.runMasks)
+                    for (int k = 0; k < objects; ++k) in.masks[ids[k]] = maskDev[k].view();
+            } else {
+                in.trackCamera = in.trackObjects = f > 0;
+                if (f == 0) {  // every mask is unmatched: spawn the volumes inside the frame
+                    for (int k = 0; k < objects; ++k) in.newObjectMasks.push_back(maskDev[k].view());
+                } else if (in.runMasks) {  // hand each mask to the model it overlaps best
+                    for (int k = 0; k < objects; ++k) {
+                        float iou = 0.f;
+                        const int id = emf.matchSegmentation(maskDev[k].view(), iou);
+                        if (id >= 0) in.masks[id] = maskDev[k].view();
+                    }
+                }
+            }
             emf.setFrameInputs(in);
             emf::RGBD frame;
             frame.size = params.frameSize;
             frame.depth = depth.data();
             emf.processFrame(frame);  // reference EMFusion.cpp:70
             gpuMs += emf.lastTimings().total;
+            if (autonomous && f == 0)
+                for (int id : emf.lastCreatedObjects()) spawned += id >= 0;
         }
         emf.synchronize();
+        if (autonomous) {
+            const emf::Vec3f d = emf.getCameraPose().translation() - scene.cameraPose(frames - 1).translation();
+            std::printf("autonomous: %d objects spawned from masks; camera position error after %d "
+                        "tracked frames: %.1f mm",
+                        spawned, frames - 1,
+                        1e3 * std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]));
+            if (const emf::TrackResult* r = emf.getTrackResult(0))
+                std::printf(" (last frame: %d LM steps, %d accepted)", r->iterations, r->accepted);
+            std::printf("\n");
+        }
         const double wall =
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const emf::FrameTimings& t = emf.lastTimings();
