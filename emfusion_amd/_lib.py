@@ -119,9 +119,10 @@ class EmfTrackState(C.Structure):
                 ("ttrial", C.c_float * 3), ("A", C.c_float * 36), ("b", C.c_float * 6),
                 ("x", C.c_float * 6), ("mu", C.c_float), ("nu", C.c_float), ("rho", C.c_float),
                 ("err", C.c_float), ("errNew", C.c_float), ("maxIwBits", C.c_uint32),
+                ("maxIwTrialBits", C.c_uint32),
                 ("converged", C.c_int32), ("firstIteration", C.c_int32),
                 ("evaluateGradient", C.c_int32), ("haveTrial", C.c_int32),
-                ("iterations", C.c_int32), ("accepted", C.c_int32), ("pad_", C.c_int32)]
+                ("iterations", C.c_int32), ("accepted", C.c_int32), ("iwSel", C.c_int32)]
 
 _lib = None
 

@@ -44,18 +44,19 @@ struct TrackFrame {
     Img<const float> points;
     int w, h, nblocks;
     emf_track_params_t prm;
-    char* scratch;          // per model: [w image W*H][iw image W*H][partials nblocks * 28][err nblocks]
+    char* scratch;          // per model: [w image][iw image 0][iw image 1][partials 28 x nblocks][err nblocks]
     size_t scratchStride;   // bytes per model
 };
 
 __device__ __forceinline__ float* scratch_w(const TrackFrame& f, int m) {
     return reinterpret_cast<float*>(f.scratch + f.scratchStride * m);
 }
-__device__ __forceinline__ float* scratch_iw(const TrackFrame& f, int m) {
-    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h;
+// two clamped-weight images: [sel] belongs to the current pose, [1 - sel] is filled at the trial pose
+__device__ __forceinline__ float* scratch_iw(const TrackFrame& f, int m, int sel) {
+    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h * (1 + sel);
 }
 __device__ __forceinline__ float* scratch_partials(const TrackFrame& f, int m) {
-    return scratch_iw(f, m) + static_cast<size_t>(f.w) * f.h;
+    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h * 3;
 }
 __device__ __forceinline__ float* scratch_err(const TrackFrame& f, int m) {
     return scratch_partials(f, m) + static_cast<size_t>(f.nblocks) * kSums;
@@ -115,10 +116,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 // sum of p[i * stride], i < n, over the 64 lanes of the calling wave: lane-strided partial sums in
-// double, then a fixed xor tree -- the same order on every run
+// double, then a fixed xor tree -- the same order on every run.  The loads of a lane are issued in
+// batches of 8 before any of them is added: a plain `acc += p[i]` loop is not pipelined by the
+// compiler (the double add is a dependency chain) and exposes one memory latency per element --
+// that alone made the per-model kernels take 22 us.
 __device__ __forceinline__ double wave_strided_sum(const float* p, int n, int stride, int lane) {
     double acc = 0.0;
-    for (int i = lane; i < n; i += 64) acc += static_cast<double>(p[static_cast<size_t>(i) * stride]);
+    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + 64 * j;
+            v[j] = i < n ? p[static_cast<size_t>(i) * stride] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += static_cast<double>(v[j]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     return acc;
@@ -134,7 +147,9 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) {
     const int m = blockIdx.y;
     emf_track_state_t& st = f.states[m];
-    if (st.converged || !st.evaluateGradient) return;  // TSDF.cpp:212-214
+    // only the first iteration of a stage: afterwards the weights of an accepted pose were already
+    // looked up by k_track_error when that pose was the trial (TSDF.cpp:212-214, 234)
+    if (st.converged || !st.firstIteration) return;
     const emf_model_t& md = f.models[m];
     size_t pix;
     V3 pc;
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) 
         iw = lookup1(md.weights, state_R(st.R), v3(st.t[0], st.t[1], st.t[2]), pc,
                      I3{md.res[0], md.res[1], md.res[2]}, md.voxelSize);
         iw = fminf(iw, f.prm.maxWeight);  // cv::cuda::min(intWeights, maxTSDFWeight), TSDF.cpp:234
-        scratch_iw(f, m)[pix] = iw;
+        scratch_iw(f, m, st.iwSel)[pix] = iw;
     }
     __shared__ float red[kTrackBlock / 64];
     const float wmx = wave_max(fabsf(iw));
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f)
         const float a = fabsf(r);
         float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
         tw = fminf(tw, 1.0f);
-        w = scratch_iw(f, m)[pix] * scale;
+        w = scratch_iw(f, m, st.iwSel)[pix] * scale;
         w = tw * w;               // multiply(trackWeights, intWeights)
         w = w * md.assoc[pix];    // multiply(intWeights, associationWeights)
         scratch_w(f, m)[pix] = w;
@@ -212,26 +227,41 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f)
 }
 
 __global__ __launch_bounds__(kTrackBlock) void k_track_error(const TrackFrame f) {
-    __shared__ float red[kTrackBlock / 64];
+    __shared__ float red[kTrackBlock / 64], redMax[kTrackBlock / 64];
     const int m = blockIdx.y;
-    const emf_track_state_t& st = f.states[m];
+    emf_track_state_t& st = f.states[m];
     if (st.converged || !st.haveTrial) return;
     const emf_model_t& md = f.models[m];
     size_t pix;
     V3 pc;
-    float e = 0.f;
+    float e = 0.f, iw = 0.f;
     if (load_point(f, pix, pc)) {
-        const float r = lookup1(md.tsdf, state_R(st.Rtrial), v3(st.ttrial[0], st.ttrial[1], st.ttrial[2]),
-                                pc, I3{md.res[0], md.res[1], md.res[2]}, md.voxelSize);
+        const M33 R = state_R(st.Rtrial);
+        const V3 t = v3(st.ttrial[0], st.ttrial[1], st.ttrial[2]);
+        const I3 n{md.res[0], md.res[1], md.res[2]};
+        const float r = lookup1(md.tsdf, R, t, pc, n, md.voxelSize);
         e = (r * r) * scratch_w(f, m)[pix];
+        // the clamped integration weights at the trial pose: if the step is accepted they are the
+        // next iteration's (same lookup, same values), so that iteration needs no extra pass
+        iw = fminf(lookup1(md.weights, R, t, pc, n, md.voxelSize), f.prm.maxWeight);
+        scratch_iw(f, m, 1 - st.iwSel)[pix] = iw;
     }
     e = wave_sum(e);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    const float wmx = wave_max(fabsf(iw));
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = e;
+        redMax[threadIdx.x >> 6] = wmx;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float v = red[0];
-        for (int i = 1; i < kTrackBlock / 64; ++i) v += red[i];
+        float v = red[0], mx = redMax[0];
+        for (int i = 1; i < kTrackBlock / 64; ++i) {
+            v += red[i];
+            mx = fmaxf(mx, redMax[i]);
+        }
         scratch_err(f, m)[blockIdx.x] = v;
+        const unsigned bits = __float_as_uint(mx);
+        if (bits > __atomic_load_n(&st.maxIwTrialBits, __ATOMIC_RELAXED)) atomicMax(&st.maxIwTrialBits, bits);
     }
 }
 
@@ -299,59 +329,70 @@ __host__ __device__ inline float se3_log_norm(const M33& R, const V3& t) {
     return sqrtf(dot(u, u) + th2);
 }
 
-// Solve M x = b (6 x 6) by LU with partial pivoting, float -- cv::solve(DECOMP_LU) on CV_32F.
-// Returns false for a singular system (cv::solve then returns x = 0).
+// Solve M x = b (6 x 6), float.  The reference calls cv::solve(DECOMP_LU): LU with partial pivoting.
+// M = A + mu I with A = sum w g g^T (w >= 0) and mu > 0 is symmetric positive definite, for which
+// Gaussian elimination WITHOUT pivoting is backward stable too -- and, fully unrolled, it runs in
+// registers, whereas pivot swaps need dynamically indexed arrays that the compiler puts in scratch
+// memory (a memory round trip per element: 22 us for this 6 x 6 system).  The two differ at the
+// rounding level only.  Returns false and x = 0 for a (numerically) singular system, as cv::solve.
 __host__ __device__ inline bool solve6(float M[6][6], float rhs[6], float x[6]) {
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 6; ++r)
-            if (fabsf(M[r][c]) > fabsf(M[p][c])) p = r;
-        if (fabsf(M[p][c]) < 1.1920929e-06f) {  // FLT_EPSILON * 10, the threshold of cv::hal::LU32f
-            for (int i = 0; i < 6; ++i) x[i] = 0.f;
-            return false;
-        }
-        if (p != c) {
-            for (int k = c; k < 6; ++k) {
-                const float tmp = M[c][k];
-                M[c][k] = M[p][k];
-                M[p][k] = tmp;
-            }
-            const float tmp = rhs[c];
-            rhs[c] = rhs[p];
-            rhs[p] = tmp;
-        }
+        ok = ok && fabsf(M[c][c]) >= 1.1920929e-06f;  // FLT_EPSILON * 10, threshold of cv::hal::LU32f
         const float d = -1.f / M[c][c];
+#pragma unroll
         for (int r = c + 1; r < 6; ++r) {
             const float alpha = M[r][c] * d;
+#pragma unroll
             for (int k = c + 1; k < 6; ++k) M[r][k] += alpha * M[c][k];
             rhs[r] += alpha * rhs[c];
         }
     }
+#pragma unroll
     for (int r = 5; r >= 0; --r) {
-        float s = rhs[r];
-        for (int k = r + 1; k < 6; ++k) s -= M[r][k] * x[k];
-        x[r] = s / M[r][r];
+        float acc = rhs[r];
+#pragma unroll
+        for (int k = r + 1; k < 6; ++k) acc -= M[r][k] * x[k];
+        x[r] = acc / M[r][r];
     }
-    return true;
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    }
+    return ok;
 }
 
 // ---- per-model kernels (one wave each) -----------------------------------------------------------
 
-constexpr int kSolveWaves = 8;
+constexpr int kSolveWaves = 16;  // 28 columns of partials: at most two per wave
+
+// The two per-model kernels run their scalar Levenberg-Marquardt logic on a copy of the state in
+// LDS: on the global-memory struct every access of the single working lane was a dependent ~0.5 us
+// round trip (22 us per launch); the state is copied in and out cooperatively instead.
+constexpr int kStateWords = sizeof(emf_track_state_t) / 4;
+
+__device__ __forceinline__ void state_copy(unsigned* dst, const unsigned* src, int tid, int nthreads) {
+    for (int i = tid; i < kStateWords; i += nthreads) dst[i] = src[i];
+}
 
 __global__ __launch_bounds__(64 * kSolveWaves) void k_track_solve(const TrackFrame f) {
     __shared__ double sums[kSums];
+    __shared__ emf_track_state_t st;
     const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    emf_track_state_t& st = f.states[m];
-    if (st.converged) return;
-    if (st.evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); otherwise A, b, err are kept
+    if (f.states[m].converged) return;
+    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(&f.states[m]),
+               threadIdx.x, 64 * kSolveWaves);
+    if (f.states[m].evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); else A, b, err are kept
         for (int c = wave; c < kSums; c += kSolveWaves) {
             const double v = wave_strided_sum(scratch_partials(f, m) + static_cast<size_t>(c) * f.nblocks,
                                               f.nblocks, 1, lane);
             if (lane == 0) sums[c] = v;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (st.evaluateGradient) {
             int q = 0;
             for (int j = 0; j < 6; ++j)
                 for (int k = j; k < 6; ++k) {
@@ -367,51 +408,61 @@ __global__ __launch_bounds__(64 * kSolveWaves) void k_track_solve(const TrackFra
             st.err = static_cast<float>(sums[27]);
             if (maxB < f.prm.eps1) st.converged = 1;  // TSDF.cpp:276-278
         }
+        if (!st.converged) {
+            // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
+            if (st.firstIteration) {
+                float maxA = st.A[0];
+                for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
+                st.mu = f.prm.tau * maxA;
+                st.firstIteration = 0;
+            }
+            float M[6][6], rhs[6], x[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
+                rhs[j] = st.b[j];
+            }
+            solve6(M, rhs, x);
+            float nx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                st.x[j] = x[j];
+                nx += x[j] * x[j];
+            }
+            nx = sqrtf(nx);
+            const M33 R = state_R(st.R);
+            const V3 t = v3(st.t[0], st.t[1], st.t[2]);
+            if (nx < f.prm.eps2 * (se3_log_norm(R, t) + f.prm.eps2)) {
+                st.converged = 1;
+            } else {
+                float mx[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) mx[j] = -x[j];
+                const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
+                const M33 Rn = mat_mul(inc.R, R);
+                const V3 tn = mul(inc.R, t) + inc.t;
+                st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
+                st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
+                st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
+                st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
+                st.maxIwTrialBits = 0u;
+                st.haveTrial = 1;
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x != 0 || st.converged) return;
-    // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
-    if (st.firstIteration) {
-        float maxA = st.A[0];
-        for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
-        st.mu = f.prm.tau * maxA;
-        st.firstIteration = 0;
-    }
-    float M[6][6], rhs[6], x[6];
-    for (int j = 0; j < 6; ++j) {
-        for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
-        rhs[j] = st.b[j];
-    }
-    solve6(M, rhs, x);
-    float nx = 0.f;
-    for (int j = 0; j < 6; ++j) {
-        st.x[j] = x[j];
-        nx += x[j] * x[j];
-    }
-    nx = sqrtf(nx);
-    const M33 R = state_R(st.R);
-    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
-    if (nx < f.prm.eps2 * (se3_log_norm(R, t) + f.prm.eps2)) {
-        st.converged = 1;
-        return;
-    }
-    float mx[6];
-    for (int j = 0; j < 6; ++j) mx[j] = -x[j];
-    const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
-    const M33 Rn = mat_mul(inc.R, R);
-    const V3 tn = mul(inc.R, t) + inc.t;
-    st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
-    st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
-    st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
-    st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
-    st.haveTrial = 1;
+    state_copy(reinterpret_cast<unsigned*>(&f.states[m]), reinterpret_cast<const unsigned*>(&st),
+               threadIdx.x, 64 * kSolveWaves);
 }
 
 __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
+    __shared__ emf_track_state_t st;
     const int m = blockIdx.x, lane = threadIdx.x;
-    emf_track_state_t& st = f.states[m];
-    if (st.converged || !st.haveTrial) return;
+    if (f.states[m].converged || !f.states[m].haveTrial) return;
+    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(&f.states[m]), lane, 64);
     const double total = wave_strided_sum(scratch_err(f, m), f.nblocks, 1, lane);
+    __syncthreads();
     if (lane == 0) {
         const float errNew = static_cast<float>(total);
         st.errNew = errNew;
@@ -431,7 +482,8 @@ __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
             st.nu = f.prm.nuInit;
             st.evaluateGradient = 1;
             st.accepted += 1;
-            st.maxIwBits = 0u;  // the next iteration recomputes the weight maximum
+            st.iwSel ^= 1;  // the trial pose's weights (k_track_error) become the current ones
+            st.maxIwBits = st.maxIwTrialBits;
         } else {  // reject (TSDF.cpp:328-336)
             st.mu *= st.nu;
             st.nu *= f.prm.nuInit;
@@ -439,6 +491,8 @@ __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
         }
         st.haveTrial = 0;
     }
+    __syncthreads();
+    state_copy(reinterpret_cast<unsigned*>(&f.states[m]), reinterpret_cast<const unsigned*>(&st), lane, 64);
 }
 
 struct PrepareArgs {
@@ -459,7 +513,8 @@ __global__ void k_track_prepare(const PrepareArgs a) {
     st.mu = 0.f;
     st.nu = a.nuInit;  // TSDF.cpp:188-191
     st.rho = st.err = st.errNew = 0.f;
-    st.maxIwBits = 0u;
+    st.maxIwBits = st.maxIwTrialBits = 0u;
+    st.iwSel = 0;
     st.converged = 0;
     st.firstIteration = 1;
     st.evaluateGradient = 1;
@@ -527,7 +582,7 @@ extern "C" {
 size_t emf_hip_trackScratchBytes(int width, int height) {
     const size_t px = static_cast<size_t>(width) * height;
     const size_t nblocks = ceil_div(px, kTrackBlock);
-    const size_t bytes = (2 * px + nblocks * (kSums + 1)) * sizeof(float);
+    const size_t bytes = (3 * px + nblocks * (kSums + 1)) * sizeof(float);
     return (bytes + 255) / 256 * 256;
 }
 
@@ -594,5 +649,5 @@ int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const em
 
 }  // extern "C"
 
-static_assert(sizeof(emf_track_state_t) == 340, "emf_track_state_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_track_state_t) == 344, "emf_track_state_t layout is mirrored in _lib.py");
 static_assert(sizeof(emf_model_t) == 144, "emf_model_t layout is mirrored in _lib.py");

@@ -419,14 +419,15 @@ typedef struct emf_track_state {
     float Rtrial[9], ttrial[3];
     float A[36], b[6], x[6];
     float mu, nu, rho, err, errNew;
-    uint32_t maxIwBits;        /* float bits of max |min(intWeights, maxWeight)| */
+    uint32_t maxIwBits;        /* float bits of max |min(intWeights, maxWeight)| at the current pose */
+    uint32_t maxIwTrialBits;   /* ... at the trial pose */
     int32_t converged;         /* trackingConverged */
     int32_t firstIteration;
     int32_t evaluateGradient;
     int32_t haveTrial;
     int32_t iterations;        /* trial steps evaluated */
     int32_t accepted;          /* ... of which accepted (rho > 0) */
-    int32_t pad_;
+    int32_t iwSel;             /* which of the two weight images belongs to the current pose */
 } emf_track_state_t;
 
 /* bytes of scratch per model for emf_hip_trackIterate on a width x height image */

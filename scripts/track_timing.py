@@ -24,7 +24,9 @@ for f in range(frames):
     fus.process_frame(ops.image_view(d), R, t, poses, {i: ops.image_view(m) for i, m in masks.items()}, rm)
     fus.synchronize()
     dt = time.perf_counter() - t0
-    rows.append((f, 1e3 * np.linalg.norm(fus.pose(0)[1] - t), 1e3 * dt, fus.track_result(0) if f else None))
+    rows.append((f, 1e3 * np.linalg.norm(fus.pose(0)[1] - t), 1e3 * dt,
+                 {i: (r["iterations"], r["accepted"], int(r["converged"])) for i in [0] + ids
+                  for r in [fus.track_result(i)]} if f else None))
 for e in rows[::4]:
     print("frame %d cam err %.2f mm  wall %.2f ms  %s" % e)
 print("mean wall per frame (frames 1..): %.2f ms" % np.mean([r[2] for r in rows[1:]]))
