@@ -21,8 +21,8 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
     // once per volume: is 1 / voxelSize usable in place of the march's divisions?  (exhaustive
     // device check, ~3 ms; EMF_VOXEL_RCP=0 keeps the divisions for A/B measurements)
     const char* vr = std::getenv("EMF_VOXEL_RCP");
-    if (!(vr && vr[0] == '0'))
-        emfCheck(emf_hip_voxelReciprocal(voxelSize, &rcpVoxel), "TSDF: voxelReciprocal");
+    if (!(vr && vr[0] == '0') && emf_hip_voxelReciprocal(voxelSize, &rcpVoxel) != EMF_OK)
+        rcpVoxel = 0.f;  // voxel size outside the checked range: the march divides
     reset(_pose);
 }
 
