@@ -401,6 +401,12 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     stamp(kIntegrate);
 
     if ((in.runMasks || !in.newObjectMasks.empty()) && !masks.empty()) integrateMasks(masks);
+    lastDeleted.clear();
+    if (in.cleanUp) {
+        if (in.runMasks)  // initOrMatchObjs' bookkeeping (EMFusion.cpp:358-369)
+            for (auto& obj : objects) obj.updateExProb(masks.count(obj.getID()) != 0);
+        lastDeleted = cleanUpObjs(in.runMasks, masks);
+    }
     stamp(kMasks);
 
     if (timingsOn) {
@@ -423,14 +429,18 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
 
 // ---- object creation / matching from masks ---------------------------------------------------------
 
+void EMFusion::ensureLifecycleBuffers() {
+    if (!statsScratch.empty()) return;
+    statsScratch = DeviceBuffer(emf_hip_pointStatsScratchBytes());
+    statsDev = DeviceBuffer(sizeof(emf_point_stats_t));
+    overlapDev = DeviceBuffer(513 * sizeof(uint32_t));
+    massDev = DeviceBuffer(sizeof(emf_mask_mass_t));
+    hipCheck(hipHostMalloc(&lifecycleHost, 513 * sizeof(uint32_t), hipHostMallocDefault),
+             "hipHostMalloc");
+}
+
 emf_point_stats_t EMFusion::maskedStats(const emf_image_t& mask, const Affine3f& frame) {
-    if (statsScratch.empty()) {
-        statsScratch = DeviceBuffer(emf_hip_pointStatsScratchBytes());
-        statsDev = DeviceBuffer(sizeof(emf_point_stats_t));
-        overlapDev = DeviceBuffer(513 * sizeof(uint32_t));
-        hipCheck(hipHostMalloc(&lifecycleHost, 513 * sizeof(uint32_t), hipHostMallocDefault),
-                 "hipHostMalloc");
-    }
+    ensureLifecycleBuffers();
     const emf_image_t pv = points.view();
     emfCheck(emf_hip_maskedPointStats(&pv, &mask, frame.rotation().val, frame.translation().val,
                                       statsScratch.data(), statsDev.as<emf_point_stats_t>(),
@@ -489,7 +499,7 @@ int EMFusion::initNewObjVolume(const emf_image_t& mask) {
 
 int EMFusion::matchSegmentation(const emf_image_t& mask, float& match_iou) {
     refreshVisibleFromDevice();
-    if (statsScratch.empty()) (void)maskedStats(mask, Affine3f());  // allocates the buffers
+    ensureLifecycleBuffers();
     const emf_image_t seg = modelSegmentation.view();
     emfCheck(emf_hip_maskOverlap(&mask, &seg, overlapDev.as<uint32_t>(), main.abi()), "maskOverlap");
     hipCheck(hipMemcpyAsync(lifecycleHost, overlapDev.data(), 513 * sizeof(uint32_t),
@@ -510,6 +520,53 @@ int EMFusion::matchSegmentation(const emf_image_t& mask, float& match_iou) {
         }
     }
     return match_iou > params.matchIOUThresh ? match_id : -1;
+}
+
+void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989
+    streams.erase(id);
+    objImages.erase(id);
+    vis_objs.erase(id);
+    trackResults.erase(id);
+}
+
+std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_image_t>& matches) {
+    if (sharded) throw HipError("EMFusion::cleanUpObjs: not available on the sharded path", EMF_E_ARG);
+    refreshVisibleFromDevice();  // the host copy of vis_objs decides (one synchronisation)
+    std::set<int> spurious;
+    if (maskFrame)
+        for (const auto& obj : objects)
+            if (obj.getExProb() < params.existenceThresh) spurious.insert(obj.getID());
+    ensureLifecycleBuffers();
+    for (const auto& obj : objects) {
+        const int id = obj.getID();
+        if (!vis_objs.count(id)) continue;
+        const ObjImages& im = objImages.at(id);
+        const emf_image_t seg = im.modelSegmentation.view(), assoc = im.associationWeights.view();
+        auto it = matches.find(id);
+        emfCheck(emf_hip_maskAssociationMass(&seg, it == matches.end() ? nullptr : &it->second, &assoc,
+                                             massDev.as<emf_mask_mass_t>(), main.abi()),
+                 "maskAssociationMass");
+        hipCheck(hipMemcpyAsync(lifecycleHost, massDev.data(), sizeof(emf_mask_mass_t),
+                                hipMemcpyDeviceToHost, main.get()),
+                 "hipMemcpyAsync");
+        main.waitForCompletion();
+        const emf_mask_mass_t mm = *static_cast<emf_mask_mass_t*>(lifecycleHost);
+        if (params.assocThresh * static_cast<float>(mm.count) > mm.sum) spurious.insert(id);
+    }
+    std::vector<int> deleted;
+    for (auto it = objects.begin(); it != objects.end();) {
+        const int id = it->getID();
+        if (spurious.count(id) || !vis_objs.count(id)) {
+            deleted.push_back(id);
+            synchronize();  // nothing in flight may still use the volume
+            deleteObj(id);
+            it = objects.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    if (!deleted.empty()) rebuildModelTable();
+    return deleted;
 }
 
 // ---- tracking -------------------------------------------------------------------------------------

@@ -51,6 +51,11 @@ struct FrameInputs {
     // before the integration each one runs through initNewObjVolume (EMFusion.cpp:446-494, 104-109
     // of processFrame); a created object integrates this frame's depth and this mask.
     std::vector<emf_image_t> newObjectMasks;
+    // Run the reference's cleanUpObjs at the end of the frame (EMFusion.cpp:922-980): objects with
+    // a low existence probability (mask frames), with too little association mass under their
+    // mask, or not visible are deleted.  Needs the visible set on the host (one synchronisation),
+    // which is why it is a switch here.
+    bool cleanUp = false;
 };
 
 /** Outcome of the last tracking run of one model (0 = camera against the background). */
@@ -98,6 +103,9 @@ public:
      * -1.  match_iou is updated as in the reference (in/out).
      */
     int matchSegmentation(const emf_image_t& mask, float& match_iou);
+    /** Reference EMFusion::cleanUpObjs (EMFusion.cpp:922-980); returns the deleted ids. */
+    std::vector<int> cleanUpObjs(bool maskFrame, const std::map<int, emf_image_t>& matches);
+    const std::vector<int>& lastDeletedObjects() const { return lastDeleted; }
     /** Reference EMFusion::preprocessDepth (EMFusion.cpp:294-305), one launch. */
     void preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& depthOut);
     /** Result of the last tracking run of model `id` (0 = camera), or nullptr. */
@@ -229,7 +237,10 @@ private:
     // ---- object creation / matching (SURVEY f-3) ----
     emf_point_stats_t maskedStats(const emf_image_t& mask, const Affine3f& frame);  // synchronises
     DeviceBuffer statsScratch, statsDev, overlapDev;
-    std::vector<int> lastCreated;
+    std::vector<int> lastCreated, lastDeleted;
+    DeviceBuffer massDev;
+    void deleteObj(int id);
+    void ensureLifecycleBuffers();
     void* lifecycleHost = nullptr;  // pinned: emf_point_stats_t / 513 x u32
 
     // ---- tracking (SURVEY f-1) ----

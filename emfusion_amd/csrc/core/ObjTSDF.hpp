@@ -22,6 +22,9 @@ public:
     bool operator==(const ObjTSDF& o) const { return id == o.id; }
     bool operator!=(const ObjTSDF& o) const { return id != o.id; }
     int getID() const { return id; }
+    /** Existence bookkeeping of the reference (ObjTSDF.cpp:61-68). */
+    void updateExProb(bool exists) { exCount += exists; nonExCount += 1 - exists; }
+    float getExProb() const { return static_cast<float>(exCount) / (exCount + nonExCount); }
 
     /** Also clears the fg/bg counts (reference ObjTSDF.cpp:58-61) and the derived volumes. */
     void reset(const Affine3f& pose) override;
@@ -59,6 +62,7 @@ public:
     const uint8_t* fgVolMaskPtr() const { return fgVolMask.as<uint8_t>(); }
 
 private:
+    int exCount = 0, nonExCount = 0;
     static int nextID;
     int id;
     DeviceBuffer fgBgProbs;  // N^3 x 2 f32 counts

@@ -15,7 +15,7 @@ struct emf_comm {
 };
 struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
-    bool trackCamera = false, trackObjects = false, preprocess = false;
+    bool trackCamera = false, trackObjects = false, preprocess = false, cleanUp = false;
     std::vector<emf_image_t> queuedMasks;
 };
 struct emf_synth {
@@ -163,6 +163,7 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.trackCamera = h->trackCamera;
         in.trackObjects = h->trackObjects;
         in.preprocessDepth = h->preprocess;
+        in.cleanUp = h->cleanUp;
         in.newObjectMasks.swap(h->queuedMasks);
         h->impl->processFrame(*depth_dev, in);
     });
@@ -204,6 +205,22 @@ int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id,
     REQ(id);
     REQ(iou);
     return guarded([&] { *id = h->impl->matchSegmentation(*mask, *iou); });
+}
+
+int emf_fusion_set_cleanup(emf_fusion_t* h, int on) {
+    REQ(h);
+    h->cleanUp = on != 0;
+    return EMF_OK;
+}
+
+int emf_fusion_last_deleted(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count) {
+    REQ(h);
+    REQ(count);
+    return guarded([&] {
+        const auto& v = h->impl->lastDeletedObjects();
+        *count = static_cast<int32_t>(v.size());
+        for (int i = 0; ids && i < capacity && i < static_cast<int>(v.size()); ++i) ids[i] = v[i];
+    });
 }
 
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on) {

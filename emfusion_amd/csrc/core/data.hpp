@@ -72,13 +72,13 @@ public:
     int maxTrackingIter = 100;
     /** Mask frames: fg/bg probabilities are integrated every maskRCNNFrames-th frame. */
     int maskRCNNFrames = 30;
-    float existenceThresh = 0.1f;  // unused here (object lifecycle)
+    float existenceThresh = 0.1f;
     float volIOUThresh = 0.5f;
     float matchIOUThresh = 0.2f;
     float distanceThresh = 5.f;
     /** Minimum number of segmentation pixels for an object to count as visible. */
     int visibilityThresh = 40 * 40;
-    float assocThresh = 0.1f;  // unused here
+    float assocThresh = 0.1f;
     /** Image border (pixels) ignored by the visibility count. */
     int boundary = 20;
 

@@ -163,6 +163,67 @@ __global__ __launch_bounds__(kLcBlock) void k_mask_overlap(const IouArgs a) {
     if (threadIdx.x == 0 && maskPx) atomicAdd(&a.counts[0], maskPx);
 }
 
+// ---- association mass under an object's mask (cleanUpObjs, EMFusion.cpp:936-949) ----------------
+
+struct MassArgs {
+    Img<const uint8_t> objSeg;  // the object's own raycast mask (0 / 1)
+    Img<const uint8_t> match;   // matched instance mask or data == nullptr
+    Img<const float> assoc;     // the object's association weights
+    int w, h;
+    emf_mask_mass_t* out;
+};
+
+// one workgroup, fixed summation order (deterministic); the image is small and this runs once per
+// visible object on mask frames
+__global__ __launch_bounds__(1024) void k_mask_mass(const MassArgs a) {
+    __shared__ double sums[16];
+    __shared__ unsigned counts[16];
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    double s = 0.0;
+    unsigned c = 0;
+    for (size_t i0 = threadIdx.x; i0 < n; i0 += 1024 * 4) {
+        float v[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // loads first, then the dependent double adds
+            const size_t i = i0 + 1024 * static_cast<size_t>(j);
+            in[j] = false;
+            v[j] = 0.f;
+            if (i < n) {
+                const int y = static_cast<int>(i / a.w), x = static_cast<int>(i - static_cast<size_t>(y) * a.w);
+                in[j] = a.objSeg.row(y)[x] != 0 || (a.match.data && a.match.row(y)[x] != 0);
+                v[j] = a.assoc.row(y)[x];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (in[j]) {
+                s += static_cast<double>(v[j]);
+                ++c;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sums[threadIdx.x >> 6] = s;
+        counts[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0;
+        unsigned tc = 0;
+        for (int i = 0; i < 16; ++i) {
+            ts += sums[i];
+            tc += counts[i];
+        }
+        a.out->count = tc;
+        a.out->sum = ts;
+    }
+}
+
 __global__ void k_clear_u32(unsigned* p, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
 }
@@ -205,6 +266,28 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
         hipLaunchKernelGGL(k_stats_pick, dim3(1), dim3(64), 0, s, a);
     }
     return launch_status("maskedPointStats");
+}
+
+int emf_hip_maskAssociationMass(const emf_image_t* objSeg, const emf_image_t* matchMask,
+                                const emf_image_t* assoc, emf_mask_mass_t* out_dev,
+                                emf_stream_t stream) {
+    EMF_TRY(check_image(objSeg, 1, "maskAssociationMass: objSeg"));
+    EMF_TRY(check_image(assoc, 4, "maskAssociationMass: assoc"));
+    EMF_TRY(check_same_size(objSeg, assoc, "objSeg", "assoc"));
+    if (matchMask) {
+        EMF_TRY(check_image(matchMask, 1, "maskAssociationMass: matchMask"));
+        EMF_TRY(check_same_size(objSeg, matchMask, "objSeg", "matchMask"));
+    }
+    EMF_REQUIRE_PTR(out_dev);
+    MassArgs a;
+    a.objSeg = img<const uint8_t>(objSeg);
+    a.match = matchMask ? img<const uint8_t>(matchMask) : Img<const uint8_t>{nullptr, 0};
+    a.assoc = img<const float>(assoc);
+    a.w = objSeg->width;
+    a.h = objSeg->height;
+    a.out = out_dev;
+    hipLaunchKernelGGL(k_mask_mass, dim3(1), dim3(1024), 0, as_stream(stream), a);
+    return launch_status("maskAssociationMass");
 }
 
 int emf_hip_maskOverlap(const emf_image_t* seg, const emf_image_t* modelSeg, uint32_t* counts_dev,

@@ -425,3 +425,13 @@ def mask_overlap(seg, model_seg, stream=None):
                                  _ptr(counts), _stream(stream)))
     c = counts.numpy()
     return int(c[0]), c[1:257].copy(), c[257:513].copy()
+
+
+def mask_association_mass(obj_seg, match_mask, assoc, stream=None):
+    """(count, sum) of cleanUpObjs' association test; match_mask may be None (synchronises)."""
+    out = DeviceArray.zeros((2,), np.float64)
+    check("emf_hip_maskAssociationMass",
+          _L.emf_hip_maskAssociationMass(C.byref(image_view(obj_seg)), _opt_view(match_mask),
+                                         C.byref(image_view(assoc)), _ptr(out), _stream(stream)))
+    raw = out.numpy()
+    return int(raw.view(np.uint32)[2]), float(raw[0])

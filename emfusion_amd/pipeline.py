@@ -97,6 +97,8 @@ def load() -> C.CDLL:
                                      C.c_int],
         "emf_fusion_set_tracking": [vp, C.c_int, C.c_int],
         "emf_fusion_set_preprocess": [vp, C.c_int],
+        "emf_fusion_set_cleanup": [vp, C.c_int],
+        "emf_fusion_last_deleted": [vp, ip, C.c_int, ip],
         "emf_fusion_create_object_from_mask": [vp, img, ip],
         "emf_fusion_match_mask": [vp, img, ip, fp],
         "emf_fusion_queue_new_object_masks": [vp, C.c_int, img],
@@ -301,6 +303,15 @@ class Fusion:
         _check("emf_fusion_match_mask",
                load().emf_fusion_match_mask(self._h, C.byref(mask_view), C.byref(i), C.byref(iou)))
         return i.value, iou.value
+
+    def set_cleanup(self, on=True):
+        """Run the reference's cleanUpObjs at the end of every frame."""
+        _check("emf_fusion_set_cleanup", load().emf_fusion_set_cleanup(self._h, int(on)))
+
+    def last_deleted(self):
+        ids, n = (C.c_int32 * 64)(), C.c_int32(0)
+        _check("emf_fusion_last_deleted", load().emf_fusion_last_deleted(self._h, ids, 64, C.byref(n)))
+        return [ids[i] for i in range(min(n.value, 64))]
 
     def set_preprocess(self, on=True):
         """Filter incoming depth maps as the reference's preprocessDepth does (bilateral + patches)."""

@@ -101,6 +101,11 @@ int emf_fusion_create_object_from_mask(emf_fusion_t* h, const emf_image_t* mask,
 int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t* masks);
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);
+/* From the next frame on, run the reference's cleanUpObjs at the end of every frame (delete objects
+ * that are not visible, whose association mass does not fit their mask, or -- on mask frames --
+ * whose existence probability is low); last_deleted lists the ids the last frame removed. */
+int emf_fusion_set_cleanup(emf_fusion_t* h, int on);
+int emf_fusion_last_deleted(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);

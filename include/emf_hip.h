@@ -389,6 +389,19 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
                              const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
                              emf_stream_t stream);
 
+/* The two numbers of EMFusion::cleanUpObjs' association test (EMFusion.cpp:936-949):
+ * count = |objSeg OR matchMask| (matchMask may be NULL), sum = sum of `assoc` over those pixels
+ * (double accumulation like cv::cuda::sum, fixed order).  The object is spurious if
+ * assocThresh * count > sum. */
+typedef struct emf_mask_mass {
+    double sum;
+    uint32_t count;
+    uint32_t pad_;
+} emf_mask_mass_t;
+int emf_hip_maskAssociationMass(const emf_image_t* objSeg, const emf_image_t* matchMask,
+                                const emf_image_t* assoc, emf_mask_mass_t* out_dev,
+                                emf_stream_t stream);
+
 /* The counts behind EMFusion::matchSegmentation (EMFusion.cpp:797-825) for ALL objects at once:
  * counts_dev[0] = pixels of `seg`; counts_dev[1 + id] = |seg AND (modelSeg == id)|;
  * counts_dev[257 + id] = |modelSeg == id|, id = 1..255 (513 uint32, cleared by the call).

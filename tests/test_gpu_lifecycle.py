@@ -152,3 +152,55 @@ def test_objects_are_created_and_matched_from_masks(oracle, dev):
                       np.full(3, -.5, np.float32), np.full(3, .5, np.float32)) == pytest.approx(1.0)
     fus.close()
     synth.close()
+
+
+def test_mask_association_mass(ops, dev):
+    rng = np.random.default_rng(8)
+    seg = (rng.uniform(size=(H, W)) < 0.2).astype(np.uint8)
+    match = (rng.uniform(size=(H, W)) < 0.1).astype(np.uint8) * 255
+    assoc = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    for m in (None, match):
+        inside = (seg != 0) if m is None else ((seg != 0) | (m != 0))
+        n, total = ops.mask_association_mass(to_dev(seg, dev, 2), None if m is None else to_dev(m, dev),
+                                             to_dev(assoc, dev))
+        assert n == int(inside.sum())
+        assert abs(total - float(assoc[inside].astype(np.float64).sum())) < 1e-9 * n
+
+
+def test_invisible_objects_are_cleaned_up(oracle, dev):
+    """cleanUpObjs: an object that the raycast no longer sees is deleted (EMFusion.cpp:951-976)."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    Wf, Hf = 320, 240
+    prm = pipeline.make_params(Wf, Hf, 128, 0.04, 32, visibility_thresh=400, boundary=10)
+    synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 2, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    fus.set_cleanup(True)
+    centers, keep = {}, []
+    for f in range(5):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        d = to_dev(depth)
+        masks = {i: to_dev((sid == i).astype(np.uint8)) for i in centers}
+        keep += [d, masks]
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), c) for i, c in centers.items()}
+        if f == 3:  # object 2 is reported far behind the camera: the raycast cannot see it any more
+            poses[2] = (poses[2][0], np.array([0, 0, -30], np.float32))
+        if f == 0:
+            new = [to_dev((sid == k).astype(np.uint8)) for k in (1, 2)]
+            keep.append(new)
+            fus.queue_new_object_masks([image_view(m) for m in new])
+        fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, True)
+        fus.synchronize()
+        if f == 0:
+            assert fus.last_created() == [1, 2] and fus.last_deleted() == []
+            centers = {k: fus.pose(k)[1] for k in (1, 2)}
+        elif f < 3:
+            assert fus.last_deleted() == [], f
+        elif f == 3:
+            assert fus.last_deleted() == [2]
+            del centers[2]
+        else:
+            assert fus.last_deleted() == [] and sorted(fus.visible_objects()) == [1]
+    fus.close()
+    synth.close()
