@@ -238,6 +238,11 @@ def main():
         result["hbm_copy_GBs"] = copy_gbs  # attainable D2D stream bandwidth of THIS box (read + write)
         # work aggregate for the scaling curves: every rank's volumes advance one frame per step
         result["volume_frames_per_s"] = round(fps * (world + nobj_total), 1)
+        result["scaling_note"] = ("weak scaling of ONE RGB-D stream: every GPU adds --objects-per-gpu "
+                                  "object volumes to the scene and re-integrates / raycasts its replica of "
+                                  "the background, so frames/s of the joint scene is flat by design (ideal "
+                                  "= the N=1 value); volume_frames_per_s is the aggregate work rate, which "
+                                  "grows with N")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
 
