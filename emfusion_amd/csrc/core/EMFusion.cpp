@@ -9,6 +9,12 @@
 //            one HIP stream per volume joined by events, host-side visibility gate
 #include "EMFusion.hpp"
 
+#include <sys/stat.h>
+
+#include <cerrno>
+
+#include "Output.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cmath>
@@ -397,6 +403,11 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         if (id >= 0) masks[id] = m;
     }
 
+    if (poseLog) {  // storePoses (EMFusion.cpp:322-327)
+        poses[frameCount] = pose;
+        for (const auto& obj : objects) obj_poses[obj.getID()][frameCount] = obj.getPose();
+    }
+
     integrateDepth();
     stamp(kIntegrate);
 
@@ -520,6 +531,28 @@ int EMFusion::matchSegmentation(const emf_image_t& mask, float& match_iou) {
         }
     }
     return match_iou > params.matchIOUThresh ? match_id : -1;
+}
+
+void EMFusion::writeResults(const std::string& dir, bool volumes) {
+    synchronize();
+    io::writePoseFile(dir + "/poses-cam.txt", poses);
+    for (const auto& op : obj_poses)
+        io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + ".txt", op.second);
+    if (!volumes) return;
+    const std::string t = dir + "/tsdfs";
+    if (mkdir(t.c_str(), 0777) != 0 && errno != EEXIST)
+        throw std::runtime_error("EMFusion::writeResults: cannot create " + t);
+    auto dump = [&](const std::string& name, const std::vector<float>& v, const TSDF& vol) {
+        io::writeVolume(t + "/" + name + ".bin", v.data(), sizeof(float), vol.getVolumeRes(),
+                        vol.getVoxelSize());
+    };
+    dump("bg_tsdf", background.getTSDF(), background);
+    for (auto& obj : objects) {
+        const std::string id = std::to_string(obj.getID());
+        dump("tsdf_" + id, obj.getTSDF(), obj);
+        dump("weights_" + id, obj.getWeightsVol(), obj);
+        dump("fgProbs_" + id, obj.getFgProbVol(), obj);
+    }
 }
 
 void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989

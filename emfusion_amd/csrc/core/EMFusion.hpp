@@ -14,6 +14,7 @@
 
 #include <list>
 #include <map>
+#include <string>
 #include <memory>
 #include <set>
 #include <vector>
@@ -110,6 +111,14 @@ public:
     void preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& depthOut);
     /** Result of the last tracking run of model `id` (0 = camera), or nullptr. */
     const TrackResult* getTrackResult(int id) const;
+    /**
+     * Keep the camera / object poses of every processed frame (reference EMFusion::storePoses,
+     * EMFusion.cpp:322-327) and write them and the volumes in the reference's formats:
+     * <dir>/poses-cam.txt, poses-<id>.txt (writePoses, EMFusion.cpp:991-999) and, with volumes,
+     * <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin (writeTSDFs, EMFusion.cpp:1187-1218).
+     */
+    void enablePoseLog(bool on) { poseLog = on; }
+    void writeResults(const std::string& dir, bool volumes);
     /** Ids returned by initNewObjVolume for FrameInputs::newObjectMasks of the last frame (-1: none). */
     const std::vector<int>& lastCreatedObjects() const { return lastCreated; }
     Affine3f getCameraPose() const { return pose; }
@@ -238,6 +247,9 @@ private:
     emf_point_stats_t maskedStats(const emf_image_t& mask, const Affine3f& frame);  // synchronises
     DeviceBuffer statsScratch, statsDev, overlapDev;
     std::vector<int> lastCreated, lastDeleted;
+    bool poseLog = false;
+    std::map<int, Affine3f> poses;                    // frame -> camera pose
+    std::map<int, std::map<int, Affine3f>> obj_poses;  // id -> frame -> pose
     DeviceBuffer massDev;
     void deleteObj(int id);
     void ensureLifecycleBuffers();

@@ -1,0 +1,34 @@
+// Output.hpp -- the reference's on-disk result formats that need no mesh:
+// raw volume dumps (EMFusion::writeVolume, EMFusion.cpp:1302-1313) and TUM-style pose files
+// (EMFusion::writePoseFile / writePoses, EMFusion.cpp:991-1007, 1238-1254).  Host code only.
+#pragma once
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "types.hpp"
+
+namespace emf {
+namespace io {
+
+/**
+ * "<name>.bin": int32 resolution[3], size_t element size (8 bytes), float voxel size, then the
+ * voxels, x fastest -- byte for byte what the reference writes, so its evaluation scripts read it.
+ */
+void writeVolume(const std::string& filename, const void* voxels, size_t elemSize,
+                 const Vec3i& resolution, float voxelSize);
+/** Inverse of writeVolume (float volumes); throws std::runtime_error on a malformed file. */
+std::vector<float> readVolume(const std::string& filename, Vec3i& resolution, float& voxelSize);
+
+/** Unit quaternion (x, y, z, w) of a rotation matrix, Eigen's Quaternion(Matrix3) algorithm. */
+void rotationToQuaternion(const Matx33f& R, float q[4]);
+
+/**
+ * One line per frame: "frame tx ty tz qx qy qz qw", default ostream formatting (6 significant
+ * digits), frames in ascending order -- the TUM trajectory format of the reference's pose files.
+ */
+void writePoseFile(const std::string& filename, const std::map<int, Affine3f>& poses);
+
+}  // namespace io
+}  // namespace emf

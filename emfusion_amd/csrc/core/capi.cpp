@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "EMFusion.hpp"
+#include "Output.hpp"
 #include "SyntheticScene.hpp"
 #include "emf_fusion.h"
 
@@ -205,6 +206,42 @@ int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id,
     REQ(id);
     REQ(iou);
     return guarded([&] { *id = h->impl->matchSegmentation(*mask, *iou); });
+}
+
+int emf_fusion_enable_pose_log(emf_fusion_t* h, int on) {
+    REQ(h);
+    return guarded([&] { h->impl->enablePoseLog(on != 0); });
+}
+
+int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes) {
+    REQ(h);
+    REQ(dir);
+    return guarded([&] { h->impl->writeResults(dir, volumes != 0); });
+}
+
+int emf_io_write_volume(const char* filename, const float* voxels, const int32_t res[3], float voxel_size) {
+    REQ(filename);
+    REQ(voxels);
+    REQ(res);
+    return guarded([&] {
+        io::writeVolume(filename, voxels, sizeof(float), Vec3i(res[0], res[1], res[2]), voxel_size);
+    });
+}
+
+int emf_io_write_pose_file(const char* filename, int n, const int32_t* frames, const float* R,
+                           const float* t) {
+    REQ(filename);
+    if (n > 0) {
+        REQ(frames);
+        REQ(R);
+        REQ(t);
+    }
+    return guarded([&] {
+        std::map<int, Affine3f> poses;
+        for (int i = 0; i < n; ++i)
+            poses[frames[i]] = Affine3f(m33(R + 9 * i), Vec3f(t[3 * i], t[3 * i + 1], t[3 * i + 2]));
+        io::writePoseFile(filename, poses);
+    });
 }
 
 int emf_fusion_set_cleanup(emf_fusion_t* h, int on) {

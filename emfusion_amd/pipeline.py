@@ -98,6 +98,10 @@ def load() -> C.CDLL:
         "emf_fusion_set_tracking": [vp, C.c_int, C.c_int],
         "emf_fusion_set_preprocess": [vp, C.c_int],
         "emf_fusion_set_cleanup": [vp, C.c_int],
+        "emf_fusion_enable_pose_log": [vp, C.c_int],
+        "emf_fusion_write_results": [vp, C.c_char_p, C.c_int],
+        "emf_io_write_volume": [C.c_char_p, fp, ip, C.c_float],
+        "emf_io_write_pose_file": [C.c_char_p, C.c_int, ip, fp, fp],
         "emf_fusion_last_deleted": [vp, ip, C.c_int, ip],
         "emf_fusion_create_object_from_mask": [vp, img, ip],
         "emf_fusion_match_mask": [vp, img, ip, fp],
@@ -304,6 +308,14 @@ class Fusion:
                load().emf_fusion_match_mask(self._h, C.byref(mask_view), C.byref(i), C.byref(iou)))
         return i.value, iou.value
 
+    def enable_pose_log(self, on=True):
+        _check("emf_fusion_enable_pose_log", load().emf_fusion_enable_pose_log(self._h, int(on)))
+
+    def write_results(self, directory: str, volumes: bool = True):
+        """poses-cam.txt, poses-<id>.txt and tsdfs/*.bin in the reference's formats."""
+        _check("emf_fusion_write_results",
+               load().emf_fusion_write_results(self._h, os.fspath(directory).encode(), int(volumes)))
+
     def set_cleanup(self, on=True):
         """Run the reference's cleanUpObjs at the end of every frame."""
         _check("emf_fusion_set_cleanup", load().emf_fusion_set_cleanup(self._h, int(on)))
@@ -416,3 +428,24 @@ class Fusion:
 
     def owns_object(self, obj_id: int) -> bool:
         return bool(load().emf_fusion_owns_object(self._h, obj_id))
+
+
+def write_volume(filename, volume: np.ndarray, voxel_size: float):
+    """Reference volume dump (EMFusion::writeVolume): volume is float32 (Nz, Ny, Nx)."""
+    v = np.ascontiguousarray(volume, np.float32)
+    nz, ny, nx = v.shape
+    _check("emf_io_write_volume",
+           load().emf_io_write_volume(os.fspath(filename).encode(), v.ctypes.data_as(C.POINTER(C.c_float)),
+                                      (C.c_int32 * 3)(nx, ny, nz), float(voxel_size)))
+
+
+def write_pose_file(filename, poses: Dict[int, tuple]):
+    """TUM-style pose file from {frame: (R 3x3, t 3)} (EMFusion::writePoseFile)."""
+    frames = sorted(poses)
+    R = np.ascontiguousarray([np.asarray(poses[f][0], np.float32).reshape(9) for f in frames], np.float32)
+    t = np.ascontiguousarray([np.asarray(poses[f][1], np.float32).reshape(3) for f in frames], np.float32)
+    _check("emf_io_write_pose_file",
+           load().emf_io_write_pose_file(os.fspath(filename).encode(), len(frames),
+                                         (C.c_int32 * max(len(frames), 1))(*frames),
+                                         R.ctypes.data_as(C.POINTER(C.c_float)),
+                                         t.ctypes.data_as(C.POINTER(C.c_float))))

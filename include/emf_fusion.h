@@ -106,6 +106,15 @@ int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id,
  * whose existence probability is low); last_deleted lists the ids the last frame removed. */
 int emf_fusion_set_cleanup(emf_fusion_t* h, int on);
 int emf_fusion_last_deleted(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
+/* Results in the reference's formats (SURVEY f-4, mesh-free part): enable the per-frame pose log
+ * before processing, then write <dir>/poses-cam.txt, poses-<id>.txt (TUM: "frame tx ty tz qx qy qz
+ * qw") and, if volumes != 0, <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin
+ * (int32 res[3], uint64 element size, float voxel size, voxels).  emf_io_* are host-only helpers. */
+int emf_fusion_enable_pose_log(emf_fusion_t* h, int on);
+int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes);
+int emf_io_write_volume(const char* filename, const float* voxels, const int32_t res[3], float voxel_size);
+int emf_io_write_pose_file(const char* filename, int n, const int32_t* frames, const float* R,
+                           const float* t);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);
