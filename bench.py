@@ -251,7 +251,11 @@ def main():
     if comm is not None:
         comm.close()
     if rank == 0:
-        print(json.dumps(result))
+        # libraries (RCCL's version banner) write to C stdio: flush that first so that the JSON line
+        # is the last line of the output whatever the buffering
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -59,8 +59,8 @@ SIGNATURES = {
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
-    "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP,
-                               _STREAM],
+    "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, C.c_int,
+                               C.c_int, _FP, _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
     "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],

@@ -100,6 +100,7 @@ struct RaycastBatchArgs {
     int chunk;  // tiles per XCD = ceil(tilesX * tilesY / 8)
     float fx, fy, cx, cy;
     unsigned divideMask;  // bit m: model m must divide by voxelSize (pose out of the checked range)
+    int bandTile0, bandTiles;  // slot 0 only: tile rows this rank marches (bandTiles == 0: all)
     unsigned long long* stats;
 };
 
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     const int tile = (i & 7) * a.chunk + (i >> 3);
     if (tile >= a.tilesX * a.tilesY) return;  // block-uniform
     const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
+    // multi-GPU: the replicated background is marched in row bands, one per rank; the rows of the
+    // other bands are neither marched nor written here (they arrive by all-gather)
+    if (m == 0 && a.bandTiles > 0 && (tyy < a.bandTile0 || tyy >= a.bandTile0 + a.bandTiles)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = txx * kRbTile + (wave & 1) * 8 + (lane & 7);
     const int y = tyy * kRbTile + (wave >> 1) * 8 + (lane >> 3);
@@ -354,9 +358,12 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
-                           const float K[9], int useBrickFlags, uint64_t* stats,
-                           emf_stream_t stream) {
+                           const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
+                           uint64_t* stats, emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
+    if (bgBandRows < 0 || bgBandRow0 < 0 || bgBandRow0 % kRbTile || bgBandRows % kRbTile)
+        return fail(EMF_E_ARG, "raycastBatched: band [%d, +%d) must be non-negative multiples of %d rows",
+                    bgBandRow0, bgBandRows, kRbTile);
     EMF_REQUIRE_PTR(res_host);
     EMF_REQUIRE_PTR(K);
     if (width <= 0 || height <= 0)
@@ -382,6 +389,8 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.cx = K[2];
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
+    a.bandTile0 = bgBandRow0 / kRbTile;
+    a.bandTiles = bgBandRows / kRbTile;
     const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk);
     if (useBrickFlags || !offsets32)  // the wave march addresses with 32-bit byte offsets
         hipLaunchKernelGGL(k_raycast_batched<false>, grid, dim3(64 * kRbWaves), 0,

@@ -1,6 +1,8 @@
 // Communicator.cpp -- RCCL implementation of the cross-GPU exchanges.
 #include "Communicator.hpp"
 
+#include <algorithm>
+
 #include <rccl/rccl.h>
 
 #include <cstring>
@@ -34,6 +36,19 @@ public:
     void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
         ncclCheck(ncclAllReduce(dev, dev, count, ncclUint64, ncclMin, comm_, s.get()),
                   "ncclAllReduce(min,u64)");
+    }
+    void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows,
+                        Stream& s) override {
+        ncclCheck(ncclGroupStart(), "ncclGroupStart");
+        for (int r = 0; r < world_; ++r) {
+            const int r0 = r * bandRows;
+            const int n = std::min(bandRows, totalRows - r0);
+            if (n <= 0) break;
+            char* p = static_cast<char*>(dev) + static_cast<size_t>(r0) * bytesPerRow;
+            ncclCheck(ncclBroadcast(p, p, static_cast<size_t>(n) * bytesPerRow, ncclUint8, r, comm_, s.get()),
+                      "ncclBroadcast(band)");
+        }
+        ncclCheck(ncclGroupEnd(), "ncclGroupEnd");
     }
     void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
         ncclCheck(ncclBroadcast(dev, dev, bytes, ncclUint8, root, comm_, s.get()),

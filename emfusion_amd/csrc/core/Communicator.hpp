@@ -24,10 +24,23 @@ public:
     virtual void allReduceSumF32(float* dev, size_t count, Stream& stream) = 0;
     virtual void allReduceMinU64(uint64_t* dev, size_t count, Stream& stream) = 0;
     virtual void broadcast(void* dev, size_t bytes, int root, Stream& stream) = 0;
+    /**
+     * In place gather of row bands of an image: rank r owns rows [r * bandRows, (r + 1) * bandRows)
+     * clipped to totalRows; afterwards every rank holds all rows.  One group of per-band
+     * broadcasts (bands may be ragged or empty, which an all-gather's equal counts cannot express).
+     */
+    virtual void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows,
+                                Stream& stream) = 0;
 };
 
 /** Rank that owns an object volume: round-robin by (1-based) object id. */
 inline int ownerOf(int objectId, int worldSize) { return (objectId - 1) % worldSize; }
+
+/** Rows per rank of the background-raycast band split: whole 16-row tiles, ceil(tiles / world). */
+inline int bgBandRows(int height, int worldSize) {
+    const int tiles = (height + 15) / 16;
+    return ((tiles + worldSize - 1) / worldSize) * 16;
+}
 
 constexpr size_t kRcclUniqueIdBytes = 128;
 

@@ -72,6 +72,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     const char* env = std::getenv("EMF_PER_VOLUME");
     forceLegacy = env && env[0] == '1';
     // EMF_LAMBDA_TABLE=0: integrate with the inline 1 / lambda (A/B measurements; same results)
+    // EMF_BG_BANDS=0: every rank raycasts the whole (replicated) background itself
+    const char* bb = std::getenv("EMF_BG_BANDS");
+    bgBands = !(bb && bb[0] == '0');
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
@@ -792,9 +795,19 @@ void EMFusion::raycastBatched() {
         // One grid for all models.  (Measured alternative: the objects' grid on a second stream so
         // that their waves need not queue behind the resident background -- 3 % slower, the two
         // queues did not interleave usefully; scripts/raycast_timeline.py shows the queueing.)
+        // Sharded: the background is replicated, so its raycast -- the largest kernel of the frame
+        // -- is split into row bands, one per rank (Plan A); raylengths and hit mask of
+        // the bands are then gathered (1.5 MB at VGA).  Background vertices / normals stay
+        // band-local: like the remote objects' they only feed rendering.
+        const int band = sharded && bgBands ? bgBandRows(h, world) : 0;
         emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
-                                        flags, stats, main.abi()),
+                                        flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
+                                        band, stats, main.abi()),
                  "raycastBatched");
+        if (band) {
+            comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), band, h, main);
+            comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), band, h, main);
+        }
     }
     stamp(kRaycast);
     compositeAndVisibility(true);

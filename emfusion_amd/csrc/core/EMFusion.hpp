@@ -242,6 +242,7 @@ private:
     DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
+    bool bgBands = true;  // sharded path: split the background raycast into row bands per rank
 
     // ---- object creation / matching (SURVEY f-3) ----
     emf_point_stats_t maskedStats(const emf_image_t& mask, const Affine3f& frame);  // synchronises

@@ -297,12 +297,13 @@ def voxel_reciprocal(voxel_size) -> float:
 
 
 def raycast_batched(models_dev, poses_co, res_list, width, height, K, stats=None,
-                    use_brick_flags=False, stream=None):
+                    use_brick_flags=False, stream=None, bg_band=(0, 0)):
+    """bg_band = (row0, rows): march only that row band of table slot 0 (multi-GPU background split)."""
     res = (C.c_int32 * (3 * len(poses_co)))(*[int(v) for r in res_list for v in r])
     check("emf_hip_raycastBatched",
           _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width,
-                                    height, _f(K, 9), int(use_brick_flags), _ptr(stats),
-                                    _stream(stream)))
+                                    height, _f(K, 9), int(use_brick_flags), int(bg_band[0]),
+                                    int(bg_band[1]), _ptr(stats), _stream(stream)))
 
 
 def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None,

@@ -16,6 +16,15 @@ def owner_of(object_id: int, world: int) -> int:
     return (object_id - 1) % world
 
 
+def bg_band(rank: int, world: int, height: int, tile: int = 16):
+    """(first row, rows) of the background-raycast band of `rank` (Communicator.hpp bgBandRows):
+    whole 16-row tiles, ceil(tiles / world) per rank; trailing ranks may get a short or empty band."""
+    tiles = (height + tile - 1) // tile
+    rows = ((tiles + world - 1) // world) * tile
+    r0 = min(rank * rows, tiles * tile)
+    return r0, max(0, min(rows, height - r0))
+
+
 def local_objects(ids, rank: int, world: int):
     return [i for i in ids if owner_of(i, world) == rank]
 

@@ -288,11 +288,14 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
  *   useBrickFlags != 0: march with the models' brick flags (fast-forward through uniform bricks);
  *   0: ignore them and use the wave-scheduled march (default; faster on the bench scene).
  * Both produce the same images.  Models whose table entry carries rcpVoxel != 0 divide by the
- * voxel size with the checked reciprocal (emf_hip_voxelReciprocal), same results. */
+ * voxel size with the checked reciprocal (emf_hip_voxelReciprocal), same results.
+ *   bgBandRow0, bgBandRows: multi-GPU split of the REPLICATED background (table slot 0): only the
+ *   image rows [bgBandRow0, bgBandRow0 + bgBandRows) of slot 0 are marched and written, the others
+ *   are left untouched for an all-gather of the ranks' bands (multiples of 16; 0, 0 = all rows). */
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
-                           const float K[9], int useBrickFlags, uint64_t* stats,
-                           emf_stream_t stream);
+                           const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
+                           uint64_t* stats, emf_stream_t stream);
 
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera

@@ -158,3 +158,15 @@ def test_sharded_composite_matches_list_order_rule(two_ranks, oracle):
         assert np.array_equal(got["ray"], pre_ray)
         assert np.array_equal(got["ray"], ray)  # composite raylength is never replaced by bg
     assert (pre_seg[:10] == 2).any()  # tie rows: the earlier object (id 2) beats id 4
+
+
+def test_background_bands_partition_the_rows():
+    from emfusion_amd import sharding
+    for height in (480, 120, 960, 16, 17):
+        for world in (1, 2, 3, 4, 8):
+            rows = []
+            for rank in range(world):
+                r0, n = sharding.bg_band(rank, world, height)
+                assert r0 % 16 == 0 and n >= 0
+                rows += list(range(r0, r0 + n))
+            assert rows == list(range(height)), (height, world)

@@ -90,3 +90,53 @@ def test_two_rank_composite_equals_single_gpu_composite(ops, oracle, dev, nobj, 
         ops.visibility_flags_indexed(vis, [0] + lp, 300, visible)
         assert to_np(visible).tolist() == [1] + [int(w_vis[p] > 300) for p in lp]
     assert w_vis.sum() > 0 and (w_seg > 0).any()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_background_raycast_bands_tile_the_image(ops, oracle, dev, world):
+    """Multi-GPU background split: every emulated rank marches only its row band of table slot 0
+    into the shared images (what the gather of the bands leaves on every rank); the result must be
+    the full raycast, bit for bit, and the objects' images must not depend on the band."""
+    from tests.scenes import Pose, camera_path, intrinsics, rel_CO, rel_OC, render_depth
+    K = intrinsics(W, H)
+    spheres = [((0.25, 0.05, 1.3), 0.22)]
+    vols = [dict(n=(64, 64, 64), vox=0.04, pose=Pose(t=[0, 0, 1.28])),
+            dict(n=(32, 32, 32), vox=0.02, pose=Pose(t=spheres[0][0]))]
+    keep, entries = [], []
+    for k, v in enumerate(vols):
+        n = v["n"]
+        tsdf, wts = np.zeros((n[2], n[1], n[0]), np.float32), np.zeros((n[2], n[1], n[0]), np.float32)
+        for i in range(3):
+            cam = camera_path(i)
+            depth, _ = render_depth(W, H, K, cam, spheres, noise=0.002, dropout=0.01, seed=40 + i)
+            oc = rel_OC(cam, v["pose"])
+            oracle.update_tsdf(depth, np.ones((H, W), np.float32), tsdf, wts, oc.R32, oc.t32, K, v["vox"],
+                               10 * v["vox"], 64.0)
+        d = dict(tsdf=to_dev(tsdf), wts=to_dev(wts), assoc=dev_full((H, W), 1.0), ray=dev_full((H, W), 7.0),
+                 vert=dev_full((H, W, 3), 7.0), nrm=dev_full((H, W, 3), 7.0), hit=dev_full((H, W), 7, np.uint8))
+        keep.append(d)
+        entries.append(ops.make_model(d["tsdf"], d["wts"], d["assoc"], d["ray"], d["vert"], d["nrm"], d["hit"],
+                                      float(np.float32(v["vox"])), float(np.float32(10 * v["vox"])), 64.0,
+                                      0.02, 0.8, 1.0, model_id=k, rcp_voxel=ops.voxel_reciprocal(v["vox"])))
+    table = ops.upload_models(entries)
+    cam = camera_path(3)
+    poses = [(rel_CO(cam, v["pose"]).R32, rel_CO(cam, v["pose"]).t32) for v in vols]
+    res = [v["n"] for v in vols]
+    ops.raycast_batched(table, poses, res, W, H, K)  # single GPU: all rows
+    full = {k: [to_np(keep[m][k]) for m in (0, 1)] for k in ("ray", "vert", "nrm", "hit")}
+    assert full["hit"][0].sum() > 5000
+    for d in keep:  # poison, then let the emulated ranks fill their bands
+        d["ray"].copy_from(np.full((H, W), 9, np.float32))
+        d["hit"].copy_from(np.full((H, W), 9, np.uint8))
+    covered = np.zeros(H, bool)
+    for rank in range(world):
+        r0, rows = sharding.bg_band(rank, world, H)
+        band_rows = ((((H + 15) // 16) + world - 1) // world) * 16
+        ops.raycast_batched(table, poses, res, W, H, K, bg_band=(r0, band_rows))
+        covered[r0:r0 + rows] = True
+    assert covered.all()
+    for k in ("ray", "hit"):
+        assert to_np(keep[0][k]).tobytes() == full[k][0].tobytes(), k   # background: union of bands
+        assert to_np(keep[1][k]).tobytes() == full[k][1].tobytes(), k   # object: untouched by bands
+    with pytest.raises(Exception):
+        ops.raycast_batched(table, poses, res, W, H, K, bg_band=(8, 16))  # not tile aligned
