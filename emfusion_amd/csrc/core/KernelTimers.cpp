@@ -24,7 +24,7 @@ void KernelTimers::enable(size_t maxLaunches) {
 
 KernelTimers::Scope::Scope(KernelTimers* t, Kind k, double units, hipStream_t s)
     : timers(t), stream(s), slot(-1) {
-    if (!t || t->pairs.empty()) return;
+    if (!t || t->pairs.empty() || !((t->kindMask >> k) & 1u)) return;
     if (t->used >= t->pairs.size()) {
         ++t->dropped;
         return;

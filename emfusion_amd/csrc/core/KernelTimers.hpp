@@ -38,6 +38,11 @@ public:
     /** Allocate `maxLaunches` event pairs and start recording; 0 disables. */
     void enable(size_t maxLaunches);
     bool enabled() const { return !pairs.empty(); }
+    /**
+     * Which kinds get an event pair (bit k = Kind k; default: all).  Two event records around a
+     * 5 us kernel cost more than the kernel: bench.py brackets only the large kernels by default.
+     */
+    void select(uint32_t mask) { kindMask = mask; }
     /** Drop recorded launches, keep the pool. */
     void clear() { used = 0; dropped = 0; }
     /** After the device is idle: per-kind launch count, summed duration and work units. */
@@ -65,6 +70,7 @@ private:
         double units = 0.0;
     };
     std::vector<Pair> pairs;
+    uint32_t kindMask = 0xffffffffu;
     size_t used = 0, dropped = 0;
 };
 

@@ -119,6 +119,7 @@ def load() -> C.CDLL:
         "emf_fusion_raycast_stats": [vp, C.POINTER(C.c_uint64)],
         "emf_fusion_kernel_timers_enable": [vp, C.c_uint64],
         "emf_fusion_kernel_timers_clear": [vp],
+        "emf_fusion_kernel_timers_select": [vp, C.c_uint32],
         "emf_fusion_kernel_timers_collect": [vp, C.POINTER(KernelSummary), C.POINTER(C.c_uint64)],
         "emf_fusion_get_image": [vp, C.c_int, C.c_int, img],
         "emf_fusion_get_volume": [vp, C.c_int, C.c_int, C.POINTER(vp), ip],
@@ -374,6 +375,13 @@ class Fusion:
     def kernel_timers_enable(self, max_launches: int):
         _check("emf_fusion_kernel_timers_enable",
                load().emf_fusion_kernel_timers_enable(self._h, int(max_launches)))
+
+    def kernel_timers_select(self, kinds):
+        """Bracket only these kernel kinds (names from KERNEL_KINDS) with event pairs."""
+        mask = 0
+        for k in kinds:
+            mask |= 1 << KERNEL_KINDS.index(k)
+        _check("emf_fusion_kernel_timers_select", load().emf_fusion_kernel_timers_select(self._h, mask))
 
     def kernel_timers_clear(self):
         _check("emf_fusion_kernel_timers_clear", load().emf_fusion_kernel_timers_clear(self._h))

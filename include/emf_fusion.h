@@ -149,6 +149,8 @@ typedef struct emf_kernel_summary {
 } emf_kernel_summary_t;
 int emf_fusion_kernel_timers_enable(emf_fusion_t* h, uint64_t max_launches);
 int emf_fusion_kernel_timers_clear(emf_fusion_t* h);
+/* restrict the event pairs to the kinds whose bit (1 << emf_kernel_kind) is set; default all */
+int emf_fusion_kernel_timers_select(emf_fusion_t* h, uint32_t kind_mask);
 int emf_fusion_kernel_timers_collect(emf_fusion_t* h, emf_kernel_summary_t out[EMF_K_NUM_KINDS],
                                      uint64_t* dropped);
 
