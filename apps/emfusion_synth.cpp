@@ -85,15 +85,12 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < objects; ++k) in.masks[ids[k]] = maskDev[k].view();
             } else {
                 in.trackCamera = in.trackObjects = f > 0;
-                if (f == 0) {  // every mask is unmatched: spawn the volumes inside the frame
-                    for (int k = 0; k < objects; ++k) in.newObjectMasks.push_back(maskDev[k].view());
-                } else if (in.runMasks) {  // hand each mask to the model it overlaps best
-                    for (int k = 0; k < objects; ++k) {
-                        float iou = 0.f;
-                        const int id = emf.matchSegmentation(maskDev[k].view(), iou);
-                        if (id >= 0) in.masks[id] = maskDev[k].view();
-                    }
-                }
+                in.cleanUp = true;
+                // a "Mask R-CNN frame": all instance masks go through initOrMatchObjs inside the
+                // frame (match / spawn / existence bookkeeping), then integrateMasks, cleanUpObjs
+                if (in.runMasks)
+                    for (int k = 0; k < objects; ++k) in.instanceMasks.push_back(maskDev[k].view());
+                in.runMasks = false;
             }
             emf.setFrameInputs(in);
             emf::RGBD frame;
@@ -101,7 +98,7 @@ int main(int argc, char** argv) {
             frame.depth = depth.data();
             emf.processFrame(frame);  // reference EMFusion.cpp:70
             gpuMs += emf.lastTimings().total;
-            if (autonomous && f == 0)
+            if (autonomous)
                 for (int id : emf.lastCreatedObjects()) spawned += id >= 0;
         }
         emf.synchronize();

@@ -405,6 +405,13 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         lastCreated.push_back(id);
         if (id >= 0) masks[id] = m;
     }
+    lastAssigned.clear();
+    const bool instances = !in.instanceMasks.empty();
+    if (instances) {  // reference EMFusion.cpp:100-101
+        std::vector<emf_image_t> segs = in.instanceMasks;
+        masks = initOrMatchObjs(segs, lastAssigned);
+        masks.erase(-1);
+    }
 
     if (poseLog) {  // storePoses (EMFusion.cpp:322-327)
         poses[frameCount] = pose;
@@ -414,12 +421,13 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     integrateDepth();
     stamp(kIntegrate);
 
-    if ((in.runMasks || !in.newObjectMasks.empty()) && !masks.empty()) integrateMasks(masks);
+    if ((in.runMasks || instances || !in.newObjectMasks.empty()) && !masks.empty())
+        integrateMasks(masks);
     lastDeleted.clear();
     if (in.cleanUp) {
-        if (in.runMasks)  // initOrMatchObjs' bookkeeping (EMFusion.cpp:358-369)
+        if (in.runMasks && !instances)  // initOrMatchObjs' bookkeeping (EMFusion.cpp:358-369)
             for (auto& obj : objects) obj.updateExProb(masks.count(obj.getID()) != 0);
-        lastDeleted = cleanUpObjs(in.runMasks, masks);
+        lastDeleted = cleanUpObjs(in.runMasks || instances, masks);
     }
     stamp(kMasks);
 
@@ -556,6 +564,81 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
         dump("weights_" + id, obj.getWeightsVol(), obj);
         dump("fgProbs_" + id, obj.getFgProbVol(), obj);
     }
+}
+
+std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& segs,
+                                                     std::vector<int>& assigned) {
+    if (sharded) throw HipError("EMFusion::initOrMatchObjs: not available on the sharded path", EMF_E_ARG);
+    ensureLifecycleBuffers();
+    std::map<int, emf_image_t> matches;
+    std::vector<int> unmatched;
+    assigned.assign(segs.size(), -1);
+    const emf_image_t modelSeg = modelSegmentation.view();
+    auto overlapCounts = [&](const emf_image_t& seg) -> const uint32_t* {
+        emfCheck(emf_hip_maskOverlap(&seg, &modelSeg, overlapDev.as<uint32_t>(), main.abi()), "maskOverlap");
+        hipCheck(hipMemcpyAsync(lifecycleHost, overlapDev.data(), 513 * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, main.get()),
+                 "hipMemcpyAsync");
+        main.waitForCompletion();
+        return static_cast<const uint32_t*>(lifecycleHost);
+    };
+    // ---- matchSegmentation over all masks (EMFusion.cpp:417-444) ----
+    for (size_t i = 0; i < segs.size(); ++i) {
+        int matched = -1;
+        if (frameCount > 0) {
+            float new_iou = 0.f;
+            matched = matchSegmentation(segs[i], new_iou);
+            if (matched >= 0 && matches.count(matched)) {
+                // a second mask for the same model: keep the better one; THIS mask goes on as
+                // unmatched either way, as in the reference
+                const uint32_t* c = overlapCounts(matches[matched]);
+                const float prev_iou = static_cast<float>(c[1 + matched]) /
+                                       static_cast<float>(c[0] + c[257 + matched] - c[1 + matched]);
+                if (new_iou > prev_iou) {
+                    for (size_t k = 0; k < i; ++k)
+                        if (assigned[k] == matched) assigned[k] = -1;
+                    matches[matched] = segs[i];
+                    assigned[i] = matched;
+                }
+                matched = -1;
+            }
+        }
+        if (matched >= 0) {
+            matches[matched] = segs[i];
+            assigned[i] = matched;
+        } else {
+            unmatched.push_back(static_cast<int>(i));
+        }
+    }
+    // ---- initObjsFromUnmatched (EMFusion.cpp:446-494) ----
+    for (int i : unmatched) {
+        if (assigned[i] >= 0) continue;  // it replaced an earlier match above: already in use
+        for (const auto& obj : objects) {
+            const int id = obj.getID();
+            if (id > 255) continue;
+            auto it = matches.find(id);
+            emfCheck(emf_hip_carveMask(&segs[i], &modelSeg, id, it == matches.end() ? nullptr : &it->second,
+                                       overlapDev.as<uint32_t>(), main.abi()),
+                     "carveMask");
+            hipCheck(hipMemcpyAsync(lifecycleHost, overlapDev.data(), 2 * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, main.get()),
+                     "hipMemcpyAsync");
+            main.waitForCompletion();
+            const uint32_t* c = static_cast<const uint32_t*>(lifecycleHost);
+            // more than half of the mask belonged to an existing object: no new volume from it
+            if (static_cast<float>(c[1]) / static_cast<float>(c[0]) < .5f)
+                hipCheck(hipMemset2DAsync(segs[i].data, segs[i].pitch, 0, static_cast<size_t>(segs[i].width),
+                                          static_cast<size_t>(segs[i].height), main.get()),
+                         "hipMemset2DAsync");
+        }
+        const int id = initNewObjVolume(segs[i]);
+        lastCreated.push_back(id);
+        matches[id] = segs[i];  // the reference inserts even id == -1; callers drop that key
+        assigned[i] = id;
+    }
+    for (auto& obj : objects)  // EMFusion.cpp:358-369 (updateObj / resize needs the mesh: not built)
+        obj.updateExProb(matches.count(obj.getID()) != 0);
+    return matches;
 }
 
 void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989

@@ -52,6 +52,12 @@ struct FrameInputs {
     // before the integration each one runs through initNewObjVolume (EMFusion.cpp:446-494, 104-109
     // of processFrame); a created object integrates this frame's depth and this mask.
     std::vector<emf_image_t> newObjectMasks;
+    // The instance masks of a Mask R-CNN frame (device u8 W x H, MODIFIED in place by the carving
+    // step): after the raycast they run through the reference's initOrMatchObjs -- match against
+    // the visible models, resolve double matches, carve and spawn the unmatched ones, existence
+    // bookkeeping (EMFusion.cpp:329-372, 417-494) -- and the resulting id -> mask map feeds
+    // integrateMasks and cleanUpObjs.  Takes the place of `masks` / `newObjectMasks`.
+    std::vector<emf_image_t> instanceMasks;
     // Run the reference's cleanUpObjs at the end of the frame (EMFusion.cpp:922-980): objects with
     // a low existence probability (mask frames), with too little association mass under their
     // mask, or not visible are deleted.  Needs the visible set on the host (one synchronisation),
@@ -104,6 +110,13 @@ public:
      * -1.  match_iou is updated as in the reference (in/out).
      */
     int matchSegmentation(const emf_image_t& mask, float& match_iou);
+    /**
+     * Reference EMFusion::initOrMatchObjs (EMFusion.cpp:329-372) without the class-score and mesh
+     * parts: returns object id -> mask; `assigned[i]` = the id mask i ended up with (-1: none).
+     */
+    std::map<int, emf_image_t> initOrMatchObjs(std::vector<emf_image_t>& segs,
+                                               std::vector<int>& assigned);
+    const std::vector<int>& lastMaskAssignment() const { return lastAssigned; }
     /** Reference EMFusion::cleanUpObjs (EMFusion.cpp:922-980); returns the deleted ids. */
     std::vector<int> cleanUpObjs(bool maskFrame, const std::map<int, emf_image_t>& matches);
     const std::vector<int>& lastDeletedObjects() const { return lastDeleted; }
@@ -247,7 +260,7 @@ private:
     // ---- object creation / matching (SURVEY f-3) ----
     emf_point_stats_t maskedStats(const emf_image_t& mask, const Affine3f& frame);  // synchronises
     DeviceBuffer statsScratch, statsDev, overlapDev;
-    std::vector<int> lastCreated, lastDeleted;
+    std::vector<int> lastCreated, lastDeleted, lastAssigned;
     bool poseLog = false;
     std::map<int, Affine3f> poses;                    // frame -> camera pose
     std::map<int, std::map<int, Affine3f>> obj_poses;  // id -> frame -> pose

@@ -17,7 +17,7 @@ struct emf_comm {
 struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
     bool trackCamera = false, trackObjects = false, preprocess = false, cleanUp = false;
-    std::vector<emf_image_t> queuedMasks;
+    std::vector<emf_image_t> queuedMasks, queuedInstances;
 };
 struct emf_synth {
     std::unique_ptr<SyntheticScene> impl;
@@ -166,6 +166,7 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.preprocessDepth = h->preprocess;
         in.cleanUp = h->cleanUp;
         in.newObjectMasks.swap(h->queuedMasks);
+        in.instanceMasks.swap(h->queuedInstances);
         h->impl->processFrame(*depth_dev, in);
     });
 }
@@ -188,6 +189,22 @@ int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t*
     REQ(h);
     if (n > 0) REQ(masks);
     return guarded([&] { h->queuedMasks.assign(masks, masks + (n > 0 ? n : 0)); });
+}
+
+int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* masks) {
+    REQ(h);
+    if (n > 0) REQ(masks);
+    return guarded([&] { h->queuedInstances.assign(masks, masks + (n > 0 ? n : 0)); });
+}
+
+int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count) {
+    REQ(h);
+    REQ(count);
+    return guarded([&] {
+        const auto& v = h->impl->lastMaskAssignment();
+        *count = static_cast<int32_t>(v.size());
+        for (int i = 0; ids && i < capacity && i < static_cast<int>(v.size()); ++i) ids[i] = v[i];
+    });
 }
 
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count) {

@@ -163,6 +163,41 @@ __global__ __launch_bounds__(kLcBlock) void k_mask_overlap(const IouArgs a) {
     if (threadIdx.x == 0 && maskPx) atomicAdd(&a.counts[0], maskPx);
 }
 
+// ---- carving an object's footprint out of an unmatched mask (initObjsFromUnmatched) ----------------
+
+struct CarveArgs {
+    Img<uint8_t> seg;             // unmatched instance mask, modified in place
+    Img<const uint8_t> modelSeg;  // composite model segmentation
+    Img<const uint8_t> match;     // the mask matched to the object, or data == nullptr
+    int id, w, h;
+    unsigned* counts;             // [0] pixels before, [1] pixels after
+};
+
+// seg &= !((modelSeg == id) | match)   (EMFusion.cpp:462-478), counting |seg| before and after
+__global__ __launch_bounds__(kLcBlock) void k_carve_mask(const CarveArgs a) {
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    unsigned pre = 0, post = 0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kLcBlock + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kLcBlock) {
+        const int y = static_cast<int>(i / a.w), x = static_cast<int>(i - static_cast<size_t>(y) * a.w);
+        uint8_t& s = a.seg.row(y)[x];
+        if (!s) continue;
+        ++pre;
+        const bool taken = a.modelSeg.row(y)[x] == a.id || (a.match.data && a.match.row(y)[x] != 0);
+        if (taken) s = 0;
+        else ++post;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        pre += __shfl_xor(pre, o);
+        post += __shfl_xor(post, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (pre) atomicAdd(&a.counts[0], pre);
+        if (post) atomicAdd(&a.counts[1], post);
+    }
+}
+
 // ---- association mass under an object's mask (cleanUpObjs, EMFusion.cpp:936-949) ----------------
 
 struct MassArgs {
@@ -266,6 +301,33 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
         hipLaunchKernelGGL(k_stats_pick, dim3(1), dim3(64), 0, s, a);
     }
     return launch_status("maskedPointStats");
+}
+
+int emf_hip_carveMask(const emf_image_t* seg, const emf_image_t* modelSeg, int id,
+                      const emf_image_t* matchMask, uint32_t* counts_dev, emf_stream_t stream) {
+    EMF_TRY(check_image(seg, 1, "carveMask: seg"));
+    EMF_TRY(check_image(modelSeg, 1, "carveMask: modelSeg"));
+    EMF_TRY(check_same_size(seg, modelSeg, "seg", "modelSeg"));
+    if (matchMask) {
+        EMF_TRY(check_image(matchMask, 1, "carveMask: matchMask"));
+        EMF_TRY(check_same_size(seg, matchMask, "seg", "matchMask"));
+    }
+    EMF_REQUIRE_PTR(counts_dev);
+    if (id < 1 || id > 255) return fail(EMF_E_ARG, "carveMask: object id %d outside 1..255", id);
+    CarveArgs a;
+    a.seg = img<uint8_t>(seg);
+    a.modelSeg = img<const uint8_t>(modelSeg);
+    a.match = matchMask ? img<const uint8_t>(matchMask) : Img<const uint8_t>{nullptr, 0};
+    a.id = id;
+    a.w = seg->width;
+    a.h = seg->height;
+    a.counts = counts_dev;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_clear_u32, dim3(1), dim3(64), 0, s, counts_dev, 2);
+    const size_t n = static_cast<size_t>(a.w) * a.h;
+    hipLaunchKernelGGL(k_carve_mask, dim3(static_cast<unsigned>(ceil_div(n, kLcBlock * 4))),
+                       dim3(kLcBlock), 0, s, a);
+    return launch_status("carveMask");
 }
 
 int emf_hip_maskAssociationMass(const emf_image_t* objSeg, const emf_image_t* matchMask,

@@ -436,3 +436,13 @@ def mask_association_mass(obj_seg, match_mask, assoc, stream=None):
                                          C.byref(image_view(assoc)), _ptr(out), _stream(stream)))
     raw = out.numpy()
     return int(raw.view(np.uint32)[2]), float(raw[0])
+
+
+def carve_mask(seg, model_seg, obj_id, match_mask=None, stream=None):
+    """seg &= !((model_seg == obj_id) | match_mask) in place; returns (pixels before, after)."""
+    counts = DeviceArray.zeros((2,), np.uint32)
+    check("emf_hip_carveMask",
+          _L.emf_hip_carveMask(C.byref(image_view(seg)), C.byref(image_view(model_seg)), int(obj_id),
+                               _opt_view(match_mask), _ptr(counts), _stream(stream)))
+    c = counts.numpy()
+    return int(c[0]), int(c[1])

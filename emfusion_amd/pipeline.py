@@ -107,6 +107,8 @@ def load() -> C.CDLL:
         "emf_fusion_match_mask": [vp, img, ip, fp],
         "emf_fusion_queue_new_object_masks": [vp, C.c_int, img],
         "emf_fusion_last_created": [vp, ip, C.c_int, ip],
+        "emf_fusion_queue_instance_masks": [vp, C.c_int, img],
+        "emf_fusion_last_mask_assignment": [vp, ip, C.c_int, ip],
         "emf_fusion_get_pose": [vp, C.c_int, fp, fp],
         "emf_fusion_track_result": [vp, C.c_int, ip, ip, ip, fp],
         "emf_fusion_stage_estep": [vp],
@@ -296,6 +298,19 @@ class Fusion:
         arr = (EmfImage * max(len(mask_views), 1))(*mask_views)
         _check("emf_fusion_queue_new_object_masks",
                load().emf_fusion_queue_new_object_masks(self._h, len(mask_views), arr))
+
+    def queue_instance_masks(self, mask_views):
+        """The instance masks of a Mask R-CNN frame for the next process_frame (initOrMatchObjs);
+        the masks are modified in place by the carving step."""
+        arr = (EmfImage * max(len(mask_views), 1))(*mask_views)
+        _check("emf_fusion_queue_instance_masks",
+               load().emf_fusion_queue_instance_masks(self._h, len(mask_views), arr))
+
+    def last_mask_assignment(self):
+        ids, n = (C.c_int32 * 64)(), C.c_int32(0)
+        _check("emf_fusion_last_mask_assignment",
+               load().emf_fusion_last_mask_assignment(self._h, ids, 64, C.byref(n)))
+        return [ids[i] for i in range(min(n.value, 64))]
 
     def last_created(self):
         ids, n = (C.c_int32 * 64)(), C.c_int32(0)

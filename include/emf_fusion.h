@@ -99,6 +99,12 @@ int emf_fusion_create_object_from_mask(emf_fusion_t* h, const emf_image_t* mask,
  * queued here are run through initNewObjVolume by the NEXT process_frame, after its raycast and
  * before its integration; last_created returns the ids (-1 = rejected), in queue order. */
 int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t* masks);
+/* The instance masks of a Mask R-CNN frame for the NEXT process_frame: it runs the reference's
+ * initOrMatchObjs on them after its raycast (match, resolve double matches, carve and spawn the
+ * unmatched -- the masks are MODIFIED in place), integrates the matched masks and, if clean-up is
+ * on, deletes spurious objects.  last_mask_assignment: the object id each mask ended up with. */
+int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* masks);
+int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);
 /* From the next frame on, run the reference's cleanUpObjs at the end of every frame (delete objects

@@ -392,6 +392,13 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
                              const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
                              emf_stream_t stream);
 
+/* EMFusion::initObjsFromUnmatched's carving step (EMFusion.cpp:462-478): removes from the unmatched
+ * instance mask `seg` (in place) the pixels the object `id` already claims -- its footprint in the
+ * model segmentation, plus `matchMask` if a mask was matched to it (may be NULL) -- and counts the
+ * mask's pixels before ([0]) and after ([1]).  The caller zeroes the mask if after / before < 0.5. */
+int emf_hip_carveMask(const emf_image_t* seg, const emf_image_t* modelSeg, int id,
+                      const emf_image_t* matchMask, uint32_t* counts_dev, emf_stream_t stream);
+
 /* The two numbers of EMFusion::cleanUpObjs' association test (EMFusion.cpp:936-949):
  * count = |objSeg OR matchMask| (matchMask may be NULL), sum = sum of `assoc` over those pixels
  * (double accumulation like cv::cuda::sum, fixed order).  The object is spurious if

@@ -204,3 +204,58 @@ def test_invisible_objects_are_cleaned_up(oracle, dev):
             assert fus.last_deleted() == [] and sorted(fus.visible_objects()) == [1]
     fus.close()
     synth.close()
+
+
+def test_carve_mask(ops, dev):
+    rng = np.random.default_rng(2)
+    seg = (rng.uniform(size=(H, W)) < 0.5).astype(np.uint8) * 3
+    model = rng.integers(0, 4, (H, W)).astype(np.uint8)
+    match = (rng.uniform(size=(H, W)) < 0.2).astype(np.uint8)
+    for m in (None, match):
+        d_seg = to_dev(seg, dev, 1)
+        taken = (model == 2) if m is None else ((model == 2) | (m != 0))
+        pre, post = ops.carve_mask(d_seg, to_dev(model, dev), 2, None if m is None else to_dev(m, dev))
+        want = np.where(taken, 0, seg)
+        assert pre == int((seg != 0).sum()) and post == int((want != 0).sum())
+        assert np.array_equal(d_seg.numpy(), want)
+
+
+def test_instance_masks_run_the_reference_control_flow(oracle, dev):
+    """initOrMatchObjs inside the frame: spawn on frame 0, match afterwards, a second mask on the
+    same model goes through the unmatched path, is carved to (almost) nothing and spawns nothing."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    Wf, Hf = 320, 240
+    prm = pipeline.make_params(Wf, Hf, 128, 0.04, 32, visibility_thresh=400, boundary=10)
+    synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 2, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    fus.set_cleanup(True)
+    centers, keep = {}, []
+    for f in range(4):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        d = to_dev(depth)
+        inst = [to_dev((sid == k).astype(np.uint8)) for k in (1, 2)]
+        if f == 2:  # Mask R-CNN reports sphere 1 twice: a slightly eroded duplicate
+            dup = (sid == 1).astype(np.uint8)
+            dup[:, : Wf // 2 - 10] = 0
+            inst.append(to_dev(dup))
+        keep += [d, inst]
+        fus.queue_instance_masks([image_view(m) for m in inst])
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), c) for i, c in centers.items()}
+        fus.process_frame(image_view(d), R, t, poses, {}, False)
+        fus.synchronize()
+        a = fus.last_mask_assignment()
+        if f == 0:
+            assert a == [1, 2] and fus.last_created() == [1, 2]
+            centers = {k: fus.pose(k)[1] for k in (1, 2)}
+        elif f == 2:
+            assert a[:2] == [1, 2] and a[2] == -1 and fus.last_created() == [-1]
+            assert inst[2].numpy().sum() < 0.5 * ((sid == 1).sum())  # carved in place
+        else:
+            assert a == [1, 2] and fus.last_created() == []
+        assert fus.last_deleted() == []
+    assert sorted(fus.visible_objects()) == [1, 2]
+    assert (fus.volume("fgmask", 1) > 0).sum() > 50  # the matched masks were integrated
+    fus.close()
+    synth.close()
