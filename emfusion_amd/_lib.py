@@ -69,6 +69,8 @@ SIGNATURES = {
     "emf_hip_maskOverlap": [_IMG, _IMG, _FP, _STREAM],
     "emf_hip_maskAssociationMass": [_IMG, _IMG, _IMG, _FP, _STREAM],
     "emf_hip_carveMask": [_IMG, _IMG, C.c_int, _IMG, _FP, _STREAM],
+    "emf_hip_objectExtentStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _STREAM],
+    "emf_hip_copyValues": [_FP, _FP, C.c_int, _I3, _I3, _I3, _STREAM],
     "emf_hip_trackScratchBytes": [C.c_int, C.c_int],
     "emf_hip_trackPrepare": [_FP, _FP, C.c_int, C.c_float, _STREAM],
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,

@@ -84,6 +84,131 @@ __global__ __launch_bounds__(kLcBlock) void k_stats_hist(const StatsArgs a) {
     if (a.pass == 0 && local) atomicAdd(&a.scratch[0], local);
 }
 
+// ---- second source of the statistics: the vertex cloud of the object's iso-surface -----------------
+// EMFusion::updateObj (EMFusion.cpp:827-863) takes the percentiles over obj.getMesh().cloud plus the
+// new points.  The reference's marching cubes (TSDF.cu:855-1152) emits, per cube whose 8 voxels all
+// pass the mask (weights > 0, and fgVolMask for objects: ObjTSDF.cpp:251-252), one vertex per edge
+// whose end points differ in sign (popcount of edgeTable[class]), interpolated by vertexInterp --
+// the triangle table only decides connectivity.  So the cloud needs no mesh: each cube streams its
+// edge vertices into the same histograms.
+
+struct MeshSource {
+    const float* tsdf;
+    const float* weights;
+    const uint8_t* fg;  // fgVolMask or nullptr
+    I3 n;
+    float voxelSize;
+};
+
+__device__ __forceinline__ V3 vertex_interp(const V3& p1, const V3& p2, float v1, float v2) {
+    // TSDF.cu:909-920; the comparisons are against the double literal 0.00001
+    if (static_cast<double>(fabsf(v1)) < 0.00001) return p1;
+    if (static_cast<double>(fabsf(v2)) < 0.00001) return p2;
+    if (static_cast<double>(fabsf(v1 - v2)) < 0.00001) return p1;
+    const float mu = -v1 / (v2 - v1);
+    const V3 d = v3(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z);  // p1 + mu * (p2 - p1)
+    return p1 + d * mu;
+}
+
+// corner i of cube (x, y, z) in the reference's numbering (TSDF.cu:896-903): x + (i ^ (i >> 1)) & 1,
+// z + (i >> 1) & 1, y + (i >> 2) & 1
+__device__ __forceinline__ void cube_corner(int i, int& dx, int& dy, int& dz) {
+    dx = ((i & 1) ^ ((i >> 1) & 1));
+    dz = (i >> 1) & 1;
+    dy = (i >> 2) & 1;
+}
+
+struct MeshStatsArgs {
+    MeshSource src;
+    unsigned* scratch;
+    int pass;
+};
+
+__global__ __launch_bounds__(kLcBlock) void k_stats_hist_mesh(const MeshStatsArgs a) {
+    __shared__ unsigned hist[6][256];
+    for (int i = threadIdx.x; i < 6 * 256; i += kLcBlock) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const I3 n = a.src.n;
+    const size_t cubes = static_cast<size_t>(n.x - 1) * (n.y - 1) * (n.z - 1);
+    const int shift = 24 - 8 * a.pass;
+    const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
+    const V3 half = half_extent(n);
+    unsigned local = 0;
+    for (size_t c = static_cast<size_t>(blockIdx.x) * kLcBlock + threadIdx.x; c < cubes;
+         c += static_cast<size_t>(gridDim.x) * kLcBlock) {
+        const int x = static_cast<int>(c % (n.x - 1));
+        const size_t r = c / (n.x - 1);
+        const int y = static_cast<int>(r % (n.y - 1)), z = static_cast<int>(r / (n.y - 1));
+        const size_t base = static_cast<size_t>(z) * sz + static_cast<size_t>(y) * sy + x;
+        float val[8];
+        V3 ps[8];
+        bool valid = true;
+        unsigned cls = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int dx, dy, dz;
+            cube_corner(i, dx, dy, dz);
+            const size_t idx = base + dx + dy * sy + dz * sz;
+            valid = valid && a.src.weights[idx] > 0.f && (!a.src.fg || a.src.fg[idx] != 0);
+            val[i] = a.src.tsdf[idx];
+            cls |= (val[i] < 0.f ? 1u : 0u) << i;
+            // ( x + 1 - ( volSize.x - 1 ) / 2.f ) * voxelSize  (TSDF.cu:945-968)
+            ps[i] = v3((static_cast<float>(x + dx) - half.x) * a.src.voxelSize,
+                       (static_cast<float>(y + dy) - half.y) * a.src.voxelSize,
+                       (static_cast<float>(z + dz) - half.z) * a.src.voxelSize);
+        }
+        if (!valid || cls == 0u || cls == 255u) continue;
+        constexpr int e0[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3};
+        constexpr int e1[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            if ((((cls >> e0[e]) ^ (cls >> e1[e])) & 1u) == 0u) continue;  // = bit e of edgeTable[cls]
+            const V3 p = vertex_interp(ps[e0[e]], ps[e1[e]], val[e0[e]], val[e1[e]]);
+            ++local;
+            const unsigned key[3] = {order_key(p.x), order_key(p.y), order_key(p.z)};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const unsigned k = key[s >> 1];
+                const bool match = a.pass == 0 || (k >> (shift + 8)) == a.scratch[1 + s];
+                if (match) atomicAdd(&hist[s][(k >> shift) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * 256; i += kLcBlock) {
+        const unsigned v = (&hist[0][0])[i];
+        if (v) atomicAdd(&a.scratch[kHistBase + i], v);
+    }
+    if (a.pass == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+        if ((threadIdx.x & 63) == 0 && local) atomicAdd(&a.scratch[0], local);
+    }
+}
+
+// ---- kernel_copyValues (TSDF.cu:768-819) as a gather over the destination --------------------------
+// dst(x', y', z') = src(x' + off) where that lies inside the source, else 0: the same result as the
+// reference's setTo(0) + scatter, in one pass and without a separate clear.
+struct CopyArgs {
+    const float* src;
+    float* dst;
+    int channels;
+    I3 off, srcRes, dstRes;
+};
+
+__global__ __launch_bounds__(kLcBlock) void k_copy_values(const CopyArgs a) {
+    const size_t total = static_cast<size_t>(a.dstRes.x) * a.dstRes.y * a.dstRes.z;
+    const size_t i = static_cast<size_t>(blockIdx.x) * kLcBlock + threadIdx.x;
+    if (i >= total) return;
+    const int x = static_cast<int>(i % a.dstRes.x);
+    const size_t r = i / a.dstRes.x;
+    const int y = static_cast<int>(r % a.dstRes.y), z = static_cast<int>(r / a.dstRes.y);
+    const int sx = x + a.off.x, sy = y + a.off.y, sz = z + a.off.z;  // x_new = x - offset
+    const bool in = sx >= 0 && sx < a.srcRes.x && sy >= 0 && sy < a.srcRes.y && sz >= 0 && sz < a.srcRes.z;
+    const size_t si = (static_cast<size_t>(sz) * a.srcRes.y + sy) * a.srcRes.x + sx;
+    for (int c = 0; c < a.channels; ++c) a.dst[i * a.channels + c] = in ? a.src[si * a.channels + c] : 0.f;
+}
+
 // one wave: pick, for each of the 6 selections, the bucket that holds the wanted rank; extend the
 // prefix, reduce the rank, clear the histograms for the next pass; after the last pass write the
 // result
@@ -272,9 +397,49 @@ extern "C" {
 
 size_t emf_hip_pointStatsScratchBytes(void) { return (kHistBase + 6 * 256) * sizeof(unsigned); }
 
+namespace {
+int point_stats(const emf_image_t* points, const emf_image_t* mask, const float R[9], const float t[3],
+                const MeshSource* mesh, void* scratch_dev, emf_point_stats_t* stats_dev,
+                emf_stream_t stream);
+}
+
 int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask, const float R[9],
                              const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
                              emf_stream_t stream) {
+    return point_stats(points, mask, R, t, nullptr, scratch_dev, stats_dev, stream);
+}
+
+int emf_hip_objectExtentStats(const emf_image_t* points, const emf_image_t* mask, const float R[9],
+                              const float t[3], const float* tsdf, const float* weights,
+                              const uint8_t* fgVolMask, const int32_t res[3], float voxelSize,
+                              void* scratch_dev, emf_point_stats_t* stats_dev, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(tsdf);
+    EMF_REQUIRE_PTR(weights);
+    EMF_TRY(check_res(res));
+    if (res[0] < 2 || res[1] < 2 || res[2] < 2) return fail(EMF_E_SHAPE, "objectExtentStats: volume too small");
+    MeshSource m{tsdf, weights, fgVolMask, i3_from(res), voxelSize};
+    return point_stats(points, mask, R, t, &m, scratch_dev, stats_dev, stream);
+}
+
+int emf_hip_copyValues(const float* src, float* dst, int channels, const int32_t offset[3],
+                       const int32_t srcRes[3], const int32_t dstRes[3], emf_stream_t stream) {
+    EMF_REQUIRE_PTR(src);
+    EMF_REQUIRE_PTR(dst);
+    EMF_REQUIRE_PTR(offset);
+    EMF_TRY(check_res(srcRes));
+    EMF_TRY(check_res(dstRes));
+    if (channels < 1 || channels > 3) return fail(EMF_E_ARG, "copyValues: %d channels", channels);
+    CopyArgs a{src, dst, channels, i3_from(offset), i3_from(srcRes), i3_from(dstRes)};
+    const size_t total = static_cast<size_t>(dstRes[0]) * dstRes[1] * dstRes[2];
+    hipLaunchKernelGGL(k_copy_values, dim3(static_cast<unsigned>(ceil_div(total, kLcBlock))), dim3(kLcBlock),
+                       0, as_stream(stream), a);
+    return launch_status("copyValues");
+}
+
+namespace {
+int point_stats(const emf_image_t* points, const emf_image_t* mask, const float R[9], const float t[3],
+                const MeshSource* mesh, void* scratch_dev, emf_point_stats_t* stats_dev,
+                emf_stream_t stream) {
     EMF_TRY(check_image(points, 12, "maskedPointStats: points"));
     EMF_TRY(check_image(mask, 1, "maskedPointStats: mask"));
     EMF_TRY(check_same_size(points, mask, "points", "mask"));
@@ -295,13 +460,26 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
     hipLaunchKernelGGL(k_stats_clear, dim3(1), dim3(256), 0, s, a.scratch);
     const size_t n = static_cast<size_t>(a.w) * a.h;
     const unsigned blocks = static_cast<unsigned>(ceil_div(n, kLcBlock * 4));
+    MeshStatsArgs ma{};
+    unsigned meshBlocks = 0;
+    if (mesh) {
+        ma.src = *mesh;
+        ma.scratch = a.scratch;
+        const size_t cubes = static_cast<size_t>(mesh->n.x - 1) * (mesh->n.y - 1) * (mesh->n.z - 1);
+        meshBlocks = static_cast<unsigned>(ceil_div(cubes, kLcBlock * 4));
+    }
     for (int pass = 0; pass < 4; ++pass) {
         a.pass = pass;
         hipLaunchKernelGGL(k_stats_hist, dim3(blocks), dim3(kLcBlock), 0, s, a);
+        if (mesh) {
+            ma.pass = pass;
+            hipLaunchKernelGGL(k_stats_hist_mesh, dim3(meshBlocks), dim3(kLcBlock), 0, s, ma);
+        }
         hipLaunchKernelGGL(k_stats_pick, dim3(1), dim3(64), 0, s, a);
     }
     return launch_status("maskedPointStats");
 }
+}  // namespace
 
 int emf_hip_carveMask(const emf_image_t* seg, const emf_image_t* modelSeg, int id,
                       const emf_image_t* matchMask, uint32_t* counts_dev, emf_stream_t stream) {

@@ -446,3 +446,23 @@ def carve_mask(seg, model_seg, obj_id, match_mask=None, stream=None):
                                _opt_view(match_mask), _ptr(counts), _stream(stream)))
     c = counts.numpy()
     return int(c[0]), int(c[1])
+
+
+def object_extent_stats(points, mask, R, t, tsdf, weights, fg_mask, voxel_size, stream=None):
+    """updateObj's statistics: masked points (R x + t) plus the object's iso-surface vertex cloud."""
+    scratch = DeviceArray.zeros((int(_L.emf_hip_pointStatsScratchBytes()) // 4,), np.uint32)
+    out = DeviceArray.zeros((7,), np.float32)
+    check("emf_hip_objectExtentStats",
+          _L.emf_hip_objectExtentStats(C.byref(image_view(points)), C.byref(image_view(mask)), _f(R, 9),
+                                       _f(t, 3), _ptr(tsdf), _ptr(weights), _ptr(fg_mask), _res(tsdf),
+                                       voxel_size, _ptr(scratch), _ptr(out), _stream(stream)))
+    raw = out.numpy()
+    return int(raw.view(np.uint32)[0]), raw[1:4].copy(), raw[4:7].copy()
+
+
+def copy_values(src, dst, offset, stream=None):
+    """dst(v) = src(v + offset) inside src, else 0 (kernel_copyValues); volumes (Nz, Ny, Nx[, C])."""
+    ch = 1 if len(src.shape) == 3 else src.shape[3]
+    check("emf_hip_copyValues",
+          _L.emf_hip_copyValues(_ptr(src), _ptr(dst), ch, (C.c_int32 * 3)(*[int(v) for v in offset]),
+                                _res(src), _res(dst), _stream(stream)))

@@ -392,6 +392,23 @@ int emf_hip_maskedPointStats(const emf_image_t* points, const emf_image_t* mask,
                              const float t[3], void* scratch_dev, emf_point_stats_t* stats_dev,
                              emf_stream_t stream);
 
+/* The statistics of EMFusion::updateObj (EMFusion.cpp:827-863): as emf_hip_maskedPointStats, but
+ * over the masked points (already transformed into the object's frame by R, t) TOGETHER WITH the
+ * vertex cloud of the object's marching-cubes mesh (TSDF.cu:855-1152, ObjTSDF.cpp:247-268): one
+ * vertex per sign-changing edge of every cube whose 8 voxels have weight > 0 (and fgVolMask != 0 if
+ * given), interpolated by vertexInterp.  The cloud does not depend on the triangle table, so no
+ * mesh is built: the vertices are streamed into the same radix select. */
+int emf_hip_objectExtentStats(const emf_image_t* points, const emf_image_t* mask, const float R[9],
+                              const float t[3], const float* tsdf, const float* weights,
+                              const uint8_t* fgVolMask, const int32_t res[3], float voxelSize,
+                              void* scratch_dev, emf_point_stats_t* stats_dev, emf_stream_t stream);
+
+/* Replaces emf::cuda::TSDF::copyValues (TSDF.cu:768-819) used by ObjTSDF::resize: dst (dstRes,
+ * `channels` floats per voxel) receives src shifted by `offset` voxels -- dst(v) = src(v + offset)
+ * inside the source, 0 elsewhere (the reference clears dst first; this call writes every voxel). */
+int emf_hip_copyValues(const float* src, float* dst, int channels, const int32_t offset[3],
+                       const int32_t srcRes[3], const int32_t dstRes[3], emf_stream_t stream);
+
 /* EMFusion::initObjsFromUnmatched's carving step (EMFusion.cpp:462-478): removes from the unmatched
  * instance mask `seg` (in place) the pixels the object `id` already claims -- its footprint in the
  * model segmentation, plus `matchMask` if a mask was matched to it (may be NULL) -- and counts the

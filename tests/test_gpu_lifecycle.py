@@ -259,3 +259,90 @@ def test_instance_masks_run_the_reference_control_flow(oracle, dev):
     assert (fus.volume("fgmask", 1) > 0).sum() > 50  # the matched masks were integrated
     fus.close()
     synth.close()
+
+
+# ---- updateObj / resize: iso-surface vertex cloud + points, copyValues ------------------------------
+
+def mesh_cloud(tsdf, weights, fg, voxel):
+    """Vertex cloud of the reference's marching cubes (TSDF.cu:855-1152, ObjTSDF.cpp:247-268) in numpy:
+    one vertex per sign-changing edge of every cube whose 8 voxels pass the mask, vertexInterp."""
+    f32 = np.float32
+    nz, ny, nx = tsdf.shape
+    ok = weights > 0 if fg is None else (weights > 0) & (fg != 0)
+    corner = [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)]  # dx, dy, dz
+    sub = lambda a, c: a[c[2]:nz - 1 + c[2], c[1]:ny - 1 + c[1], c[0]:nx - 1 + c[0]]
+    valid = np.ones((nz - 1, ny - 1, nx - 1), bool)
+    for c in corner:
+        valid &= sub(ok, c)
+    zz, yy, xx = np.meshgrid(np.arange(nz - 1), np.arange(ny - 1), np.arange(nx - 1), indexing="ij")
+    half = [f32(n - 1) / f32(2) for n in (nx, ny, nz)]
+    pos = lambda c: np.stack([(f32(1) * (xx + c[0]).astype(f32) - half[0]) * f32(voxel),
+                              ((yy + c[1]).astype(f32) - half[1]) * f32(voxel),
+                              ((zz + c[2]).astype(f32) - half[2]) * f32(voxel)], -1).astype(f32)
+    out = []
+    for a, b in [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]:
+        v1, v2 = sub(tsdf, corner[a]), sub(tsdf, corner[b])
+        sel = valid & ((v1 < 0) != (v2 < 0))
+        p1, p2, v1, v2 = pos(corner[a])[sel], pos(corner[b])[sel], v1[sel], v2[sel]
+        mu = (-v1 / (v2 - v1)).astype(f32)
+        p = (p1 + (mu[:, None] * (p2 - p1)).astype(f32)).astype(f32)
+        use1 = (np.abs(v1).astype(np.float64) < 1e-5)
+        use2 = ~use1 & (np.abs(v2).astype(np.float64) < 1e-5)
+        use3 = ~use1 & ~use2 & (np.abs(v1 - v2).astype(np.float64) < 1e-5)
+        p[use1 | use3] = p1[use1 | use3]
+        p[use2] = p2[use2]
+        out.append(p)
+    return np.concatenate(out) if out else np.zeros((0, 3), f32)
+
+
+def test_object_extent_stats_equal_mesh_cloud_plus_points(oracle, ops, dev):
+    from tests.scenes import rel_CO, rel_OC
+    f32 = np.float32
+    n, vox, pose = (32, 32, 32), 0.02, Pose(t=SPHERES[0][0])
+    tsdf, wts = np.zeros((32, 32, 32), f32), np.zeros((32, 32, 32), f32)
+    for i in range(3):
+        cam = camera_path(i)
+        depth, _ = render_depth(W, H, K, cam, SPHERES, noise=0.002, dropout=0.01, seed=70 + i)
+        oc = rel_OC(cam, pose)
+        oracle.update_tsdf(depth, np.ones((H, W), f32), tsdf, wts, oc.R32, oc.t32, K, vox, 10 * vox, 64.0)
+    rng = np.random.default_rng(4)
+    fg = (rng.uniform(size=tsdf.shape) < 0.9).astype(np.uint8) * 255
+    cam = camera_path(3)
+    depth, ids = render_depth(W, H, K, cam, SPHERES, noise=0.003, dropout=0.02, seed=74)
+    points = oracle.compute_points(depth, K)
+    mask = (ids == 1).astype(np.uint8)
+    co = rel_CO(cam, pose)
+    for fgm in (None, fg):
+        cloud = mesh_cloud(tsdf, wts, fgm, vox)
+        assert len(cloud) > 300
+        valid = (mask != 0) & np.any(points != 0, axis=2)
+        R = co.R32.reshape(3, 3)
+        p = points[valid]
+        q = np.stack([f32(f32(f32(R[i, 0] * p[:, 0]) + f32(R[i, 1] * p[:, 1])) + f32(R[i, 2] * p[:, 2])) + co.t32[i]
+                      for i in range(3)], -1).astype(f32)
+        allp = np.concatenate([q, cloud])
+        s = np.sort(allp, axis=0)
+        cnt = len(allp)
+        want10, want90 = s[int(f32(cnt) * f32(.1))], s[int(f32(cnt) * f32(.9))]
+        got_n, g10, g90 = ops.object_extent_stats(to_dev(points), to_dev(mask), co.R32, co.t32, to_dev(tsdf),
+                                                  to_dev(wts), None if fgm is None else to_dev(fgm), vox)
+        assert got_n == cnt
+        assert g10.tobytes() == want10.tobytes() and g90.tobytes() == want90.tobytes()
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_copy_values(ops, dev, channels):
+    rng = np.random.default_rng(6)
+    src = rng.standard_normal((6, 5, 8) if channels == 1 else (6, 5, 8, channels)).astype(np.float32)  # (Nz,Ny,Nx)
+    for off, dres in (((-2, 1, 0), (12, 6, 6)), ((3, -1, 2), (4, 8, 4)), ((0, 0, 0), (8, 5, 6))):
+        dshape = (dres[2], dres[1], dres[0]) + (() if channels == 1 else (channels,))
+        dst = dev_full(dshape, 7.0)
+        ops.copy_values(to_dev(src), dst, off)
+        want = np.zeros(dshape, np.float32)
+        for z in range(6):
+            for y in range(5):
+                for x in range(8):  # kernel_copyValues: x_new = x - offset
+                    xn, yn, zn = x - off[0], y - off[1], z - off[2]
+                    if 0 <= xn < dres[0] and 0 <= yn < dres[1] and 0 <= zn < dres[2]:
+                        want[zn, yn, xn] = src[z, y, x]
+        assert np.array_equal(dst.numpy(), want), (off, dres)
