@@ -279,6 +279,49 @@ __global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchA
                    lds);
 }
 
+// Models whose Nx is not a multiple of 4 (object volumes after ObjTSDF::resize, which only keeps the
+// resolution even) cannot use the float4 tiles: their voxels go one per lane, in 256-voxel chunks of
+// the linear index, with the same per-voxel code and the same device-side visibility gate.
+__global__ __launch_bounds__(256) void k_integrate_batched_linear(const IntegrateBatchArgs a) {
+    int m = 0;
+    while (m + 1 < a.nmodels && static_cast<int>(blockIdx.x) >= a.tileStart[m + 1]) ++m;
+    if (a.visible && a.visible[m] == 0) return;
+    const emf_model_t& md = a.models[m];
+    IntegrateGeom g;
+    g.depth = a.depth;
+    g.invLambda = a.invLambda;
+    g.assoc = Img<const float>{md.assoc, static_cast<size_t>(a.w) * sizeof(float)};
+    g.w = a.w;
+    g.h = a.h;
+    g.R = pose_R(a.poses.p[m]);
+    g.t = pose_t(a.poses.p[m]);
+    g.K = a.K;
+    g.pinhole = a.pinhole;
+    g.n = I3{md.res[0], md.res[1], md.res[2]};
+    g.voxelSize = md.voxelSize;
+    g.truncdist = md.truncdist;
+    g.maxWeight = md.maxWeight;
+    const size_t total = static_cast<size_t>(g.n.x) * g.n.y * g.n.z;
+    const int b = blockIdx.x - a.tileStart[m];
+    if (a.stats && b == 0 && threadIdx.x == 0) atomicAdd(a.stats, static_cast<unsigned long long>(total));
+    const size_t i = static_cast<size_t>(b) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t row = i / g.n.x;
+    const int x = static_cast<int>(i - row * g.n.x);
+    const int y = static_cast<int>(row % g.n.y), z = static_cast<int>(row / g.n.y);
+    float samp = 0.f, aw = 0.f;
+    const int kind = classify_voxel(g, half_extent(g.n), x, y, z, samp, aw);
+    if (kind == kSkip) return;
+    float wv = md.weights[i];
+    float tv = kind == kFuse ? md.tsdf[i] : 0.f;
+    const int changed = apply_voxel(kind, samp, aw, g.maxWeight, tv, wv);
+    if (changed & 1) md.tsdf[i] = tv;
+    if (changed & 2) md.weights[i] = wv;
+    if (md.brickFlags && (changed & 1))  // conservative, as in k_update_tsdf_linear
+        md.brickFlags[(static_cast<size_t>(z >> kBrickShift) * bricks_along(g.n.y) + (y >> kBrickShift)) *
+                          bricks_along(g.n.x) + (x >> kBrickShift)] = kBrickMixed;
+}
+
 // refresh the dilated flags of every model that has a flag buffer (one thread per brick)
 struct DilateBatchArgs {
     const emf_model_t* models;
@@ -423,19 +466,25 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
     }
     EMF_REQUIRE_PTR(K);
     IntegrateBatchArgs a;
+    int linStart[EMF_MAX_BATCH + 1];  // 256-voxel chunks of the models that cannot be tiled
     a.models = models_dev;
     a.nmodels = nmodels;
     a.tileStart[0] = 0;
+    linStart[0] = 0;
     for (int m = 0; m < nmodels; ++m) {
         const int32_t* r = res_host + 3 * m;
         EMF_TRY(check_res(r));
-        if (r[0] % 4 != 0)
-            return fail(EMF_E_SHAPE, "integrateBatched: model %d has Nx = %d, needs Nx %% 4 == 0 "
-                        "(use emf_hip_updateTSDF)", m, r[0]);
         a.poses.p[m] = poseOC_host[m];
-        a.tileStart[m + 1] = a.tileStart[m] + static_cast<int>(ceil_div(r[0], kTileX)) *
-                                                  static_cast<int>(ceil_div(r[1], kTileY)) *
-                                                  static_cast<int>(ceil_div(r[2], kTileZ));
+        const bool tiled = r[0] % 4 == 0;  // float4 tiles; otherwise one voxel per lane
+        const size_t voxels = static_cast<size_t>(r[0]) * r[1] * r[2];
+        if (!tiled && ceil_div(voxels, size_t(256)) > size_t(0x7fffffff) - linStart[m])
+            return fail(EMF_E_LIMIT, "integrateBatched: model %d (Nx = %d, not a multiple of 4) is too "
+                        "large for the one-voxel-per-lane launch", m, r[0]);
+        a.tileStart[m + 1] = a.tileStart[m] + (tiled ? static_cast<int>(ceil_div(r[0], kTileX)) *
+                                                           static_cast<int>(ceil_div(r[1], kTileY)) *
+                                                           static_cast<int>(ceil_div(r[2], kTileZ))
+                                                     : 0);
+        linStart[m + 1] = linStart[m] + (tiled ? 0 : static_cast<int>(ceil_div(voxels, size_t(256))));
     }
     a.visible = visible_dev;
     a.stats = reinterpret_cast<unsigned long long*>(stats);
@@ -445,8 +494,14 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
     a.h = depth->height;
     a.K = m33_from(K);
     a.pinhole = is_pinhole(a.K);
-    hipLaunchKernelGGL(k_integrate_batched, dim3(static_cast<unsigned>(a.tileStart[nmodels])),
-                       dim3(256), 0, as_stream(stream), a);
+    if (a.tileStart[nmodels] > 0)
+        hipLaunchKernelGGL(k_integrate_batched, dim3(static_cast<unsigned>(a.tileStart[nmodels])),
+                           dim3(256), 0, as_stream(stream), a);
+    if (linStart[nmodels] > 0) {
+        for (int m = 0; m <= nmodels; ++m) a.tileStart[m] = linStart[m];
+        hipLaunchKernelGGL(k_integrate_batched_linear, dim3(static_cast<unsigned>(linStart[nmodels])),
+                           dim3(256), 0, as_stream(stream), a);
+    }
     if (!maintainBrickFlags) return launch_status("integrateBatched");
     DilateBatchArgs d;
     d.models = models_dev;

@@ -243,12 +243,8 @@ void EMFusion::rebuildModelTable() {
         o.hitMask = im.modelSegmentation.ptr();
         modelsHost.push_back(o);
     }
-    bool tileable = true;
-    for (const auto& md : modelsHost) {
-        resHost.insert(resHost.end(), md.res, md.res + 3);
-        tileable &= md.res[0] % 4 == 0;
-    }
-    batched = !forceLegacy && tileable && gradMode == TSDF::Gradients::OnTheFly &&
+    for (const auto& md : modelsHost) resHost.insert(resHost.end(), md.res, md.res + 3);
+    batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly &&
               static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
     if (batched) {
         hipCheck(hipMemcpy(modelTable.data(), modelsHost.data(),
@@ -549,6 +545,8 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
     io::writePoseFile(dir + "/poses-cam.txt", poses);
     for (const auto& op : obj_poses)
         io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + ".txt", op.second);
+    for (const auto& op : addPoseOffsets(obj_poses, obj_pose_offsets))  // EMFusion.cpp:1000-1006
+        io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + "-corrected.txt", op.second);
     if (!volumes) return;
     const std::string t = dir + "/tsdfs";
     if (mkdir(t.c_str(), 0777) != 0 && errno != EEXIST)
@@ -636,9 +634,83 @@ std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& s
         matches[id] = segs[i];  // the reference inserts even id == -1; callers drop that key
         assigned[i] = id;
     }
-    for (auto& obj : objects)  // EMFusion.cpp:358-369 (updateObj / resize needs the mesh: not built)
-        obj.updateExProb(matches.count(obj.getID()) != 0);
+    bool resized = false;
+    for (auto& obj : objects) {  // EMFusion.cpp:358-369
+        auto it = matches.find(obj.getID());
+        if (it != matches.end()) {
+            const Vec3i before = obj.getVolumeRes();
+            const Vec3f offset = updateObj(obj, it->second);
+            if (poseLog) obj_pose_offsets[obj.getID()][frameCount] = offset;
+            resized |= offset[0] != 0.f || offset[1] != 0.f || offset[2] != 0.f ||
+                       before[0] != obj.getVolumeRes()[0];
+        }
+        obj.updateExProb(it != matches.end());
+    }
+    if (resized) rebuildModelTable();  // new buffers, new resolution, new pose
     return matches;
+}
+
+// Reference EMFusion::updateObj (EMFusion.cpp:827-863) without the class scores: percentiles of the
+// object's surface (the vertex cloud of its mesh) united with the newly matched points, in the
+// object's frame, decide whether the volume has to grow or move (ObjTSDF::resize).  No mesh is
+// built: emf_hip_objectExtentStats streams the marching-cubes vertices into the selection.
+Vec3f EMFusion::updateObj(ObjTSDF& obj, const emf_image_t& mask) {
+    ensureLifecycleBuffers();
+    if (maskedStats(mask, pose).count == 0) return Vec3f::all(0.f);  // no valid point under the mask
+    const Affine3f frame = obj.getPose().inv() * pose;
+    const emf_image_t pv = points.view();
+    const Vec3i res = obj.getVolumeRes();
+    emfCheck(emf_hip_objectExtentStats(&pv, &mask, frame.rotation().val, frame.translation().val,
+                                       obj.tsdfPtr(), obj.weightsPtr(), obj.fgVolMaskPtr(), res.val,
+                                       obj.getVoxelSize(), statsScratch.data(),
+                                       statsDev.as<emf_point_stats_t>(), main.abi()),
+             "objectExtentStats");
+    hipCheck(hipMemcpyAsync(lifecycleHost, statsDev.data(), sizeof(emf_point_stats_t),
+                            hipMemcpyDeviceToHost, main.get()),
+             "hipMemcpyAsync");
+    main.waitForCompletion();
+    const emf_point_stats_t s = *static_cast<emf_point_stats_t*>(lifecycleHost);
+    const Vec3f offset = obj.resize(Vec3f(s.p10[0], s.p10[1], s.p10[2]),
+                                    Vec3f(s.p90[0], s.p90[1], s.p90[2]), params.volPad, main);
+    // the pose may have moved with the volume centre (EMFusion.cpp:858-860)
+    if (poseLog) obj_poses[obj.getID()][frameCount] = obj.getPose();
+    return offset;
+}
+
+Vec3f EMFusion::updateObject(int id, const emf_image_t& mask) {
+    if (sharded) throw HipError("EMFusion::updateObject: not available on the sharded path", EMF_E_ARG);
+    for (auto& obj : objects)
+        if (obj.getID() == id) {
+            synchronize();
+            const Vec3f offset = updateObj(obj, mask);
+            if (poseLog) {  // several calls between two frames add up
+                Vec3f& logged = obj_pose_offsets[id][frameCount];
+                logged = logged + offset;
+            }
+            rebuildModelTable();
+            return offset;
+        }
+    throw HipError("EMFusion::updateObject: no object " + std::to_string(id), EMF_E_ARG);
+}
+
+// Reference EMFusion::addPoseOffsets (EMFusion.cpp:1220-1236): undo the accumulated centre shifts so
+// that the trajectory refers to the volume centre the object was created with.
+std::map<int, std::map<int, Affine3f>> EMFusion::addPoseOffsets(
+    const std::map<int, std::map<int, Affine3f>>& all,
+    const std::map<int, std::map<int, Vec3f>>& offsets) {
+    std::map<int, std::map<int, Affine3f>> cleaned;
+    for (const auto& op : all) {
+        Vec3f cum = Vec3f::all(0.f);
+        const auto off = offsets.find(op.first);
+        for (const auto& fp : op.second) {
+            if (off != offsets.end()) {
+                const auto o = off->second.find(fp.first);
+                if (o != off->second.end()) cum = cum - o->second;
+            }
+            cleaned[op.first][fp.first] = fp.second.translate(fp.second.rotation() * cum);
+        }
+    }
+    return cleaned;
 }
 
 void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989
@@ -716,7 +788,7 @@ Matx33f orthonormalised(const Matx33f& M) {
 void EMFusion::trackModels(int first, int count) {
     if (count <= 0) return;
     if (!batched)
-        throw HipError("EMFusion: tracking needs the batched path (<= 32 models, Nx % 4 == 0)",
+        throw HipError("EMFusion: tracking needs the batched path (<= 32 models, on-the-fly gradients)",
                        EMF_E_LIMIT);
     const int w = params.frameSize.width, h = params.frameSize.height;
     const size_t per = emf_hip_trackScratchBytes(w, h);

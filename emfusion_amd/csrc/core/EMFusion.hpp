@@ -111,12 +111,22 @@ public:
      */
     int matchSegmentation(const emf_image_t& mask, float& match_iou);
     /**
-     * Reference EMFusion::initOrMatchObjs (EMFusion.cpp:329-372) without the class-score and mesh
-     * parts: returns object id -> mask; `assigned[i]` = the id mask i ended up with (-1: none).
+     * Reference EMFusion::initOrMatchObjs (EMFusion.cpp:329-372) without the class scores:
+     * returns object id -> mask; `assigned[i]` = the id mask i ended up with (-1: none).
      */
     std::map<int, emf_image_t> initOrMatchObjs(std::vector<emf_image_t>& segs,
                                                std::vector<int>& assigned);
     const std::vector<int>& lastMaskAssignment() const { return lastAssigned; }
+    /**
+     * Reference EMFusion::updateObj (EMFusion.cpp:827-863): grow / recentre a matched object's
+     * volume around its surface and the newly matched points; returns the centre shift (0: none).
+     * updateObject(id, mask) is the stand-alone form (looks the object up, refreshes the model table).
+     */
+    Vec3f updateObj(ObjTSDF& obj, const emf_image_t& mask);
+    Vec3f updateObject(int id, const emf_image_t& mask);
+    static std::map<int, std::map<int, Affine3f>> addPoseOffsets(
+        const std::map<int, std::map<int, Affine3f>>& poses,
+        const std::map<int, std::map<int, Vec3f>>& offsets);
     /** Reference EMFusion::cleanUpObjs (EMFusion.cpp:922-980); returns the deleted ids. */
     std::vector<int> cleanUpObjs(bool maskFrame, const std::map<int, emf_image_t>& matches);
     const std::vector<int>& lastDeletedObjects() const { return lastDeleted; }
@@ -127,7 +137,8 @@ public:
     /**
      * Keep the camera / object poses of every processed frame (reference EMFusion::storePoses,
      * EMFusion.cpp:322-327) and write them and the volumes in the reference's formats:
-     * <dir>/poses-cam.txt, poses-<id>.txt (writePoses, EMFusion.cpp:991-999) and, with volumes,
+     * <dir>/poses-cam.txt, poses-<id>.txt, poses-<id>-corrected.txt (writePoses, EMFusion.cpp:991-1007)
+     * and, with volumes,
      * <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin (writeTSDFs, EMFusion.cpp:1187-1218).
      */
     void enablePoseLog(bool on) { poseLog = on; }
@@ -264,6 +275,7 @@ private:
     bool poseLog = false;
     std::map<int, Affine3f> poses;                    // frame -> camera pose
     std::map<int, std::map<int, Affine3f>> obj_poses;  // id -> frame -> pose
+    std::map<int, std::map<int, Vec3f>> obj_pose_offsets;  // id -> frame -> centre shift of resize()
     DeviceBuffer massDev;
     void deleteObj(int id);
     void ensureLifecycleBuffers();

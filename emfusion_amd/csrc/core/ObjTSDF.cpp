@@ -1,6 +1,9 @@
 // ObjTSDF.cpp -- emf::ObjTSDF over the emf_hip_* C ABI (see ObjTSDF.hpp).
 #include "ObjTSDF.hpp"
 
+#include <algorithm>
+#include <cmath>
+
 namespace emf {
 
 int ObjTSDF::nextID = 0;
@@ -72,6 +75,58 @@ void ObjTSDF::computeFgProbs(Stream& stream) {
     emfCheck(emf_hip_computeFgProbs(fgBgProbs.as<float>(), fgProbs.as<float>(),
                                     fgVolMask.as<uint8_t>(), volumeRes.val, stream.abi()),
              "ObjTSDF::computeFgProbs");
+}
+
+Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& stream) {
+    Vec3f half;  // corners of the voxel-centre box, ObjTSDF.cpp:82-87
+    for (int i = 0; i < 3; ++i) half[i] = (static_cast<float>(volumeRes[i]) - 1.f) * .5f * voxelSize;
+    bool contained = true;
+    for (int i = 0; i < 3 && contained; ++i) contained = !(p10[i] < -half[i] || p90[i] > half[i]);
+    if (contained) return Vec3f::all(0.f);
+
+    Vec3f newCenter = (p10 + p90) / 2.f;
+    const Vec3f centerVox = newCenter / voxelSize;
+    Vec3i pixOffset;  // cv::Vec3f -> cv::Vec3i rounds to nearest even (cvRound)
+    for (int i = 0; i < 3; ++i) pixOffset[i] = static_cast<int>(std::lrintf(centerVox[i]));
+    for (int i = 0; i < 3; ++i) newCenter[i] = static_cast<float>(pixOffset[i]) * voxelSize;
+    pose = pose.translate(pose.rotation() * newCenter);
+
+    const Vec3f dims = p90 - p10;
+    const float newVolSize = volPad * std::max(dims[0], std::max(dims[1], dims[2])) / voxelSize;
+    const int n = (static_cast<int>(std::ceil(newVolSize)) + 1) / 2 * 2;  // next even >= size
+    const Vec3i newRes = Vec3i::all(n);
+    if (n < 2) throw HipError("ObjTSDF::resize: degenerate extent", EMF_E_ARG);
+    for (int i = 0; i < 3; ++i) pixOffset[i] -= (newRes[i] - volumeRes[i]) / 2;
+
+    const size_t nv = static_cast<size_t>(n) * n * n;
+    DeviceBuffer newVol(nv * sizeof(float)), newWeights(nv * sizeof(float)),
+        newFgBg(nv * 2 * sizeof(float));
+    auto shift = [&](const DeviceBuffer& src, DeviceBuffer& dst, int channels) {
+        emfCheck(emf_hip_copyValues(src.as<float>(), dst.as<float>(), channels, pixOffset.val,
+                                    volumeRes.val, newRes.val, stream.abi()),
+                 "ObjTSDF::resize");
+    };
+    shift(tsdfVol, newVol, 1);
+    shift(tsdfWeights, newWeights, 1);
+    shift(fgBgProbs, newFgBg, 2);
+    DeviceBuffer newGrads;
+    if (gradMode == Gradients::Materialized) {
+        newGrads = DeviceBuffer(nv * 3 * sizeof(float));
+        shift(tsdfGrads, newGrads, 3);
+    }
+    stream.waitForCompletion();  // the old buffers are released below
+    tsdfVol = std::move(newVol);
+    tsdfWeights = std::move(newWeights);
+    tsdfGrads = std::move(newGrads);
+    fgBgProbs = std::move(newFgBg);
+    volumeRes = newRes;
+    fgProbs = DeviceBuffer(nv * sizeof(float));
+    fgVolMask = DeviceBuffer(nv);
+    const size_t nb = static_cast<size_t>((n + 3) / 4) * ((n + 3) / 4) * ((n + 3) / 4);
+    brickFlags = DeviceBuffer(2 * nb);
+    brickFlags.setZero(stream);  // every brick "mixed": always correct; integrate() refines them
+    computeFgProbs(stream);
+    return newCenter;
 }
 
 void ObjTSDF::describe(emf_model_t& m) const {

@@ -2,9 +2,9 @@
 //
 // Keeps the per-frame surface of the reference's emf::ObjTSDF (reference
 // include/EMFusion/core/ObjTSDF.h:40-216, src/core/ObjTSDF.cpp:167-226): integrateMask,
-// computeAssociation (foreground-weighted), raycast (foreground-masked weights), computeFgProbs
-// and the getters.  resize() and the existence / class-probability bookkeeping belong to the
-// object lifecycle and are not part of this build.
+// computeAssociation (foreground-weighted), raycast (foreground-masked weights), computeFgProbs,
+// the getters, resize() (ObjTSDF.cpp:80-165) and the existence bookkeeping.  Class probabilities
+// (Mask R-CNN scores) are outside the path.
 #pragma once
 
 #include "TSDF.hpp"
@@ -52,6 +52,15 @@ public:
 
     /** fgProbs = fg / (fg + bg), fgVolMask = fgProbs > 0.5 (reference ObjTSDF.cpp:218-226). */
     void computeFgProbs(Stream& stream = Stream::Null());
+
+    /**
+     * Grow / recentre the volume when the 10th / 90th percentile box [p10, p90] (volume frame) leaves
+     * it (reference ObjTSDF::resize, ObjTSDF.cpp:80-165): new centre = box centre snapped to the
+     * voxel grid, new cubic resolution = next even integer >= volPad * longest side / voxelSize,
+     * contents shifted with emf_hip_copyValues, pose translated by R * newCentre.  Returns the
+     * centre shift in the old volume frame (0 if the box was contained and nothing changed).
+     */
+    Vec3f resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& stream = Stream::Null());
 
     std::vector<float> getFgProbVol();
     std::vector<uint8_t> getFgVolMask();

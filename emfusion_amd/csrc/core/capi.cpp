@@ -225,6 +225,16 @@ int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id,
     return guarded([&] { *id = h->impl->matchSegmentation(*mask, *iou); });
 }
 
+int emf_fusion_update_object(emf_fusion_t* h, int id, const emf_image_t* mask, float offset[3]) {
+    REQ(h);
+    REQ(mask);
+    REQ(offset);
+    return guarded([&] {
+        const emf::Vec3f o = h->impl->updateObject(id, *mask);
+        for (int i = 0; i < 3; ++i) offset[i] = o[i];
+    });
+}
+
 int emf_fusion_enable_pose_log(emf_fusion_t* h, int on) {
     REQ(h);
     return guarded([&] { h->impl->enablePoseLog(on != 0); });

@@ -43,7 +43,12 @@ inline Vec3f operator-(const Vec3f& a, const Vec3f& b) {
 }
 inline Vec3f operator-(const Vec3f& a) { return Vec3f(-a[0], -a[1], -a[2]); }
 inline Vec3f operator*(const Vec3f& a, float f) { return Vec3f(a[0] * f, a[1] * f, a[2] * f); }
-inline Vec3f operator/(const Vec3f& a, float f) { return Vec3f(a[0] / f, a[1] / f, a[2] / f); }
+// cv::Vec / float multiplies by the reciprocal (opencv2/core/matx.hpp, Matx_ScaleOp with 1.f / alpha):
+// the same rounding is needed where the reference's host code divides a vector
+inline Vec3f operator/(const Vec3f& a, float f) {
+    const float r = 1.f / f;
+    return Vec3f(a[0] * r, a[1] * r, a[2] * r);
+}
 
 // Row-major 3x3, same memory as cv::Matx33f.
 struct Matx33f {

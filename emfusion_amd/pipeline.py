@@ -105,6 +105,7 @@ def load() -> C.CDLL:
         "emf_fusion_last_deleted": [vp, ip, C.c_int, ip],
         "emf_fusion_create_object_from_mask": [vp, img, ip],
         "emf_fusion_match_mask": [vp, img, ip, fp],
+        "emf_fusion_update_object": [vp, C.c_int, img, fp],
         "emf_fusion_queue_new_object_masks": [vp, C.c_int, img],
         "emf_fusion_last_created": [vp, ip, C.c_int, ip],
         "emf_fusion_queue_instance_masks": [vp, C.c_int, img],
@@ -323,6 +324,13 @@ class Fusion:
         _check("emf_fusion_match_mask",
                load().emf_fusion_match_mask(self._h, C.byref(mask_view), C.byref(i), C.byref(iou)))
         return i.value, iou.value
+
+    def update_object(self, obj_id: int, mask_view: EmfImage):
+        """EMFusion::updateObj + ObjTSDF::resize; returns the centre shift (zeros: unchanged)."""
+        off = (C.c_float * 3)()
+        _check("emf_fusion_update_object",
+               load().emf_fusion_update_object(self._h, int(obj_id), C.byref(mask_view), off))
+        return np.array(list(off), np.float32)
 
     def enable_pose_log(self, on=True):
         _check("emf_fusion_enable_pose_log", load().emf_fusion_enable_pose_log(self._h, int(on)))

@@ -107,6 +107,11 @@ int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* m
 int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);
+/* EMFusion::updateObj + ObjTSDF::resize (EMFusion.cpp:827-863, ObjTSDF.cpp:80-165) for one object and
+ * one mask of the current frame's points: the volume grows / recentres if the 10th..90th percentile
+ * box of (surface vertices + masked points) leaves it.  offset: the centre shift in the old volume
+ * frame (all 0: nothing changed).  process_frame does this for every matched instance mask. */
+int emf_fusion_update_object(emf_fusion_t* h, int id, const emf_image_t* mask, float offset[3]);
 /* From the next frame on, run the reference's cleanUpObjs at the end of every frame (delete objects
  * that are not visible, whose association mass does not fit their mask, or -- on mask frames --
  * whose existence probability is low); last_deleted lists the ids the last frame removed. */

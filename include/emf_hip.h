@@ -300,7 +300,9 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera
  *   res_host    : HOST int32[nmodels * 3], the resolutions stored in the table (the launch grid is
- *                 sized from them); every model needs Nx % 4 == 0
+ *                 sized from them).  Models with Nx % 4 == 0 run on 32x8x8 float4 tiles; others (an
+ *                 object after ObjTSDF::resize is only guaranteed an even Nx) run one voxel per
+ *                 lane in a second launch of the same call -- same arithmetic, same gate
  *   visible_dev : NULL, or device int32[nmodels]; models with visible_dev[m] == 0 are skipped
  *                 (EMFusion.cpp:869-872) -- evaluated on the device, no host round trip
  * Each model's `assoc` map weights its fusion; brickFlags are kept consistent when present.

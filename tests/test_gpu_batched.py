@@ -296,6 +296,63 @@ def test_integrate_batched_matches_per_model_calls_and_honours_gate(ops, oracle,
     assert int(to_np(stats)[0]) == expect_vox
 
 
+def test_integrate_batched_mixes_tiled_and_untiled_models(ops, oracle, dev):
+    # an object resized by ObjTSDF::resize only has an even Nx: it rides in the same call on the
+    # one-voxel-per-lane launch, wherever it sits in the table
+    models = [Model(ops, oracle, (34, 34, 34), 0.025, Pose(t=SPHERES[1][0]), True, 1),
+              Model(ops, oracle, (64, 64, 64), 0.04, Pose(t=[0, 0, 1.28]), False, 0),
+              Model(ops, oracle, (30, 22, 18), 0.03, Pose(rot([0, 1, 0], 5), SPHERES[0][0]), True, 2),
+              Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True, 3),
+              Model(ops, oracle, (33, 31, 35), 0.025, Pose(t=SPHERES[1][0]), True, 4)]
+    for m in models:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    rng = np.random.default_rng(21)
+    visible = dev_full((5,), 1, np.int32)
+    stats = dev_full((1,), 0, np.uint64)
+    expect_vox = 0
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        gate = [1, 1, 0 if i == 1 else 1, 1, 0 if i == 2 else 1]
+        visible.copy_from(np.array(gate, np.int32))
+        mtab = ops.upload_models([m.table_entry() for m in models])
+        poses = []
+        for m, g in zip(models, gate):
+            assoc = rng.uniform(0, 1, (H, W)).astype(np.float32)
+            m.d_assoc.copy_from(assoc)
+            oc = rel_OC(cam, m.pose)
+            poses.append((oc.R32, oc.t32))
+            if g:
+                oracle.update_tsdf(depth, assoc, m.tsdf, m.wts, oc.R32, oc.t32, K, m.vox, m.trunc,
+                                   MAXW)
+                expect_vox += m.tsdf.size
+        ops.integrate_batched(mtab, poses, [m.res for m in models], visible, to_dev(depth), K, stats)
+        dev.synchronize()
+    for m in models:
+        assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
+        assert_parity(to_np(m.d_wts), m.wts, f"weights model {m.id}", exact=True)
+        want, got = brick_classes(m.tsdf), to_np(m.d_flags)
+        if m.res[0] % 4 == 0:
+            check_flags(got, m.tsdf, f"model {m.id}")
+        else:
+            assert np.all((got[0] == want) | (got[0] == 0))
+    assert int(to_np(stats)[0]) == expect_vox
+    # a table of untiled models only: the tiled launch is skipped
+    only = [models[0], models[2]]
+    cam, depth, _ = frame(3)
+    mtab = ops.upload_models([m.table_entry() for m in only])
+    poses = []
+    for m in only:
+        assoc = np.ones((H, W), np.float32)
+        m.d_assoc.copy_from(assoc)
+        oc = rel_OC(cam, m.pose)
+        poses.append((oc.R32, oc.t32))
+        oracle.update_tsdf(depth, assoc, m.tsdf, m.wts, oc.R32, oc.t32, K, m.vox, m.trunc, MAXW)
+    ops.integrate_batched(mtab, poses, [m.res for m in only], None, to_dev(depth), K, None)
+    dev.synchronize()
+    for m in only:
+        assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
+
+
 def test_visibility_flags(ops, dev):
     counts = to_dev(np.array([1601, 1600, 0, 99999], np.int32))
     vis = dev_full((5,), -1, np.int32)
@@ -313,7 +370,3 @@ def test_batched_argument_checks(ops, dev):
     with pytest.raises(EmfHipError) as e:
         ops.estep_batched(table, [(np.eye(3), np.zeros(3))], pts, normalize=False)
     assert e.value.code == -1  # objSum required
-    with pytest.raises(EmfHipError) as e:
-        ops.integrate_batched(table, [(np.eye(3), np.zeros(3))], [(30, 22, 18)], None,
-                              dev_full((H, W), 1.0), K)
-    assert e.value.code == -2  # Nx % 4

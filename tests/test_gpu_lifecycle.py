@@ -346,3 +346,131 @@ def test_copy_values(ops, dev, channels):
                     if 0 <= xn < dres[0] and 0 <= yn < dres[1] and 0 <= zn < dres[2]:
                         want[zn, yn, xn] = src[z, y, x]
         assert np.array_equal(dst.numpy(), want), (off, dres)
+
+
+def f32_transform(R, t, p):
+    f32 = np.float32
+    return np.stack([f32(f32(f32(R[i, 0] * p[:, 0]) + f32(R[i, 1] * p[:, 1])) + f32(R[i, 2] * p[:, 2])) + t[i]
+                     for i in range(3)], -1).astype(f32)
+
+
+def expected_resize(res, vox, p10, p90, vol_pad=2.0):
+    """ObjTSDF::resize (ObjTSDF.cpp:80-165) in float32 numpy: (new centre, new res, voxel offset) or None."""
+    f32 = np.float32
+    half = (np.array(res, f32) - f32(1)) * f32(.5) * f32(vox)
+    if not (np.any(p10 < -half) or np.any(p90 > half)):
+        return None
+    center = (p10 + p90) * f32(.5)
+    pix = np.rint(center * (f32(1) / f32(vox))).astype(np.int32)  # cvRound: half to even
+    center = pix.astype(f32) * f32(vox)
+    size = f32(f32(vol_pad) * np.max(p90 - p10)) / f32(vox)
+    n = (int(np.ceil(size)) + 1) // 2 * 2
+    return center, n, pix - (n - np.array(res, np.int32)) // 2
+
+
+def shifted(src, off, n):
+    """copyValues: dst(v) = src(v + off) inside the source, 0 elsewhere; arrays are (z, y, x[, c])."""
+    dst = np.zeros((n, n, n) + src.shape[3:], src.dtype)
+    sz, sy, sx = src.shape[:3]
+    lo = [max(0, -o) for o in off]                          # first dst index with a source
+    hi = [min(n, s - o) for o, s in zip(off, (sx, sy, sz))]  # one past the last
+    if all(h > l for l, h in zip(lo, hi)):
+        dst[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]] = \
+            src[lo[2] + off[2]:hi[2] + off[2], lo[1] + off[1]:hi[1] + off[1], lo[0] + off[0]:hi[0] + off[0]]
+    return dst
+
+
+def test_matched_object_outgrows_its_volume_and_is_resized(oracle, dev, tmp_path):
+    """updateObj + ObjTSDF::resize against a numpy restatement, then one more frame on the resized
+    (Nx % 4 != 0 allowed) volume against the oracle's integration."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    f32 = np.float32
+    Wf, Hf = 320, 240
+    prm = pipeline.make_params(Wf, Hf, 128, 0.04, 32, visibility_thresh=100, boundary=10)
+    Kf = np.array(prm.K, np.float32).reshape(3, 3)
+    synth = pipeline.SyntheticStream(Wf, Hf, Kf, 2, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    fus.enable_pose_log(True)
+    keep = []
+    depth, sid = synth.render(0)
+    ys, xs = np.nonzero(sid == 1)
+    cy, cx = int(ys.mean()), int(xs.mean())
+    patch = np.zeros((Hf, Wf), np.uint8)
+    patch[cy - 6:cy + 6, cx - 6:cx + 6] = 1
+    patch &= (sid == 1).astype(np.uint8)
+    centre = None
+    for f in range(3):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        d, full = to_dev(depth), to_dev((sid == 1).astype(np.uint8))
+        keep += [d, full]
+        if f == 0:
+            pm = to_dev(patch)
+            keep.append(pm)
+            fus.queue_new_object_masks([image_view(pm)])
+            fus.process_frame(image_view(d), R, t, {}, {}, True)
+            assert fus.last_created() == [1]
+            centre = fus.pose(1)[1]
+            continue
+        fus.process_frame(image_view(d), R, t, {1: (np.eye(3, dtype=f32).reshape(-1), centre)},
+                          {1: image_view(full)}, True)
+    fus.synchronize()
+    assert 1 in fus.visible_objects()
+    before = {k: fus.volume(k, 1) for k in ("tsdf", "weights", "fgprobs", "fgmask")}
+    res = before["tsdf"].shape[::-1]
+    assert res == (32, 32, 32)
+    pts = oracle.compute_points(depth, Kf.reshape(-1))
+    depth0, _ = synth.render(0)
+    R0, t0 = synth.camera_pose(0)
+    n0, w10, w90 = sorted_stats(oracle.compute_points(depth0, Kf.reshape(-1)), patch, R0.reshape(3, 3), t0)
+    vox = f32(f32(2) * np.max(w90 - w10)) / f32(32)  # EMFusion.cpp:535-547
+    # expected percentiles: surface vertices of the volume + masked points, object frame
+    Ro, to = fus.pose(1)
+    Rc, tc = R.reshape(3, 3).astype(f32), t.astype(f32)
+    assert np.array_equal(Ro, np.eye(3, dtype=f32))
+    rel_t = (tc + (-to)).astype(f32)
+    mask = (sid == 1).astype(np.uint8)
+    valid = (mask != 0) & np.any(pts != 0, axis=2)
+    allp = np.concatenate([f32_transform(Rc, rel_t, pts[valid]),
+                           mesh_cloud(before["tsdf"], before["weights"], before["fgmask"], vox)])
+    s = np.sort(allp, axis=0)
+    p10, p90 = s[int(f32(len(allp)) * f32(.1))], s[int(f32(len(allp)) * f32(.9))]
+    want = expected_resize(res, vox, p10, p90)
+    assert want is not None, ("the scenario must outgrow the volume", p10, p90, vox, len(allp), int(valid.sum()))
+    centre_shift, n, off = want
+    got_shift = fus.update_object(1, image_view(full))
+    assert got_shift.tobytes() == centre_shift.astype(f32).tobytes()
+    after = {k: fus.volume(k, 1) for k in ("tsdf", "weights", "fgprobs", "fgmask")}
+    assert after["tsdf"].shape == (n, n, n) and n > 32
+    for k in after:
+        assert np.array_equal(after[k], shifted(before[k], off, n)), k
+    assert (after["weights"] > 0).sum() == (before["weights"] > 0).sum() > 0  # nothing was cropped here
+    Rn, tn = fus.pose(1)
+    assert np.array_equal(Rn, Ro) and tn.tobytes() == (to + centre_shift).astype(f32).tobytes()
+    assert not np.any(fus.update_object(1, image_view(full)))  # contained now: no second resize
+    # the next frame runs on the resized volume (batched path, any Nx) and integrates like the oracle
+    depth, sid = synth.render(3)
+    R, t = synth.camera_pose(3)
+    d, full = to_dev(depth), to_dev((sid == 1).astype(np.uint8))
+    fus.process_frame(image_view(d), R, t, {1: (np.eye(3, dtype=f32).reshape(-1), tn)}, {1: image_view(full)}, True)
+    fus.synchronize()
+    assert 1 in fus.visible_objects()
+    tsdf, wts = after["tsdf"].copy(), after["weights"].copy()
+    assoc = fus.image("obj_assoc", 1)
+    Rc, tc = R.reshape(3, 3).astype(f32), t.astype(f32)
+    R_oc = Rc.T.copy()                       # camera^-1 * object pose, object rotation = identity
+    t_oc = (f32_transform(R_oc, np.zeros(3, f32), tn[None])[0] + (-f32_transform(R_oc, np.zeros(3, f32), tc[None])[0])).astype(f32)
+    oracle.update_tsdf(depth, assoc, tsdf, wts, R_oc.reshape(-1), t_oc, Kf.reshape(-1), float(vox),
+                       float(f32(prm.obj_rel_truncdist) * vox), float(prm.max_tsdf_weight))
+    assert np.array_equal(fus.volume("weights", 1), wts)
+    assert np.array_equal(fus.volume("tsdf", 1), tsdf)
+    # pose files: raw trajectory jumps with the centre, the corrected one does not
+    fus.write_results(str(tmp_path), volumes=False)
+    raw = np.loadtxt(tmp_path / "poses-1.txt")
+    cor = np.loadtxt(tmp_path / "poses-1-corrected.txt")
+    assert raw.shape == cor.shape and raw.shape[0] >= 3
+    assert np.allclose(cor[:, 1:4], raw[0, 1:4], atol=1e-5)
+    assert np.abs(raw[-1, 1:4] - raw[0, 1:4]).max() > 1e-3
+    fus.close()
+    synth.close()
