@@ -71,6 +71,9 @@ SIGNATURES = {
     "emf_hip_carveMask": [_IMG, _IMG, C.c_int, _IMG, _FP, _STREAM],
     "emf_hip_objectExtentStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _STREAM],
     "emf_hip_copyValues": [_FP, _FP, C.c_int, _I3, _I3, _I3, _STREAM],
+    "emf_hip_meshScratchBytes": [_I3],
+    "emf_hip_meshCount": [_FP, _FP, _FP, _I3, _FP, _FP, _STREAM],
+    "emf_hip_meshEmit": [_FP, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _FP, _FP, _STREAM],
     "emf_hip_trackScratchBytes": [C.c_int, C.c_int],
     "emf_hip_trackPrepare": [_FP, _FP, C.c_int, C.c_float, _STREAM],
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
@@ -155,6 +158,7 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.emf_hip_trackScratchBytes.restype = C.c_size_t
     lib.emf_hip_pointStatsScratchBytes.restype = C.c_size_t
+    lib.emf_hip_meshScratchBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

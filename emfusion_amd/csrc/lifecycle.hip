@@ -12,7 +12,7 @@
 // sorted copy.  The selected values are elements of the data, so the result is bit-identical to
 // sorting.  matchSegmentation's per-object compare / and / or / countNonZero chain (two host
 // round trips per object) is one kernel that counts intersection and union for all objects.
-#include "common.hpp"
+#include "mesh_core.hpp"
 
 namespace emf_hip {
 namespace {
@@ -91,32 +91,6 @@ __global__ __launch_bounds__(kLcBlock) void k_stats_hist(const StatsArgs a) {
 // whose end points differ in sign (popcount of edgeTable[class]), interpolated by vertexInterp --
 // the triangle table only decides connectivity.  So the cloud needs no mesh: each cube streams its
 // edge vertices into the same histograms.
-
-struct MeshSource {
-    const float* tsdf;
-    const float* weights;
-    const uint8_t* fg;  // fgVolMask or nullptr
-    I3 n;
-    float voxelSize;
-};
-
-__device__ __forceinline__ V3 vertex_interp(const V3& p1, const V3& p2, float v1, float v2) {
-    // TSDF.cu:909-920; the comparisons are against the double literal 0.00001
-    if (static_cast<double>(fabsf(v1)) < 0.00001) return p1;
-    if (static_cast<double>(fabsf(v2)) < 0.00001) return p2;
-    if (static_cast<double>(fabsf(v1 - v2)) < 0.00001) return p1;
-    const float mu = -v1 / (v2 - v1);
-    const V3 d = v3(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z);  // p1 + mu * (p2 - p1)
-    return p1 + d * mu;
-}
-
-// corner i of cube (x, y, z) in the reference's numbering (TSDF.cu:896-903): x + (i ^ (i >> 1)) & 1,
-// z + (i >> 1) & 1, y + (i >> 2) & 1
-__device__ __forceinline__ void cube_corner(int i, int& dx, int& dy, int& dz) {
-    dx = ((i & 1) ^ ((i >> 1) & 1));
-    dz = (i >> 1) & 1;
-    dy = (i >> 2) & 1;
-}
 
 struct MeshStatsArgs {
     MeshSource src;

@@ -1,0 +1,302 @@
+// meshing.hip -- marching cubes over a TSDF volume: the mesh that
+// TSDF::getMesh / ObjTSDF::getMesh hand to the PLY writer (reference TSDF.cu:855-1152,
+// TSDF.cpp:356-373, ObjTSDF.cpp:247-268).
+//
+// The reference classifies every cube into three N^3-sized buffers (class u8, vertex count i32,
+// triangle count i32 -- 9 bytes per voxel, 1.2 GB for the 512^3 background), sums them, runs two
+// device-wide thrust::exclusive_scan passes over them and reads them back in the emit kernel.
+// Here nothing per cube is stored: a 256-cube workgroup recomputes the class from the TSDF in both
+// passes (the volume is read twice, 8 + 8 bytes per voxel in total, mostly from L2 the second time
+// for object volumes) and only ONE pair of counters per workgroup goes through memory:
+//   k_mesh_count   per workgroup: sum of vertices / triangles of its 256 cubes  -> blockSums[b]
+//   k_mesh_scan    one workgroup: exclusive scan of blockSums in place, totals  -> counts
+//   k_mesh_emit    class again, exclusive scan inside the workgroup (wave shuffles + LDS) on top of
+//                  blockSums[b]: vertices, normals, triangles land where the reference puts them
+// The output is element-for-element the reference's: cubes in (z, y, x) order, a cube's vertices
+// in edge-bit order, triangles as (3, i0, i1, i2) in table order.  Normals are the interpolated RAW
+// gradients: the reference's `ns[i] /= norm(ns[i])` and `normals[..] /= norm(..)` call an
+// operator/= that takes its left side by const reference and returns the quotient (common.cuh:170-173),
+// so nothing is normalised (quirk Q19).
+#include "mesh_core.hpp"
+
+#include "mc_tables.h"
+
+namespace emf_hip {
+namespace {
+
+constexpr int kMcBlock = 256;
+
+struct MeshArgs {
+    MeshSource src;
+    const float* grads;  // N^3 x 3 gradient volume, or nullptr: forward differences on the fly
+    uint2* blockSums;    // per workgroup (vertices, triangles); after k_mesh_scan their exclusive scan
+    emf_mesh_counts_t* counts;
+    float* vertices;
+    float* normals;
+    int32_t* triangles;
+    unsigned nblocks;
+};
+
+struct Cube {
+    int x, y, z;
+    size_t base;
+    unsigned cls;  // 0 when the cube is masked out or carries no surface
+};
+
+__device__ __forceinline__ Cube classify(const MeshSource& s, size_t c, size_t cubes) {
+    Cube q{0, 0, 0, 0, 0u};
+    if (c >= cubes) return q;
+    const I3 n = s.n;
+    q.x = static_cast<int>(c % (n.x - 1));
+    const size_t r = c / (n.x - 1);
+    q.y = static_cast<int>(r % (n.y - 1));
+    q.z = static_cast<int>(r / (n.y - 1));
+    const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
+    q.base = static_cast<size_t>(q.z) * sz + static_cast<size_t>(q.y) * sy + q.x;
+    bool valid = true;  // kernel_classifyCubes: all 8 corners observed (and foreground)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int dx, dy, dz;
+        cube_corner(i, dx, dy, dz);
+        const size_t idx = q.base + dx + dy * sy + dz * sz;
+        valid = valid && s.weights[idx] > 0.f && (!s.fg || s.fg[idx] != 0);
+    }
+    if (!valid) return q;
+    unsigned cls = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int dx, dy, dz;
+        cube_corner(i, dx, dy, dz);
+        cls |= (s.tsdf[q.base + dx + dy * sy + dz * sz] < 0.f ? 1u : 0u) << i;
+    }
+    q.cls = cls == 255u ? 0u : cls;
+    return q;
+}
+
+__device__ __forceinline__ unsigned triangles_of(unsigned cls) {
+    unsigned n = 0;
+    while (n < 5 && emf_mc_tri_table[cls][3 * n] >= 0) ++n;
+    return n;
+}
+
+// sums over the workgroup (all lanes get the totals) and the exclusive prefix of this lane
+__device__ __forceinline__ uint2 block_scan(uint2 v, uint2& total, uint2* lds /* [8] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned ax = __shfl_up(inc.x, o), ay = __shfl_up(inc.y, o);
+        if (lane >= o) {
+            inc.x += ax;
+            inc.y += ay;
+        }
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint2 before = make_uint2(0u, 0u);
+    total = make_uint2(0u, 0u);
+#pragma unroll
+    for (int w = 0; w < kMcBlock / 64; ++w) {
+        const uint2 t = lds[w];
+        if (w < wave) {
+            before.x += t.x;
+            before.y += t.y;
+        }
+        total.x += t.x;
+        total.y += t.y;
+    }
+    __syncthreads();
+    return make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
+}
+
+__global__ __launch_bounds__(kMcBlock) void k_mesh_count(const MeshArgs a) {
+    __shared__ uint2 lds[8];
+    const size_t cubes = static_cast<size_t>(a.src.n.x - 1) * (a.src.n.y - 1) * (a.src.n.z - 1);
+    const Cube q = classify(a.src, static_cast<size_t>(blockIdx.x) * kMcBlock + threadIdx.x, cubes);
+    uint2 v = make_uint2(0u, 0u);
+    if (q.cls) v = make_uint2(__popc(active_edges(q.cls)), triangles_of(q.cls));
+    uint2 total;
+    block_scan(v, total, lds);
+    if (threadIdx.x == 0) a.blockSums[blockIdx.x] = total;
+}
+
+// one workgroup walks the per-workgroup sums in chunks of 1024 (a 512^3 volume has 0.5 M of them)
+__global__ __launch_bounds__(1024) void k_mesh_scan(const MeshArgs a) {
+    __shared__ uint2 lds[16];
+    __shared__ uint2 carry;
+    if (threadIdx.x == 0) carry = make_uint2(0u, 0u);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned start = 0; start < a.nblocks; start += 1024) {
+        const unsigned i = start + threadIdx.x;
+        const uint2 v = i < a.nblocks ? a.blockSums[i] : make_uint2(0u, 0u);
+        uint2 inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned ax = __shfl_up(inc.x, o), ay = __shfl_up(inc.y, o);
+            if (lane >= o) {
+                inc.x += ax;
+                inc.y += ay;
+            }
+        }
+        if (lane == 63) lds[wave] = inc;
+        __syncthreads();
+        uint2 before = carry, total = make_uint2(0u, 0u);
+        for (int w = 0; w < 16; ++w) {
+            const uint2 t = lds[w];
+            if (w < wave) {
+                before.x += t.x;
+                before.y += t.y;
+            }
+            total.x += t.x;
+            total.y += t.y;
+        }
+        if (i < a.nblocks) a.blockSums[i] = make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry.x += total.x;
+            carry.y += total.y;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.counts->vertices = carry.x;
+        a.counts->triangles = carry.y;
+    }
+}
+
+// gradient of the corner voxel: the gradient volume if there is one, else what
+// kernel_computeTSDFGrads would have stored there (forward differences, zero on the last planes)
+__device__ __forceinline__ V3 corner_gradient(const MeshArgs& a, size_t idx, int x, int y, int z) {
+    if (a.grads) return v3(a.grads[3 * idx], a.grads[3 * idx + 1], a.grads[3 * idx + 2]);
+    const I3 n = a.src.n;
+    if (x >= n.x - 1 || y >= n.y - 1 || z >= n.z - 1) return v3(0.f, 0.f, 0.f);
+    const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
+    const float t = a.src.tsdf[idx];
+    return v3(a.src.tsdf[idx + 1] - t, a.src.tsdf[idx + sy] - t, a.src.tsdf[idx + sz] - t);
+}
+
+__global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
+    __shared__ uint2 lds[8];
+    const I3 n = a.src.n;
+    const size_t cubes = static_cast<size_t>(n.x - 1) * (n.y - 1) * (n.z - 1);
+    const Cube q = classify(a.src, static_cast<size_t>(blockIdx.x) * kMcBlock + threadIdx.x, cubes);
+    const unsigned edges = q.cls ? active_edges(q.cls) : 0u;
+    uint2 v = make_uint2(0u, 0u);
+    if (q.cls) v = make_uint2(__popc(edges), triangles_of(q.cls));
+    uint2 total;
+    const uint2 mine = block_scan(v, total, lds);
+    if (!q.cls) return;
+    const uint2 blockBase = a.blockSums[blockIdx.x];
+    const unsigned vertBase = blockBase.x + mine.x;
+    const unsigned triBase = 4u * (blockBase.y + mine.y);  // (3, i0, i1, i2) per triangle
+    const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
+    const V3 half = half_extent(n);
+    int offsets[12];
+    unsigned k = 0;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        offsets[e] = 0;
+        if (!((edges >> e) & 1u)) continue;
+        V3 p[2], g[2];
+        float val[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            int dx, dy, dz;
+            cube_corner(emf_mc_edge_corner[e][s], dx, dy, dz);
+            const size_t idx = q.base + dx + dy * sy + dz * sz;
+            val[s] = a.src.tsdf[idx];
+            // ( x + 1 - ( volSize.x - 1 ) / 2.f ) * voxelSize  (TSDF.cu:945-968)
+            p[s] = v3((static_cast<float>(q.x + dx) - half.x) * a.src.voxelSize,
+                      (static_cast<float>(q.y + dy) - half.y) * a.src.voxelSize,
+                      (static_cast<float>(q.z + dz) - half.z) * a.src.voxelSize);
+            g[s] = corner_gradient(a, idx, q.x + dx, q.y + dy, q.z + dz);
+        }
+        const V3 pv = vertex_interp(p[0], p[1], val[0], val[1]);
+        const V3 nv = vertex_interp(g[0], g[1], val[0], val[1]);  // not normalised: Q19
+        float* vo = a.vertices + 3 * static_cast<size_t>(vertBase + k);
+        float* no = a.normals + 3 * static_cast<size_t>(vertBase + k);
+        vo[0] = pv.x;
+        vo[1] = pv.y;
+        vo[2] = pv.z;
+        no[0] = nv.x;
+        no[1] = nv.y;
+        no[2] = nv.z;
+        offsets[e] = static_cast<int>(k++);
+    }
+    for (unsigned t = 0; t < v.y; ++t) {
+        int32_t* to = a.triangles + triBase + 4 * t;
+        to[0] = 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = emf_mc_tri_table[q.cls][3 * t + j];
+            int o = 0;  // offsets[e] without a dynamically indexed register array
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o = e == i ? offsets[i] : o;
+            to[1 + j] = static_cast<int32_t>(vertBase) + o;
+        }
+    }
+}
+
+int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_t* fg,
+              const int32_t res[3], float voxelSize, void* scratch) {
+    EMF_REQUIRE_PTR(tsdf);
+    EMF_REQUIRE_PTR(weights);
+    EMF_REQUIRE_PTR(scratch);
+    EMF_TRY(check_res(res));
+    const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
+    if ((cubes + kMcBlock - 1) / kMcBlock > 0x7fffffffull)
+        return fail(EMF_E_LIMIT, "mesh: %zu cubes exceed one launch", cubes);
+    a.src = MeshSource{tsdf, weights, fg, i3_from(res), voxelSize};
+    a.grads = nullptr;
+    a.blockSums = static_cast<uint2*>(scratch);
+    a.counts = nullptr;
+    a.vertices = a.normals = nullptr;
+    a.triangles = nullptr;
+    a.nblocks = static_cast<unsigned>((cubes + kMcBlock - 1) / kMcBlock);
+    return EMF_OK;
+}
+
+}  // namespace
+}  // namespace emf_hip
+
+using namespace emf_hip;
+
+extern "C" {
+
+size_t emf_hip_meshScratchBytes(const int32_t res[3]) {
+    if (!res || res[0] < 2 || res[1] < 2 || res[2] < 2) return 0;
+    const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
+    return ((cubes + kMcBlock - 1) / kMcBlock) * sizeof(uint2);
+}
+
+int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fgVolMask,
+                      const int32_t res[3], void* scratch_dev, emf_mesh_counts_t* counts_dev,
+                      emf_stream_t stream) {
+    MeshArgs a;
+    EMF_TRY(fill_args(a, tsdf, weights, fgVolMask, res, 1.f, scratch_dev));
+    EMF_REQUIRE_PTR(counts_dev);
+    a.counts = counts_dev;
+    hipLaunchKernelGGL(k_mesh_count, dim3(a.nblocks), dim3(kMcBlock), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(1024), 0, as_stream(stream), a);
+    return launch_status("meshCount");
+}
+
+int emf_hip_meshEmit(const float* tsdf, const float* grads, const float* weights,
+                     const uint8_t* fgVolMask, const int32_t res[3], float voxelSize,
+                     const void* scratch_dev, float* vertices, float* normals, int32_t* triangles,
+                     emf_stream_t stream) {
+    MeshArgs a;
+    EMF_TRY(fill_args(a, tsdf, weights, fgVolMask, res, voxelSize, const_cast<void*>(scratch_dev)));
+    EMF_REQUIRE_PTR(vertices);
+    EMF_REQUIRE_PTR(normals);
+    EMF_REQUIRE_PTR(triangles);
+    a.grads = grads;
+    a.vertices = vertices;
+    a.normals = normals;
+    a.triangles = triangles;
+    hipLaunchKernelGGL(k_mesh_emit, dim3(a.nblocks), dim3(kMcBlock), 0, as_stream(stream), a);
+    return launch_status("meshEmit");
+}
+
+}  // extern "C"

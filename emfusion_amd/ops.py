@@ -460,6 +460,26 @@ def object_extent_stats(points, mask, R, t, tsdf, weights, fg_mask, voxel_size, 
     return int(raw.view(np.uint32)[0]), raw[1:4].copy(), raw[4:7].copy()
 
 
+def extract_mesh(tsdf, weights, voxel_size, fg_mask=None, grads=None, stream=None):
+    """TSDF::getMesh / ObjTSDF::getMesh: (vertices (n, 3) f32, normals (n, 3) f32, triangles (m, 4) i32)
+    as numpy arrays; two launches to count, one read-back, one launch to emit."""
+    res = _res(tsdf)
+    scratch = DeviceArray.zeros((max(int(_L.emf_hip_meshScratchBytes(res)) // 4, 2),), np.uint32)
+    counts = DeviceArray.zeros((2,), np.uint32)
+    check("emf_hip_meshCount",
+          _L.emf_hip_meshCount(_ptr(tsdf), _ptr(weights), _ptr(fg_mask), res, _ptr(scratch), _ptr(counts),
+                               _stream(stream)))
+    nv, nt = (int(v) for v in counts.numpy())
+    verts = DeviceArray.zeros((max(nv, 1), 3), np.float32)
+    norms = DeviceArray.zeros((max(nv, 1), 3), np.float32)
+    tris = DeviceArray.zeros((max(nt, 1), 4), np.int32)
+    if nv:
+        check("emf_hip_meshEmit",
+              _L.emf_hip_meshEmit(_ptr(tsdf), _ptr(grads), _ptr(weights), _ptr(fg_mask), res, voxel_size,
+                                  _ptr(scratch), _ptr(verts), _ptr(norms), _ptr(tris), _stream(stream)))
+    return verts.numpy()[:nv], norms.numpy()[:nv], tris.numpy()[:nt]
+
+
 def copy_values(src, dst, offset, stream=None):
     """dst(v) = src(v + offset) inside src, else 0 (kernel_copyValues); volumes (Nz, Ny, Nx[, C])."""
     ch = 1 if len(src.shape) == 3 else src.shape[3]

@@ -411,6 +411,39 @@ int emf_hip_objectExtentStats(const emf_image_t* points, const emf_image_t* mask
 int emf_hip_copyValues(const float* src, float* dst, int channels, const int32_t offset[3],
                        const int32_t srcRes[3], const int32_t dstRes[3], emf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Meshes: cuda::TSDF::marchingCubes (TSDF.cu:855-1152) behind
+ * TSDF::getMesh / ObjTSDF::getMesh (TSDF.cpp:356-373, ObjTSDF.cpp:247-268)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct emf_mesh_counts {
+    uint32_t vertices;  /* = mesh.cloud.cols */
+    uint32_t triangles; /* = mesh.polygons.cols / 4 */
+} emf_mesh_counts_t;
+
+/* Bytes of device scratch the two calls below share for a volume of this resolution (8 bytes per
+ * 256 cubes; the reference keeps 9 bytes per cube in cubeClasses / vertIdxBuffer / triIdxBuffer). */
+size_t emf_hip_meshScratchBytes(const int32_t res[3]);
+
+/* Pass 1 -- kernel_classifyCubes + the two sums + the two exclusive scans: counts the vertices and
+ * triangles of the iso-surface over the cubes whose 8 voxels all have weights > 0 (and
+ * fgVolMask != 0 when given: ObjTSDF::getMesh), and leaves the per-workgroup offsets in scratch.
+ * counts_dev: device memory; read it back, allocate the outputs, then call emf_hip_meshEmit with
+ * the same volume and the same scratch. */
+int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fgVolMask,
+                      const int32_t res[3], void* scratch_dev, emf_mesh_counts_t* counts_dev,
+                      emf_stream_t stream);
+
+/* Pass 2 -- kernel_createTriangles: vertices and normals (3 floats each per vertex, volume frame)
+ * and triangles (4 int32 each: 3, i0, i1, i2), element for element what the reference's mesh
+ * holds.  grads: the N^3 x 3 gradient volume, or NULL to take the same forward differences on the
+ * fly.  Normals are the interpolated gradients as they are -- the reference's normalisations are
+ * no-ops (common.cuh:170-173). */
+int emf_hip_meshEmit(const float* tsdf, const float* grads, const float* weights,
+                     const uint8_t* fgVolMask, const int32_t res[3], float voxelSize,
+                     const void* scratch_dev, float* vertices, float* normals, int32_t* triangles,
+                     emf_stream_t stream);
+
 /* EMFusion::initObjsFromUnmatched's carving step (EMFusion.cpp:462-478): removes from the unmatched
  * instance mask `seg` (in place) the pixels the object `id` already claims -- its footprint in the
  * model segmentation, plus `matchMask` if a mask was matched to it (may be NULL) -- and counts the

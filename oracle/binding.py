@@ -246,3 +246,23 @@ def preprocess_depth(raw, ksz=7, sigma_depth=0.04, sigma_spatial=4.5, fma=False)
     lib(fma).orc_preprocessDepth(_p(raw), w, h, int(ksz), C.c_float(sigma_depth),
                                  C.c_float(sigma_spatial), _p(out))
     return out
+
+
+# ---- f-4: marching cubes -----------------------------------------------------------------------
+
+def marching_cubes(tsdf, weights, voxel_size, fg=None, grads=None, fma=False):
+    """(vertices (n, 3), normals (n, 3), triangles (m, 4)) of the reference's mesh."""
+    t, w = _c(tsdf), _c(weights)
+    nz, ny, nx = t.shape
+    res = (C.c_int * 3)(nx, ny, nz)
+    fgp = None if fg is None else _c(fg, np.uint8)
+    gp = None if grads is None else _c(grads)
+    nv, nt = C.c_int(), C.c_int()
+    L = lib(fma)
+    L.orc_marchingCubesCount(_p(t), _p(w), None if fgp is None else _p(fgp), res, C.byref(nv), C.byref(nt))
+    v = np.empty((nv.value, 3), np.float32)
+    n = np.empty((nv.value, 3), np.float32)
+    tri = np.empty((nt.value, 4), np.int32)
+    L.orc_marchingCubes(_p(t), None if gp is None else _p(gp), _p(w), None if fgp is None else _p(fgp),
+                        res, C.c_float(voxel_size), _p(v), _p(n), _p(tri))
+    return v, n, tri

@@ -635,3 +635,117 @@ void orc_preprocessDepth(const float* raw, int w, int h, int ksz, float sigmaDep
             out[(size_t)y * w + x] = o;
         }
 }
+
+/* ==== f-4: marching cubes (cuda::TSDF::marchingCubes, TSDF.cu:855-1152) ========================= */
+
+/* the lookup table is shared with the device code (a data table, checked against the digest of the
+ * reference's in tests/test_mc_tables.py); everything else below is restated independently */
+#include "../emfusion_amd/csrc/mc_tables.h"
+
+static inline int mc_edge_bits(int cls) { /* edgeTable[cls]: bit e set iff edge e changes sign */
+    int m = 0;
+    for (int e = 0; e < 12; ++e)
+        m |= (((cls >> emf_mc_edge_corner[e][0]) ^ (cls >> emf_mc_edge_corner[e][1])) & 1) << e;
+    return m;
+}
+
+/* corner i of the cube at (x, y, z): the reference indexes tsdf(y_ + dy + Ny * dz, x + dx) with
+ * (dx, dy, dz) = 0:(0,0,0) 1:(1,0,0) 2:(1,0,1) 3:(0,0,1) 4:(0,1,0) 5:(1,1,0) 6:(1,1,1) 7:(0,1,1) */
+static const int mc_dx[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+static const int mc_dy[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+static const int mc_dz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+
+/* kernel_classifyCubes (TSDF.cu:872-907): 0 for masked-out cubes (the buffers are pre-zeroed) */
+static int mc_classify(const float* tsdf, const float* weights, const uint8_t* fg, const int res[3],
+                       int x, int y, int z) {
+    const size_t sy = (size_t)res[0], sz = sy * res[1];
+    const size_t base = (size_t)z * sz + (size_t)y * sy + x;
+    for (int i = 0; i < 8; ++i) { /* mask = weights > 0 [& fgVolMask] */
+        const size_t idx = base + ((i >> 2) & 1) * sz + ((i >> 1) & 1) * sy + (i & 1);
+        if (!(weights[idx] > 0.f) || (fg && !fg[idx])) return 0;
+    }
+    int cls = 0;
+    for (int i = 0; i < 8; ++i)
+        cls |= (tsdf[base + mc_dx[i] + mc_dy[i] * sy + mc_dz[i] * sz] < 0.f) << i;
+    return cls;
+}
+
+static v3 mc_interp(v3 p1, v3 p2, float v1, float v2) { /* vertexInterp, TSDF.cu:909-920 */
+    if (fabs(v1) < 0.00001) return p1;
+    if (fabs(v2) < 0.00001) return p2;
+    if (fabs(v1 - v2) < 0.00001) return p1;
+    const float mu = -v1 / (v2 - v1);
+    return add3(p1, scale3(mk(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z), mu));
+}
+
+void orc_marchingCubesCount(const float* tsdf, const float* weights, const uint8_t* fg,
+                            const int res[3], int* numVerts, int* numTris) {
+    int nv = 0, nt = 0;
+    for (int z = 0; z < res[2] - 1; ++z)
+        for (int y = 0; y < res[1] - 1; ++y)
+            for (int x = 0; x < res[0] - 1; ++x) {
+                const int cls = mc_classify(tsdf, weights, fg, res, x, y, z);
+                for (int m = mc_edge_bits(cls); m; m >>= 1) nv += m & 1; /* countVerts */
+                for (int i = 0; emf_mc_tri_table[cls][i] != -1; i += 3) ++nt; /* countTris */
+            }
+    *numVerts = nv;
+    *numTris = nt;
+}
+
+/* kernel_createTriangles (TSDF.cu:922-1108) over the cubes in buffer order (z, y, x), which is the
+ * order the exclusive scans assign.  grads: N^3 x 3 gradient volume, or NULL for the values
+ * kernel_computeTSDFGrads would have stored.  The normals are NOT normalised: `ns[i] /= norm(ns[i])`
+ * and `normals[..] /= norm(..)` call operator/=(const float3&, float), which returns the quotient
+ * and leaves its left side alone (common.cuh:170-173). */
+void orc_marchingCubes(const float* tsdf, const float* grads, const float* weights,
+                       const uint8_t* fg, const int res[3], float voxelSize, float* vertices,
+                       float* normals, int* triangles) {
+    const size_t sy = (size_t)res[0], sz = sy * res[1];
+    int vertBase = 0, triBase = 0;
+    for (int z = 0; z < res[2] - 1; ++z)
+        for (int y = 0; y < res[1] - 1; ++y)
+            for (int x = 0; x < res[0] - 1; ++x) {
+                const int cls = mc_classify(tsdf, weights, fg, res, x, y, z);
+                const int edges = mc_edge_bits(cls);
+                if (edges == 0) continue;
+                const size_t base = (size_t)z * sz + (size_t)y * sy + x;
+                v3 ps[8], ns[8];
+                float vals[8];
+                for (int i = 0; i < 8; ++i) {
+                    const int cx = x + mc_dx[i], cy = y + mc_dy[i], cz = z + mc_dz[i];
+                    const size_t idx = base + mc_dx[i] + mc_dy[i] * sy + mc_dz[i] * sz;
+                    ps[i] = mk(((float)cx - (float)(res[0] - 1) / 2.f) * voxelSize,
+                               ((float)cy - (float)(res[1] - 1) / 2.f) * voxelSize,
+                               ((float)cz - (float)(res[2] - 1) / 2.f) * voxelSize);
+                    if (grads)
+                        ns[i] = mk(grads[3 * idx], grads[3 * idx + 1], grads[3 * idx + 2]);
+                    else if (cx < res[0] - 1 && cy < res[1] - 1 && cz < res[2] - 1)
+                        ns[i] = mk(tsdf[idx + 1] - tsdf[idx], tsdf[idx + sy] - tsdf[idx],
+                                   tsdf[idx + sz] - tsdf[idx]);
+                    else
+                        ns[i] = mk(0.f, 0.f, 0.f);
+                    vals[i] = tsdf[idx];
+                }
+                int offsets[12], offset = 0;
+                for (int e = 0; e < 12; ++e) {
+                    if (!((edges >> e) & 1)) continue;
+                    const int a = emf_mc_edge_corner[e][0], b = emf_mc_edge_corner[e][1];
+                    const v3 p = mc_interp(ps[a], ps[b], vals[a], vals[b]);
+                    const v3 n = mc_interp(ns[a], ns[b], vals[a], vals[b]);
+                    float* vo = vertices + 3 * (size_t)(vertBase + offset);
+                    float* no = normals + 3 * (size_t)(vertBase + offset);
+                    vo[0] = p.x; vo[1] = p.y; vo[2] = p.z;
+                    no[0] = n.x; no[1] = n.y; no[2] = n.z;
+                    offsets[e] = offset++;
+                }
+                int j = 0;
+                for (int i = 0; emf_mc_tri_table[cls][i] != -1; i += 3, j += 4) {
+                    triangles[triBase + j] = 3;
+                    triangles[triBase + j + 1] = vertBase + offsets[emf_mc_tri_table[cls][i]];
+                    triangles[triBase + j + 2] = vertBase + offsets[emf_mc_tri_table[cls][i + 1]];
+                    triangles[triBase + j + 3] = vertBase + offsets[emf_mc_tri_table[cls][i + 2]];
+                }
+                vertBase += offset;
+                triBase += j;
+            }
+}

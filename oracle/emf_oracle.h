@@ -126,6 +126,14 @@ double orc_trackingError(const float* tsdfVals, const float* intWeights, int n);
 void orc_preprocessDepth(const float* raw, int w, int h, int ksz, float sigmaDepth,
                          float sigmaSpatial, float* out);
 
+/* ---- f-4: cuda::TSDF::marchingCubes (TSDF.cu:855-1152) behind TSDF::getMesh / ObjTSDF::getMesh ---
+ * mask = weights > 0 [& fg != 0]; vertices / normals: 3 floats per vertex, triangles: 4 ints each. */
+void orc_marchingCubesCount(const float* tsdf, const float* weights, const uint8_t* fg,
+                            const int res[3], int* numVerts, int* numTris);
+void orc_marchingCubes(const float* tsdf, const float* grads, const float* weights,
+                       const uint8_t* fg, const int res[3], float voxelSize, float* vertices,
+                       float* normals, int* triangles);
+
 #ifdef __cplusplus
 }
 #endif
