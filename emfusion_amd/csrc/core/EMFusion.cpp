@@ -555,6 +555,11 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
         io::writeVolume(t + "/" + name + ".bin", v.data(), sizeof(float), vol.getVolumeRes(),
                         vol.getVoxelSize());
     };
+    // writeMeshes (EMFusion.cpp:1147-1156): the background, the live objects, and the objects that
+    // were deleted while the log was on (their last mesh, EMFusion.cpp:966)
+    io::writeMesh(dir + "/mesh_bg.ply", background.getMesh());
+    for (auto& obj : objects) meshes[obj.getID()] = obj.getMesh();
+    for (const auto& m : meshes) io::writeMesh(dir + "/mesh_" + std::to_string(m.first) + ".ply", m.second);
     dump("bg_tsdf", background.getTSDF(), background);
     for (auto& obj : objects) {
         const std::string id = std::to_string(obj.getID());
@@ -751,6 +756,7 @@ std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_i
             deleted.push_back(id);
             synchronize();  // nothing in flight may still use the volume
             deleteObj(id);
+            if (poseLog) meshes[id] = it->getMesh();  // saveOutput: EMFusion.cpp:962-966
             it = objects.erase(it);
         } else {
             ++it;
@@ -877,6 +883,33 @@ void EMFusion::trackObjects() {
 const TrackResult* EMFusion::getTrackResult(int id) const {
     auto it = trackResults.find(id);
     return it == trackResults.end() ? nullptr : &it->second;
+}
+
+void EMFusion::render(uint8_t* rgb) {
+    if (sharded)
+        throw HipError("EMFusion::render: not available on the sharded path (vertices / normals of "
+                       "remote objects and background bands stay on their ranks)", EMF_E_ARG);
+    const size_t bytes = static_cast<size_t>(params.frameSize.area()) * 3;
+    if (frameCount < 1) {
+        std::fill(rgb, rgb + bytes, uint8_t{0});
+        return;
+    }
+    if (frameCount == 1) raycast();  // frame 0 ran without one (EMFusion.cpp:135-137)
+    if (image.empty()) image = DeviceImage<uint8_t, 3>(params.frameSize);
+    const emf_image_t vv = vertices.view(), nv = normals.view(), sv = modelSegmentation.view(),
+                      iv = image.view();
+    const float light[3] = {0.f, 0.f, 0.f};  // cv::Affine3f::Identity()
+    emfCheck(emf_hip_renderPhong(&vv, &nv, &sv, colorMap.data(), light, &iv, main.abi()), "renderPhong");
+    hipCheck(hipMemcpyAsync(rgb, image.ptr(), bytes, hipMemcpyDeviceToHost, main.get()), "render D2H");
+    main.waitForCompletion();
+}
+
+Mesh EMFusion::getMesh(int id) {
+    synchronize();
+    if (id == 0) return background.getMesh();
+    for (auto& o : objects)
+        if (o.getID() == id) return o.getMesh();
+    throw HipError("EMFusion::getMesh: no object " + std::to_string(id) + " on this rank", EMF_E_ARG);
 }
 
 const ObjTSDF* EMFusion::getObject(int id) const {

@@ -22,6 +22,7 @@
 #include "Communicator.hpp"
 #include "KernelTimers.hpp"
 #include "ObjTSDF.hpp"
+#include "Output.hpp"
 #include "TSDF.hpp"
 
 namespace emf {
@@ -138,7 +139,7 @@ public:
      * Keep the camera / object poses of every processed frame (reference EMFusion::storePoses,
      * EMFusion.cpp:322-327) and write them and the volumes in the reference's formats:
      * <dir>/poses-cam.txt, poses-<id>.txt, poses-<id>-corrected.txt (writePoses, EMFusion.cpp:991-1007)
-     * and, with volumes,
+     * and, with volumes, <dir>/mesh_bg.ply, mesh_<id>.ply (writeMeshes, EMFusion.cpp:1147-1156) and
      * <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin (writeTSDFs, EMFusion.cpp:1187-1218).
      */
     void enablePoseLog(bool on) { poseLog = on; }
@@ -147,6 +148,15 @@ public:
     const std::vector<int>& lastCreatedObjects() const { return lastCreated; }
     Affine3f getCameraPose() const { return pose; }
     const ObjTSDF* getObject(int id) const;
+    /**
+     * Phong rendering of the current model view (reference EMFusion::render, EMFusion.cpp:131-160,
+     * without the viz window): rgb = W x H x 3 bytes on the host.  Black before the first frame;
+     * after the first frame the models are raycast once for it, as in the reference.
+     */
+    void render(uint8_t* rgb);
+    const std::array<uint8_t, 768>& getColorMap() const { return colorMap; }
+    /** getMesh() of the background (id 0) or of an object held by this rank. */
+    Mesh getMesh(int id);
 
     /**
      * Create an object volume centred at `center` (world) with edge length `volSize` metres --
@@ -276,6 +286,9 @@ private:
     std::map<int, Affine3f> poses;                    // frame -> camera pose
     std::map<int, std::map<int, Affine3f>> obj_poses;  // id -> frame -> pose
     std::map<int, std::map<int, Vec3f>> obj_pose_offsets;  // id -> frame -> centre shift of resize()
+    std::array<uint8_t, 768> colorMap = io::randomColors();
+    DeviceImage<uint8_t, 3> image;  // rendering
+    std::map<int, Mesh> meshes;                            // id -> last mesh (deleted objects keep theirs)
     DeviceBuffer massDev;
     void deleteObj(int id);
     void ensureLifecycleBuffers();

@@ -129,6 +129,8 @@ Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& 
     return newCenter;
 }
 
+Mesh ObjTSDF::getMesh() { return extractMesh(fgVolMask.as<uint8_t>()); }
+
 void ObjTSDF::describe(emf_model_t& m) const {
     TSDF::describe(m);
     m.fgProbs = fgProbs.as<float>();

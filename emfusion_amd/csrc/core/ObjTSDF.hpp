@@ -62,6 +62,9 @@ public:
      */
     Vec3f resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& stream = Stream::Null());
 
+    /** Mesh of the foreground part only (reference ObjTSDF::getMesh, ObjTSDF.cpp:247-268). */
+    Mesh getMesh() override;
+
     std::vector<float> getFgProbVol();
     std::vector<uint8_t> getFgVolMask();
     std::vector<float> getFgBgCounts() const;

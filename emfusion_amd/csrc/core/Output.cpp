@@ -1,7 +1,9 @@
 #include "Output.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <fstream>
 #include <stdexcept>
 
@@ -73,6 +75,72 @@ void writePoseFile(const std::string& filename, const std::map<int, Affine3f>& p
     }
     f.close();
     if (!f.good()) throw std::runtime_error("emf::io::writePoseFile: error writing " + filename);
+}
+
+std::array<uint8_t, 768> randomColors() {
+    float rgb[256][3];
+    for (int i = 0; i < 256; ++i) {
+        // hsv = (i / 256 * 360, 1, 1); OpenCV's HSV2RGB_f with hrange 360: sector + fraction of h * 6 / 360
+        float h = i == 0 ? 0.f : (static_cast<float>(i) / 256.f) * 360.f;
+        const float s = i == 0 ? 0.f : 1.f, v = i == 0 ? 0.f : 1.f;
+        float r = v, g = v, b = v;
+        if (s != 0.f) {
+            static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+            h *= 6.f / 360.f;
+            while (h < 0.f) h += 6.f;
+            while (h >= 6.f) h -= 6.f;
+            int sector = static_cast<int>(std::floor(h));
+            h -= static_cast<float>(sector);
+            if (static_cast<unsigned>(sector) >= 6u) {
+                sector = 0;
+                h = 0.f;
+            }
+            const float tab[4] = {v, v * (1.f - s), v * (1.f - s * h), v * (1.f - s * (1.f - h))};
+            b = tab[sector_data[sector][0]];
+            g = tab[sector_data[sector][1]];
+            r = tab[sector_data[sector][2]];
+        }
+        rgb[i][0] = r;
+        rgb[i][1] = g;
+        rgb[i][2] = b;
+    }
+    std::array<uint8_t, 768> out{};
+    for (int i = 0; i < 256; ++i)
+        for (int c = 0; c < 3; ++c) {  // convertTo(CV_8U, 255): saturate_cast<uchar>(cvRound(x * 255))
+            const long q = std::lrintf(rgb[i][c] * 255.f);
+            out[3 * i + c] = static_cast<uint8_t>(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+    // cv::randShuffle(rgb, 1, &rng) with cv::RNG rng(6893): multiply-with-carry generator,
+    // for i in [0, n): swap(a[rng % n], a[i])
+    uint64_t state = 6893;
+    for (unsigned i = 0; i < 256; ++i) {
+        state = static_cast<uint64_t>(static_cast<uint32_t>(state)) * 4164903690ull + static_cast<uint32_t>(state >> 32);
+        const unsigned j = static_cast<uint32_t>(state) % 256u;
+        for (int c = 0; c < 3; ++c) std::swap(out[3 * j + c], out[3 * i + c]);
+    }
+    out[0] = out[1] = out[2] = 255;
+    return out;
+}
+
+void writeMesh(const std::string& filename, const Mesh& mesh) {
+    FILE* file = std::fopen(filename.c_str(), "w");
+    if (!file) throw std::runtime_error("Could not write ply file: " + filename);
+    const int nv = static_cast<int>(mesh.vertices()), nf = static_cast<int>(mesh.triangles());
+    std::fprintf(file,
+                 "ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                 "property float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+                 "element face %d\nproperty list uchar int vertex_index\nend_header\n",
+                 nv, nf);
+    for (int i = 0; i < nv; ++i) {
+        const float* v = &mesh.cloud[3 * static_cast<size_t>(i)];
+        const float* n = &mesh.normals[3 * static_cast<size_t>(i)];
+        std::fprintf(file, "%f %f %f %f %f %f\n", v[0], v[1], v[2], n[0], n[1], n[2]);
+    }
+    for (int i = 0; i < nf; ++i) {
+        const int32_t* t = &mesh.polygons[4 * static_cast<size_t>(i)];
+        std::fprintf(file, "%d %d %d %d\n", t[0], t[1], t[2], t[3]);
+    }
+    if (std::fclose(file) != 0) throw std::runtime_error("emf::io::writeMesh: error writing " + filename);
 }
 
 }  // namespace io

@@ -1,8 +1,10 @@
-// Output.hpp -- the reference's on-disk result formats that need no mesh:
+// Output.hpp -- the reference's on-disk result formats: PLY meshes
+// (EMFusion::writeMesh, EMFusion.cpp:1263-1300),
 // raw volume dumps (EMFusion::writeVolume, EMFusion.cpp:1302-1313) and TUM-style pose files
 // (EMFusion::writePoseFile / writePoses, EMFusion.cpp:991-1007, 1238-1254).  Host code only.
 #pragma once
 
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -29,6 +31,21 @@ void rotationToQuaternion(const Matx33f& R, float q[4]);
  * digits), frames in ascending order -- the TUM trajectory format of the reference's pose files.
  */
 void writePoseFile(const std::string& filename, const std::map<int, Affine3f>& poses);
+
+/**
+ * The label colours of the renderings (reference EMFusion::randomColors, EMFusion.cpp:614-633): 255
+ * fully saturated hues, converted with cv::cvtColor(COLOR_HSV2RGB), shuffled with
+ * cv::randShuffle(cv::RNG(6893)), label 0 white.  256 x RGB.  The two OpenCV routines are third-party
+ * code outside the reference tree, restated from their published algorithms (parity unpinned); the
+ * reference leaves hsv[0] uninitialised before the shuffle, it is black here.
+ */
+std::array<uint8_t, 768> randomColors();
+
+/**
+ * ASCII PLY as the reference writes it (EMFusion::writeMesh, EMFusion.cpp:1263-1300): vertices
+ * "x y z nx ny nz" with %f, faces "3 i0 i1 i2".
+ */
+void writeMesh(const std::string& filename, const Mesh& mesh);
 
 }  // namespace io
 }  // namespace emf

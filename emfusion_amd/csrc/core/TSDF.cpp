@@ -1,6 +1,7 @@
 // TSDF.cpp -- emf::TSDF over the emf_hip_* C ABI (see TSDF.hpp).
 #include "TSDF.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace emf {
@@ -130,6 +131,40 @@ void TSDF::describe(emf_model_t& m) const {
     m.reserved = mode == 2 ? 2 : 0;
     m.rcpVoxel = rcpVoxel;
     m.pad_ = 0;
+}
+
+Mesh TSDF::getMesh() { return extractMesh(nullptr); }
+
+// count -> read back two numbers -> emit; the gradient volume is used when it is materialised
+Mesh TSDF::extractMesh(const uint8_t* fgVolMask) {
+    hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    Stream& s = Stream::Null();
+    DeviceBuffer scratch(std::max<size_t>(emf_hip_meshScratchBytes(volumeRes.val), 8));
+    DeviceBuffer countsDev(sizeof(emf_mesh_counts_t));
+    emfCheck(emf_hip_meshCount(tsdfVol.as<float>(), tsdfWeights.as<float>(), fgVolMask, volumeRes.val,
+                               scratch.data(), countsDev.as<emf_mesh_counts_t>(), s.abi()),
+             "TSDF::getMesh");
+    emf_mesh_counts_t counts{};
+    countsDev.download(&counts, s);
+    Mesh mesh;
+    if (counts.vertices == 0) return mesh;
+    DeviceBuffer v(counts.vertices * 3 * sizeof(float)), n(counts.vertices * 3 * sizeof(float)),
+        t(std::max<size_t>(counts.triangles, 1) * 4 * sizeof(int32_t));
+    emfCheck(emf_hip_meshEmit(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(), fgVolMask,
+                              volumeRes.val, voxelSize, scratch.data(), v.as<float>(), n.as<float>(),
+                              t.as<int32_t>(), s.abi()),
+             "TSDF::getMesh");
+    mesh.cloud.resize(counts.vertices * 3);
+    mesh.normals.resize(counts.vertices * 3);
+    mesh.polygons.resize(static_cast<size_t>(counts.triangles) * 4);
+    v.download(mesh.cloud.data(), s);
+    n.download(mesh.normals.data(), s);
+    if (counts.triangles) {
+        std::vector<int32_t> all(std::max<size_t>(counts.triangles, 1) * 4);
+        t.download(all.data(), s);
+        mesh.polygons.assign(all.begin(), all.begin() + static_cast<size_t>(counts.triangles) * 4);
+    }
+    return mesh;
 }
 
 std::vector<float> TSDF::getTSDF() const {

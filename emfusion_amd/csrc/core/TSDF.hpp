@@ -77,6 +77,12 @@ public:
                             const emf_image_t& associationWeights,
                             Stream& stream = Stream::Null());
 
+    /**
+     * Iso-surface of the observed part of the volume (weights > 0), marching cubes on the device
+     * (reference TSDF::getMesh, TSDF.cpp:356-373).  Synchronises.
+     */
+    virtual Mesh getMesh();
+
     /** Host copies in the reference layout, (Nz*Ny) rows x Nx cols (TSDF.cpp:398-408). */
     std::vector<float> getTSDF() const;
     std::vector<float> getWeightsVol() const;
@@ -96,6 +102,7 @@ public:
     static int brickFlagMode();
 
 protected:
+    Mesh extractMesh(const uint8_t* fgVolMask);
     TSDFParams params;
     Vec3i volumeRes;
     float voxelSize;

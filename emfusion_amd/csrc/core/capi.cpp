@@ -18,6 +18,7 @@ struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
     bool trackCamera = false, trackObjects = false, preprocess = false, cleanUp = false;
     std::vector<emf_image_t> queuedMasks, queuedInstances;
+    emf::Mesh mesh;  // result of the last emf_fusion_extract_mesh
 };
 struct emf_synth {
     std::unique_ptr<SyntheticScene> impl;
@@ -232,6 +233,53 @@ int emf_fusion_update_object(emf_fusion_t* h, int id, const emf_image_t* mask, f
     return guarded([&] {
         const emf::Vec3f o = h->impl->updateObject(id, *mask);
         for (int i = 0; i < 3; ++i) offset[i] = o[i];
+    });
+}
+
+int emf_fusion_extract_mesh(emf_fusion_t* h, int id, uint32_t* num_vertices, uint32_t* num_triangles) {
+    REQ(h);
+    REQ(num_vertices);
+    REQ(num_triangles);
+    return guarded([&] {
+        h->mesh = h->impl->getMesh(id);
+        *num_vertices = static_cast<uint32_t>(h->mesh.vertices());
+        *num_triangles = static_cast<uint32_t>(h->mesh.triangles());
+    });
+}
+
+int emf_fusion_copy_mesh(emf_fusion_t* h, float* vertices, float* normals, int32_t* triangles) {
+    REQ(h);
+    return guarded([&] {
+        const emf::Mesh& m = h->mesh;
+        if (vertices) std::copy(m.cloud.begin(), m.cloud.end(), vertices);
+        if (normals) std::copy(m.normals.begin(), m.normals.end(), normals);
+        if (triangles) std::copy(m.polygons.begin(), m.polygons.end(), triangles);
+    });
+}
+
+int emf_io_write_mesh(const char* filename, uint32_t num_vertices, const float* vertices,
+                      const float* normals, uint32_t num_triangles, const int32_t* triangles) {
+    REQ(filename);
+    if (num_vertices) {
+        REQ(vertices);
+        REQ(normals);
+    }
+    if (num_triangles) REQ(triangles);
+    return guarded([&] {
+        emf::Mesh m;
+        m.cloud.assign(vertices, vertices + 3 * static_cast<size_t>(num_vertices));
+        m.normals.assign(normals, normals + 3 * static_cast<size_t>(num_vertices));
+        m.polygons.assign(triangles, triangles + 4 * static_cast<size_t>(num_triangles));
+        io::writeMesh(filename, m);
+    });
+}
+
+int emf_fusion_render(emf_fusion_t* h, uint8_t* rgb, uint8_t* color_map) {
+    REQ(h);
+    REQ(rgb);
+    return guarded([&] {
+        h->impl->render(rgb);
+        if (color_map) std::copy(h->impl->getColorMap().begin(), h->impl->getColorMap().end(), color_map);
     });
 }
 

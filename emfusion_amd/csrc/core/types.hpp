@@ -102,6 +102,16 @@ private:
     Vec3f t_;
 };
 
+// What cv::viz::Mesh carries in the reference (TSDF.cpp:365-371): vertex cloud, per-vertex normals,
+// polygons as (3, i0, i1, i2) quadruples.
+struct Mesh {
+    std::vector<float> cloud;       // 3 per vertex, volume frame
+    std::vector<float> normals;     // 3 per vertex (interpolated gradients, not normalised)
+    std::vector<int32_t> polygons;  // 4 per triangle
+    size_t vertices() const { return cloud.size() / 3; }
+    size_t triangles() const { return polygons.size() / 4; }
+};
+
 struct Size {
     int width = 0, height = 0;
     Size() = default;

@@ -330,6 +330,66 @@ __global__ __launch_bounds__(kBfX* kBfY) void k_preprocess_depth(const Bilateral
     a.out.row(y)[x] = o;
 }
 
+// ---- f-4: kernel_renderPhong + renderGPU's colour lookup (EMFusion.cu:100-186) ---------------------
+// One launch: the label -> colour lookup (cv::cuda::LookUpTable on a 3-channel copy of the
+// segmentation) happens in registers from a table passed by value, and background pixels are
+// written as 0 here instead of by a preceding image.setTo(0).
+struct PhongArgs {
+    Img<const float> points, normals;
+    Img<const uint8_t> seg;
+    Img<uint8_t> image;  // u8 x 3
+    int w, h;
+    V3 light;
+    uint8_t colors[256 * 3];
+};
+
+__device__ __forceinline__ float fastpow(float base, int exp) {  // EMFusion.cu:100-113
+    float result = 1.f;
+    while (exp) {
+        if (exp & 1) result *= base;
+        base *= base;
+        exp >>= 1;
+    }
+    return result;
+}
+
+// static_cast<uchar>(float) is undefined for values outside [0, 256) in the reference; values that
+// can occur are < 1 * 255 (the three coefficients sum to 1) and slightly negative ones where the
+// normal faces away from the light: those and NaN become 0 here
+__device__ __forceinline__ uint8_t to_u8(float v) {
+    return v >= 0.f ? static_cast<uint8_t>(v < 255.f ? static_cast<int>(v) : 255) : uint8_t{0};
+}
+
+__global__ __launch_bounds__(256) void k_render_phong(const PhongArgs a) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= a.w || y >= a.h) return;
+    const float* pp = a.points.row(y) + 3 * x;
+    const float* np = a.normals.row(y) + 3 * x;
+    const V3 p = v3(pp[0], pp[1], pp[2]), n = v3(np[0], np[1], np[2]);
+    uint8_t* out = a.image.row(y) + 3 * x;
+    if (p.x == 0.f && p.y == 0.f && p.z == 0.f) {
+        out[0] = out[1] = out[2] = 0;
+        return;
+    }
+    const uint8_t* c = a.colors + 3 * a.seg.row(y)[x];
+    const float ka = 0.3f, kd = 0.5f, ks = 0.2f;
+    const V3 Rd = v3(static_cast<float>(c[0]) / 255.f, static_cast<float>(c[1]) / 255.f,
+                     static_cast<float>(c[2]) / 255.f);
+    V3 l = v3(a.light.x - p.x, a.light.y - p.y, a.light.z - p.z);
+    l = l / norm(l);
+    const V3 v = v3(-p.x, -p.y, -p.z) / norm(p);
+    const V3 two = n * (2.f * dot(l, n));
+    V3 r = v3(two.x - l.x, two.y - l.y, two.z - l.z);
+    r = r / norm(r);
+    const float diff = dot(n, l), spec = fastpow(dot(r, v), 20);
+    // ka * Ra + kd * Rd * dot(n, l) + ks * Rs * pow, Ra = Rs = (1, 1, 1), summed left to right
+    const V3 I = v3(ka * 1.f + (kd * Rd.x) * diff + (ks * 1.f) * spec, ka * 1.f + (kd * Rd.y) * diff + (ks * 1.f) * spec,
+                    ka * 1.f + (kd * Rd.z) * diff + (ks * 1.f) * spec);
+    out[0] = to_u8(I.x * 255.f);
+    out[1] = to_u8(I.y * 255.f);
+    out[2] = to_u8(I.z * 255.f);
+}
+
 }  // namespace
 }  // namespace emf_hip
 
@@ -638,6 +698,33 @@ int emf_hip_preprocessDepth(const emf_image_t* depthRaw, const emf_image_t* dept
                        dim3(static_cast<unsigned>(ceil_div(a.w, kBfX)), static_cast<unsigned>(ceil_div(a.h, kBfY))),
                        dim3(kBfX, kBfY), 0, as_stream(stream), a);
     return launch_status("preprocessDepth");
+}
+
+int emf_hip_renderPhong(const emf_image_t* vertices, const emf_image_t* normals,
+                        const emf_image_t* segmentation, const uint8_t colorMap[768],
+                        const float lightPos[3], const emf_image_t* image, emf_stream_t stream) {
+    EMF_TRY(check_image(vertices, 12, "renderPhong: vertices"));
+    EMF_TRY(check_image(normals, 12, "renderPhong: normals"));
+    EMF_TRY(check_image(segmentation, 1, "renderPhong: segmentation"));
+    EMF_TRY(check_image(image, 3, "renderPhong: image"));
+    EMF_TRY(check_same_size(vertices, normals, "vertices", "normals"));
+    EMF_TRY(check_same_size(vertices, segmentation, "vertices", "segmentation"));
+    EMF_TRY(check_same_size(vertices, image, "vertices", "image"));
+    EMF_REQUIRE_PTR(colorMap);
+    EMF_REQUIRE_PTR(lightPos);
+    PhongArgs a;
+    a.points = img<const float>(vertices);
+    a.normals = img<const float>(normals);
+    a.seg = img<const uint8_t>(segmentation);
+    a.image = img<uint8_t>(image);
+    a.w = vertices->width;
+    a.h = vertices->height;
+    a.light = v3_from(lightPos);
+    for (int i = 0; i < 768; ++i) a.colors[i] = colorMap[i];
+    hipLaunchKernelGGL(k_render_phong,
+                       dim3(static_cast<unsigned>(ceil_div(a.w, 32)), static_cast<unsigned>(ceil_div(a.h, 8))),
+                       dim3(256), 0, as_stream(stream), a);
+    return launch_status("renderPhong");
 }
 
 }  // extern "C"

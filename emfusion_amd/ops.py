@@ -460,6 +460,17 @@ def object_extent_stats(points, mask, R, t, tsdf, weights, fg_mask, voxel_size, 
     return int(raw.view(np.uint32)[0]), raw[1:4].copy(), raw[4:7].copy()
 
 
+def render_phong(vertices, normals, segmentation, color_map, image, light=(0.0, 0.0, 0.0), stream=None):
+    """renderGPU: Phong-shaded RGB image (H, W, 3) u8 of the composited raycast; color_map (256, 3) u8 host."""
+    cm = np.ascontiguousarray(color_map, np.uint8)
+    assert cm.size == 768
+    check("emf_hip_renderPhong",
+          _L.emf_hip_renderPhong(C.byref(image_view(vertices)), C.byref(image_view(normals)),
+                                 C.byref(image_view(segmentation)), cm.ctypes.data, _f(light, 3),
+                                 C.byref(image_view(image)), _stream(stream)))
+    return image
+
+
 def extract_mesh(tsdf, weights, voxel_size, fg_mask=None, grads=None, stream=None):
     """TSDF::getMesh / ObjTSDF::getMesh: (vertices (n, 3) f32, normals (n, 3) f32, triangles (m, 4) i32)
     as numpy arrays; two launches to count, one read-back, one launch to emit."""

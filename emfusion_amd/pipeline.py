@@ -106,6 +106,10 @@ def load() -> C.CDLL:
         "emf_fusion_create_object_from_mask": [vp, img, ip],
         "emf_fusion_match_mask": [vp, img, ip, fp],
         "emf_fusion_update_object": [vp, C.c_int, img, fp],
+        "emf_fusion_render": [vp, C.c_void_p, C.c_void_p],
+        "emf_fusion_extract_mesh": [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+        "emf_fusion_copy_mesh": [vp, C.c_void_p, C.c_void_p, C.c_void_p],
+        "emf_io_write_mesh": [C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p],
         "emf_fusion_queue_new_object_masks": [vp, C.c_int, img],
         "emf_fusion_last_created": [vp, ip, C.c_int, ip],
         "emf_fusion_queue_instance_masks": [vp, C.c_int, img],
@@ -332,6 +336,25 @@ class Fusion:
                load().emf_fusion_update_object(self._h, int(obj_id), C.byref(mask_view), off))
         return np.array(list(off), np.float32)
 
+    def render(self):
+        """EMFusion::render: (image (H, W, 3) u8 RGB, colour map (256, 3) u8)."""
+        rgb = np.empty((self.params.height, self.params.width, 3), np.uint8)
+        cmap = np.empty((256, 3), np.uint8)
+        _check("emf_fusion_render", load().emf_fusion_render(self._h, rgb.ctypes.data, cmap.ctypes.data))
+        return rgb, cmap
+
+    def mesh(self, obj_id: int = 0):
+        """TSDF::getMesh / ObjTSDF::getMesh: (vertices (n, 3), normals (n, 3), triangles (m, 4))."""
+        nv, nt = C.c_uint32(), C.c_uint32()
+        _check("emf_fusion_extract_mesh",
+               load().emf_fusion_extract_mesh(self._h, int(obj_id), C.byref(nv), C.byref(nt)))
+        v = np.empty((nv.value, 3), np.float32)
+        n = np.empty((nv.value, 3), np.float32)
+        t = np.empty((nt.value, 4), np.int32)
+        _check("emf_fusion_copy_mesh",
+               load().emf_fusion_copy_mesh(self._h, v.ctypes.data, n.ctypes.data, t.ctypes.data))
+        return v, n, t
+
     def enable_pose_log(self, on=True):
         _check("emf_fusion_enable_pose_log", load().emf_fusion_enable_pose_log(self._h, int(on)))
 
@@ -468,6 +491,17 @@ def write_volume(filename, volume: np.ndarray, voxel_size: float):
     _check("emf_io_write_volume",
            load().emf_io_write_volume(os.fspath(filename).encode(), v.ctypes.data_as(C.POINTER(C.c_float)),
                                       (C.c_int32 * 3)(nx, ny, nz), float(voxel_size)))
+
+
+def write_mesh(filename, vertices, normals, triangles):
+    """ASCII PLY of the reference (EMFusion::writeMesh)."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, np.int32).reshape(-1, 4)
+    assert len(v) == len(n)
+    _check("emf_io_write_mesh",
+           load().emf_io_write_mesh(os.fspath(filename).encode(), len(v), v.ctypes.data, n.ctypes.data,
+                                    len(t), t.ctypes.data))
 
 
 def write_pose_file(filename, poses: Dict[int, tuple]):

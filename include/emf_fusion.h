@@ -121,6 +121,16 @@ int emf_fusion_last_deleted(emf_fusion_t* h, int32_t* ids, int capacity, int32_t
  * before processing, then write <dir>/poses-cam.txt, poses-<id>.txt (TUM: "frame tx ty tz qx qy qz
  * qw") and, if volumes != 0, <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin
  * (int32 res[3], uint64 element size, float voxel size, voxels).  emf_io_* are host-only helpers. */
+/* TSDF::getMesh / ObjTSDF::getMesh of model `id` (0 = background): extract runs marching cubes and
+ * keeps the result in the handle, copy hands it out (vertices, normals: 3 floats per vertex;
+ * triangles: 4 int32 per triangle = 3, i0, i1, i2).  emf_io_write_mesh writes the reference's PLY. */
+int emf_fusion_extract_mesh(emf_fusion_t* h, int id, uint32_t* num_vertices, uint32_t* num_triangles);
+int emf_fusion_copy_mesh(emf_fusion_t* h, float* vertices, float* normals, int32_t* triangles);
+int emf_io_write_mesh(const char* filename, uint32_t num_vertices, const float* vertices,
+                      const float* normals, uint32_t num_triangles, const int32_t* triangles);
+/* EMFusion::render (EMFusion.cpp:131-160): Phong-shaded RGB view of the models, width*height*3 bytes
+ * into host memory; color_map (may be NULL) receives the 256 x RGB label colours. */
+int emf_fusion_render(emf_fusion_t* h, uint8_t* rgb, uint8_t* color_map);
 int emf_fusion_enable_pose_log(emf_fusion_t* h, int on);
 int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes);
 int emf_io_write_volume(const char* filename, const float* voxels, const int32_t res[3], float voxel_size);

@@ -444,6 +444,15 @@ int emf_hip_meshEmit(const float* tsdf, const float* grads, const float* weights
                      const void* scratch_dev, float* vertices, float* normals, int32_t* triangles,
                      emf_stream_t stream);
 
+/* Replaces cuda::EMFusion::renderGPU (EMFusion.cu:100-186): Phong shading of the composited raycast
+ * (vertices, normals f32x3; segmentation u8) into image (u8x3, RGB), coloured per label through
+ * colorMap (256 x RGB, HOST memory, passed by value to the kernel).  Pixels without a vertex are
+ * written as 0, so the reference's image.setTo(0) is not needed.  lightPos: the translation of
+ * renderGPU's lightPose (EMFusion::render passes the identity, i.e. the camera centre). */
+int emf_hip_renderPhong(const emf_image_t* vertices, const emf_image_t* normals,
+                        const emf_image_t* segmentation, const uint8_t colorMap[768],
+                        const float lightPos[3], const emf_image_t* image, emf_stream_t stream);
+
 /* EMFusion::initObjsFromUnmatched's carving step (EMFusion.cpp:462-478): removes from the unmatched
  * instance mask `seg` (in place) the pixels the object `id` already claims -- its footprint in the
  * model segmentation, plus `matchMask` if a mask was matched to it (may be NULL) -- and counts the

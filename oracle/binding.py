@@ -266,3 +266,13 @@ def marching_cubes(tsdf, weights, voxel_size, fg=None, grads=None, fma=False):
     L.orc_marchingCubes(_p(t), None if gp is None else _p(gp), _p(w), None if fgp is None else _p(fgp),
                         res, C.c_float(voxel_size), _p(v), _p(n), _p(tri))
     return v, n, tri
+
+
+def render_phong(points, normals, seg, color_map, light=(0.0, 0.0, 0.0), fma=False):
+    p, n = _c(points), _c(normals)
+    s, cm = _c(seg, np.uint8), _c(color_map, np.uint8)
+    h, w = s.shape
+    assert cm.size == 768
+    out = np.empty((h, w, 3), np.uint8)
+    lib(fma).orc_renderPhong(_p(p), _p(n), _p(s), _p(cm), _farr(light, 3), w, h, _p(out))
+    return out

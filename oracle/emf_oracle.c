@@ -749,3 +749,45 @@ void orc_marchingCubes(const float* tsdf, const float* grads, const float* weigh
                 triBase += j;
             }
 }
+
+/* ==== f-4: kernel_renderPhong (EMFusion.cu:100-186) ============================================= */
+
+static float orc_fastpow(float base, int exp) {
+    float result = 1;
+    while (exp) {
+        if (exp & 1) result *= base;
+        base *= base;
+        exp >>= 1;
+    }
+    return result;
+}
+
+/* static_cast<uchar>(float): undefined outside [0, 256) in the reference; negative and NaN -> 0 */
+static uint8_t orc_to_u8(float v) { return v >= 0.f ? (uint8_t)(v < 255.f ? (int)v : 255) : 0; }
+
+/* image (H x W x 3) is fully written: 0 where the vertex is (0, 0, 0) (image.setTo(0) + early out) */
+void orc_renderPhong(const float* points, const float* normals, const uint8_t* seg,
+                     const uint8_t* colorMap, const float lightPos[3], int w, int h, uint8_t* image) {
+    const float ka = 0.3f, kd = 0.5f, ks = 0.2f;
+    const int alpha = 20;
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        const v3 p = mk(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+        const v3 n = mk(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+        uint8_t* out = image + 3 * i;
+        out[0] = out[1] = out[2] = 0;
+        if (p.x == 0.f && p.y == 0.f && p.z == 0.f) continue;
+        const uint8_t* c = colorMap + 3 * seg[i]; /* LookUpTable on the 3-channel copy of the labels */
+        const v3 Rd = mk((float)c[0] / 255.f, (float)c[1] / 255.f, (float)c[2] / 255.f);
+        v3 l = mk(lightPos[0] - p.x, lightPos[1] - p.y, lightPos[2] - p.z);
+        l = div3(l, norm3(l));
+        const v3 v = div3(mk(-p.x, -p.y, -p.z), norm3(p));
+        const v3 two = scale3(n, 2.f * dot3(l, n));
+        v3 r = mk(two.x - l.x, two.y - l.y, two.z - l.z);
+        r = div3(r, norm3(r));
+        const float diff = dot3(n, l), spec = orc_fastpow(dot3(r, v), alpha);
+        const float I[3] = {ka * 1.f + (kd * Rd.x) * diff + (ks * 1.f) * spec,
+                            ka * 1.f + (kd * Rd.y) * diff + (ks * 1.f) * spec,
+                            ka * 1.f + (kd * Rd.z) * diff + (ks * 1.f) * spec};
+        for (int k = 0; k < 3; ++k) out[k] = orc_to_u8(I[k] * 255.f);
+    }
+}

@@ -134,6 +134,10 @@ void orc_marchingCubes(const float* tsdf, const float* grads, const float* weigh
                        const uint8_t* fg, const int res[3], float voxelSize, float* vertices,
                        float* normals, int* triangles);
 
+/* kernel_renderPhong + the colour lookup of renderGPU (EMFusion.cu:100-186); image: H x W x 3 u8. */
+void orc_renderPhong(const float* points, const float* normals, const uint8_t* seg,
+                     const uint8_t* colorMap, const float lightPos[3], int w, int h, uint8_t* image);
+
 #ifdef __cplusplus
 }
 #endif

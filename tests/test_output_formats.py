@@ -1,4 +1,4 @@
-"""The reference's on-disk result formats (SURVEY f-4, mesh-free part): raw volume dumps
+"""The reference's on-disk result formats (SURVEY f-4): PLY meshes (writeMesh, EMFusion.cpp:1263-1300), raw volume dumps
 (EMFusion::writeVolume, EMFusion.cpp:1302-1313) and TUM-style pose files (writePoseFile,
 EMFusion.cpp:1238-1254).  Host-only code of libemf_fusion.so: runs without a GPU."""
 import struct
@@ -40,6 +40,38 @@ def test_pose_file_is_tum_format(tmp_path):
     assert rows[1][1] == "1.5" and rows[1][2] == "-2.25"  # default ostream formatting
 
 
+def read_ply(path):
+    lines = path.read_text().splitlines()
+    end = lines.index("end_header")
+    nv = int([l for l in lines[:end] if l.startswith("element vertex")][0].split()[-1])
+    nf = int([l for l in lines[:end] if l.startswith("element face")][0].split()[-1])
+    body = lines[end + 1:]
+    assert len(body) == nv + nf
+    v = np.array([l.split() for l in body[:nv]], np.float64).reshape(nv, 6)
+    f = np.array([l.split() for l in body[nv:]], np.int64).reshape(nf, 4)
+    return lines[:end + 1], v, f
+
+
+def test_ply_is_the_reference_layout(tmp_path):
+    from emfusion_amd import pipeline
+    v = np.array([[0, 0.5, -1.25], [1e-7, 2, 3], [1, 1, 1]], np.float32)
+    n = np.array([[0, 0, 1], [0.25, 0.5, 0.125], [-1, 0, 0]], np.float32)
+    t = np.array([[3, 0, 2, 1]], np.int32)
+    f = tmp_path / "mesh_bg.ply"
+    pipeline.write_mesh(f, v, n, t)
+    text = f.read_text().splitlines()
+    assert text[:12] == ["ply", "format ascii 1.0", "element vertex 3", "property float x",
+                         "property float y", "property float z", "property float nx", "property float ny",
+                         "property float nz", "element face 1", "property list uchar int vertex_index",
+                         "end_header"]
+    assert text[12] == "0.000000 0.500000 -1.250000 0.000000 0.000000 1.000000"  # %f
+    assert text[13].startswith("0.000000 2.000000 3.000000 0.250000")
+    assert text[15] == "3 0 2 1" and len(text) == 16
+    pipeline.write_mesh(tmp_path / "empty.ply", np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 4)))
+    hdr, vv, ff = read_ply(tmp_path / "empty.ply")
+    assert len(vv) == 0 and len(ff) == 0
+
+
 @pytest.mark.gpu
 def test_write_results_of_a_run(tmp_path, dev):
     from emfusion_amd import pipeline
@@ -72,5 +104,20 @@ def test_write_results_of_a_run(tmp_path, dev):
     assert np.array_equal(got, fus.volume("tsdf", 0))
     for name in (f"tsdf_{oid}", f"weights_{oid}", f"fgProbs_{oid}"):
         assert (tmp_path / "tsdfs" / f"{name}.bin").stat().st_size == 24 + 32 ** 3 * 4
+    # meshes: the files hold what getMesh returns, which is what the oracle's marching cubes gives
+    from oracle import binding as orc
+    for mid, name, vox in ((0, "mesh_bg.ply", 0.04), (oid, f"mesh_{oid}.ply", None)):
+        v, n, t = fus.mesh(mid)
+        _, fv, ff = read_ply(tmp_path / name)
+        assert len(v) > 50 and fv.shape == (len(v), 6) and np.array_equal(ff, t)
+        assert np.allclose(fv[:, :3], v, atol=1e-6) and np.allclose(fv[:, 3:], n, atol=1e-6)
+        if vox is not None:
+            want = orc.marching_cubes(fus.volume("tsdf", 0), fus.volume("weights", 0), vox)
+            assert all(a.tobytes() == b.tobytes() for a, b in zip((v, n, t), want))
+    # the object's mesh only covers foreground voxels (ObjTSDF::getMesh)
+    vs_obj = np.float32(vs) / np.float32(32)
+    want = orc.marching_cubes(fus.volume("tsdf", oid), fus.volume("weights", oid), float(vs_obj),
+                              fg=fus.volume("fgmask", oid))
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(fus.mesh(oid), want))
     fus.close()
     synth.close()
