@@ -5,13 +5,19 @@
 // The reference classifies every cube into three N^3-sized buffers (class u8, vertex count i32,
 // triangle count i32 -- 9 bytes per voxel, 1.2 GB for the 512^3 background), sums them, runs two
 // device-wide thrust::exclusive_scan passes over them and reads them back in the emit kernel.
-// Here nothing per cube is stored: a 256-cube workgroup recomputes the class from the TSDF in both
-// passes (the volume is read twice, 8 + 8 bytes per voxel in total, mostly from L2 the second time
-// for object volumes) and only ONE pair of counters per workgroup goes through memory:
-//   k_mesh_count   per workgroup: sum of vertices / triangles of its 256 cubes  -> blockSums[b]
-//   k_mesh_scan    one workgroup: exclusive scan of blockSums in place, totals  -> counts
-//   k_mesh_emit    class again, exclusive scan inside the workgroup (wave shuffles + LDS) on top of
-//                  blockSums[b]: vertices, normals, triangles land where the reference puts them
+// Here nothing per cube is stored.  Cubes are taken in chunks of 256 consecutive ones (the
+// reference's buffer order) and only per-chunk numbers go through memory (9 bytes per 256 cubes):
+//   k_mesh_count  a workgroup classifies 8 chunks; per chunk the packed (vertices, triangles) total
+//                 -> chunkTot[g], per workgroup their sum -> blockSums[b], and the ids of the
+//                 chunks that hold surface -> list[] (any order)
+//   k_mesh_scan   one workgroup: exclusive scan of blockSums in place (65 k pairs at 512^3), totals
+//   k_mesh_emit   a fixed grid walks list[]: classify the chunk again, scan inside the workgroup (wave
+//                 shuffles + LDS) on top of blockSums[g / 8] + the chunk totals before it, and write
+//                 vertices, normals and triangles where the reference puts them
+// so the volume is streamed once (count) plus the surface chunks once more (emit; a workgroup per
+// chunk that returns when its total is 0 measured 0.57 ms at 512^3 for launching 0.5 M workgroups
+// alone).  Counting workgroups are mapped so that each XCD walks a contiguous eighth of the volume
+// (its own z-slabs stay in its L2).
 // The output is element-for-element the reference's: cubes in (z, y, x) order, a cube's vertices
 // in edge-bit order, triangles as (3, i0, i1, i2) in table order.  Normals are the interpolated RAW
 // gradients: the reference's `ns[i] /= norm(ns[i])` and `normals[..] /= norm(..)` call an
@@ -25,11 +31,25 @@ namespace emf_hip {
 namespace {
 
 constexpr int kMcBlock = 256;
+constexpr int kMcChunks = 8;                   // chunks per counting workgroup
+constexpr int kMcSpan = kMcBlock * kMcChunks;  // = 4 rows of a 512-wide volume: neighbours in y hit L1
+constexpr unsigned kXcds = 8;
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give XCD k the k-th
+// contiguous eighth of the sequence (whole z-slabs of a large volume), so that the planes two
+// neighbouring rows / slices share are fetched into ONE L2 instead of eight.
+__device__ __forceinline__ unsigned logical_block(unsigned n) {
+    const unsigned per = (n + kXcds - 1) / kXcds;
+    return (blockIdx.x % kXcds) * per + blockIdx.x / kXcds;
+}
 
 struct MeshArgs {
     MeshSource src;
     const float* grads;  // N^3 x 3 gradient volume, or nullptr: forward differences on the fly
-    uint2* blockSums;    // per workgroup (vertices, triangles); after k_mesh_scan their exclusive scan
+    uint2* blockSums;    // per counting workgroup (vertices, triangles); after k_mesh_scan their exclusive scan
+    unsigned* chunkTot;  // per chunk: vertices | triangles << 16 (at most 3072 and 1280)
+    unsigned* list;      // ids of the chunks with a non-zero total, in no particular order
+    unsigned* listCount;
     emf_mesh_counts_t* counts;
     float* vertices;
     float* normals;
@@ -43,14 +63,44 @@ struct Cube {
     unsigned cls;  // 0 when the cube is masked out or carries no surface
 };
 
-__device__ __forceinline__ Cube classify(const MeshSource& s, size_t c, size_t cubes) {
+// Where a chunk starts in the cube grid.  Wave-uniform; dividing is done once per workgroup, the
+// following chunks and the lanes' own coordinates are reached by carrying -- two 64-bit divisions per
+// cube were most of the counting kernel's time.
+struct Origin {
+    unsigned x, y, z;
+};
+
+__device__ __forceinline__ Origin origin_of(const I3& n, size_t c0) {
+    const unsigned nx1 = n.x - 1, ny1 = n.y - 1;
+    const size_t r0 = c0 / nx1;
+    return Origin{static_cast<unsigned>(c0 - r0 * nx1), static_cast<unsigned>(r0 % ny1),
+                  static_cast<unsigned>(r0 / ny1)};
+}
+
+__device__ __forceinline__ Origin advanced(const I3& n, Origin o, unsigned by) {
+    const unsigned nx1 = n.x - 1, ny1 = n.y - 1;
+    o.x += by;
+    while (o.x >= nx1) {  // at most once per 256 cubes when Nx > 256
+        o.x -= nx1;
+        ++o.y;
+    }
+    while (o.y >= ny1) {
+        o.y -= ny1;
+        ++o.z;
+    }
+    return o;
+}
+
+// cube `tid` of the chunk at `o`; `left` = cubes from the chunk start to the end of the volume
+__device__ __forceinline__ Cube classify(const MeshSource& s, const Origin& o, unsigned tid, size_t left) {
     Cube q{0, 0, 0, 0, 0u};
-    if (c >= cubes) return q;
+    if (tid >= left) return q;
     const I3 n = s.n;
-    q.x = static_cast<int>(c % (n.x - 1));
-    const size_t r = c / (n.x - 1);
-    q.y = static_cast<int>(r % (n.y - 1));
-    q.z = static_cast<int>(r / (n.y - 1));
+    const Origin me = advanced(n, o, tid);
+    const unsigned x = me.x, y = me.y, z = me.z;
+    q.x = static_cast<int>(x);
+    q.y = static_cast<int>(y);
+    q.z = static_cast<int>(z);
     const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
     q.base = static_cast<size_t>(q.z) * sz + static_cast<size_t>(q.y) * sy + q.x;
     bool valid = true;  // kernel_classifyCubes: all 8 corners observed (and foreground)
@@ -110,17 +160,45 @@ __device__ __forceinline__ uint2 block_scan(uint2 v, uint2& total, uint2* lds /*
 }
 
 __global__ __launch_bounds__(kMcBlock) void k_mesh_count(const MeshArgs a) {
-    __shared__ uint2 lds[8];
+    __shared__ unsigned lds[kMcBlock / 64][kMcChunks];
+    const unsigned b = logical_block(a.nblocks);
+    if (b >= a.nblocks) return;
     const size_t cubes = static_cast<size_t>(a.src.n.x - 1) * (a.src.n.y - 1) * (a.src.n.z - 1);
-    const Cube q = classify(a.src, static_cast<size_t>(blockIdx.x) * kMcBlock + threadIdx.x, cubes);
-    uint2 v = make_uint2(0u, 0u);
-    if (q.cls) v = make_uint2(__popc(active_edges(q.cls)), triangles_of(q.cls));
-    uint2 total;
-    block_scan(v, total, lds);
-    if (threadIdx.x == 0) a.blockSums[blockIdx.x] = total;
+    unsigned p[kMcChunks];
+    const size_t c0 = static_cast<size_t>(b) * kMcSpan;
+    Origin o = origin_of(a.src.n, c0);
+#pragma unroll
+    for (int c = 0; c < kMcChunks; ++c) {
+        const size_t start = c0 + static_cast<size_t>(c) * kMcBlock;
+        const Cube q = classify(a.src, o, threadIdx.x, start < cubes ? cubes - start : 0);
+        p[c] = q.cls ? __popc(active_edges(q.cls)) | (triangles_of(q.cls) << 16) : 0u;
+        o = advanced(a.src.n, o, kMcBlock);
+    }
+#pragma unroll
+    for (int c = 0; c < kMcChunks; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o);  // fields cannot carry: <= 768, 320 per wave
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6][c] = p[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < kMcChunks) {
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < kMcBlock / 64; ++w) t += lds[w][threadIdx.x];
+        const unsigned g = b * kMcChunks + threadIdx.x;
+        a.chunkTot[g] = t;
+        if (t) a.list[atomicAdd(a.listCount, 1u)] = g;
+        uint2 sum = make_uint2(t & 0xffffu, t >> 16);
+#pragma unroll
+        for (int o = 1; o < kMcChunks; o <<= 1) {
+            sum.x += __shfl_xor(sum.x, o);
+            sum.y += __shfl_xor(sum.y, o);
+        }
+        if (threadIdx.x == 0) a.blockSums[b] = sum;
+    }
 }
 
-// one workgroup walks the per-workgroup sums in chunks of 1024 (a 512^3 volume has 0.5 M of them)
+// one workgroup walks the per-workgroup sums in chunks of 1024 (a 512^3 volume has 65 k of them)
 __global__ __launch_bounds__(1024) void k_mesh_scan(const MeshArgs a) {
     __shared__ uint2 lds[16];
     __shared__ uint2 carry;
@@ -176,20 +254,38 @@ __device__ __forceinline__ V3 corner_gradient(const MeshArgs& a, size_t idx, int
     return v3(a.src.tsdf[idx + 1] - t, a.src.tsdf[idx + sy] - t, a.src.tsdf[idx + sz] - t);
 }
 
+__device__ __forceinline__ void emit_cube(const MeshArgs& a, const Cube& q, unsigned edges, unsigned ntris,
+                                          unsigned vertBase, unsigned triBase);
+
 __global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
     __shared__ uint2 lds[8];
     const I3 n = a.src.n;
     const size_t cubes = static_cast<size_t>(n.x - 1) * (n.y - 1) * (n.z - 1);
-    const Cube q = classify(a.src, static_cast<size_t>(blockIdx.x) * kMcBlock + threadIdx.x, cubes);
-    const unsigned edges = q.cls ? active_edges(q.cls) : 0u;
-    uint2 v = make_uint2(0u, 0u);
-    if (q.cls) v = make_uint2(__popc(edges), triangles_of(q.cls));
-    uint2 total;
-    const uint2 mine = block_scan(v, total, lds);
-    if (!q.cls) return;
-    const uint2 blockBase = a.blockSums[blockIdx.x];
-    const unsigned vertBase = blockBase.x + mine.x;
-    const unsigned triBase = 4u * (blockBase.y + mine.y);  // (3, i0, i1, i2) per triangle
+    const unsigned todo = *a.listCount;
+    for (unsigned i = blockIdx.x; i < todo; i += gridDim.x) {
+        const unsigned g = a.list[i];
+        const unsigned first = g & ~static_cast<unsigned>(kMcChunks - 1);
+        uint2 base = a.blockSums[g / kMcChunks];
+        for (unsigned c = first; c < g; ++c) {
+            const unsigned t = a.chunkTot[c];
+            base.x += t & 0xffffu;
+            base.y += t >> 16;
+        }
+        const size_t c0 = static_cast<size_t>(g) * kMcBlock;
+        const Cube q = classify(a.src, origin_of(n, c0), threadIdx.x, cubes - c0);
+        const unsigned edges = q.cls ? active_edges(q.cls) : 0u;
+        uint2 v = make_uint2(0u, 0u);
+        if (q.cls) v = make_uint2(__popc(edges), triangles_of(q.cls));
+        uint2 total;
+        const uint2 mine = block_scan(v, total, lds);
+        // (3, i0, i1, i2) per triangle
+        if (q.cls) emit_cube(a, q, edges, v.y, base.x + mine.x, 4u * (base.y + mine.y));
+    }
+}
+
+__device__ __forceinline__ void emit_cube(const MeshArgs& a, const Cube& q, unsigned edges, unsigned ntris,
+                                          unsigned vertBase, unsigned triBase) {
+    const I3 n = a.src.n;
     const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
     const V3 half = half_extent(n);
     int offsets[12];
@@ -224,7 +320,7 @@ __global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
         no[2] = nv.z;
         offsets[e] = static_cast<int>(k++);
     }
-    for (unsigned t = 0; t < v.y; ++t) {
+    for (unsigned t = 0; t < ntris; ++t) {
         int32_t* to = a.triangles + triBase + 4 * t;
         to[0] = 3;
 #pragma unroll
@@ -238,6 +334,8 @@ __global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
     }
 }
 
+unsigned launch_blocks(unsigned nblocks) { return ((nblocks + kXcds - 1) / kXcds) * kXcds; }
+
 int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_t* fg,
               const int32_t res[3], float voxelSize, void* scratch) {
     EMF_REQUIRE_PTR(tsdf);
@@ -245,15 +343,19 @@ int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_
     EMF_REQUIRE_PTR(scratch);
     EMF_TRY(check_res(res));
     const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
-    if ((cubes + kMcBlock - 1) / kMcBlock > 0x7fffffffull)
+    if ((cubes + kMcBlock - 1) / kMcBlock > 0x7ffffff0ull)
         return fail(EMF_E_LIMIT, "mesh: %zu cubes exceed one launch", cubes);
+    const unsigned nblocks = static_cast<unsigned>((cubes + kMcSpan - 1) / kMcSpan);
     a.src = MeshSource{tsdf, weights, fg, i3_from(res), voxelSize};
     a.grads = nullptr;
     a.blockSums = static_cast<uint2*>(scratch);
+    a.chunkTot = reinterpret_cast<unsigned*>(a.blockSums + nblocks);
+    a.list = a.chunkTot + static_cast<size_t>(nblocks) * kMcChunks;
+    a.listCount = a.list + static_cast<size_t>(nblocks) * kMcChunks;
     a.counts = nullptr;
     a.vertices = a.normals = nullptr;
     a.triangles = nullptr;
-    a.nblocks = static_cast<unsigned>((cubes + kMcBlock - 1) / kMcBlock);
+    a.nblocks = nblocks;
     return EMF_OK;
 }
 
@@ -267,7 +369,7 @@ extern "C" {
 size_t emf_hip_meshScratchBytes(const int32_t res[3]) {
     if (!res || res[0] < 2 || res[1] < 2 || res[2] < 2) return 0;
     const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
-    return ((cubes + kMcBlock - 1) / kMcBlock) * sizeof(uint2);
+    return ((cubes + kMcSpan - 1) / kMcSpan) * (sizeof(uint2) + 2 * kMcChunks * sizeof(unsigned)) + 16;
 }
 
 int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fgVolMask,
@@ -277,7 +379,12 @@ int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fg
     EMF_TRY(fill_args(a, tsdf, weights, fgVolMask, res, 1.f, scratch_dev));
     EMF_REQUIRE_PTR(counts_dev);
     a.counts = counts_dev;
-    hipLaunchKernelGGL(k_mesh_count, dim3(a.nblocks), dim3(kMcBlock), 0, as_stream(stream), a);
+    const hipError_t e = hipMemsetAsync(a.listCount, 0, sizeof(unsigned), as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("meshCount: memset: %s", hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(k_mesh_count, dim3(launch_blocks(a.nblocks)), dim3(kMcBlock), 0, as_stream(stream), a);
     hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(1024), 0, as_stream(stream), a);
     return launch_status("meshCount");
 }
@@ -295,7 +402,8 @@ int emf_hip_meshEmit(const float* tsdf, const float* grads, const float* weights
     a.vertices = vertices;
     a.normals = normals;
     a.triangles = triangles;
-    hipLaunchKernelGGL(k_mesh_emit, dim3(a.nblocks), dim3(kMcBlock), 0, as_stream(stream), a);
+    const unsigned nchunks = a.nblocks * kMcChunks;  // fixed grid over the list of surface chunks
+    hipLaunchKernelGGL(k_mesh_emit, dim3(nchunks < 4096u ? nchunks : 4096u), dim3(kMcBlock), 0, as_stream(stream), a);
     return launch_status("meshEmit");
 }
 

@@ -137,7 +137,7 @@ def test_full_size_frame_invariants(bench_scene):
 
 
 def test_full_size_against_the_oracle(oracle, ops, dev):
-    """Two integrations and a raycast of the 512^3 background, HIP vs oracle, every voxel / pixel."""
+    """Two integrations, a raycast and the mesh of the 512^3 background, HIP vs oracle, every voxel / pixel / vertex."""
     from emfusion_amd import pipeline
     oracle.set_threads(os.cpu_count() or 8)
     n, vox = 512, 0.01
@@ -167,5 +167,11 @@ def test_full_size_against_the_oracle(oracle, ops, dev):
     for got, w_, name in zip((ray, vert, nrm, hit), want, ("ray", "vert", "normal", "mask")):
         assert_parity(to_np(got), w_, f"{name} 640x480 / 512^3", exact=True)
     assert int(to_np(st)[0]) == int(want[4].sum()) and want[3].sum() > 250000
+    # the mesh of the same volume: every vertex, normal and triangle index (133 M cubes)
+    mesh_want = oracle.marching_cubes(tsdf, wts, vox)
+    mesh_got = ops.extract_mesh(d_t, d_w, vox)
+    assert len(mesh_want[0]) > 100000
+    for g, w_, name in zip(mesh_got, mesh_want, ("vertices", "normals", "triangles")):
+        assert g.shape == w_.shape and g.tobytes() == w_.tobytes(), f"mesh {name} 512^3"
     synth.close()
     oracle.set_threads(min(8, os.cpu_count() or 1))
