@@ -24,6 +24,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("sequence", help="TUM sequence directory (associations.txt, depth/*.png)")
+    ap.add_argument("--cofusion", nargs=2, metavar=("COLORDIR", "DEPTHDIR"),
+                    help="the sequence is a Co-Fusion style dataset (reference ImageReader): "
+                         "<sequence>/COLORDIR/ColorNNNN.png, <sequence>/DEPTHDIR/DepthNNNN.exr")
+    ap.add_argument("--intrinsics", nargs=4, type=float, metavar=("FX", "FY", "CX", "CY"),
+                    help="camera intrinsics (default: 525 px focal length scaled to the image width)")
     ap.add_argument("--masks", help="directory with Mask%%04d.plk files of the reference's preprocessing")
     ap.add_argument("--out", default="emfusion_out")
     ap.add_argument("--frames", type=int, default=0, help="0 = all")
@@ -40,14 +45,22 @@ def main():
     from emfusion_amd.devmem import DeviceArray
     from emfusion_amd.ops import image_view
 
-    reader = readers.TUMReader(args.sequence)
+    if args.cofusion:
+        reader = readers.ImageReader(args.sequence, *args.cofusion)
+        index0 = reader.first
+    else:
+        reader = readers.TUMReader(args.sequence)
+        index0 = 0
     n = len(reader) if args.frames <= 0 else min(args.frames, len(reader))
-    first = reader.depth(0)
+    first = reader.depth(index0)
     h, w = first.shape
     scale = w / 640.0
     prm = pipeline.make_params(w, h, args.bg_res, args.bg_voxel, args.obj_res,
                                visibility_thresh=args.visibility_thresh or int(round(1600 * scale * scale)),
                                boundary=int(round(20 * scale)), mask_frames=args.mask_frames)
+    if args.intrinsics:
+        fx, fy, cx, cy = args.intrinsics
+        prm.K[:] = [fx, 0, cx, 0, fy, cy, 0, 0, 1]
     fus = pipeline.Fusion(prm, None)
     fus.set_preprocess(True)
     fus.set_cleanup(True)
@@ -55,12 +68,12 @@ def main():
     eye, zero = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
     t0 = time.time()
     for f in range(n):
-        depth = np.ascontiguousarray(reader.depth(f), np.float32)
+        depth = np.ascontiguousarray(reader.depth(index0 + f), np.float32)
         depth[~np.isfinite(depth)] = 0
         d = DeviceArray.from_numpy(depth)
         keep = [d]
         if args.masks and f % prm.mask_frames == 0:
-            plk = Path(args.masks) / f"Mask{f:04d}.plk"
+            plk = Path(args.masks) / f"Mask{index0 + f:04d}.plk"
             if plk.exists():
                 _, masks, _ = readers.load_preprocessed_masks(plk)
                 dev_masks = [DeviceArray.from_numpy(m) for m in masks]

@@ -129,6 +129,145 @@ class TUMReader:
             yield i, self.depth(i)
 
 
+# ---- OpenEXR scan-line files (the depth images of the Co-Fusion datasets) ---------------------------
+
+_EXR_LINES = {0: 1, 1: 1, 2: 1, 3: 16}  # scan lines per block: NONE, RLE, ZIPS, ZIP
+_EXR_PIXEL = {0: np.dtype("<u4"), 1: np.dtype("<f2"), 2: np.dtype("<f4")}
+
+
+def _exr_unrle(data: bytes, size: int) -> bytes:
+    out, i = bytearray(), 0
+    while i < len(data):
+        n = data[i] - 256 if data[i] > 127 else data[i]
+        i += 1
+        if n < 0:  # -n literal bytes
+            out += data[i:i - n]
+            i -= n
+        else:      # the next byte n + 1 times
+            out += data[i:i + 1] * (n + 1)
+            i += 1
+    if len(out) != size:
+        raise ValueError("EXR: RLE block decodes to %d bytes, expected %d" % (len(out), size))
+    return bytes(out)
+
+
+def _exr_unpredict(buf: bytes) -> bytes:
+    """Undo the byte predictor and the even / odd split OpenEXR applies before RLE / ZIP."""
+    t = np.frombuffer(buf, np.uint8).astype(np.int64)
+    t[1:] -= 128
+    t = (np.cumsum(t) & 0xFF).astype(np.uint8)
+    half = (len(t) + 1) // 2
+    out = np.empty(len(t), np.uint8)
+    out[0::2] = t[:half]
+    out[1::2] = t[half:]
+    return out.tobytes()
+
+
+def read_exr(path, channel: str | None = None) -> np.ndarray:
+    """One channel of a single-part scan-line OpenEXR file as float32 (H, W): what
+    cv::imread(IMREAD_UNCHANGED) gives the reference for the Co-Fusion depth files
+    (ImageReader.cpp:105-110).  Compression NONE, RLE, ZIPS and ZIP; HALF, FLOAT and UINT pixels.
+    channel: name to read; default the only channel, else the first of Z, Y, R that exists.
+    Written from the published file-format description (openexr.com, "OpenEXR File Layout")."""
+    raw = Path(path).read_bytes()
+    if len(raw) < 8 or raw[:4] != b"\x76\x2f\x31\x01":
+        raise ValueError("%s is not an OpenEXR file" % path)
+    version = int.from_bytes(raw[4:8], "little")
+    if version & 0xFF != 2 or version & 0x1A00:  # tiled, deep, multi-part
+        raise ValueError("%s: only single-part scan-line EXR files are supported" % path)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        end = raw.index(b"\0", pos)
+        name = raw[pos:end].decode()
+        tend = raw.index(b"\0", end + 1)
+        size = int.from_bytes(raw[tend + 1:tend + 5], "little")
+        attrs[name] = raw[tend + 5:tend + 5 + size]
+        pos = tend + 5 + size
+    pos += 1
+    chans, c = [], attrs["channels"]
+    i = 0
+    while c[i] != 0:
+        end = c.index(b"\0", i)
+        ptype, _, xs, ys = struct.unpack_from("<iIii", c, end + 1)
+        chans.append((c[i:end].decode(), ptype, xs, ys))
+        i = end + 17
+    comp = attrs["compression"][0]
+    if comp not in _EXR_LINES:
+        raise ValueError("%s: EXR compression %d is not supported (NONE, RLE, ZIPS, ZIP are)" % (path, comp))
+    xmin, ymin, xmax, ymax = struct.unpack("<4i", attrs["dataWindow"])
+    w, h = xmax - xmin + 1, ymax - ymin + 1
+    if any(xs != 1 or ys != 1 for _, _, xs, ys in chans):
+        raise ValueError("%s: sub-sampled EXR channels are not supported" % path)
+    names = [n for n, _, _, _ in chans]
+    if channel is None:
+        channel = names[0] if len(names) == 1 else next((n for n in ("Z", "Y", "R") if n in names), None)
+    if channel not in names:
+        raise ValueError("%s: no channel %r among %s" % (path, channel, names))
+    line_bytes = sum(_EXR_PIXEL[t].itemsize * w for _, t, _, _ in chans)
+    offset_in_line, dtype = 0, None
+    for n, t, _, _ in chans:  # channels are stored in the order of the list (alphabetical)
+        if n == channel:
+            dtype = _EXR_PIXEL[t]
+            break
+        offset_in_line += _EXR_PIXEL[t].itemsize * w
+    per_block = _EXR_LINES[comp]
+    nblocks = (h + per_block - 1) // per_block
+    offsets = struct.unpack_from("<%dQ" % nblocks, raw, pos)
+    out = np.zeros((h, w), np.float32)
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", raw, off)
+        lines = min(per_block, ymax - y + 1)
+        want = lines * line_bytes
+        data = raw[off + 8:off + 8 + size]
+        if comp != 0 and size < want:  # a block that does not shrink is stored as it is
+            data = _exr_unpredict(zlib.decompress(data) if comp in (2, 3) else _exr_unrle(data, want))
+        if len(data) != want:
+            raise ValueError("%s: EXR block at line %d has %d bytes, expected %d" % (path, y, len(data), want))
+        for l in range(lines):
+            start = l * line_bytes + offset_in_line
+            out[y - ymin + l] = np.frombuffer(data, dtype, w, start).astype(np.float32)
+    return out
+
+
+class ImageReader:
+    """Depth frames of a Co-Fusion style dataset (reference ImageReader.cpp): <base>/<colordir>/
+    ColorNNNN.png and <base>/<depthdir>/DepthNNNN.exr, depth in metres, values above 100 set to 0.
+    Frames start at the first index for which both files exist."""
+
+    def __init__(self, base, colordir="colour", depthdir="depth"):
+        self.color, self.depth_dir = Path(base) / colordir, Path(base) / depthdir
+        if not (self.color.is_dir() and self.depth_dir.is_dir()):
+            raise RuntimeError("Could not read color or depth dir!")
+        rgbs = sum(1 for f in self.color.iterdir() if f.suffix == ".png")
+        depths = sum(1 for f in self.depth_dir.iterdir() if f.suffix == ".exr")
+        if rgbs != depths:
+            raise RuntimeError("Different number of rgb and depth files!")
+        self.num_frames, self.first = rgbs, 0
+        while not (self._color(self.first).exists() and self._depth(self.first).exists()):
+            self.first += 1
+            if self.first >= rgbs:
+                raise RuntimeError("Could not find starting index!")
+
+    def _color(self, i):
+        return self.color / ("Color%04d.png" % i)
+
+    def _depth(self, i):
+        return self.depth_dir / ("Depth%04d.exr" % i)
+
+    def __len__(self):
+        return self.num_frames
+
+    def depth(self, index: int) -> np.ndarray:
+        d = read_exr(self._depth(index))
+        d[d > 100] = 0
+        return d
+
+    def __iter__(self) -> Iterator[Tuple[int, np.ndarray]]:
+        for i in range(self.first, self.first + self.num_frames):
+            if self._depth(i).exists():
+                yield i, self.depth(i)
+
+
 def load_preprocessed_masks(filename):
     """A Mask R-CNN result file of the reference's preprocessing script (maskrcnn.in.py:258-268,
     read by MaskRCNN::loadPreprocessed): a pickle of (boxes (N, 4), masks (H, W, N) bool / uint8,

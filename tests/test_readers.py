@@ -7,7 +7,11 @@ import zlib
 import numpy as np
 import pytest
 
+from pathlib import Path
+
 from emfusion_amd import readers
+
+ROOT = Path(__file__).resolve().parents[1]
 
 
 def _png_with_filters(path, img16):
@@ -88,3 +92,131 @@ def test_preprocessed_masks(tmp_path):
     b, m, s = readers.load_preprocessed_masks(tmp_path / "Mask0000.plk")
     assert len(m) == 2 and m[0].dtype == np.uint8 and m[0].sum() == 6 and m[1].sum() == 5
     assert np.array_equal(b, boxes) and np.allclose(s, scores)
+
+
+# ---- OpenEXR depth files (Co-Fusion datasets, reference ImageReader.cpp) ---------------------------
+
+def write_exr(path, channels, compression=3, pixel="f"):
+    """Minimal scan-line OpenEXR writer for the tests (inverse of readers.read_exr, from the same
+    published layout): channels = {name: (H, W) array}; compression 0 NONE, 1 RLE, 2 ZIPS, 3 ZIP."""
+    import struct
+    import zlib
+    names = sorted(channels)
+    h, w = channels[names[0]].shape
+    dt = {"f": np.dtype("<f4"), "h": np.dtype("<f2"), "u": np.dtype("<u4")}[pixel]
+    ptype = {"u": 0, "h": 1, "f": 2}[pixel]
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iIii", ptype, 0, 1, 1) for n in names) + b"\0"
+    head = b"\x76\x2f\x31\x01" + struct.pack("<i", 2)
+    head += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    head += attr("dataWindow", "box2i", struct.pack("<4i", 0, 0, w - 1, h - 1))
+    head += attr("displayWindow", "box2i", struct.pack("<4i", 0, 0, w - 1, h - 1))
+    head += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1))
+    head += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0))
+    head += attr("screenWindowWidth", "float", struct.pack("<f", 1)) + b"\0"
+    per = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
+
+    def rle(b):
+        out, i = bytearray(), 0
+        while i < len(b):
+            run = 1
+            while i + run < len(b) and b[i + run] == b[i] and run < 128:
+                run += 1
+            if run >= 3:
+                out += bytes([run - 1, b[i]])
+                i += run
+            else:
+                j = i
+                while j < len(b) and j - i < 127 and not (j + 2 < len(b) and b[j] == b[j + 1] == b[j + 2]):
+                    j += 1
+                out += bytes([(i - j) & 0xFF]) + b[i:j]
+                i = j
+        return bytes(out)
+    blocks = []
+    for y0 in range(0, h, per):
+        rawb = b"".join(np.ascontiguousarray(channels[n][y], dt).tobytes()
+                        for y in range(y0, min(y0 + per, h)) for n in names)
+        data = rawb
+        if compression:
+            t = np.frombuffer(rawb, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int64)
+            p = t.copy()
+            p[1:] = (t[1:] - t[:-1] + 128 + 256) & 0xFF
+            pb = p.astype(np.uint8).tobytes()
+            cand = rle(pb) if compression == 1 else zlib.compress(pb)
+            if len(cand) < len(rawb):
+                data = cand
+        blocks.append(struct.pack("<ii", y0, len(data)) + data)
+    table_at = len(head)
+    offs, pos = [], table_at + 8 * len(blocks)
+    for b in blocks:
+        offs.append(pos)
+        pos += len(b)
+    with open(path, "wb") as f:
+        f.write(head + struct.pack("<%dQ" % len(offs), *offs) + b"".join(blocks))
+
+
+def test_exr_reader_on_a_real_file():
+    """python_logo.exr was written by the OpenEXR library (tests/golden/make_exr_golden.py): 4 HALF
+    channels, uncompressed; the same image as an 8-bit PNG gives the expected values."""
+    from emfusion_amd.readers import read_exr
+    gold = ROOT / "tests" / "golden"
+    want = np.load(gold / "python_logo_rgba.npy").astype(np.float32) / np.float32(255)
+    for k, c in enumerate("RGBA"):
+        got = read_exr(gold / "python_logo.exr", c)
+        assert got.shape == (16, 16) and got.dtype == np.float32
+        assert np.abs(got - want[..., k]).max() < 5e-4
+    assert np.array_equal(read_exr(gold / "python_logo.exr"), read_exr(gold / "python_logo.exr", "R"))
+    with pytest.raises(ValueError):
+        read_exr(gold / "python_logo.exr", "Z")
+    with pytest.raises(ValueError):
+        read_exr(gold / "python_logo_rgba.npy")
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+@pytest.mark.parametrize("pixel", ["f", "h"])
+def test_exr_roundtrip(tmp_path, compression, pixel):
+    from emfusion_amd.readers import read_exr
+    rng = np.random.default_rng(compression * 7 + ord(pixel))
+    h, w = 37, 53  # not a multiple of the 16-line ZIP block
+    z = (rng.uniform(0.4, 6.0, (h, w)) * (rng.uniform(size=(h, w)) > 0.1)).astype(np.float32)
+    z[5:9] = 2.5  # constant rows: runs for RLE
+    if pixel == "h":
+        z = z.astype(np.float16).astype(np.float32)
+    other = rng.standard_normal((h, w)).astype(np.float32 if pixel == "f" else np.float16).astype(np.float32)
+    f = tmp_path / "Depth0000.exr"
+    write_exr(f, {"Z": z}, compression, pixel)
+    assert np.array_equal(read_exr(f), z)
+    write_exr(f, {"A": other, "Z": z, "R": other * 2}, compression, pixel)  # stored alphabetically: A, R, Z
+    assert np.array_equal(read_exr(f), z) and np.array_equal(read_exr(f, "A"), other)
+
+
+def test_image_reader_directory_layout(tmp_path):
+    from emfusion_amd.readers import ImageReader, write_png_gray16
+    (tmp_path / "colour").mkdir()
+    (tmp_path / "depth").mkdir()
+    rng = np.random.default_rng(2)
+    frames = {}
+    for i in range(3, 7):  # the sequence starts at index 3
+        d = rng.uniform(0.5, 4.0, (24, 32)).astype(np.float32)
+        d[0, :5] = 1e4      # "infinitely far" background of the synthetic datasets
+        d[1, 1] = 100.0     # exactly 100 stays
+        frames[i] = d
+        write_exr(tmp_path / "depth" / ("Depth%04d.exr" % i), {"Z": d}, 3, "f")
+        write_png_gray16(tmp_path / "colour" / ("Color%04d.png" % i), np.zeros((24, 32), np.uint16))
+    r = ImageReader(tmp_path)
+    assert len(r) == 4 and r.first == 3
+    got = dict(r)
+    assert sorted(got) == [3, 4, 5, 6]
+    for i, d in frames.items():
+        want = d.copy()
+        want[want > 100] = 0
+        assert np.array_equal(got[i], want)
+    assert got[3][0, 0] == 0 and got[3][1, 1] == 100.0
+    (tmp_path / "depth" / "Depth0006.exr").unlink()
+    with pytest.raises(RuntimeError):
+        ImageReader(tmp_path)  # different number of colour and depth files
+    with pytest.raises(RuntimeError):
+        ImageReader(tmp_path / "nowhere")
