@@ -65,6 +65,9 @@ def parse_args():
                          "large kernels (raycast, integrate, tracking) are bracketed")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernel launches with HIP events in the timed region")
+    ap.add_argument("--no-depth-broadcast", action="store_true",
+                    help="multi-GPU: every rank already holds the frame; skip the per-frame "
+                         "ncclBroadcast of the depth image from rank 0")
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the cross-rank exchange path (RCCL all-reduces) even with one "
                          "rank, to exercise the multi-GPU code on a single GPU")
@@ -129,6 +132,11 @@ def main():
 
     synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
     fus = pipeline.Fusion(prm, comm)
+    depth_broadcast = comm is not None and not args.no_depth_broadcast
+    if depth_broadcast:
+        # north_star: "depth maps are broadcast once per frame" -- rank 0's image is the source;
+        # the other ranks' (identical, synthetic) copies are overwritten by it inside the timed step
+        fus.set_depth_broadcast(0)
     ids = []
     for k in range(nobj_total):
         c, r, vs = synth.sphere(k, 0)
@@ -226,6 +234,10 @@ def main():
                 "background": "replicated" if world > 1 else "single",
                 "gradients": args.grads,
                 "estep_per_frame": 3,
+                "collectives_per_frame": ("none" if comm is None else
+                                          ("broadcast(depth) + " if depth_broadcast else "") +
+                                          "3 x all-reduce(sum f32, normaliser) + all-reduce(min u64, hits)"
+                                          " + grouped broadcast(bg raycast bands)"),
                 "tracking": "camera + objects, weighted LM-ICP, <= 100 iterations" if args.track
                             else "none (poses supplied, SURVEY 8d)",
                 "mask_frames_every": mask_every,

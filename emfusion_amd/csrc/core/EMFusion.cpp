@@ -352,6 +352,8 @@ void EMFusion::preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& d
 void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     depth = depthDev;
     stamp(kStart);
+    if (sharded && depthRoot >= 0)  // 1.2 MB at VGA, once per frame
+        comm->broadcast(depthDev.data, depthDev.pitch * static_cast<size_t>(depthDev.height), depthRoot, main);
     if (in.preprocessDepth) {
         preprocessDepth(depthDev, depthFiltered.view());
         depth = depthFiltered.view();

@@ -155,6 +155,14 @@ public:
      */
     void render(uint8_t* rgb);
     const std::array<uint8_t, 768>& getColorMap() const { return colorMap; }
+    /**
+     * Multi-GPU: the depth image enters the node on ONE rank.  With a root >= 0 every frame starts
+     * with a broadcast of the depth buffer handed to processFrame (source on `root`, destination on
+     * the other ranks: same size and pitch everywhere) over the communicator -- the per-frame
+     * broadcast SURVEY 8(e) lists next to the two reductions.  -1 (default): every rank already
+     * holds the frame.
+     */
+    void setDepthBroadcastRoot(int root) { depthRoot = root; }
     /** getMesh() of the background (id 0) or of an object held by this rank. */
     Mesh getMesh(int id);
 
@@ -276,6 +284,7 @@ private:
     DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
+    int depthRoot = -1;  // sharded path: rank whose depth image is broadcast each frame (-1: none)
     bool bgBands = true;  // sharded path: split the background raycast into row bands per rank
 
     // ---- object creation / matching (SURVEY f-3) ----

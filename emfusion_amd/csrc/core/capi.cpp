@@ -283,6 +283,11 @@ int emf_fusion_render(emf_fusion_t* h, uint8_t* rgb, uint8_t* color_map) {
     });
 }
 
+int emf_fusion_set_depth_broadcast(emf_fusion_t* h, int root) {
+    REQ(h);
+    return guarded([&] { h->impl->setDepthBroadcastRoot(root); });
+}
+
 int emf_fusion_enable_pose_log(emf_fusion_t* h, int on) {
     REQ(h);
     return guarded([&] { h->impl->enablePoseLog(on != 0); });

@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         "emf_fusion_create_object_from_mask": [vp, img, ip],
         "emf_fusion_match_mask": [vp, img, ip, fp],
         "emf_fusion_update_object": [vp, C.c_int, img, fp],
+        "emf_fusion_set_depth_broadcast": [vp, C.c_int],
         "emf_fusion_render": [vp, C.c_void_p, C.c_void_p],
         "emf_fusion_extract_mesh": [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "emf_fusion_copy_mesh": [vp, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -335,6 +336,10 @@ class Fusion:
         _check("emf_fusion_update_object",
                load().emf_fusion_update_object(self._h, int(obj_id), C.byref(mask_view), off))
         return np.array(list(off), np.float32)
+
+    def set_depth_broadcast(self, root: int = 0):
+        """Multi-GPU: every frame's depth image is broadcast from rank `root` first (-1: off)."""
+        _check("emf_fusion_set_depth_broadcast", load().emf_fusion_set_depth_broadcast(self._h, int(root)))
 
     def render(self):
         """EMFusion::render: (image (H, W, 3) u8 RGB, colour map (256, 3) u8)."""

@@ -131,6 +131,10 @@ int emf_io_write_mesh(const char* filename, uint32_t num_vertices, const float* 
 /* EMFusion::render (EMFusion.cpp:131-160): Phong-shaded RGB view of the models, width*height*3 bytes
  * into host memory; color_map (may be NULL) receives the 256 x RGB label colours. */
 int emf_fusion_render(emf_fusion_t* h, uint8_t* rgb, uint8_t* color_map);
+/* Multi-GPU: broadcast the depth image of every frame from rank `root` (whose process_frame argument
+ * is the source; on the other ranks it is the destination and must have the same size and pitch)
+ * before anything else runs.  root < 0 (default): every rank is handed the frame itself. */
+int emf_fusion_set_depth_broadcast(emf_fusion_t* h, int root);
 int emf_fusion_enable_pose_log(emf_fusion_t* h, int on);
 int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes);
 int emf_io_write_volume(const char* filename, const float* voxels, const int32_t res[3], float voxel_size);

@@ -22,7 +22,7 @@ def run(request, oracle, dev):
     reference-shaped one-stream-per-volume path (EMF_PER_VOLUME=1), and the object-sharded
     multi-GPU path driven through a real RCCL communicator of ONE rank (EMF_FORCE_SHARDED=1):
     E-step partial sum -> ncclAllReduce(sum) -> normalise, hit keys -> ncclAllReduce(min) ->
-    composite from keys, indexed device-side visibility gate."""
+    composite from keys, indexed device-side visibility gate, per-frame depth broadcast."""
     import os
 
     from emfusion_amd import pipeline
@@ -40,6 +40,8 @@ def run(request, oracle, dev):
     K = np.array(prm.K, np.float32)
     synth = pipeline.SyntheticStream(W, H, K, NOBJ, seed=0xE3F5)
     fus = pipeline.Fusion(prm, comm)
+    if comm is not None:
+        fus.set_depth_broadcast(0)  # the per-frame ncclBroadcast of the depth image (rank 0 = source)
     orc = OraclePipeline(oracle, W, H, K, BG_RES, BG_VOX, list(prm.volume_pose_t), OBJ_RES,
                          visibility_thresh=100, boundary=5)
     fus.enable_raycast_stats(True)
