@@ -218,6 +218,21 @@ __device__ __forceinline__ V3 project(const IntegrateGeom& a, const V3& p) {
     return mul(a.K, p);
 }
 
+#ifndef EMF_INT_FAST
+#define EMF_INT_FAST 1  // 0: always take the IEEE division / square root sequences (A/B builds)
+#endif
+
+// round(x / z) to the pixel grid WITHOUT the IEEE division when that is provably the same integer.
+// q~ = x * rcp(z): v_rcp_f32 is accurate to 1 ulp and the product rounds once, so
+// |q~ - fl(x / z)| <= |q~| * 2^-22.  Unless q~ lies within twice that of a rounding tie k + 1/2 (or
+// is huge / not finite, where float -> int conversion or rcp of a denormal could differ), q~ and the
+// correctly rounded quotient round to the same integer.  `risky` lanes divide (about one quotient
+// in 1500 on a VGA image).
+__device__ __forceinline__ bool quotient_is_risky(float q) {
+    const float f = q - floorf(q);
+    return !(fabsf(q) < 1048576.f) || fabsf(f - 0.5f) <= fabsf(q) * 0x1p-21f;
+}
+
 // Where a voxel lands in the image: everything of classify_voxel that needs no memory.
 struct VoxelShot {
     int px, py;    // rounded pixel (valid only if inImage)
@@ -232,8 +247,19 @@ __device__ __forceinline__ VoxelShot shoot_voxel(const IntegrateGeom& a, const V
     s.behind = pcam.z <= 0.f;
     const V3 proj = project(a, pcam);
     // for `behind` voxels the quotients are never used (the reference returns before dividing)
+#if EMF_INT_FAST
+    const float rz = __builtin_amdgcn_rcpf(proj.z);
+    float qx = proj.x * rz, qy = proj.y * rz;
+    if (!s.behind && (quotient_is_risky(qx) || quotient_is_risky(qy))) {
+        qx = proj.x / proj.z;
+        qy = proj.y / proj.z;
+    }
+    s.px = __float2int_rn(qx);  // round-half-even, TSDF.cu:360-361
+    s.py = __float2int_rn(qy);
+#else
     s.px = __float2int_rn(proj.x / proj.z);  // round-half-even, TSDF.cu:360-361
     s.py = __float2int_rn(proj.y / proj.z);
+#endif
     s.inImage = !s.behind && s.px >= 0 && s.px < a.w && s.py >= 0 && s.py < a.h;
     s.n2 = pcam.x * pcam.x + pcam.y * pcam.y + pcam.z * pcam.z;
     return s;
@@ -249,6 +275,23 @@ __device__ __forceinline__ int classify_shot(const IntegrateGeom& a, const Voxel
     if (s.behind) return kZeroIfUnseen;
     if (!s.inImage) return kSkip;
     if (d <= 0.f) return kZeroIfUnseen;
+#if EMF_INT_FAST
+    // Far from the surface only the SIDE of the truncation band matters: free space fuses the
+    // constant +1 with weight 1, voxels behind the band are left alone.  With the 1-ulp v_sqrt_f32,
+    // sdf~ = d - il * sqrt~ differs from the reference's value by at most (|d| + |il n|) * 2^-21
+    // (one ulp of the root, one rounding of the product, one of the difference, each side); outside
+    // twice that margin around +-truncdist the branch -- and the clamped sample -- are decided
+    // without the IEEE square root and without the division by truncdist.
+    {
+        const float t = il * __builtin_amdgcn_sqrtf(s.n2);
+        const float approx = d - t, margin = (fabsf(d) + fabsf(t)) * 0x1p-20f;
+        if (approx - margin > a.truncdist) {  // sdf > truncdist: |sdf / truncdist| >= 1 -> sample +1
+            tsdfSample = 1.f;
+            return kFuse;
+        }
+        if (approx + margin < -a.truncdist) return kNegIfUnseen;
+    }
+#endif
     const float sdf = d - il * sqrtf(s.n2);
     if (sdf >= -a.truncdist) {
         tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
