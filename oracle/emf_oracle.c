@@ -680,6 +680,7 @@ static v3 mc_interp(v3 p1, v3 p2, float v1, float v2) { /* vertexInterp, TSDF.cu
 
 void orc_marchingCubesCount(const float* tsdf, const float* weights, const uint8_t* fg,
                             const int res[3], int* numVerts, int* numTris) {
+    emf_mc_init();
     int nv = 0, nt = 0;
     for (int z = 0; z < res[2] - 1; ++z)
         for (int y = 0; y < res[1] - 1; ++y)
@@ -700,6 +701,7 @@ void orc_marchingCubesCount(const float* tsdf, const float* weights, const uint8
 void orc_marchingCubes(const float* tsdf, const float* grads, const float* weights,
                        const uint8_t* fg, const int res[3], float voxelSize, float* vertices,
                        float* normals, int* triangles) {
+    emf_mc_init();
     const size_t sy = (size_t)res[0], sz = sy * res[1];
     int vertBase = 0, triBase = 0;
     for (int z = 0; z < res[2] - 1; ++z)

@@ -13,10 +13,14 @@ CORNER = [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0), (1, 1, 0), (1, 
 
 def load_tables():
     text = (ROOT / "emfusion_amd/csrc/mc_tables.h").read_text()
-    body = lambda name: re.search(name + r"\[\d+\]\[\d+\]\s*=\s*\{(.*?)\};", text, re.S).group(1)
-    ints = lambda s: [int(v) for v in re.findall(r"-?\d+", s)]
-    edges = np.array(ints(body("emf_mc_edge_corner")), np.int64).reshape(12, 2)
-    tri = np.array(ints(body("emf_mc_tri_table")), np.int8).reshape(256, 16)
+    ints = lambda t: [int(v) for v in re.findall(r"-?\d+", t)]
+    edges = np.array(ints(re.search(r"emf_mc_edge_corner_init\[12\]\[2\]\s*=\s*\{(.*?)\};", text, re.S).group(1)),
+                     np.int64).reshape(12, 2)
+    rows = re.findall(r'"([0-9ab]*)"', re.search(r"#define EMF_MC_ROWS(.*?)\n\n", text, re.S).group(1))
+    assert len(rows) == 256
+    tri = np.full((256, 16), -1, np.int8)  # the layout the kernels index: edges, then -1
+    for c, r in enumerate(rows):
+        tri[c, :len(r)] = [int(ch, 16) for ch in r]
     return edges, tri
 
 
