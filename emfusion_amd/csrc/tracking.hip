@@ -23,6 +23,9 @@
 //   k_track_update  one wave per model: gain ratio, accept / reject, damping update
 // Kernels of a converged model, or of an iteration that may not re-evaluate the gradient
 // (TSDF.cpp `evaluateGradient`), return at once on a device-side flag.
+// Measured and dropped: running solve / update in the LAST workgroup of the per-pixel kernel before
+// them (ticket counter, __threadfence) to save two launches per iteration -- on this multi-XCD part a
+// device-scope release writes the XCD's L2 back, 1200 times per kernel: 51 -> 325 us per iteration.
 //
 // Parity: per-pixel quantities follow the reference's operations one by one (the pose gradient
 // is bit-identical to the oracle; tests/test_gpu_tracking.py).  Sums are formed in a different --
@@ -611,7 +614,9 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
     hipStream_t s = as_stream(stream);
     for (int i = 0; i < iterations; ++i) {
-        hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
+        // the weight maximum is looked up at the first pose of a stage only (device flag): later
+        // iterations of this call cannot need it, the first of a later call returns at once
+        if (i == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_accum, px, dim3(kTrackBlock), 0, s, f);
         hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(64 * kSolveWaves), 0, s, f);
         hipLaunchKernelGGL(k_track_error, px, dim3(kTrackBlock), 0, s, f);
