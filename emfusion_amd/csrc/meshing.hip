@@ -5,11 +5,18 @@
 // The reference classifies every cube into three N^3-sized buffers (class u8, vertex count i32,
 // triangle count i32 -- 9 bytes per voxel, 1.2 GB for the 512^3 background), sums them, runs two
 // device-wide thrust::exclusive_scan passes over them and reads them back in the emit kernel.
-// Here nothing per cube is stored.  Cubes are taken in chunks of 256 consecutive ones (the
-// reference's buffer order) and only per-chunk numbers go through memory (9 bytes per 256 cubes):
-//   k_mesh_count  a workgroup classifies 8 chunks; per chunk the packed (vertices, triangles) total
-//                 -> chunkTot[g], per workgroup their sum -> blockSums[b], and the ids of the
-//                 chunks that hold surface -> list[] (any order)
+// Here nothing per cube is stored.  The cube anchored at voxel (x, y, z) is visited in voxel order
+// (= the reference's buffer order with empty slots where x, y or z is the last index) in chunks of
+// 252 positions -- 4 waves of 63 cubes; lane 63 only lends its voxel to lane 62 -- and only per-chunk
+// numbers go through memory (9 bytes per chunk):
+//   k_mesh_count  a workgroup classifies 8 chunks.  A lane loads ITS voxel of the four rows
+//                 (y, z), (y+1, z), (y, z+1), (y+1, z+1) -- 8 coalesced loads instead of 16
+//                 gathers -- and the "observed" and "negative" predicates become 64-bit wave masks
+//                 (a v_cmp each); the x+1 neighbour is the mask shifted by one, so which cubes are
+//                 complete and which hold a sign change is a handful of SCALAR and / or / shift
+//                 instructions per wave.  Only lanes with surface (rare) build their class.  Per
+//                 chunk the packed (vertices, triangles) total -> chunkTot[g], per workgroup their
+//                 sum -> blockSums[b], and the ids of the chunks that hold surface -> list[]
 //   k_mesh_scan   one workgroup: exclusive scan of blockSums in place (65 k pairs at 512^3), totals
 //   k_mesh_emit   a fixed grid walks list[]: classify the chunk again, scan inside the workgroup (wave
 //                 shuffles + LDS) on top of blockSums[g / 8] + the chunk totals before it, and write
@@ -31,16 +38,23 @@ namespace emf_hip {
 namespace {
 
 constexpr int kMcBlock = 256;
-constexpr int kMcChunks = 8;                   // chunks per counting workgroup
-constexpr int kMcSpan = kMcBlock * kMcChunks;  // = 4 rows of a 512-wide volume: neighbours in y hit L1
+constexpr int kMcWaveCubes = 63;                               // positions per wave (lanes 0..62)
+constexpr int kMcChunk = kMcWaveCubes * (kMcBlock / 64);       // 252 positions per chunk
+constexpr int kMcChunks = 8;                                   // chunks per counting workgroup
+constexpr int kMcSpan = kMcChunk * kMcChunks;                  // ~4 rows of a 512-wide volume
 constexpr unsigned kXcds = 8;
 
-// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give XCD k the k-th
-// contiguous eighth of the sequence (whole z-slabs of a large volume), so that the planes two
-// neighbouring rows / slices share are fetched into ONE L2 instead of eight.
-__device__ __forceinline__ unsigned logical_block(unsigned n) {
-    const unsigned per = (n + kXcds - 1) / kXcds;
-    return (blockIdx.x % kXcds) * per + blockIdx.x / kXcds;
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.  A cube needs the
+// planes z and z + 1, so every plane is read twice, one plane's worth of workgroups apart -- 2 MiB of
+// tsdf + weights per 512^2 plane, which does not survive in an L2 that streams the whole plane.
+// Each XCD therefore takes the same BAND of every plane (an eighth of its rows) and walks z: the data
+// it has to keep between the two uses is an eighth of a plane.  `wpp` = workgroups per plane.
+__device__ __forceinline__ unsigned logical_block(unsigned nblocks, unsigned wpp) {
+    const unsigned band = (wpp + kXcds - 1) / kXcds;
+    const unsigned k = blockIdx.x % kXcds, i = blockIdx.x / kXcds;
+    const unsigned col = k * band + i % band;
+    const unsigned b = (i / band) * wpp + col;
+    return col < wpp ? b : nblocks;  // nblocks = nothing to do
 }
 
 struct MeshArgs {
@@ -55,6 +69,7 @@ struct MeshArgs {
     float* normals;
     int32_t* triangles;
     unsigned nblocks;
+    unsigned wpp;  // counting workgroups per z plane (at least 1)
 };
 
 struct Cube {
@@ -63,44 +78,43 @@ struct Cube {
     unsigned cls;  // 0 when the cube is masked out or carries no surface
 };
 
-// Where a chunk starts in the cube grid.  Wave-uniform; dividing is done once per workgroup, the
-// following chunks and the lanes' own coordinates are reached by carrying -- two 64-bit divisions per
-// cube were most of the counting kernel's time.
+// Voxel coordinates of a linear position.  Dividing is done once per workgroup (wave-uniform
+// values); chunks, waves and lanes are reached from there by carrying -- two 64-bit divisions per
+// cube were most of the first counting kernel's time.
 struct Origin {
     unsigned x, y, z;
 };
 
-__device__ __forceinline__ Origin origin_of(const I3& n, size_t c0) {
-    const unsigned nx1 = n.x - 1, ny1 = n.y - 1;
-    const size_t r0 = c0 / nx1;
-    return Origin{static_cast<unsigned>(c0 - r0 * nx1), static_cast<unsigned>(r0 % ny1),
-                  static_cast<unsigned>(r0 / ny1)};
+__device__ __forceinline__ Origin origin_of(const I3& n, size_t p) {
+    const unsigned nx = n.x, ny = n.y;
+    const size_t r = p / nx;
+    return Origin{static_cast<unsigned>(p - r * nx), static_cast<unsigned>(r % ny), static_cast<unsigned>(r / ny)};
 }
 
 __device__ __forceinline__ Origin advanced(const I3& n, Origin o, unsigned by) {
-    const unsigned nx1 = n.x - 1, ny1 = n.y - 1;
+    const unsigned nx = n.x, ny = n.y;
     o.x += by;
-    while (o.x >= nx1) {  // at most once per 256 cubes when Nx > 256
-        o.x -= nx1;
+    while (o.x >= nx) {  // at most once per wave when Nx >= 64
+        o.x -= nx;
         ++o.y;
     }
-    while (o.y >= ny1) {
-        o.y -= ny1;
+    while (o.y >= ny) {
+        o.y -= ny;
         ++o.z;
     }
     return o;
 }
 
-// cube `tid` of the chunk at `o`; `left` = cubes from the chunk start to the end of the volume
-__device__ __forceinline__ Cube classify(const MeshSource& s, const Origin& o, unsigned tid, size_t left) {
+// the cube anchored at voxel `o` (emit pass: its 16 corner values are gathered by the lane itself)
+__device__ __forceinline__ Cube classify(const MeshSource& s, const Origin& o, bool inRange) {
     Cube q{0, 0, 0, 0, 0u};
-    if (tid >= left) return q;
     const I3 n = s.n;
-    const Origin me = advanced(n, o, tid);
-    const unsigned x = me.x, y = me.y, z = me.z;
-    q.x = static_cast<int>(x);
-    q.y = static_cast<int>(y);
-    q.z = static_cast<int>(z);
+    if (!inRange || o.x + 1 >= static_cast<unsigned>(n.x) || o.y + 1 >= static_cast<unsigned>(n.y) ||
+        o.z + 1 >= static_cast<unsigned>(n.z))
+        return q;
+    q.x = static_cast<int>(o.x);
+    q.y = static_cast<int>(o.y);
+    q.z = static_cast<int>(o.z);
     const size_t sy = static_cast<size_t>(n.x), sz = sy * n.y;
     q.base = static_cast<size_t>(q.z) * sz + static_cast<size_t>(q.y) * sy + q.x;
     bool valid = true;  // kernel_classifyCubes: all 8 corners observed (and foreground)
@@ -121,6 +135,84 @@ __device__ __forceinline__ Cube classify(const MeshSource& s, const Origin& o, u
     }
     q.cls = cls == 255u ? 0u : cls;
     return q;
+}
+
+// The same decision for the 63 cubes of a wave at once (count pass).  `ow` / `pw`: coordinates and
+// linear position of the wave's first voxel (wave-uniform); lane l holds voxel pw + l.  Returns the
+// lane's class (0: no surface here); all lanes of the wave call together.
+__device__ __forceinline__ unsigned classify_wave(const MeshSource& s, const Origin& ow, size_t pw, size_t nvox,
+                                                  int lane) {
+    const I3 n = s.n;
+    const unsigned nx = n.x, ny = n.y, nz = n.z;
+    const size_t sy = static_cast<size_t>(nx), sz = sy * ny;
+    unsigned x = ow.x + lane, y = ow.y, z = ow.z;
+    if (nx >= 64u) {  // a wave wraps at most once
+        if (x >= nx) {
+            x -= nx;
+            ++y;
+        }
+        if (y >= ny) {
+            y -= ny;
+            ++z;
+        }
+    } else {
+        while (x >= nx) {
+            x -= nx;
+            ++y;
+        }
+        while (y >= ny) {
+            y -= ny;
+            ++z;
+        }
+    }
+    const bool in = pw + lane < nvox;
+    const bool rowY = in && y + 1 < ny, rowZ = in && z + 1 < nz;
+    const bool row[4] = {in, rowY, rowZ, rowY && rowZ};
+    const size_t rowOff[4] = {0, sy, sz, sy + sz};
+    float w[4], t[4];
+    unsigned char g[4];
+    if (pw + 64 + sy + sz <= nvox) {
+        // every address of the wave lies inside the arrays (all but the last plane): scalar row bases,
+        // the lane index as the only per-lane part of the address.  A row that does not exist for a
+        // lane (y + 1 == Ny, z + 1 == Nz) yields a neighbouring row's values; V masks them out.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w[r] = (s.weights + pw + rowOff[r])[lane];
+            t[r] = (s.tsdf + pw + rowOff[r])[lane];
+            g[r] = s.fg ? (s.fg + pw + rowOff[r])[lane] : 1;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // clamped addresses, still unconditional loads
+            const size_t q = row[r] ? pw + lane + rowOff[r] : 0;
+            w[r] = s.weights[q];
+            t[r] = s.tsdf[q];
+            g[r] = s.fg ? s.fg[q] : 1;
+        }
+    }
+    unsigned long long V[4], N[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        V[r] = __ballot(row[r] && w[r] > 0.f && g[r] != 0);
+        N[r] = __ballot(t[r] < 0.f);  // only read where V says the cube is complete
+    }
+    // lanes 0..62 whose x + 1 exists; the rows' existence is already in V
+    unsigned long long complete = __ballot(x + 1 < nx) & 0x7fffffffffffffffull;
+    unsigned long long all = ~0ull, any = 0ull;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        complete &= V[r] & (V[r] >> 1);
+        all &= N[r] & (N[r] >> 1);
+        any |= N[r] | (N[r] >> 1);
+    }
+    const unsigned long long surface = complete & any & ~all;  // both signs among the 8 corners
+    if (surface == 0ull) return 0u;  // wave-uniform: the common case
+    if (!((surface >> lane) & 1ull)) return 0u;
+    auto bit = [&](unsigned long long m, int d) { return static_cast<unsigned>((m >> (lane + d)) & 1ull); };
+    // corners 0:(0,0,0) 1:(1,0,0) 2:(1,0,1) 3:(0,0,1) 4:(0,1,0) 5:(1,1,0) 6:(1,1,1) 7:(0,1,1); rows (dy, dz):
+    // N[0] = (0,0), N[1] = (1,0), N[2] = (0,1), N[3] = (1,1)
+    return bit(N[0], 0) | bit(N[0], 1) << 1 | bit(N[2], 1) << 2 | bit(N[2], 0) << 3 | bit(N[1], 0) << 4 |
+           bit(N[1], 1) << 5 | bit(N[3], 1) << 6 | bit(N[3], 0) << 7;
 }
 
 __device__ __forceinline__ unsigned triangles_of(unsigned cls) {
@@ -161,24 +253,28 @@ __device__ __forceinline__ uint2 block_scan(uint2 v, uint2& total, uint2* lds /*
 
 __global__ __launch_bounds__(kMcBlock) void k_mesh_count(const MeshArgs a) {
     __shared__ unsigned lds[kMcBlock / 64][kMcChunks];
-    const unsigned b = logical_block(a.nblocks);
+    const unsigned b = logical_block(a.nblocks, a.wpp);
     if (b >= a.nblocks) return;
-    const size_t cubes = static_cast<size_t>(a.src.n.x - 1) * (a.src.n.y - 1) * (a.src.n.z - 1);
+    const I3 n = a.src.n;
+    const size_t nvox = static_cast<size_t>(n.x) * n.y * n.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned p[kMcChunks];
-    const size_t c0 = static_cast<size_t>(b) * kMcSpan;
-    Origin o = origin_of(a.src.n, c0);
+    size_t pw = static_cast<size_t>(b) * kMcSpan + static_cast<size_t>(wave) * kMcWaveCubes;  // this wave, chunk 0
+    Origin o = origin_of(n, pw);
 #pragma unroll
     for (int c = 0; c < kMcChunks; ++c) {
-        const size_t start = c0 + static_cast<size_t>(c) * kMcBlock;
-        const Cube q = classify(a.src, o, threadIdx.x, start < cubes ? cubes - start : 0);
-        p[c] = q.cls ? __popc(active_edges(q.cls)) | (triangles_of(q.cls) << 16) : 0u;
-        o = advanced(a.src.n, o, kMcBlock);
+        const unsigned cls = classify_wave(a.src, o, pw, nvox, lane);
+        p[c] = cls ? __popc(active_edges(cls)) | (triangles_of(cls) << 16) : 0u;
+        pw += kMcChunk;
+        o = advanced(n, o, kMcChunk);
     }
 #pragma unroll
     for (int c = 0; c < kMcChunks; ++c) {
+        if (__ballot(p[c] != 0u) != 0ull) {  // wave-uniform: most waves hold no surface
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) p[c] += __shfl_xor(p[c], o);  // fields cannot carry: <= 768, 320 per wave
-        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6][c] = p[c];
+            for (int o2 = 32; o2 > 0; o2 >>= 1) p[c] += __shfl_xor(p[c], o2);  // fields cannot carry: <= 756, 315 per wave
+        }
+        if (lane == 0) lds[wave][c] = p[c];
     }
     __syncthreads();
     if (threadIdx.x < kMcChunks) {
@@ -190,9 +286,9 @@ __global__ __launch_bounds__(kMcBlock) void k_mesh_count(const MeshArgs a) {
         if (t) a.list[atomicAdd(a.listCount, 1u)] = g;
         uint2 sum = make_uint2(t & 0xffffu, t >> 16);
 #pragma unroll
-        for (int o = 1; o < kMcChunks; o <<= 1) {
-            sum.x += __shfl_xor(sum.x, o);
-            sum.y += __shfl_xor(sum.y, o);
+        for (int o2 = 1; o2 < kMcChunks; o2 <<= 1) {
+            sum.x += __shfl_xor(sum.x, o2);
+            sum.y += __shfl_xor(sum.y, o2);
         }
         if (threadIdx.x == 0) a.blockSums[b] = sum;
     }
@@ -260,7 +356,8 @@ __device__ __forceinline__ void emit_cube(const MeshArgs& a, const Cube& q, unsi
 __global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
     __shared__ uint2 lds[8];
     const I3 n = a.src.n;
-    const size_t cubes = static_cast<size_t>(n.x - 1) * (n.y - 1) * (n.z - 1);
+    const size_t nvox = static_cast<size_t>(n.x) * n.y * n.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned todo = *a.listCount;
     for (unsigned i = blockIdx.x; i < todo; i += gridDim.x) {
         const unsigned g = a.list[i];
@@ -271,8 +368,8 @@ __global__ __launch_bounds__(kMcBlock) void k_mesh_emit(const MeshArgs a) {
             base.x += t & 0xffffu;
             base.y += t >> 16;
         }
-        const size_t c0 = static_cast<size_t>(g) * kMcBlock;
-        const Cube q = classify(a.src, origin_of(n, c0), threadIdx.x, cubes - c0);
+        const size_t p = static_cast<size_t>(g) * kMcChunk + static_cast<size_t>(wave) * kMcWaveCubes + lane;
+        const Cube q = classify(a.src, origin_of(n, p), lane < kMcWaveCubes && p < nvox);
         const unsigned edges = q.cls ? active_edges(q.cls) : 0u;
         uint2 v = make_uint2(0u, 0u);
         if (q.cls) v = make_uint2(__popc(edges), triangles_of(q.cls));
@@ -334,7 +431,11 @@ __device__ __forceinline__ void emit_cube(const MeshArgs& a, const Cube& q, unsi
     }
 }
 
-unsigned launch_blocks(unsigned nblocks) { return ((nblocks + kXcds - 1) / kXcds) * kXcds; }
+// grid of the counting pass: 8 XCDs x ceil(wpp / 8) columns x planes (see logical_block)
+unsigned launch_blocks(unsigned nblocks, unsigned wpp) {
+    const unsigned band = (wpp + kXcds - 1) / kXcds, rows = (nblocks + wpp - 1) / wpp;
+    return kXcds * band * rows;
+}
 
 int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_t* fg,
               const int32_t res[3], float voxelSize, void* scratch) {
@@ -342,10 +443,10 @@ int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_
     EMF_REQUIRE_PTR(weights);
     EMF_REQUIRE_PTR(scratch);
     EMF_TRY(check_res(res));
-    const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
-    if ((cubes + kMcBlock - 1) / kMcBlock > 0x7ffffff0ull)
-        return fail(EMF_E_LIMIT, "mesh: %zu cubes exceed one launch", cubes);
-    const unsigned nblocks = static_cast<unsigned>((cubes + kMcSpan - 1) / kMcSpan);
+    const size_t nvox = static_cast<size_t>(res[0]) * res[1] * res[2];
+    if ((nvox + kMcChunk - 1) / kMcChunk > 0x7ffffff0ull)
+        return fail(EMF_E_LIMIT, "mesh: %zu voxels exceed one launch", nvox);
+    const unsigned nblocks = static_cast<unsigned>((nvox + kMcSpan - 1) / kMcSpan);
     a.src = MeshSource{tsdf, weights, fg, i3_from(res), voxelSize};
     a.grads = nullptr;
     a.blockSums = static_cast<uint2*>(scratch);
@@ -356,6 +457,8 @@ int fill_args(MeshArgs& a, const float* tsdf, const float* weights, const uint8_
     a.vertices = a.normals = nullptr;
     a.triangles = nullptr;
     a.nblocks = nblocks;
+    const size_t plane = static_cast<size_t>(res[0]) * res[1];
+    a.wpp = static_cast<unsigned>(plane / kMcSpan > 0 ? plane / kMcSpan : 1);
     return EMF_OK;
 }
 
@@ -368,8 +471,8 @@ extern "C" {
 
 size_t emf_hip_meshScratchBytes(const int32_t res[3]) {
     if (!res || res[0] < 2 || res[1] < 2 || res[2] < 2) return 0;
-    const size_t cubes = static_cast<size_t>(res[0] - 1) * (res[1] - 1) * (res[2] - 1);
-    return ((cubes + kMcSpan - 1) / kMcSpan) * (sizeof(uint2) + 2 * kMcChunks * sizeof(unsigned)) + 16;
+    const size_t nvox = static_cast<size_t>(res[0]) * res[1] * res[2];
+    return ((nvox + kMcSpan - 1) / kMcSpan) * (sizeof(uint2) + 2 * kMcChunks * sizeof(unsigned)) + 16;
 }
 
 int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fgVolMask,
@@ -384,7 +487,7 @@ int emf_hip_meshCount(const float* tsdf, const float* weights, const uint8_t* fg
         set_error("meshCount: memset: %s", hipGetErrorString(e));
         return static_cast<int>(e);
     }
-    hipLaunchKernelGGL(k_mesh_count, dim3(launch_blocks(a.nblocks)), dim3(kMcBlock), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_mesh_count, dim3(launch_blocks(a.nblocks, a.wpp)), dim3(kMcBlock), 0, as_stream(stream), a);
     hipLaunchKernelGGL(k_mesh_scan, dim3(1), dim3(1024), 0, as_stream(stream), a);
     return launch_status("meshCount");
 }
