@@ -5,8 +5,12 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 namespace emf {
 namespace {
@@ -60,7 +64,106 @@ private:
     int rank_, world_;
 };
 
+// ---- in-process rehearsal group (see Communicator.hpp) -----------------------------------------------
+
+struct LocalGroup {
+    explicit LocalGroup(int n) : world(n), slots(n) {}
+    const int world;
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned long generation = 0;
+    std::vector<std::vector<unsigned char>> slots;  // what each rank published for the running collective
+
+    // all ranks arrive, then all leave; a rank that waits too long means the ranks disagree about
+    // the sequence of collectives
+    void barrier() {
+        std::unique_lock<std::mutex> lock(m);
+        const unsigned long gen = generation;
+        if (++waiting == world) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+            return;
+        }
+        if (!cv.wait_for(lock, std::chrono::seconds(30), [&] { return generation != gen; }))
+            throw HipError("local communicator: a rank did not arrive at the collective within 30 s "
+                           "(ranks disagree about the sequence of collectives?)", EMF_E_ARG);
+    }
+};
+
+class LocalCommunicator final : public Communicator {
+public:
+    LocalCommunicator(std::shared_ptr<LocalGroup> g, int rank) : g_(std::move(g)), rank_(rank) {}
+    int rank() const override { return rank_; }
+    int size() const override { return g_->world; }
+
+    void allReduceSumF32(float* dev, size_t count, Stream& s) override {
+        publish(dev, count * sizeof(float), s);
+        std::vector<float> acc(count, 0.f);
+        for (int r = 0; r < g_->world; ++r) {  // rank order: the same sum on every rank
+            const float* v = reinterpret_cast<const float*>(g_->slots[r].data());
+            if (r == 0) std::copy(v, v + count, acc.begin());
+            else for (size_t i = 0; i < count; ++i) acc[i] += v[i];
+        }
+        finish(dev, acc.data(), count * sizeof(float), s);
+    }
+    void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
+        publish(dev, count * sizeof(uint64_t), s);
+        std::vector<uint64_t> acc(count);
+        for (int r = 0; r < g_->world; ++r) {
+            const uint64_t* v = reinterpret_cast<const uint64_t*>(g_->slots[r].data());
+            for (size_t i = 0; i < count; ++i) acc[i] = r == 0 ? v[i] : std::min(acc[i], v[i]);
+        }
+        finish(dev, acc.data(), count * sizeof(uint64_t), s);
+    }
+    void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
+        publish(dev, bytes, s);
+        std::vector<unsigned char> v(g_->slots[root]);
+        finish(dev, v.data(), bytes, s);
+    }
+    void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows, Stream& s) override {
+        const size_t bytes = bytesPerRow * static_cast<size_t>(totalRows);
+        publish(dev, bytes, s);
+        std::vector<unsigned char> v(bytes);
+        for (int r = 0; r < g_->world; ++r) {
+            const int r0 = r * bandRows, n = std::min(bandRows, totalRows - r0);
+            if (n <= 0) break;
+            const size_t off = static_cast<size_t>(r0) * bytesPerRow;
+            std::memcpy(v.data() + off, g_->slots[r].data() + off, static_cast<size_t>(n) * bytesPerRow);
+        }
+        // rows beyond the last band (none: the bands cover the image) would keep this rank's values
+        finish(dev, v.data(), bytes, s);
+    }
+
+private:
+    // device -> this rank's slot, then wait until every rank has published
+    void publish(const void* dev, size_t bytes, Stream& s) {
+        auto& slot = g_->slots[rank_];
+        slot.resize(bytes);
+        hipCheck(hipMemcpyAsync(slot.data(), dev, bytes, hipMemcpyDeviceToHost, s.get()), "local comm D2H");
+        s.waitForCompletion();
+        g_->barrier();
+    }
+    // result -> device, then wait until every rank has consumed the slots (they are reused)
+    void finish(void* dev, const void* host, size_t bytes, Stream& s) {
+        hipCheck(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s.get()), "local comm H2D");
+        s.waitForCompletion();
+        g_->barrier();
+    }
+    std::shared_ptr<LocalGroup> g_;
+    int rank_;
+};
+
 }  // namespace
+
+std::vector<std::shared_ptr<Communicator>> makeLocalCommunicators(int worldSize) {
+    if (worldSize < 1) throw HipError("makeLocalCommunicators: world size < 1", EMF_E_ARG);
+    auto g = std::make_shared<LocalGroup>(worldSize);
+    std::vector<std::shared_ptr<Communicator>> out;
+    for (int r = 0; r < worldSize; ++r) out.push_back(std::make_shared<LocalCommunicator>(g, r));
+    return out;
+}
 
 void rcclGetUniqueId(void* out) {
     ncclUniqueId id;

@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <vector>
 
 #include "types.hpp"
 
@@ -48,5 +49,15 @@ constexpr size_t kRcclUniqueIdBytes = 128;
 void rcclGetUniqueId(void* out);
 /** ncclCommInitRank on the current device.  Throws HipError on failure. */
 std::shared_ptr<Communicator> makeRcclCommunicator(const void* uniqueId, int rank, int worldSize);
+
+/**
+ * Rehearsal backend: `worldSize` communicators of ONE process that share a GPU, one per host thread.
+ * RCCL refuses two ranks on one device, so the sharded pipeline cannot be run with world > 1 on a
+ * single-GPU box through it; this group lets N EMFusion instances on N threads go through exactly the
+ * code path of an N-GPU run (ownership, band split, the sequence of collectives -- a mismatch shows
+ * as a time-out instead of a hang).  Collectives are staged through host memory and synchronise the
+ * calling stream: a test vehicle, not a transport.
+ */
+std::vector<std::shared_ptr<Communicator>> makeLocalCommunicators(int worldSize);
 
 }  // namespace emf

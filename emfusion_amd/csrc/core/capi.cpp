@@ -571,6 +571,18 @@ int emf_comm_create(const void* unique_id128, int rank, int world, emf_comm_t** 
 
 void emf_comm_destroy(emf_comm_t* c) { delete c; }
 
+int emf_comm_create_local_group(int world, emf_comm_t** out) {
+    REQ(out);
+    return guarded([&] {
+        auto group = makeLocalCommunicators(world);
+        for (int r = 0; r < world; ++r) {
+            auto c = std::make_unique<emf_comm>();
+            c->impl = group[r];
+            out[r] = c.release();
+        }
+    });
+}
+
 int emf_synth_create(int width, int height, const float K[9], int num_spheres, uint64_t seed,
                      float noise_sigma, float dropout, emf_synth_t** out) {
     REQ(K);

@@ -137,6 +137,7 @@ def load() -> C.CDLL:
         "emf_comm_unique_id": [vp],
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
         "emf_comm_destroy": [vp],
+        "emf_comm_create_local_group": [C.c_int, C.POINTER(vp)],
         "emf_synth_create": [C.c_int, C.c_int, fp, C.c_int, C.c_uint64, C.c_float, C.c_float,
                              C.POINTER(vp)],
         "emf_synth_destroy": [vp],
@@ -193,6 +194,19 @@ class Communicator:
         buf = C.create_string_buffer(unique_id, 128)
         _check("emf_comm_create", load().emf_comm_create(buf, rank, world, C.byref(self._h)))
         self.rank, self.world = rank, world
+
+    @classmethod
+    def local_group(cls, world: int):
+        """`world` communicators of THIS process for `world` Fusion objects on `world` threads sharing one
+        GPU (rehearsal of the multi-GPU code path; collectives are staged through host memory)."""
+        handles = (C.c_void_p * world)()
+        _check("emf_comm_create_local_group", load().emf_comm_create_local_group(world, handles))
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c._h, c.rank, c.world = C.c_void_p(handles[r]), r, world
+            out.append(c)
+        return out
 
     @staticmethod
     def unique_id() -> bytes:

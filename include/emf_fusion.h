@@ -194,6 +194,10 @@ int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);
 int emf_comm_unique_id(void* out128);
 int emf_comm_create(const void* unique_id128, int rank, int world, emf_comm_t** out);
 void emf_comm_destroy(emf_comm_t* c);
+/* Rehearsal backend: `world` communicators of one process sharing one GPU, one per host thread (RCCL
+ * refuses two ranks on a device).  N emf_fusion handles driven from N threads then run the code path
+ * of an N-GPU job; collectives are staged through host memory.  out: array of `world` handles. */
+int emf_comm_create_local_group(int world, emf_comm_t** out);
 
 /* ---- synthetic RGB-D stream (host side, replaces the dataset readers) ---- */
 int emf_synth_create(int width, int height, const float K[9], int num_spheres, uint64_t seed,
