@@ -68,6 +68,10 @@ def parse_args():
     ap.add_argument("--no-depth-broadcast", action="store_true",
                     help="multi-GPU: every rank already holds the frame; skip the per-frame "
                          "ncclBroadcast of the depth image from rank 0")
+    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
+                    help="rccl: the product's transport (one GPU per rank).  gloo: rehearsal -- the "
+                         "collectives are staged through host memory and carried by torch.distributed, "
+                         "so N ranks can share fewer than N GPUs; not a measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the cross-rank exchange path (RCCL all-reduces) even with one "
                          "rank, to exercise the multi-GPU code on a single GPU")
@@ -125,10 +129,13 @@ def main():
     if world > 1 or args.force_sharded:
         if args.force_sharded:
             os.environ["EMF_FORCE_SHARDED"] = "1"
-        uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
-        if dist is not None:
-            dist.broadcast_object_list(uid, src=0)  # ncclUniqueId travels over the gloo group
-        comm = pipeline.Communicator(uid[0], rank, world)
+        if args.comm == "gloo" and dist is not None:
+            comm = pipeline.Communicator.host_staged(dist)
+        else:
+            uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)  # ncclUniqueId travels over the gloo group
+            comm = pipeline.Communicator(uid[0], rank, world)
 
     synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
     fus = pipeline.Fusion(prm, comm)
@@ -222,7 +229,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: collectives over gloo, ranks may share a GPU -- not a "
+                                   "measurement)" if comm is not None and args.comm == "gloo" else ""),
             "config": {
                 "workload": (f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj_total} obj "
                              f"{args.obj_res}^3, {W}x{H}, full EM association + weighted fusion"

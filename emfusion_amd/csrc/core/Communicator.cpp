@@ -155,7 +155,64 @@ private:
     int rank_;
 };
 
+class HostStagedCommunicator final : public Communicator {
+public:
+    explicit HostStagedCommunicator(const HostStagedCallbacks& cb) : cb_(cb) {
+        if (!cb.allReduceSumF32 || !cb.allReduceMinU64 || !cb.broadcast || cb.world < 1 || cb.rank < 0 ||
+            cb.rank >= cb.world)
+            throw HipError("makeHostStagedCommunicator: incomplete callbacks", EMF_E_ARG);
+    }
+    int rank() const override { return cb_.rank; }
+    int size() const override { return cb_.world; }
+    void allReduceSumF32(float* dev, size_t count, Stream& s) override {
+        down(dev, count * sizeof(float), s);
+        check(cb_.allReduceSumF32(cb_.user, reinterpret_cast<float*>(host_.data()), count), "all-reduce(sum)");
+        up(dev, count * sizeof(float), s);
+    }
+    void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
+        down(dev, count * sizeof(uint64_t), s);
+        check(cb_.allReduceMinU64(cb_.user, reinterpret_cast<uint64_t*>(host_.data()), count), "all-reduce(min)");
+        up(dev, count * sizeof(uint64_t), s);
+    }
+    void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
+        down(dev, bytes, s);
+        check(cb_.broadcast(cb_.user, host_.data(), bytes, root), "broadcast");
+        up(dev, bytes, s);
+    }
+    void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows, Stream& s) override {
+        const size_t bytes = bytesPerRow * static_cast<size_t>(totalRows);
+        down(dev, bytes, s);
+        for (int r = 0; r < cb_.world; ++r) {
+            const int r0 = r * bandRows, n = std::min(bandRows, totalRows - r0);
+            if (n <= 0) break;
+            check(cb_.broadcast(cb_.user, host_.data() + static_cast<size_t>(r0) * bytesPerRow,
+                                static_cast<size_t>(n) * bytesPerRow, r), "broadcast(band)");
+        }
+        up(dev, bytes, s);
+    }
+
+private:
+    static void check(int rc, const char* what) {
+        if (rc != 0) throw HipError(std::string("host-staged communicator: ") + what + " failed", rc);
+    }
+    void down(const void* dev, size_t bytes, Stream& s) {
+        host_.resize(bytes);
+        hipCheck(hipMemcpyAsync(host_.data(), dev, bytes, hipMemcpyDeviceToHost, s.get()), "staged D2H");
+        s.waitForCompletion();
+    }
+    void up(void* dev, size_t bytes, Stream& s) {
+        hipCheck(hipMemcpyAsync(dev, host_.data(), bytes, hipMemcpyHostToDevice, s.get()), "staged H2D");
+        s.waitForCompletion();
+    }
+    HostStagedCallbacks cb_;
+    std::vector<unsigned char> host_;
+};
+
 }  // namespace
+
+std::shared_ptr<Communicator> makeHostStagedCommunicator(const HostStagedCallbacks& cb) {
+    return std::make_shared<HostStagedCommunicator>(cb);
+}
 
 std::vector<std::shared_ptr<Communicator>> makeLocalCommunicators(int worldSize) {
     if (worldSize < 1) throw HipError("makeLocalCommunicators: world size < 1", EMF_E_ARG);

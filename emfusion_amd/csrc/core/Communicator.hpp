@@ -60,4 +60,19 @@ std::shared_ptr<Communicator> makeRcclCommunicator(const void* uniqueId, int ran
  */
 std::vector<std::shared_ptr<Communicator>> makeLocalCommunicators(int worldSize);
 
+/**
+ * Rehearsal backend for one PROCESS per rank: every collective is staged through host memory and
+ * handed to caller-supplied functions (the Python harness passes torch.distributed / gloo).  With it
+ * `torchrun --nproc-per-node N bench.py --gpus N --comm gloo` runs the whole multi-rank job on a box
+ * with fewer than N GPUs.  Callbacks return 0 on success.
+ */
+struct HostStagedCallbacks {
+    int rank = 0, world = 1;
+    int (*allReduceSumF32)(void* user, float* host, size_t count) = nullptr;
+    int (*allReduceMinU64)(void* user, uint64_t* host, size_t count) = nullptr;
+    int (*broadcast)(void* user, void* host, size_t bytes, int root) = nullptr;
+    void* user = nullptr;
+};
+std::shared_ptr<Communicator> makeHostStagedCommunicator(const HostStagedCallbacks& cb);
+
 }  // namespace emf

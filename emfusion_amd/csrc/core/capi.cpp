@@ -571,6 +571,23 @@ int emf_comm_create(const void* unique_id128, int rank, int world, emf_comm_t** 
 
 void emf_comm_destroy(emf_comm_t* c) { delete c; }
 
+int emf_comm_create_host_staged(const emf_comm_callbacks_t* cb, emf_comm_t** out) {
+    REQ(cb);
+    REQ(out);
+    return guarded([&] {
+        HostStagedCallbacks h;
+        h.rank = cb->rank;
+        h.world = cb->world;
+        h.allReduceSumF32 = cb->all_reduce_sum_f32;
+        h.allReduceMinU64 = cb->all_reduce_min_u64;
+        h.broadcast = cb->broadcast;
+        h.user = cb->user;
+        auto c = std::make_unique<emf_comm>();
+        c->impl = makeHostStagedCommunicator(h);
+        *out = c.release();
+    });
+}
+
 int emf_comm_create_local_group(int world, emf_comm_t** out) {
     REQ(out);
     return guarded([&] {

@@ -138,6 +138,7 @@ def load() -> C.CDLL:
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
         "emf_comm_destroy": [vp],
         "emf_comm_create_local_group": [C.c_int, C.POINTER(vp)],
+        "emf_comm_create_host_staged": [vp, C.POINTER(vp)],
         "emf_synth_create": [C.c_int, C.c_int, fp, C.c_int, C.c_uint64, C.c_float, C.c_float,
                              C.POINTER(vp)],
         "emf_synth_destroy": [vp],
@@ -207,6 +208,52 @@ class Communicator:
             c._h, c.rank, c.world = C.c_void_p(handles[r]), r, world
             out.append(c)
         return out
+
+    @classmethod
+    def host_staged(cls, dist):
+        """One process per rank, collectives staged through host memory and carried by the given
+        torch.distributed module (gloo): rehearsal of the N-rank job on fewer than N GPUs."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def view(ptr, count, dtype):
+            return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dtype)), shape=(count,)))
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # noqa: BLE001 - reported through the C++ exception
+                    print("host-staged collective failed:", repr(e), flush=True)
+                    return 1
+            return wrapped
+
+        def sum_f32(user, ptr, count):
+            dist.all_reduce(view(ptr, count, C.c_float), op=dist.ReduceOp.SUM)
+
+        def min_u64(user, ptr, count):
+            t = view(ptr, count, C.c_int64)
+            t ^= -(2 ** 63)          # unsigned order -> signed order
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            t ^= -(2 ** 63)
+
+        def bcast(user, ptr, nbytes, root):
+            dist.broadcast(view(ptr, nbytes, C.c_uint8), src=root)
+
+        f_red = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+        f_bc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+        class Callbacks(C.Structure):
+            _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("sum", f_red), ("min", f_red),
+                        ("bcast", f_bc), ("user", C.c_void_p)]
+        c = cls.__new__(cls)
+        c._keep = (f_red(guard(sum_f32)), f_red(guard(min_u64)), f_bc(guard(bcast)))
+        cb = Callbacks(rank, world, c._keep[0], c._keep[1], c._keep[2], None)
+        c._h = C.c_void_p()
+        _check("emf_comm_create_host_staged", load().emf_comm_create_host_staged(C.byref(cb), C.byref(c._h)))
+        c.rank, c.world = rank, world
+        return c
 
     @staticmethod
     def unique_id() -> bytes:

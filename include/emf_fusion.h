@@ -198,6 +198,17 @@ void emf_comm_destroy(emf_comm_t* c);
  * refuses two ranks on a device).  N emf_fusion handles driven from N threads then run the code path
  * of an N-GPU job; collectives are staged through host memory.  out: array of `world` handles. */
 int emf_comm_create_local_group(int world, emf_comm_t** out);
+/* Rehearsal backend, one process per rank: collectives are staged through host memory and handed to
+ * the caller's functions (0 = success), e.g. torch.distributed over gloo -- lets the N-rank job run on
+ * a box with fewer than N GPUs (bench.py --comm gloo). */
+typedef struct emf_comm_callbacks {
+    int32_t rank, world;
+    int (*all_reduce_sum_f32)(void* user, float* host, size_t count);
+    int (*all_reduce_min_u64)(void* user, uint64_t* host, size_t count);
+    int (*broadcast)(void* user, void* host, size_t bytes, int root);
+    void* user;
+} emf_comm_callbacks_t;
+int emf_comm_create_host_staged(const emf_comm_callbacks_t* cb, emf_comm_t** out);
 
 /* ---- synthetic RGB-D stream (host side, replaces the dataset readers) ---- */
 int emf_synth_create(int width, int height, const float K[9], int num_spheres, uint64_t seed,
