@@ -31,8 +31,21 @@ def _vol(n):
     return np.zeros((n, n, n), np.float32)
 
 
-@pytest.mark.parametrize("n,vox", [(256, 0.02), (512, 0.01)], ids=["config0_256", "config1_512"])
+def _host_gib_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.parametrize("n,vox", [(256, 0.02), (512, 0.01), (1024, 0.005)],
+                         ids=["config0_256", "config1_512", "config4_1024"])
 def test_wall_known_answers(ops, dev, n, vox):
+    if n == 1024 and _host_gib_available() < 40:  # 2 x 4 GiB volumes on the host, twice (upload, download)
+        pytest.skip("needs ~20 GiB of host memory for the 1024^3 volumes")
     D = 2.0
     depth = np.full((H, W), D, np.float32)
     pose = Pose(t=[0, 0, n * vox / 2])
@@ -70,7 +83,8 @@ def test_wall_known_answers(ops, dev, n, vox):
     assert np.abs(vert[inner][:, 2] - (D + vox / 2)).max() < 0.25 * vox
     # the projective SDF (lambda of the rounded pixel) is planar only up to a few degrees
     dev_n = np.abs(nrm[inner] - np.array([0, 0, -1], np.float32))
-    assert dev_n.max() < 0.15 and dev_n.mean() < 0.02
+    # (at 5 mm voxels the pixel footprint at 2 m, 3.8 mm, is no longer small against a voxel)
+    assert dev_n.max() < (0.15 if n < 1024 else 0.3) and dev_n.mean() < (0.02 if n < 1024 else 0.05)
     assert int(to_np(st)[1]) == int(hit.sum())
 
 
@@ -136,11 +150,15 @@ def test_full_size_frame_invariants(bench_scene):
         assert (b["ray"][own] == b["obj_ray"][i][own]).all()
 
 
-def test_full_size_against_the_oracle(oracle, ops, dev):
-    """Two integrations, a raycast and the mesh of the 512^3 background, HIP vs oracle, every voxel / pixel / vertex."""
+@pytest.mark.parametrize("n,vox", [(512, 0.01), (1024, 0.005)], ids=["config1_512", "config4_1024"])
+def test_full_size_against_the_oracle(oracle, ops, dev, n, vox):
+    """Two integrations, a raycast and (512^3) the mesh of the background, HIP vs oracle, every voxel /
+    pixel / vertex.  1024^3 is the largest volume of BASELINE.json (and the largest the 32-bit gather
+    offsets of the wave march take)."""
     from emfusion_amd import pipeline
+    if n == 1024 and _host_gib_available() < 64:
+        pytest.skip("needs ~40 GiB of host memory for the 1024^3 volumes")
     oracle.set_threads(os.cpu_count() or 8)
-    n, vox = 512, 0.01
     prm = pipeline.make_params(W, H, n, vox, 128)
     Kp = np.array(prm.K, np.float32).reshape(3, 3)
     synth = pipeline.SyntheticStream(W, H, Kp.reshape(-1), 2, seed=0xE3F5)
@@ -156,8 +174,8 @@ def test_full_size_against_the_oracle(oracle, ops, dev):
         assoc = rng.uniform(0.3, 1.0, (H, W)).astype(np.float32)
         oracle.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, Kp, vox, 10 * vox, 64.0)
         ops.update_tsdf(to_dev(depth), to_dev(assoc), d_t, d_w, oc.R32, oc.t32, Kp, vox, 10 * vox, 64.0)
-    assert_parity(to_np(d_t), tsdf, "tsdf 512^3", exact=True)
-    assert_parity(to_np(d_w), wts, "weights 512^3", exact=True)
+    assert_parity(to_np(d_t), tsdf, f"tsdf {n}^3", exact=True)
+    assert_parity(to_np(d_w), wts, f"weights {n}^3", exact=True)
     co = rel_CO(cam, pose)
     want = oracle.raycast_tsdf(tsdf, None, wts, None, W, H, co.R32, co.t32, Kp, vox, 10 * vox, count_steps=True)
     ray, vert, nrm = dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0), dev_full((H, W, 3), 0.0)
@@ -165,13 +183,13 @@ def test_full_size_against_the_oracle(oracle, ops, dev):
     ops.raycast_tsdf(d_t, None, d_w, None, ray, vert, nrm, hit, co.R32, co.t32, Kp, vox, 10 * vox, st,
                      rcp_voxel=ops.voxel_reciprocal(vox))
     for got, w_, name in zip((ray, vert, nrm, hit), want, ("ray", "vert", "normal", "mask")):
-        assert_parity(to_np(got), w_, f"{name} 640x480 / 512^3", exact=True)
+        assert_parity(to_np(got), w_, f"{name} 640x480 / {n}^3", exact=True)
     assert int(to_np(st)[0]) == int(want[4].sum()) and want[3].sum() > 250000
-    # the mesh of the same volume: every vertex, normal and triangle index (133 M cubes)
-    mesh_want = oracle.marching_cubes(tsdf, wts, vox)
-    mesh_got = ops.extract_mesh(d_t, d_w, vox)
-    assert len(mesh_want[0]) > 100000
-    for g, w_, name in zip(mesh_got, mesh_want, ("vertices", "normals", "triangles")):
-        assert g.shape == w_.shape and g.tobytes() == w_.tobytes(), f"mesh {name} 512^3"
+    if n == 512:  # the mesh of the same volume: every vertex, normal and triangle index (134 M cubes)
+        mesh_want = oracle.marching_cubes(tsdf, wts, vox)
+        mesh_got = ops.extract_mesh(d_t, d_w, vox)
+        assert len(mesh_want[0]) > 100000
+        for g, w_, name in zip(mesh_got, mesh_want, ("vertices", "normals", "triangles")):
+            assert g.shape == w_.shape and g.tobytes() == w_.tobytes(), f"mesh {name} 512^3"
     synth.close()
     oracle.set_threads(min(8, os.cpu_count() or 1))
