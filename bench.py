@@ -289,7 +289,7 @@ def main():
 
 # kernel kind -> (HIP kernel symbol for the rocprof cross-check, per-unit algorithmic bytes note)
 KERNEL_NAMES = {
-    "integrate": "k_update_tsdf",
+    "integrate": "k_integrate_cull + k_integrate_listed",
     "raycast": "k_raycast",
     "assoc": "k_assoc",
     "normalize": "k_assoc_normalize",
@@ -400,6 +400,9 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
             "frac_of_copy": round(integ["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
             "avg_launch_ms": integ["avg_ms"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"],
             "traffic": measured_traffic("integrate") if profiled else None,
+            "note": "alg_bytes = 16 B x every voxel of the integrated volumes (SURVEY 8d); boxes outside "
+                    "the view cone are culled before they are touched, so the model rate can exceed the "
+                    "HBM peak -- `traffic` is what really moves",
         }
     if dom["kind"] == "raycast":
         roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)

@@ -82,6 +82,9 @@ SIGNATURES = {
     "emf_hip_computePoseGradients": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, _FP, _STREAM],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_int, _FP,
                                  _STREAM],
+    "emf_hip_integrateCullScratchBytes": [_I3, C.c_int],
+    "emf_hip_integrateBatchedCulled": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, C.c_uint32, _FP, _FP,
+                                       _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
     "emf_hip_packHitKeys": [C.c_int, _I3, _IMG, _IMG, _FP, C.c_int, C.c_int, _STREAM],
@@ -160,6 +163,7 @@ def load() -> C.CDLL:
     lib.emf_hip_trackScratchBytes.restype = C.c_size_t
     lib.emf_hip_pointStatsScratchBytes.restype = C.c_size_t
     lib.emf_hip_meshScratchBytes.restype = C.c_size_t
+    lib.emf_hip_integrateCullScratchBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

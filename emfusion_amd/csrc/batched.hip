@@ -322,6 +322,119 @@ __global__ __launch_bounds__(256) void k_integrate_batched_linear(const Integrat
                           bricks_along(g.n.x) + (x >> kBrickShift)] = kBrickMixed;
 }
 
+// ---- two-level launch: cull 2x2x2-tile boxes first, integrate only the tiles of the survivors --------
+// Most tiles of a large volume lie outside the view cone and return after the cull test -- but
+// every one of them still costs a workgroup dispatch, and the dispatcher, not the CUs, then sets the
+// pace of the first part of the grid.  k_integrate_cull applies the same test to boxes
+// of 2x2x2 tiles (one lane per box; a box whose 8 corners project beyond the same image border, in
+// front of the camera, holds no voxel that lands in the image: every tile in it would be culled) and
+// appends the others to a list; k_integrate_listed then runs 8 workgroups per list entry.  Its grid
+// is sized by the caller from the survivor count of an EARLIER frame (the count comes back
+// asynchronously); a grid that turns out too small strides over the rest, one too large exits.
+struct IntegrateCullArgs {
+    IntegrateBatchArgs b;
+    int boxStart[EMF_MAX_BATCH + 1];  // prefix sum of boxes per model (0 boxes for untiled models)
+    unsigned* list;                    // entries: model << 24 | box index within the model
+    unsigned* count;                   // survivors appended so far (zeroed by the caller's memset)
+};
+
+__device__ __forceinline__ IntegrateGeom geom_of(const IntegrateBatchArgs& a, int m) {
+    const emf_model_t& md = a.models[m];
+    IntegrateGeom g;
+    g.depth = a.depth;
+    g.invLambda = a.invLambda;
+    g.assoc = Img<const float>{md.assoc, static_cast<size_t>(a.w) * sizeof(float)};
+    g.w = a.w;
+    g.h = a.h;
+    g.R = pose_R(a.poses.p[m]);
+    g.t = pose_t(a.poses.p[m]);
+    g.K = a.K;
+    g.pinhole = a.pinhole;
+    g.n = I3{md.res[0], md.res[1], md.res[2]};
+    g.voxelSize = md.voxelSize;
+    g.truncdist = md.truncdist;
+    g.maxWeight = md.maxWeight;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    unsigned entry = 0;
+    if (i < a.boxStart[a.b.nmodels]) {
+        int m = 0;
+        while (m + 1 < a.b.nmodels && i >= a.boxStart[m + 1]) ++m;
+        if (!a.b.visible || a.b.visible[m] != 0) {
+            const IntegrateGeom g = geom_of(a.b, m);
+            const int box = i - a.boxStart[m];
+            if (a.b.stats && box == 0) atomicAdd(a.b.stats, static_cast<unsigned long long>(g.n.x) * g.n.y * g.n.z);
+            const int nbx = (g.n.x + 2 * kTileX - 1) / (2 * kTileX), nby = (g.n.y + 2 * kTileY - 1) / (2 * kTileY);
+            const int bx = box % nbx, by = (box / nbx) % nby, bz = box / (nbx * nby);
+            const int x0 = bx * 2 * kTileX, y0 = by * 2 * kTileY, z0 = bz * 2 * kTileZ;
+            const int x1 = min(x0 + 2 * kTileX, g.n.x) - 1, y1 = min(y0 + 2 * kTileY, g.n.y) - 1,
+                      z1 = min(z0 + 2 * kTileZ, g.n.z) - 1;
+            const V3 half = half_extent(g.n);
+            bool front = true, left = true, right = true, up = true, down = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // tile_culled's test, the 8 corners in one lane
+                const V3 p = voxel_in_camera(g, half, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, (k & 4) ? z1 : z0);
+                const V3 q = mul(g.K, p);
+                const float u = q.x / q.z, v = q.y / q.z;
+                front = front && p.z > 1e-3f;
+                left = left && u < -1.5f;
+                right = right && u > static_cast<float>(g.w) + 0.5f;
+                up = up && v < -1.5f;
+                down = down && v > static_cast<float>(g.h) + 0.5f;
+            }
+            keep = !(front && (left || right || up || down));
+            entry = (static_cast<unsigned>(m) << 24) | static_cast<unsigned>(box);
+        }
+    }
+    // one atomic per wave
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == __ffsll(static_cast<long long>(mask)) - 1) base = atomicAdd(a.count, static_cast<unsigned>(__popcll(mask)));
+    base = __shfl(base, __ffsll(static_cast<long long>(mask)) - 1);
+    if (keep) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
+}
+
+// tile `sub` (0..7) of list entry e
+__device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a, unsigned e, unsigned sub,
+                                                      unsigned* lds) {
+    const unsigned entry = a.list[e];
+    const int m = static_cast<int>(entry >> 24), box = static_cast<int>(entry & 0xffffffu);
+    const IntegrateGeom g = geom_of(a.b, m);
+    const emf_model_t& md = a.b.models[m];
+    const int nbx = (g.n.x + 2 * kTileX - 1) / (2 * kTileX), nby = (g.n.y + 2 * kTileY - 1) / (2 * kTileY);
+    const int bx = box % nbx, by = (box / nbx) % nby, bz = box / (nbx * nby);
+    const int x0 = (2 * bx + static_cast<int>(sub & 1u)) * kTileX,
+              y0 = (2 * by + static_cast<int>((sub >> 1) & 1u)) * kTileY,
+              z0 = (2 * bz + static_cast<int>(sub >> 2)) * kTileZ;
+    if (x0 < g.n.x && y0 < g.n.y && z0 < g.n.z)  // block-uniform
+        integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds);
+}
+
+// one workgroup per (entry, tile): entries [0, min(count, grid / 8))
+__attribute__((amdgpu_waves_per_eu(EMF_INT_WPE, EMF_INT_WPE)))
+__global__ __launch_bounds__(256) void k_integrate_listed(const IntegrateCullArgs a) {
+    __shared__ unsigned lds[32];
+    const unsigned e = blockIdx.x >> 3;
+    if (e >= *a.count) return;
+    integrate_listed_tile(a, e, blockIdx.x & 7u, lds);
+}
+
+// the entries a too-small grid left over: a few workgroups stride over [first, count)
+__global__ __launch_bounds__(256) void k_integrate_listed_rest(const IntegrateCullArgs a, unsigned first) {
+    __shared__ unsigned lds[32];
+    const unsigned todo = *a.count;
+    for (unsigned e = first + (blockIdx.x >> 3); e < todo; e += gridDim.x >> 3) {
+        integrate_listed_tile(a, e, blockIdx.x & 7u, lds);
+        __syncthreads();
+    }
+}
+
 // refresh the dilated flags of every model that has a flag buffer (one thread per brick)
 struct DilateBatchArgs {
     const emf_model_t* models;
@@ -516,6 +629,78 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
     hipLaunchKernelGGL(k_dilate_batched, dim3(ceil_div(d.brickStart[nmodels], 256)), dim3(256), 0,
                        as_stream(stream), d);
     return launch_status("integrateBatched");
+}
+
+size_t emf_hip_integrateCullScratchBytes(const int32_t* res_host, int nmodels) {
+    size_t boxes = 0;
+    for (int m = 0; res_host && m < nmodels; ++m) {
+        const int32_t* r = res_host + 3 * m;
+        if (r[0] < 2 || r[1] < 2 || r[2] < 2) return 0;
+        boxes += static_cast<size_t>(ceil_div(r[0], 2 * kTileX)) * ceil_div(r[1], 2 * kTileY) * ceil_div(r[2], 2 * kTileZ);
+    }
+    return (boxes + 4) * sizeof(unsigned);
+}
+
+int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                                   const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                                   const emf_image_t* depth, const emf_image_t* invLambda,
+                                   const float K[9], void* scratch_dev, uint32_t launchBoxes,
+                                   uint32_t* survivors_out_dev, uint64_t* stats, emf_stream_t stream) {
+    EMF_TRY(check_batch(models_dev, poseOC_host, nmodels, "integrateBatchedCulled"));
+    EMF_REQUIRE_PTR(res_host);
+    EMF_REQUIRE_PTR(scratch_dev);
+    EMF_TRY(check_image(depth, 4, "integrateBatchedCulled: depth"));
+    if (invLambda) {
+        EMF_TRY(check_image(invLambda, 4, "integrateBatchedCulled: invLambda"));
+        EMF_TRY(check_same_size(depth, invLambda, "depth", "invLambda"));
+    }
+    EMF_REQUIRE_PTR(K);
+    IntegrateCullArgs a;
+    a.b.models = models_dev;
+    a.b.nmodels = nmodels;
+    a.boxStart[0] = 0;
+    for (int m = 0; m < nmodels; ++m) {
+        const int32_t* r = res_host + 3 * m;
+        EMF_TRY(check_res(r));
+        if (r[0] % 4 != 0)
+            return fail(EMF_E_SHAPE, "integrateBatchedCulled: model %d has Nx = %d, needs Nx %% 4 == 0 "
+                        "(use emf_hip_integrateBatched)", m, r[0]);
+        a.b.poses.p[m] = poseOC_host[m];
+        a.b.tileStart[m] = 0;
+        a.boxStart[m + 1] = a.boxStart[m] + static_cast<int>(ceil_div(r[0], 2 * kTileX)) *
+                                                static_cast<int>(ceil_div(r[1], 2 * kTileY)) *
+                                                static_cast<int>(ceil_div(r[2], 2 * kTileZ));
+    }
+    a.b.visible = visible_dev;
+    a.b.stats = reinterpret_cast<unsigned long long*>(stats);
+    a.b.depth = img<const float>(depth);
+    a.b.invLambda = invLambda ? img<const float>(invLambda) : Img<const float>{nullptr, 0};
+    a.b.w = depth->width;
+    a.b.h = depth->height;
+    a.b.K = m33_from(K);
+    a.b.pinhole = is_pinhole(a.b.K);
+    a.count = static_cast<unsigned*>(scratch_dev);
+    a.list = a.count + 4;
+    const unsigned total = static_cast<unsigned>(a.boxStart[nmodels]);
+    const hipError_t e = hipMemsetAsync(a.count, 0, sizeof(unsigned), as_stream(stream));
+    if (e != hipSuccess) {
+        set_error("integrateBatchedCulled: memset: %s", hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(k_integrate_cull, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), a);
+    const unsigned boxes = launchBoxes == 0 || launchBoxes > total ? total : launchBoxes;
+    hipLaunchKernelGGL(k_integrate_listed, dim3(8u * boxes), dim3(256), 0, as_stream(stream), a);
+    if (boxes < total)  // an estimate: whatever it missed is swept by a small strided grid
+        hipLaunchKernelGGL(k_integrate_listed_rest, dim3(8u * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+    if (survivors_out_dev) {
+        const hipError_t c = hipMemcpyAsync(survivors_out_dev, a.count, sizeof(unsigned), hipMemcpyDeviceToDevice,
+                                            as_stream(stream));
+        if (c != hipSuccess) {
+            set_error("integrateBatchedCulled: count copy: %s", hipGetErrorString(c));
+            return static_cast<int>(c);
+        }
+    }
+    return launch_status("integrateBatchedCulled");
 }
 
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,

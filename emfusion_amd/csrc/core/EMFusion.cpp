@@ -75,6 +75,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_BG_BANDS=0: every rank raycasts the whole (replicated) background itself
     const char* bb = std::getenv("EMF_BG_BANDS");
     bgBands = !(bb && bb[0] == '0');
+    // EMF_INT_CULL=0: one-level integration launch (every tile gets a workgroup and culls itself)
+    const char* ic = std::getenv("EMF_INT_CULL");
+    cullBoxes = !(ic && ic[0] == '0');
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
@@ -243,7 +246,17 @@ void EMFusion::rebuildModelTable() {
         o.hitMask = im.modelSegmentation.ptr();
         modelsHost.push_back(o);
     }
-    for (const auto& md : modelsHost) resHost.insert(resHost.end(), md.res, md.res + 3);
+    bool tiled = true;
+    for (const auto& md : modelsHost) {
+        resHost.insert(resHost.end(), md.res, md.res + 3);
+        tiled &= md.res[0] % 4 == 0;
+    }
+    // scratch of the two-level integration launch (every model on float4 tiles, no brick flags to keep)
+    integrateCullScratch = DeviceBuffer();
+    if (cullBoxes && tiled && TSDF::brickFlagMode() == 0 &&
+        static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH)
+        integrateCullScratch = DeviceBuffer(emf_hip_integrateCullScratchBytes(
+            resHost.data(), static_cast<int>(modelsHost.size())));
     batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly &&
               static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
     if (batched) {
@@ -1013,6 +1026,15 @@ void EMFusion::integrateBatched() {
     auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
     const emf_image_t il = invLambda.view();
     const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
+    if (cullBoxes && !integrateCullScratch.empty()) {
+        // two-level launch: the boxes of 2x2x2 tiles outside the view cone never get a workgroup
+        emfCheck(emf_hip_integrateBatchedCulled(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
+                                                visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
+                                                integrateCullScratch.data(), 0, nullptr,
+                                                integrateStatsDev.as<uint64_t>(), main.abi()),
+                 "integrateBatchedCulled");
+        return;
+    }
     emfCheck(emf_hip_integrateBatched(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
                                       visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
                                       TSDF::brickFlagMode() != 0,

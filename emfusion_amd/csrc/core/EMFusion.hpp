@@ -284,6 +284,8 @@ private:
     DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;
+    DeviceBuffer integrateCullScratch;  // survivor list of emf_hip_integrateBatchedCulled (empty: plain launch)
+    bool cullBoxes = true;               // EMF_INT_CULL=0 keeps the one-level launch (A/B measurements)
     int depthRoot = -1;  // sharded path: rank whose depth image is broadcast each frame (-1: none)
     bool bgBands = true;  // sharded path: split the background raycast into row bands per rank
 

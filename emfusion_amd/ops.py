@@ -316,6 +316,20 @@ def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=N
                                       _stream(stream)))
 
 
+def integrate_batched_culled(models_dev, poses_oc, res_list, visible, depth, K, launch_boxes=0, survivors=None,
+                             stats=None, stream=None, inv_lambda=None, scratch=None):
+    """emf_hip_integrateBatchedCulled; returns the scratch buffer (reusable)."""
+    res = (C.c_int32 * (3 * len(poses_oc)))(*[int(v) for r in res_list for v in r])
+    if scratch is None:
+        scratch = DeviceArray.zeros((int(_L.emf_hip_integrateCullScratchBytes(res, len(poses_oc))) // 4,), np.uint32)
+    check("emf_hip_integrateBatchedCulled",
+          _L.emf_hip_integrateBatchedCulled(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc), _ptr(visible),
+                                            C.byref(image_view(depth)), _opt_view(inv_lambda), _f(K, 9),
+                                            _ptr(scratch), int(launch_boxes), _ptr(survivors), _ptr(stats),
+                                            _stream(stream)))
+    return scratch
+
+
 def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):
     check("emf_hip_visibilityFlags",
           _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible),

@@ -318,6 +318,22 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
                              const float K[9], int maintainBrickFlags, uint64_t* stats,
                              emf_stream_t stream);
 
+/* The same integration with a two-level launch (models with Nx % 4 == 0 only, no brick flags upkeep):
+ * boxes of 2x2x2 tiles that lie outside the view cone are culled first (one lane per box), and only
+ * the tiles of the surviving boxes get a workgroup -- the culled tiles of a large volume otherwise
+ * cost a workgroup dispatch each.  Results are identical to emf_hip_integrateBatched.
+ *   scratch_dev      : emf_hip_integrateCullScratchBytes(res_host, nmodels) bytes
+ *   launchBoxes      : how many boxes the tile launch is sized for -- the survivor count of an earlier
+ *                      frame plus a margin; 0 = all boxes.  Too few: the grid strides over the rest;
+ *                      too many: the extra workgroups exit.
+ *   survivors_out_dev: NULL, or where this call's survivor count (u32) is copied at the end */
+size_t emf_hip_integrateCullScratchBytes(const int32_t* res_host, int nmodels);
+int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                                   const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                                   const emf_image_t* depth, const emf_image_t* invLambda,
+                                   const float K[9], void* scratch_dev, uint32_t launchBoxes,
+                                   uint32_t* survivors_out_dev, uint64_t* stats, emf_stream_t stream);
+
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,

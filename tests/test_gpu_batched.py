@@ -353,6 +353,61 @@ def test_integrate_batched_mixes_tiled_and_untiled_models(ops, oracle, dev):
         assert_parity(to_np(m.d_tsdf), m.tsdf, f"tsdf model {m.id}", exact=True)
 
 
+@pytest.mark.parametrize("launch", ["all", "exact", "short", "one"])
+def test_integrate_culled_launch_equals_the_plain_batched_one(ops, oracle, dev, launch):
+    """Two-level launch (cull 2x2x2-tile boxes, then only the survivors' tiles): same volumes bit for bit,
+    whatever the grid estimate -- all boxes, the exact survivor count, too few (the strided rest kernel
+    picks up the remainder), a single box."""
+    models = [Model(ops, oracle, (128, 96, 80), 0.03, Pose(t=[0, 0, 1.28]), False, 0),
+              Model(ops, oracle, (32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True, 1),
+              Model(ops, oracle, (40, 24, 36), 0.025, Pose(rot([0, 1, 0], 9), SPHERES[1][0]), True, 2)]
+    twins = [Model(ops, oracle, m.res, m.vox, m.pose, m.is_obj, m.id) for m in models]
+    for m in models + twins:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    rng = np.random.default_rng(31)
+    visible = dev_full((3,), 1, np.int32)
+    survivors = dev_full((1,), 0, np.uint32)
+    stats_a, stats_b = dev_full((1,), 0, np.uint64), dev_full((1,), 0, np.uint64)
+    nboxes = sum(-(-r[0] // 64) * -(-r[1] // 16) * -(-r[2] // 16) for r in (m.res for m in models))
+    counts = []
+    for i in range(3):
+        cam, depth, ids = frame(i)
+        gate = [1, 1, 0 if i == 1 else 1]
+        visible.copy_from(np.array(gate, np.int32))
+        poses = []
+        for m, tw in zip(models, twins):
+            assoc = rng.uniform(0, 1, (H, W)).astype(np.float32)
+            m.d_assoc.copy_from(assoc)
+            tw.d_assoc.copy_from(assoc)
+            oc = rel_OC(cam, m.pose)
+            poses.append((oc.R32, oc.t32))
+        d_depth = to_dev(depth)
+        ops.integrate_batched(ops.upload_models([m.table_entry() for m in twins]), poses, [m.res for m in twins],
+                              visible, d_depth, K, stats_b)
+        tab = ops.upload_models([m.table_entry() for m in models])
+        if launch == "all":
+            lb = 0
+        elif launch == "one":
+            lb = 1
+        else:  # learn the count from a dry run on scratch copies? no: survivors only depend on geometry + gate
+            probe = [Model(ops, oracle, m.res, m.vox, m.pose, m.is_obj, m.id) for m in models]
+            for p_ in probe:
+                p_.d_probs = p_.d_vmask = dev_full((1,), 0, np.uint8)
+            ops.integrate_batched_culled(ops.upload_models([p_.table_entry() for p_ in probe]), poses,
+                                         [m.res for m in models], visible, d_depth, K, 0, survivors)
+            dev.synchronize()
+            n = int(to_np(survivors)[0])
+            lb = n if launch == "exact" else max(1, n // 3)
+        ops.integrate_batched_culled(tab, poses, [m.res for m in models], visible, d_depth, K, lb, survivors, stats_a)
+        dev.synchronize()
+        counts.append(int(to_np(survivors)[0]))
+    assert all(0 < c < nboxes for c in counts), (counts, nboxes)  # some boxes culled, some kept
+    for m, tw in zip(models, twins):
+        assert_parity(to_np(m.d_tsdf), to_np(tw.d_tsdf), f"tsdf model {m.id}", exact=True)
+        assert_parity(to_np(m.d_wts), to_np(tw.d_wts), f"weights model {m.id}", exact=True)
+    assert int(to_np(stats_a)[0]) == int(to_np(stats_b)[0]) > 0
+
+
 def test_visibility_flags(ops, dev):
     counts = to_dev(np.array([1601, 1600, 0, 99999], np.int32))
     vis = dev_full((5,), -1, np.int32)
