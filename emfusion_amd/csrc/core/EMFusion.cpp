@@ -1027,7 +1027,7 @@ void EMFusion::integrateBatched() {
     const emf_image_t il = invLambda.view();
     const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
     if (cullBoxes && !integrateCullScratch.empty()) {
-        // two-level launch: the boxes of 2x2x2 tiles outside the view cone never get a workgroup
+        // two-level launch: the boxes of tiles outside the view cone never get a workgroup
         emfCheck(emf_hip_integrateBatchedCulled(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
                                                 visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
                                                 integrateCullScratch.data(), 0, nullptr,

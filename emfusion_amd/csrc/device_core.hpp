@@ -148,12 +148,15 @@ __device__ __forceinline__ int apply_voxel(int kind, float samp, float aw, float
             return 3;
         }
     } else if (kind == kZeroIfUnseen) {
-        if (pw == 0) {
+        // "changed" only if the stored bits change: an unseen voxel holds +0 (reset, or this branch
+        // earlier) or -1, and most of the volume behind the camera / behind surfaces would otherwise
+        // be rewritten with the value it already has, every frame
+        if (pw == 0 && __float_as_uint(tv) != 0u) {
             tv = 0.f;
             return 1;
         }
     } else if (kind == kNegIfUnseen) {
-        if (pw == 0) {
+        if (pw == 0 && __float_as_uint(tv) != 0xbf800000u) {
             tv = -1.f;
             return 1;
         }

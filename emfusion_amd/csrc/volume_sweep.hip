@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void k_update_tsdf_linear(const IntegrateGe
     const int kind = classify_voxel(a, half_extent(a.n), x, y, z, samp, aw);
     if (kind == kSkip) return;
     float wv = weights[i];
-    float tv = kind == kFuse ? tsdf[i] : 0.f;
+    float tv = tsdf[i];  // also for the "if unseen" branches: they store only a value that differs
     const int changed = apply_voxel(kind, samp, aw, a.maxWeight, tv, wv);
     if (changed & 1) tsdf[i] = tv;
     if (changed & 2) weights[i] = wv;

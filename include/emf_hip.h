@@ -319,7 +319,7 @@ int emf_hip_integrateBatched(const emf_model_t* models_dev, const emf_pose_t* po
                              emf_stream_t stream);
 
 /* The same integration with a two-level launch (models with Nx % 4 == 0 only, no brick flags upkeep):
- * boxes of 2x2x2 tiles that lie outside the view cone are culled first (one lane per box), and only
+ * boxes of 1x2x2 tiles (32 x 16 x 16 voxels) that lie outside the view cone are culled first (one lane per box), and only
  * the tiles of the surviving boxes get a workgroup -- the culled tiles of a large volume otherwise
  * cost a workgroup dispatch each.  Results are identical to emf_hip_integrateBatched.
  *   scratch_dev      : emf_hip_integrateCullScratchBytes(res_host, nmodels) bytes

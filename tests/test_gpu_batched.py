@@ -368,7 +368,7 @@ def test_integrate_culled_launch_equals_the_plain_batched_one(ops, oracle, dev, 
     visible = dev_full((3,), 1, np.int32)
     survivors = dev_full((1,), 0, np.uint32)
     stats_a, stats_b = dev_full((1,), 0, np.uint64), dev_full((1,), 0, np.uint64)
-    nboxes = sum(-(-r[0] // 64) * -(-r[1] // 16) * -(-r[2] // 16) for r in (m.res for m in models))
+    nboxes = sum(-(-r[0] // 32) * -(-r[1] // 16) * -(-r[2] // 16) for r in (m.res for m in models))
     counts = []
     for i in range(3):
         cam, depth, ids = frame(i)
