@@ -143,9 +143,13 @@ __device__ __forceinline__ int apply_voxel(int kind, float samp, float aw, float
     const float pw = wv;
     if (kind == kFuse) {
         if (pw + aw > 0) {  // TSDF.cu:392-397
-            tv = (pw * tv + aw * samp) / (pw + aw);
-            wv = fminf(pw + aw, maxWeight);
-            return 3;
+            const float nt = (pw * tv + aw * samp) / (pw + aw), nw = fminf(pw + aw, maxWeight);
+            // free space that has reached the weight cap re-fuses to the very same bits: no store
+            const int changed = (__float_as_uint(nt) != __float_as_uint(tv) ? 1 : 0) |
+                                (__float_as_uint(nw) != __float_as_uint(wv) ? 2 : 0);
+            tv = nt;
+            wv = nw;
+            return changed;
         }
     } else if (kind == kZeroIfUnseen) {
         // "changed" only if the stored bits change: an unseen voxel holds +0 (reset, or this branch
