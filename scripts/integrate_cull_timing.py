@@ -45,6 +45,6 @@ for f in (0, 10, 40, 80):
     tex = timed(lambda: ops.integrate_batched_culled(tabB, poses, res, None, d, K, n, surv, None, inv_lambda=il, scratch=scratch))
     test = timed(lambda: ops.integrate_batched_culled(tabB, poses, res, None, d, K, int(n * 1.1) + 8, surv, None, inv_lambda=il, scratch=scratch))
     tsh = timed(lambda: ops.integrate_batched_culled(tabB, poses, res, None, d, K, int(n * 0.9), surv, None, inv_lambda=il, scratch=scratch))
-    print(f"frame {f}: survivors {n} boxes of {8192 + 4 * 128}; plain {tp:.3f} ms | culled: grid=all {tall:.3f}, exact {tex:.3f}, +10% {test:.3f}, -10% {tsh:.3f} ms")
-same = all(np.array_equal(a["t"].numpy(), b["t"].numpy()) and np.array_equal(a["w"].numpy(), b["w"].numpy()) for a, b in zip(A[1:], B[1:]))
-print("object volumes identical:", same, "| bg identical:", np.array_equal(A[0]["t"].numpy(), B[0]["t"].numpy()))
+    print(f"frame {f}: survivors {n} boxes of {sum(-(-r[0] // 32) * -(-r[1] // 16) * -(-r[2] // 16) for r in res)}; plain {tp:.3f} ms | culled: grid=all {tall:.3f}, exact {tex:.3f}, +10% {test:.3f}, -10% {tsh:.3f} ms")
+# (the two sets see different numbers of launches here; bit-identity of the two launches is
+# tests/test_gpu_batched.py::test_integrate_culled_launch_equals_the_plain_batched_one)
