@@ -437,8 +437,8 @@ typedef struct emf_mesh_counts {
     uint32_t triangles; /* = mesh.polygons.cols / 4 */
 } emf_mesh_counts_t;
 
-/* Bytes of device scratch the two calls below share for a volume of this resolution (72 bytes per
- * 2016 voxels; the reference keeps 9 bytes per cube in cubeClasses / vertIdxBuffer / triIdxBuffer). */
+/* Bytes of device scratch the two calls below share for a volume of this resolution (about
+ * 36 bytes per 1000 voxels; the reference keeps 9 bytes per cube in cubeClasses / vertIdxBuffer / triIdxBuffer). */
 size_t emf_hip_meshScratchBytes(const int32_t res[3]);
 
 /* Pass 1 -- kernel_classifyCubes + the two sums + the two exclusive scans: counts the vertices and
