@@ -16,7 +16,7 @@ W, H = 160, 120
 NFRAMES, MASK_EVERY = 6, 3
 
 
-def run_job(world, nobj, depth_broadcast):
+def run_job(world, nobj, depth_broadcast, track=False):
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
     prm = pipeline.make_params(W, H, 64, 0.04, 32, visibility_thresh=100, boundary=5, mask_frames=MASK_EVERY)
@@ -48,12 +48,14 @@ def run_job(world, nobj, depth_broadcast):
                 rm = f % MASK_EVERY == 0
                 masks = {i: to_dev((sid == i).astype(np.uint8)) for i in mine} if rm else {}
                 keep += [d, masks]
+                if track and f == 1:
+                    fus.set_tracking(camera=True, objects=True)  # frame 0 defines the world frame
                 fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, rm)
             fus.synchronize()
             res = dict(mine=mine, seg=fus.image("segmentation"), ray=fus.image("raylengths"),
                        bg_ray=fus.image("bg_raylengths"), bg_assoc=fus.image("bg_assoc"),
                        bg_tsdf=fus.volume("tsdf", 0), bg_w=fus.volume("weights", 0),
-                       vis=sorted(fus.visible_objects()),
+                       vis=sorted(fus.visible_objects()), cam=fus.pose(0), poses={i: fus.pose(i) for i in mine},
                        obj={i: (fus.volume("tsdf", i), fus.volume("weights", i), fus.image("obj_assoc", i)) for i in mine})
             out[r] = res
             fus.close()
@@ -106,3 +108,25 @@ def test_sharded_job_on_threads_equals_single_gpu(dev, world, depth_broadcast):
             close(t, ts, f"tsdf of object {i}")
             assert ((w > 0) == (ws > 0)).mean() > 0.999
     assert (single["seg"] > 0).sum() > 200 and len(single["vis"]) >= 2
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_tracking_keeps_the_ranks_in_step(dev, world):
+    """With tracking on, every rank tracks the camera against ITS replica of the background and the
+    objects it owns: the camera poses must come out bit-identical on all ranks (same inputs, same
+    deterministic kernels) -- otherwise the replicas would drift -- and agree with the single-GPU run."""
+    nobj = 4
+    single = run_job(1, nobj, False, track=True)[0]
+    ranks = run_job(world, nobj, True, track=True)
+    R0, t0 = ranks[0]["cam"]
+    for r in ranks:
+        R, t = r["cam"]
+        assert np.array_equal(R, R0) and np.array_equal(t, t0)
+        assert np.array_equal(r["bg_tsdf"], ranks[0]["bg_tsdf"]) and np.array_equal(r["seg"], ranks[0]["seg"])
+        for i in r["mine"]:
+            Ro, to = r["poses"][i]
+            Rs, ts = single["poses"][i]
+            assert np.allclose(to, ts, atol=2e-3) and np.allclose(Ro, Rs, atol=2e-3), i
+    Rs, ts = single["cam"]
+    assert np.allclose(t0, ts, atol=1e-3) and np.allclose(R0, Rs, atol=1e-3)
+    assert np.linalg.norm(ts) > 1e-3  # the camera did move
