@@ -25,8 +25,14 @@ __device__ __forceinline__ V3 pose_t(const emf_pose_t& p) { return V3{p.t[0], p.
 
 // ---- fused E-step ---------------------------------------------------------------------------------
 
-constexpr int kEstepPixels = 64;  // pixels per workgroup = one wave per model lane
-constexpr int kEstepLanes = 4;    // model lanes per workgroup
+// workgroup shape, measured on the 5-model bench frame (us per E-step): 64 x 4: 13.9, 128 x 4: 14.0,
+// 256 x 4: 15.0, 64 x 5: 14.9, 64 x 8: 16.8, 128 x 8: 17.6
+#ifndef EMF_ESTEP_PIXELS
+#define EMF_ESTEP_PIXELS 64
+#define EMF_ESTEP_LANES 4
+#endif
+constexpr int kEstepPixels = EMF_ESTEP_PIXELS;  // pixels per workgroup (a multiple of 64: waves stay model-uniform)
+constexpr int kEstepLanes = EMF_ESTEP_LANES;    // model lanes per workgroup
 
 struct EstepArgs {
     const emf_model_t* models;
