@@ -186,9 +186,15 @@ struct CompositeArgs {
     Img<uint8_t> seg, noObj;
     int w, h;
     int first, last;  // chunk position
+    int32_t* zero;    // first chunk: visCounts to clear for k_vis_counts, which runs after the last chunk
+    int nzero;        // (<= 255: one workgroup's worth; saves the memset launch between the two)
 };
 
 __global__ __launch_bounds__(256) void k_composite(const CompositeTable t, const CompositeArgs a) {
+    if (a.zero && blockIdx.x == 0 && blockIdx.y == 0) {
+        const int i = threadIdx.y * blockDim.x + threadIdx.x;
+        if (i < a.nzero) a.zero[i] = 0;
+    }
     int x, y;
     if (!pixel_of(a.w, a.h, x, y)) return;
     float r = 0.f;
@@ -639,6 +645,8 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
         }
         a.first = k0 == 0;
         a.last = k0 + cnt >= nobj;
+        a.zero = a.first ? visCounts : nullptr;
+        a.nzero = nobj;
         hipLaunchKernelGGL(k_composite, g, b, 0, as_stream(stream), t, a);
         k0 += cnt;
     } while (k0 < nobj);
@@ -649,12 +657,6 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
         for (int k = 0; k < nobj; ++k)  // compare(seg, id): ids outside 1..255 never match
             if (ids_host[k] >= 1 && ids_host[k] <= 255 && slots.slot[ids_host[k]] < 0)
                 slots.slot[ids_host[k]] = static_cast<int16_t>(k);
-        const hipError_t e =
-            hipMemsetAsync(visCounts, 0, sizeof(int32_t) * nobj, as_stream(stream));
-        if (e != hipSuccess) {
-            set_error("compositeRaycast: memset visCounts: %s", hipGetErrorString(e));
-            return static_cast<int>(e);
-        }
         hipLaunchKernelGGL(k_vis_counts, g, b, 0, as_stream(stream), img<const uint8_t>(seg), w, h,
                            boundary, slots, visCounts);
         return launch_status("compositeRaycast: visibility");
