@@ -425,3 +425,29 @@ def test_batched_argument_checks(ops, dev):
     with pytest.raises(EmfHipError) as e:
         ops.estep_batched(table, [(np.eye(3), np.zeros(3))], pts, normalize=False)
     assert e.value.code == -1  # objSum required
+
+
+def test_argument_checks_of_the_newer_entry_points(ops, dev):
+    """Rejected calls enqueue nothing and name the reason (EMF_E_*): culled integration, meshes, rendering,
+    resize helpers."""
+    from emfusion_amd._lib import EmfHipError
+    table = dev_full((288,), 0, np.uint8)
+    depth = dev_full((H, W), 1.0)
+    pose = [(np.eye(3), np.zeros(3))]
+    with pytest.raises(EmfHipError) as e:  # untiled model: the two-level launch is for float4 tiles only
+        ops.integrate_batched_culled(table, pose, [(30, 22, 18)], None, depth, K)
+    assert e.value.code == -2
+    with pytest.raises(EmfHipError) as e:
+        ops.integrate_batched_culled(table, pose * 33, [(32, 32, 32)] * 33, None, depth, K)
+    assert e.value.code == -5
+    vol = dev_full((4, 4, 4), 0.0)
+    with pytest.raises(EmfHipError) as e:  # more than 3 channels
+        ops.copy_values(dev_full((4, 4, 4, 4), 0.0), dev_full((4, 4, 4, 4), 0.0), (0, 0, 0))
+    assert e.value.code == -4
+    img3 = dev_full((H, W, 3), 0.0)
+    seg = dev_full((H, W), 0, np.uint8)
+    with pytest.raises(EmfHipError) as e:  # image of another size
+        ops.render_phong(img3, img3, seg, np.zeros((256, 3), np.uint8), dev_full((H, W + 1, 3), 0, np.uint8))
+    assert e.value.code == -2
+    v, n, t = ops.extract_mesh(vol, vol, 0.01)  # smallest useful volume: nothing observed, empty mesh
+    assert len(v) == 0 and len(t) == 0
