@@ -67,3 +67,7 @@ print("  " + " ".join(line))
 # how long would the kernel be if it were only as long as its longest wave chain at the median step time?
 print(f" longest wave: {r['smax'].max()} samples x median {np.median(ns_per_step):.0f} ns = {r['smax'].max() * np.median(ns_per_step) / 1e3:.0f} us")
 fus.close(); synth.close()
+# lane utilisation: a wave loops until its longest ray is done
+bgw = (r["model"] == 0) & (r["smax"] > 0)
+print(f" background: sum of lane samples {int(r['ssum'][bgw].sum())}, sum over waves of 64 x max samples {int(64 * r['smax'][bgw].sum())}: "
+      f"lane utilisation {r['ssum'][bgw].sum() / (64.0 * r['smax'][bgw].sum()):.2f}; wave-steps {int(r['smax'][bgw].sum())}")
