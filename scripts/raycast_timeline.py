@@ -71,3 +71,10 @@ fus.close(); synth.close()
 bgw = (r["model"] == 0) & (r["smax"] > 0)
 print(f" background: sum of lane samples {int(r['ssum'][bgw].sum())}, sum over waves of 64 x max samples {int(64 * r['smax'][bgw].sum())}: "
       f"lane utilisation {r['ssum'][bgw].sum() / (64.0 * r['smax'][bgw].sum()):.2f}; wave-steps {int(r['smax'][bgw].sum())}")
+# where the long background waves sit in the image (16 x 16 tiles, 40 x 30 of them at VGA)
+lw = np.nonzero((r["model"] == 0) & (r["smax"] > 400))[0]
+tx, ty = r["tile"][lw] % 40, r["tile"][lw] // 40
+print(f" background waves with > 400 samples: {len(lw)}; tile columns {np.bincount(tx, minlength=40).tolist()}")
+print(f"   tile rows {np.bincount(ty, minlength=30).tolist()}")
+order = np.argsort(-r["smax"][lw])[:12]
+print("   longest:", [(int(tx[i]), int(ty[i]), int(r["wave"][lw][i]), int(r["smax"][lw][i])) for i in order])
