@@ -233,3 +233,52 @@ def test_hip_reproduces_frame_vectors(dev, fv):
     finally:
         if "f" in st:
             st["f"].close()
+
+
+# ---- next-row kernels (meshes, rendering, depth pre-processing): tests/golden/next_rows_v1.npz --------
+
+@pytest.fixture(scope="module")
+def nv():
+    return np.load(GOLD / "next_rows_v1.npz")
+
+
+@pytest.mark.parametrize("tag", ["cube", "ragged"])
+def test_oracle_reproduces_next_row_vectors(oracle, kv, nv, tag):
+    tsdf, wts, voxel = kv[f"{tag}_tsdf2"], kv[f"{tag}_wts2"], float(kv[f"{tag}_voxel"])
+    for prefix, fg in (("mesh", None), ("fgmesh", kv[f"{tag}_fgmask"])):
+        got = oracle.marching_cubes(tsdf, wts, voxel, fg=fg)
+        for g, name in zip(got, ("v", "n", "t")):
+            want = nv[f"{tag}_{prefix}_{name}"]
+            assert g.shape == want.shape and g.tobytes() == want.tobytes(), (tag, prefix, name)
+    assert len(nv[f"{tag}_mesh_v"]) > len(nv[f"{tag}_fgmesh_v"]) > 0
+    if tag == "cube":
+        rgb = oracle.render_phong(kv["cube_vert0"], kv["cube_nrm0"], nv["render_seg"], nv["render_cmap"])
+        assert np.array_equal(rgb, nv["render_rgb"]) and rgb.any()
+        lit = oracle.render_phong(kv["cube_vert0"], kv["cube_nrm0"], nv["render_seg"], nv["render_cmap"], (0.3, -0.2, 0.1))
+        assert np.array_equal(lit, nv["render_rgb_light"]) and not np.array_equal(lit, rgb)
+        out = oracle.preprocess_depth(nv["prep_in"], 7, 0.04, 4.5)
+        assert np.allclose(out, nv["prep_out"], rtol=1e-6, atol=1e-7)  # expf: libm-dependent last bits
+        assert np.all(out[nv["prep_in"] == 0] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cube", "ragged"])
+def test_hip_reproduces_next_row_vectors(dev, kv, nv, tag):
+    from emfusion_amd import ops
+    from tests.parity_util import dev_full, to_dev
+    tsdf, wts, voxel = kv[f"{tag}_tsdf2"], kv[f"{tag}_wts2"], float(kv[f"{tag}_voxel"])
+    for prefix, fg in (("mesh", None), ("fgmesh", kv[f"{tag}_fgmask"])):
+        got = ops.extract_mesh(to_dev(tsdf), to_dev(wts), voxel, fg_mask=None if fg is None else to_dev(fg))
+        for g, name in zip(got, ("v", "n", "t")):
+            want = nv[f"{tag}_{prefix}_{name}"]
+            assert g.shape == want.shape and g.tobytes() == want.tobytes(), (tag, prefix, name)
+    if tag == "cube":
+        h, w = nv["render_seg"].shape
+        for key, light in (("render_rgb", (0.0, 0.0, 0.0)), ("render_rgb_light", (0.3, -0.2, 0.1))):
+            img = dev_full((h, w, 3), 9, np.uint8)
+            ops.render_phong(to_dev(kv["cube_vert0"]), to_dev(kv["cube_nrm0"]), to_dev(nv["render_seg"]),
+                             nv["render_cmap"], img, light)
+            assert np.array_equal(img.numpy(), nv[key])
+        out = dev_full(nv["prep_in"].shape, -1.0)
+        ops.preprocess_depth(to_dev(nv["prep_in"]), out, 7, 0.04, 4.5)
+        assert np.allclose(out.numpy(), nv["prep_out"], rtol=1e-5, atol=1e-6)
