@@ -129,13 +129,34 @@ def main():
     if world > 1 or args.force_sharded:
         if args.force_sharded:
             os.environ["EMF_FORCE_SHARDED"] = "1"
+        transport = "rccl"
         if args.comm == "gloo" and dist is not None:
             comm = pipeline.Communicator.host_staged(dist)
+            transport = "gloo (rehearsal, --comm gloo)"
         else:
-            uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
+            err = None
+            try:
+                uid = [pipeline.Communicator.unique_id() if rank == 0 else None]
+                if dist is not None:
+                    dist.broadcast_object_list(uid, src=0)  # ncclUniqueId travels over the gloo group
+                comm = pipeline.Communicator(uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001 - reported below, loudly
+                err = repr(e)
             if dist is not None:
-                dist.broadcast_object_list(uid, src=0)  # ncclUniqueId travels over the gloo group
-            comm = pipeline.Communicator(uid[0], rank, world)
+                # every rank must take the same road: agree on whether RCCL came up everywhere
+                flags = [None] * world
+                dist.all_gather_object(flags, err)
+                bad = [f for f in flags if f]
+                if bad:
+                    print(f"bench.py: RCCL communicator could NOT be created ({bad[0]}); falling back to "
+                          "host-staged collectives over gloo -- the multi-GPU numbers of this run are NOT "
+                          "those of the product's transport", file=sys.stderr, flush=True)
+                    if comm is not None:
+                        comm.close()
+                    comm = pipeline.Communicator.host_staged(dist)
+                    transport = "gloo FALLBACK (RCCL init failed: %s)" % bad[0][:120]
+            elif err:
+                raise SystemExit("bench.py: RCCL communicator could not be created: " + err)
 
     synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
     fus = pipeline.Fusion(prm, comm)
@@ -230,7 +251,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: collectives over gloo, ranks may share a GPU -- not a "
-                                   "measurement)" if comm is not None and args.comm == "gloo" else ""),
+                                   "measurement)" if comm is not None and transport != "rccl" else ""),
             "config": {
                 "workload": (f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj_total} obj "
                              f"{args.obj_res}^3, {W}x{H}, full EM association + weighted fusion"
@@ -242,6 +263,7 @@ def main():
                 "background": "replicated" if world > 1 else "single",
                 "gradients": args.grads,
                 "estep_per_frame": 3,
+                "transport": "none (one rank)" if comm is None else transport,
                 "collectives_per_frame": ("none" if comm is None else
                                           ("broadcast(depth) + " if depth_broadcast else "") +
                                           "3 x all-reduce(sum f32, normaliser) + all-reduce(min u64, hits)"
