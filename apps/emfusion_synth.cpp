@@ -3,7 +3,9 @@
 // stream instead of a dataset reader.  Prints frames/s and per-stage GPU milliseconds.
 //
 //   emfusion_synth [--frames N] [--objects K] [--bg-res R] [--obj-res R] [--width W --height H]
-//                  [--materialize-gradients] [--autonomous]
+//                  [--materialize-gradients] [--autonomous] [--out DIR]
+// --out DIR: keep the pose log and write the reference's result files at the end (writeResults:
+// poses-*.txt, mesh_*.ply, tsdfs/*.bin; EMFusion.cpp:258-292) into the existing directory DIR.
 // --autonomous: nothing but depth and instance masks go in, as in the reference's own loop -- objects
 // are spawned from the masks of frame 0 (initNewObjVolume), camera and object poses are tracked
 // (performTracking), later masks are matched to the models (matchSegmentation); the ground-truth
@@ -22,6 +24,7 @@
 int main(int argc, char** argv) {
     int frames = 120, objects = 4, bgRes = 512, objRes = 128, width = 640, height = 480;
     bool materialize = false, autonomous = false;
+    std::string outDir;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? std::atoi(argv[++i]) : 0; };
@@ -33,6 +36,7 @@ int main(int argc, char** argv) {
         else if (a == "--height") height = next();
         else if (a == "--materialize-gradients") materialize = true;
         else if (a == "--autonomous") autonomous = true;
+        else if (a == "--out" && i + 1 < argc) outDir = argv[++i];
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
@@ -63,6 +67,7 @@ int main(int argc, char** argv) {
         std::vector<emf::DeviceImage<uint8_t>> maskDev;
         for (int k = 0; k < objects; ++k) maskDev.emplace_back(params.frameSize);
         emf.enableTimings(true);
+        if (!outDir.empty()) emf.enablePoseLog(true);
 
         double gpuMs = 0;
         int spawned = 0;
@@ -123,6 +128,12 @@ int main(int argc, char** argv) {
                     "integrate %.3f  masks %.3f | visible objects %zu | batched launches: %s\n",
                     t.points, t.estep, t.raycast, t.composite, t.integrate, t.masks,
                     emf.visibleObjects().size(), emf.usesBatchedLaunches() ? "yes" : "no");
+        if (!outDir.empty()) {
+            emf.writeResults(outDir, true);
+            const emf::Mesh bg = emf.getMesh(0);
+            std::printf("results in %s: background mesh %zu vertices, %zu triangles\n", outDir.c_str(),
+                        bg.vertices(), bg.triangles());
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "emfusion_synth: %s\n", e.what());
         return 1;
