@@ -269,12 +269,22 @@ class ImageReader:
 
 
 def load_preprocessed_masks(filename):
-    """A Mask R-CNN result file of the reference's preprocessing script (maskrcnn.in.py:258-268,
-    read by MaskRCNN::loadPreprocessed): a pickle of (boxes (N, 4), masks (H, W, N) bool / uint8,
-    scores (N, 81)).  Returns (boxes, [uint8 (H, W) 0/1 mask per instance], scores)."""
+    """A Mask R-CNN result file of the reference's preprocessing script: `generate_result`
+    (apps/maskrcnn.in.py:188-206) pickles three parallel SEQUENCES over the kept instances -- boxes
+    (4 numbers each), masks (one (H, W) array each) and the 81 class scores -- already filtered by
+    FILTER_CLASSES / STATIC_OBJECTS; MaskRCNN::loadPreprocessed (MaskRCNN.cpp:250-282) reads them item by
+    item (getSegmentation, MaskRCNN.cpp:152-172).  Returns (boxes (N, 4), [uint8 (H, W) 0/1 mask per
+    instance], scores (N, 81))."""
     with open(filename, "rb") as f:
         boxes, masks, scores = pickle.load(f, encoding="latin1")
-    masks = np.asarray(masks)
-    per_instance = [np.ascontiguousarray(masks[:, :, i] != 0, np.uint8) for i in range(masks.shape[2])] \
-        if masks.ndim == 3 else []
-    return np.asarray(boxes), per_instance, np.asarray(scores)
+    per_instance = []
+    for m in masks:  # a list of arrays, or an (N, H, W) array: one item per instance either way
+        m = np.asarray(m)
+        if m.ndim != 2:
+            raise ValueError("%s: instance masks must be 2-D, got shape %s" % (filename, m.shape))
+        per_instance.append(np.ascontiguousarray(m != 0, np.uint8))
+    boxes = np.asarray(boxes, np.float64).reshape(-1, 4)
+    scores = np.asarray(scores, np.float64).reshape(len(per_instance), -1) if len(per_instance) else np.zeros((0, 81))
+    if len(boxes) != len(per_instance):
+        raise ValueError("%s: %d boxes for %d masks" % (filename, len(boxes), len(per_instance)))
+    return boxes, per_instance, scores

@@ -27,9 +27,9 @@ def test_run_tum_on_a_staged_synthetic_sequence(tmp_path, dev):
         readers.write_png_gray16(seq / "depth" / f"{f:04d}.png", np.round(depth * 5000).astype(np.uint16))
         lines.append(f"{f / 30:.6f} rgb/{f:04d}.png {f / 30:.6f} depth/{f:04d}.png")
         if f % 2 == 0:
-            m = np.stack([(sid == 1), (sid == 2)], axis=-1)
+            m = [(sid == 1).astype(np.uint8), (sid == 2).astype(np.uint8)]  # generate_result's lists
             with open(masks / f"Mask{f:04d}.plk", "wb") as fh:
-                pickle.dump((np.zeros((2, 4)), m, np.zeros((2, 81))), fh, protocol=2)
+                pickle.dump(([[0, 0, 1, 1]] * 2, m, np.zeros((2, 81)).tolist()), fh, protocol=2)
     (seq / "associations.txt").write_text("\n".join(lines) + "\n")
     synth.close()
     out = tmp_path / "out"

@@ -82,16 +82,24 @@ def test_tum_sequence(tmp_path, rgb_first):
 
 
 def test_preprocessed_masks(tmp_path):
-    masks = np.zeros((4, 5, 2), bool)
-    masks[1:3, 1:4, 0] = True
-    masks[0, :, 1] = True
-    boxes = np.array([[1, 1, 3, 4], [0, 0, 1, 5]])
+    """The layout generate_result() of the reference's maskrcnn.in.py pickles: three parallel lists."""
+    m0, m1 = np.zeros((4, 5), bool), np.zeros((4, 5), np.uint8)
+    m0[1:3, 1:4] = True
+    m1[0, :] = 1
+    boxes = [[1, 1, 3, 4], [0, 0, 1, 5]]
     scores = np.random.default_rng(1).random((2, 81))
     with open(tmp_path / "Mask0000.plk", "wb") as f:
-        pickle.dump((boxes, masks, scores), f, protocol=2)
+        pickle.dump((boxes, [m0, m1], scores.tolist()), f, protocol=pickle.HIGHEST_PROTOCOL)
     b, m, s = readers.load_preprocessed_masks(tmp_path / "Mask0000.plk")
-    assert len(m) == 2 and m[0].dtype == np.uint8 and m[0].sum() == 6 and m[1].sum() == 5
-    assert np.array_equal(b, boxes) and np.allclose(s, scores)
+    assert len(m) == 2 and m[0].dtype == np.uint8 and m[0].shape == (4, 5) and m[0].sum() == 6 and m[1].sum() == 5
+    assert np.array_equal(b, np.array(boxes)) and np.allclose(s, scores) and s.shape == (2, 81)
+    with open(tmp_path / "Mask0001.plk", "wb") as f:  # a frame without detections
+        pickle.dump(([], [], []), f, protocol=2)
+    b, m, s = readers.load_preprocessed_masks(tmp_path / "Mask0001.plk")
+    assert b.shape == (0, 4) and m == [] and s.shape[0] == 0
+    with open(tmp_path / "Mask0002.plk", "wb") as f:  # (N, H, W) array: same items
+        pickle.dump((np.array(boxes), np.stack([m0, m1.astype(bool)]), scores), f, protocol=2)
+    assert [x.sum() for x in readers.load_preprocessed_masks(tmp_path / "Mask0002.plk")[1]] == [6, 5]
 
 
 # ---- OpenEXR depth files (Co-Fusion datasets, reference ImageReader.cpp) ---------------------------
