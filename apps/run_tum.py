@@ -29,6 +29,8 @@ def main():
                          "<sequence>/COLORDIR/ColorNNNN.png, <sequence>/DEPTHDIR/DepthNNNN.exr")
     ap.add_argument("--intrinsics", nargs=4, type=float, metavar=("FX", "FY", "CX", "CY"),
                     help="camera intrinsics (default: 525 px focal length scaled to the image width)")
+    ap.add_argument("--ignore-person", action="store_true",
+                    help="Params.ignore_person of config/tum.cfg: person objects stay out of renderings and meshes")
     ap.add_argument("--masks", help="directory with Mask%%04d.plk files of the reference's preprocessing")
     ap.add_argument("--out", default="emfusion_out")
     ap.add_argument("--frames", type=int, default=0, help="0 = all")
@@ -62,6 +64,7 @@ def main():
         fx, fy, cx, cy = args.intrinsics
         prm.K[:] = [fx, 0, cx, 0, fy, cy, 0, 0, 1]
     fus = pipeline.Fusion(prm, None)
+    fus.set_ignore_person(args.ignore_person)
     fus.set_preprocess(True)
     fus.set_cleanup(True)
     fus.enable_pose_log(True)
@@ -75,10 +78,11 @@ def main():
         if args.masks and f % prm.mask_frames == 0:
             plk = Path(args.masks) / f"Mask{index0 + f:04d}.plk"
             if plk.exists():
-                _, masks, _ = readers.load_preprocessed_masks(plk)
+                _, masks, scores = readers.load_preprocessed_masks(plk)
                 dev_masks = [DeviceArray.from_numpy(m) for m in masks]
                 keep += dev_masks
                 fus.queue_instance_masks([image_view(m) for m in dev_masks])
+                fus.queue_instance_scores(scores)
         if f == 1:
             fus.set_tracking(camera=True, objects=True)  # frame 0 defines the world frame
         fus.process_frame(image_view(d), eye, zero, {}, {}, False)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "emf_hip_objectExtentStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _STREAM],
     "emf_hip_copyValues": [_FP, _FP, C.c_int, _I3, _I3, _I3, _STREAM],
     "emf_hip_meshScratchBytes": [_I3],
+    "emf_hip_hideLabel": [_IMG, C.c_int, _IMG, _IMG, _IMG, _IMG, _STREAM],
     "emf_hip_renderPhong": [_IMG, _IMG, _IMG, C.c_void_p, _F9, _IMG, _STREAM],
     "emf_hip_meshCount": [_FP, _FP, _FP, _I3, _FP, _FP, _STREAM],
     "emf_hip_meshEmit": [_FP, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _FP, _FP, _STREAM],

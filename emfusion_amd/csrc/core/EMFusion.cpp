@@ -420,7 +420,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     const bool instances = !in.instanceMasks.empty();
     if (instances) {  // reference EMFusion.cpp:100-101
         std::vector<emf_image_t> segs = in.instanceMasks;
-        masks = initOrMatchObjs(segs, lastAssigned);
+        masks = initOrMatchObjs(segs, lastAssigned, in.instanceScores);
         masks.erase(-1);
     }
 
@@ -573,7 +573,8 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
     // writeMeshes (EMFusion.cpp:1147-1156): the background, the live objects, and the objects that
     // were deleted while the log was on (their last mesh, EMFusion.cpp:966)
     io::writeMesh(dir + "/mesh_bg.ply", background.getMesh());
-    for (auto& obj : objects) meshes[obj.getID()] = obj.getMesh();
+    for (auto& obj : objects)
+        if (!(ignorePerson && isPerson(obj))) meshes[obj.getID()] = obj.getMesh();
     for (const auto& m : meshes) io::writeMesh(dir + "/mesh_" + std::to_string(m.first) + ".ply", m.second);
     dump("bg_tsdf", background.getTSDF(), background);
     for (auto& obj : objects) {
@@ -585,7 +586,8 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
 }
 
 std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& segs,
-                                                     std::vector<int>& assigned) {
+                                                     std::vector<int>& assigned,
+                                                     const std::vector<std::vector<double>>& scores) {
     if (sharded) throw HipError("EMFusion::initOrMatchObjs: not available on the sharded path", EMF_E_ARG);
     ensureLifecycleBuffers();
     std::map<int, emf_image_t> matches;
@@ -658,6 +660,9 @@ std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& s
     for (auto& obj : objects) {  // EMFusion.cpp:358-369
         auto it = matches.find(obj.getID());
         if (it != matches.end()) {
+            // score_matches (EMFusion.cpp:442, 492): the scores of the mask that ended up with this object
+            for (size_t i = 0; i < assigned.size() && i < scores.size(); ++i)
+                if (assigned[i] == obj.getID()) obj.updateClassProbs(scores[i]);
             const Vec3i before = obj.getVolumeRes();
             const Vec3f offset = updateObj(obj, it->second);
             if (poseLog) obj_pose_offsets[obj.getID()][frameCount] = offset;
@@ -771,7 +776,8 @@ std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_i
             deleted.push_back(id);
             synchronize();  // nothing in flight may still use the volume
             deleteObj(id);
-            if (poseLog) meshes[id] = it->getMesh();  // saveOutput: EMFusion.cpp:962-966
+            if (poseLog && !(ignorePerson && isPerson(*it)))
+                meshes[id] = it->getMesh();  // saveOutput: EMFusion.cpp:962-966
             it = objects.erase(it);
         } else {
             ++it;
@@ -913,6 +919,12 @@ void EMFusion::render(uint8_t* rgb) {
     if (image.empty()) image = DeviceImage<uint8_t, 3>(params.frameSize);
     const emf_image_t vv = vertices.view(), nv = normals.view(), sv = modelSegmentation.view(),
                       iv = image.view();
+    if (ignorePerson) {  // EMFusion.cpp:139-150: in place, like the reference
+        const emf_image_t bv = bg_vertices.view(), bn = bg_normals.view();
+        for (const auto& obj : objects)
+            if (isPerson(obj))
+                emfCheck(emf_hip_hideLabel(&sv, obj.getID(), &vv, &nv, &bv, &bn, main.abi()), "hideLabel");
+    }
     const float light[3] = {0.f, 0.f, 0.f};  // cv::Affine3f::Identity()
     emfCheck(emf_hip_renderPhong(&vv, &nv, &sv, colorMap.data(), light, &iv, main.abi()), "renderPhong");
     hipCheck(hipMemcpyAsync(rgb, image.ptr(), bytes, hipMemcpyDeviceToHost, main.get()), "render D2H");

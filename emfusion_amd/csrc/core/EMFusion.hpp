@@ -59,6 +59,9 @@ struct FrameInputs {
     // bookkeeping (EMFusion.cpp:329-372, 417-494) -- and the resulting id -> mask map feeds
     // integrateMasks and cleanUpObjs.  Takes the place of `masks` / `newObjectMasks`.
     std::vector<emf_image_t> instanceMasks;
+    // The 81 class scores of each instance mask (same order; may be empty): a matched object
+    // accumulates them (ObjTSDF::updateClassProbs, EMFusion.cpp:830), which is what ignore_person reads.
+    std::vector<std::vector<double>> instanceScores;
     // Run the reference's cleanUpObjs at the end of the frame (EMFusion.cpp:922-980): objects with
     // a low existence probability (mask frames), with too little association mass under their
     // mask, or not visible are deleted.  Needs the visible set on the host (one synchronisation),
@@ -116,7 +119,16 @@ public:
      * returns object id -> mask; `assigned[i]` = the id mask i ended up with (-1: none).
      */
     std::map<int, emf_image_t> initOrMatchObjs(std::vector<emf_image_t>& segs,
-                                               std::vector<int>& assigned);
+                                               std::vector<int>& assigned,
+                                               const std::vector<std::vector<double>>& scores = {});
+    /**
+     * Params.ignore_person of the reference (data.h:198, config/tum.cfg): objects whose most likely
+     * class is "person" (COCO index 1) are tracked and fused like all others but left out of the
+     * rendering (their pixels show the background, EMFusion.cpp:139-150) and of the mesh files
+     * (EMFusion.cpp:274-278, 962-966).
+     */
+    void setIgnorePerson(bool on) { ignorePerson = on; }
+    static bool isPerson(const ObjTSDF& obj) { return obj.getClassID() == 1; }  // class_names[1]
     const std::vector<int>& lastMaskAssignment() const { return lastAssigned; }
     /**
      * Reference EMFusion::updateObj (EMFusion.cpp:827-863): grow / recentre a matched object's
@@ -286,6 +298,7 @@ private:
     bool useLambdaTable = true;
     DeviceBuffer integrateCullScratch;  // survivor list of emf_hip_integrateBatchedCulled (empty: plain launch)
     bool cullBoxes = true;               // EMF_INT_CULL=0 keeps the one-level launch (A/B measurements)
+    bool ignorePerson = false;
     int depthRoot = -1;  // sharded path: rank whose depth image is broadcast each frame (-1: none)
     bool bgBands = true;  // sharded path: split the background raycast into row bands per rank
 

@@ -129,6 +129,21 @@ Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& 
     return newCenter;
 }
 
+void ObjTSDF::updateClassProbs(const std::vector<double>& scores) {
+    if (scores.empty()) return;  // a mask that came without scores
+    if (classProbs.empty()) {
+        classProbs = scores;
+        return;
+    }
+    if (classProbs.size() != scores.size())
+        throw HipError("ObjTSDF::updateClassProbs: score vectors of different lengths", EMF_E_ARG);
+    for (size_t i = 0; i < scores.size(); ++i) classProbs[i] += scores[i];
+}
+
+int ObjTSDF::getClassID() const {
+    return static_cast<int>(std::max_element(classProbs.begin(), classProbs.end()) - classProbs.begin());
+}
+
 Mesh ObjTSDF::getMesh() { return extractMesh(fgVolMask.as<uint8_t>()); }
 
 void ObjTSDF::describe(emf_model_t& m) const {

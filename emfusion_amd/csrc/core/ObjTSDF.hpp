@@ -3,8 +3,7 @@
 // Keeps the per-frame surface of the reference's emf::ObjTSDF (reference
 // include/EMFusion/core/ObjTSDF.h:40-216, src/core/ObjTSDF.cpp:167-226): integrateMask,
 // computeAssociation (foreground-weighted), raycast (foreground-masked weights), computeFgProbs,
-// the getters, resize() (ObjTSDF.cpp:80-165) and the existence bookkeeping.  Class probabilities
-// (Mask R-CNN scores) are outside the path.
+// the getters, resize() (ObjTSDF.cpp:80-165), the existence and class-probability bookkeeping.
 #pragma once
 
 #include "TSDF.hpp"
@@ -25,6 +24,10 @@ public:
     /** Existence bookkeeping of the reference (ObjTSDF.cpp:61-68). */
     void updateExProb(bool exists) { exCount += exists; nonExCount += 1 - exists; }
     float getExProb() const { return static_cast<float>(exCount) / (exCount + nonExCount); }
+    /** Accumulate the class scores of a matched Mask R-CNN detection (reference ObjTSDF.cpp:70-78). */
+    void updateClassProbs(const std::vector<double>& scores);
+    /** Index of the largest accumulated score (reference ObjTSDF.cpp:242-245); 0 before any score. */
+    int getClassID() const;
 
     /** Also clears the fg/bg counts (reference ObjTSDF.cpp:58-61) and the derived volumes. */
     void reset(const Affine3f& pose) override;
@@ -75,6 +78,7 @@ public:
 
 private:
     int exCount = 0, nonExCount = 0;
+    std::vector<double> classProbs;
     static int nextID;
     int id;
     DeviceBuffer fgBgProbs;  // N^3 x 2 f32 counts

@@ -18,6 +18,7 @@ struct emf_fusion {
     std::unique_ptr<EMFusion> impl;
     bool trackCamera = false, trackObjects = false, preprocess = false, cleanUp = false;
     std::vector<emf_image_t> queuedMasks, queuedInstances;
+    std::vector<std::vector<double>> queuedScores;
     emf::Mesh mesh;  // result of the last emf_fusion_extract_mesh
 };
 struct emf_synth {
@@ -168,6 +169,7 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.cleanUp = h->cleanUp;
         in.newObjectMasks.swap(h->queuedMasks);
         in.instanceMasks.swap(h->queuedInstances);
+        in.instanceScores.swap(h->queuedScores);
         h->impl->processFrame(*depth_dev, in);
     });
 }
@@ -196,6 +198,32 @@ int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* m
     REQ(h);
     if (n > 0) REQ(masks);
     return guarded([&] { h->queuedInstances.assign(masks, masks + (n > 0 ? n : 0)); });
+}
+
+int emf_fusion_queue_instance_scores(emf_fusion_t* h, int n, int num_classes, const double* scores) {
+    REQ(h);
+    if (n > 0) REQ(scores);
+    return guarded([&] {
+        h->queuedScores.clear();
+        for (int i = 0; i < n; ++i)
+            h->queuedScores.emplace_back(scores + static_cast<size_t>(i) * num_classes,
+                                         scores + static_cast<size_t>(i + 1) * num_classes);
+    });
+}
+
+int emf_fusion_object_class(emf_fusion_t* h, int id, int32_t* class_id) {
+    REQ(h);
+    REQ(class_id);
+    return guarded([&] {
+        const ObjTSDF* o = h->impl->getObject(id);
+        if (!o) throw HipError("object_class: no object " + std::to_string(id), EMF_E_ARG);
+        *class_id = o->getClassID();
+    });
+}
+
+int emf_fusion_set_ignore_person(emf_fusion_t* h, int on) {
+    REQ(h);
+    return guarded([&] { h->impl->setIgnorePerson(on != 0); });
 }
 
 int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count) {

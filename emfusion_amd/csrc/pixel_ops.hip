@@ -336,6 +336,19 @@ __global__ __launch_bounds__(kBfX* kBfY) void k_preprocess_depth(const Bilateral
     a.out.row(y)[x] = o;
 }
 
+// ---- ignore_person in EMFusion::render (EMFusion.cpp:139-150): compare / setTo / 2 x masked copyTo ----
+__global__ __launch_bounds__(256) void k_hide_label(Img<uint8_t> seg, int id, Img<float> vert, Img<float> nrm,
+                                                    Img<const float> bgVert, Img<const float> bgNrm, int w, int h) {
+    int x, y;
+    if (!pixel_of(w, h, x, y)) return;
+    if (seg.row(y)[x] != id) return;
+    seg.row(y)[x] = 0;
+    for (int c = 0; c < 3; ++c) {
+        vert.row(y)[3 * x + c] = bgVert.row(y)[3 * x + c];
+        nrm.row(y)[3 * x + c] = bgNrm.row(y)[3 * x + c];
+    }
+}
+
 // ---- f-4: kernel_renderPhong + renderGPU's colour lookup (EMFusion.cu:100-186) ---------------------
 // One launch: the label -> colour lookup (cv::cuda::LookUpTable on a 3-channel copy of the
 // segmentation) happens in registers from a table passed by value, and background pixels are
@@ -700,6 +713,26 @@ int emf_hip_preprocessDepth(const emf_image_t* depthRaw, const emf_image_t* dept
                        dim3(static_cast<unsigned>(ceil_div(a.w, kBfX)), static_cast<unsigned>(ceil_div(a.h, kBfY))),
                        dim3(kBfX, kBfY), 0, as_stream(stream), a);
     return launch_status("preprocessDepth");
+}
+
+int emf_hip_hideLabel(const emf_image_t* segmentation, int id, const emf_image_t* vertices,
+                      const emf_image_t* normals, const emf_image_t* bgVertices, const emf_image_t* bgNormals,
+                      emf_stream_t stream) {
+    EMF_TRY(check_image(segmentation, 1, "hideLabel: segmentation"));
+    EMF_TRY(check_image(vertices, 12, "hideLabel: vertices"));
+    EMF_TRY(check_image(normals, 12, "hideLabel: normals"));
+    EMF_TRY(check_image(bgVertices, 12, "hideLabel: bgVertices"));
+    EMF_TRY(check_image(bgNormals, 12, "hideLabel: bgNormals"));
+    EMF_TRY(check_same_size(segmentation, vertices, "segmentation", "vertices"));
+    EMF_TRY(check_same_size(segmentation, normals, "segmentation", "normals"));
+    EMF_TRY(check_same_size(segmentation, bgVertices, "segmentation", "bgVertices"));
+    EMF_TRY(check_same_size(segmentation, bgNormals, "segmentation", "bgNormals"));
+    if (id < 1 || id > 255) return fail(EMF_E_ARG, "hideLabel: id %d is not a label", id);
+    hipLaunchKernelGGL(k_hide_label, pixel_grid(segmentation->width, segmentation->height), pixel_block(), 0,
+                       as_stream(stream), img<uint8_t>(segmentation), id, img<float>(vertices), img<float>(normals),
+                       img<const float>(bgVertices), img<const float>(bgNormals), segmentation->width,
+                       segmentation->height);
+    return launch_status("hideLabel");
 }
 
 int emf_hip_renderPhong(const emf_image_t* vertices, const emf_image_t* normals,

@@ -107,6 +107,9 @@ def load() -> C.CDLL:
         "emf_fusion_match_mask": [vp, img, ip, fp],
         "emf_fusion_update_object": [vp, C.c_int, img, fp],
         "emf_fusion_set_depth_broadcast": [vp, C.c_int],
+        "emf_fusion_queue_instance_scores": [vp, C.c_int, C.c_int, C.c_void_p],
+        "emf_fusion_object_class": [vp, C.c_int, ip],
+        "emf_fusion_set_ignore_person": [vp, C.c_int],
         "emf_fusion_render": [vp, C.c_void_p, C.c_void_p],
         "emf_fusion_extract_mesh": [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "emf_fusion_copy_mesh": [vp, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -397,6 +400,22 @@ class Fusion:
         _check("emf_fusion_update_object",
                load().emf_fusion_update_object(self._h, int(obj_id), C.byref(mask_view), off))
         return np.array(list(off), np.float32)
+
+    def queue_instance_scores(self, scores):
+        """Class scores (n, num_classes) that go with the masks of queue_instance_masks."""
+        s = np.ascontiguousarray(scores, np.float64)
+        s = s.reshape(len(s), -1) if s.size else np.zeros((0, 81))
+        _check("emf_fusion_queue_instance_scores",
+               load().emf_fusion_queue_instance_scores(self._h, s.shape[0], s.shape[1], s.ctypes.data))
+
+    def object_class(self, obj_id: int) -> int:
+        c = C.c_int32()
+        _check("emf_fusion_object_class", load().emf_fusion_object_class(self._h, int(obj_id), C.byref(c)))
+        return c.value
+
+    def set_ignore_person(self, on=True):
+        """Params.ignore_person: objects classified as person stay out of renderings and mesh files."""
+        _check("emf_fusion_set_ignore_person", load().emf_fusion_set_ignore_person(self._h, int(on)))
 
     def set_depth_broadcast(self, root: int = 0):
         """Multi-GPU: every frame's depth image is broadcast from rank `root` first (-1: off)."""

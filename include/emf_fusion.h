@@ -104,6 +104,13 @@ int emf_fusion_queue_new_object_masks(emf_fusion_t* h, int n, const emf_image_t*
  * unmatched -- the masks are MODIFIED in place), integrates the matched masks and, if clean-up is
  * on, deletes spurious objects.  last_mask_assignment: the object id each mask ended up with. */
 int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* masks);
+/* The class scores that go with the queued instance masks (n x num_classes doubles, mask-major;
+ * MaskRCNN::getScores): a matched object accumulates them.  object_class: index of its largest
+ * accumulated score (0 before any).  set_ignore_person: Params.ignore_person (config/tum.cfg) --
+ * "person" objects (COCO class 1) stay out of renderings and mesh files. */
+int emf_fusion_queue_instance_scores(emf_fusion_t* h, int n, int num_classes, const double* scores);
+int emf_fusion_object_class(emf_fusion_t* h, int id, int32_t* class_id);
+int emf_fusion_set_ignore_person(emf_fusion_t* h, int on);
 int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);

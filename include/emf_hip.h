@@ -460,6 +460,12 @@ int emf_hip_meshEmit(const float* tsdf, const float* grads, const float* weights
                      const void* scratch_dev, float* vertices, float* normals, int32_t* triangles,
                      emf_stream_t stream);
 
+/* The ignore_person block of EMFusion::render (EMFusion.cpp:139-150: compare, setTo, two masked
+ * copyTo) in one launch: pixels labelled `id` get label 0 and the background's vertex / normal. */
+int emf_hip_hideLabel(const emf_image_t* segmentation, int id, const emf_image_t* vertices,
+                      const emf_image_t* normals, const emf_image_t* bgVertices, const emf_image_t* bgNormals,
+                      emf_stream_t stream);
+
 /* Replaces cuda::EMFusion::renderGPU (EMFusion.cu:100-186): Phong shading of the composited raycast
  * (vertices, normals f32x3; segmentation u8) into image (u8x3, RGB), coloured per label through
  * colorMap (256 x RGB, HOST memory, passed by value to the kernel).  Pixels without a vertex are

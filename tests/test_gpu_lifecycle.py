@@ -474,3 +474,52 @@ def test_matched_object_outgrows_its_volume_and_is_resized(oracle, dev, tmp_path
     assert np.abs(raw[-1, 1:4] - raw[0, 1:4]).max() > 1e-3
     fus.close()
     synth.close()
+
+
+def test_class_scores_accumulate_and_ignore_person_hides_the_object(oracle, dev, tmp_path):
+    """Class probabilities (ObjTSDF::updateClassProbs / getClassID) and Params.ignore_person: the object
+    whose accumulated scores say "person" is fused and tracked like the other one, but the rendering
+    shows the background in its place and writeResults leaves its mesh out."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    Wf, Hf = 320, 240
+    prm = pipeline.make_params(Wf, Hf, 128, 0.04, 32, visibility_thresh=400, boundary=10)
+    synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 2, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    fus.enable_pose_log(True)
+    rng = np.random.default_rng(3)
+    person = np.zeros(81); person[1] = 0.9; person[57] = 0.1      # COCO: 1 = person, 57 = chair
+    chair = np.zeros(81); chair[57] = 0.6; chair[1] = 0.3
+    centers, keep = {}, []
+    for f in range(4):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        d = to_dev(depth)
+        inst = [to_dev((sid == k).astype(np.uint8)) for k in (1, 2)]
+        keep += [d, inst]
+        fus.queue_instance_masks([image_view(m) for m in inst])
+        # object 2 looks like a person on two frames of three; a noisy "chair" vote in between
+        fus.queue_instance_scores([chair + 0.01 * rng.random(81), person if f != 2 else chair])
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), c) for i, c in centers.items()}
+        fus.process_frame(image_view(d), R, t, poses, {}, False)
+        fus.synchronize()
+        if f == 0:
+            assert fus.last_mask_assignment() == [1, 2]
+            centers = {k: fus.pose(k)[1] for k in (1, 2)}
+    assert fus.object_class(1) == 57 and fus.object_class(2) == 1
+    seg = fus.image("segmentation")
+    assert (seg == 2).sum() > 100
+    shown, _ = fus.render()
+    fus.set_ignore_person(True)
+    hidden, cmap = fus.render()
+    seg_after = fus.image("segmentation")
+    assert not (seg_after == 2).any() and (seg_after == 1).sum() == (seg == 1).sum()
+    was = seg == 2
+    want = oracle.render_phong(fus.image("vertices"), fus.image("normals"), seg_after, cmap)
+    assert np.array_equal(hidden, want)
+    assert np.array_equal(hidden[~was], shown[~was]) and not np.array_equal(hidden[was], shown[was])
+    fus.write_results(str(tmp_path), volumes=True)
+    assert (tmp_path / "mesh_1.ply").exists() and not (tmp_path / "mesh_2.ply").exists()
+    assert (tmp_path / "tsdfs" / "tsdf_2.bin").exists()  # volumes are still dumped (EMFusion.cpp:1187-1218)
+    fus.close()
+    synth.close()
