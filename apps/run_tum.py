@@ -76,7 +76,7 @@ def main():
         d = DeviceArray.from_numpy(depth)
         keep = [d]
         if args.masks and f % prm.mask_frames == 0:
-            plk = Path(args.masks) / f"Mask{index0 + f:04d}.plk"
+            plk = Path(args.masks) / f"Mask{f:04d}.plk"  # numbered by frameCount (EMFusion.cpp:384-386)
             if plk.exists():
                 _, masks, scores = readers.load_preprocessed_masks(plk)
                 dev_masks = [DeviceArray.from_numpy(m) for m in masks]
