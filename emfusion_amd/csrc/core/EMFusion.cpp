@@ -194,7 +194,8 @@ int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
     if (ownsObject(id)) {
         const Affine3f obj_pose(Matx33f::eye(), center);
         const float vox = volSize / static_cast<float>(res[0]);
-        objects.emplace_back(id, res, vox, params.objRelTruncDist * vox, obj_pose,
+        // truncation distance as the reference forms it: (objRelTruncDist * volSize) / res (EMFusion.cpp:545-547)
+        objects.emplace_back(id, res, vox, params.objRelTruncDist * volSize / static_cast<float>(res[0]), obj_pose,
                              params.tsdfParams, params.frameSize, gradMode);
         createObj(id);
         streamOf(id);

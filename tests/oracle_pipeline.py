@@ -64,9 +64,10 @@ class OraclePipeline:
         self.points = None
         self.march_samples = 0
 
-    def _new_volume(self, vid, res, vox, pose, is_obj):
+    def _new_volume(self, vid, res, vox, pose, is_obj, trunc=None):
         n = (res, res, res) if np.isscalar(res) else tuple(res)
-        v = dict(id=vid, n=n, vox=f32(vox), trunc=f32(self.p["rel_trunc"] * f32(vox)), pose=pose,
+        trunc = f32(self.p["rel_trunc"] * f32(vox)) if trunc is None else f32(trunc)
+        v = dict(id=vid, n=n, vox=f32(vox), trunc=trunc, pose=pose,
                  tsdf=np.zeros((n[2], n[1], n[0]), f32), wts=np.zeros((n[2], n[1], n[0]), f32))
         if is_obj:
             v.update(fgbg=np.zeros((n[2], n[1], n[0], 2), f32),
@@ -81,7 +82,8 @@ class OraclePipeline:
         vid = len(self.objects) + 1
         res = self.obj_res
         vox = f32(f32(vol_size) / f32(res))  # EMFusion::addObject: volSize / float(res[0])
-        self.objects.append(self._new_volume(vid, res, vox, Affine32(t=center), True))
+        trunc = f32(f32(self.p["rel_trunc"] * f32(vol_size)) / f32(res))  # (rel * volSize) / res, EMFusion.cpp:545-547
+        self.objects.append(self._new_volume(vid, res, vox, Affine32(t=center), True, trunc))
         self.vis.add(vid)
         return vid
 

@@ -462,7 +462,8 @@ def test_matched_object_outgrows_its_volume_and_is_resized(oracle, dev, tmp_path
     R_oc = Rc.T.copy()                       # camera^-1 * object pose, object rotation = identity
     t_oc = (f32_transform(R_oc, np.zeros(3, f32), tn[None])[0] + (-f32_transform(R_oc, np.zeros(3, f32), tc[None])[0])).astype(f32)
     oracle.update_tsdf(depth, assoc, tsdf, wts, R_oc.reshape(-1), t_oc, Kf.reshape(-1), float(vox),
-                       float(f32(prm.obj_rel_truncdist) * vox), float(prm.max_tsdf_weight))
+                       float(f32(f32(prm.obj_rel_truncdist) * f32(f32(2) * np.max(w90 - w10))) / f32(32)),
+                       float(prm.max_tsdf_weight))
     assert np.array_equal(fus.volume("weights", 1), wts)
     assert np.array_equal(fus.volume("tsdf", 1), tsdf)
     # pose files: raw trajectory jumps with the centre, the corrected one does not
