@@ -497,7 +497,8 @@ float EMFusion::volumeIOU(const ObjTSDF& obj, const Vec3f& p10, const Vec3f& p90
     obj.getCorners(low, high);
     const Vec3f prev = obj.getVolumeSize();
     const float vol = 1.f * prev[0] * prev[1] * prev[2];
-    const float vol_new = std::pow(volSize, 3.f);
+    // pow(float, int) of the reference promotes to double (C++11 [c.math]); the float keeps its rounding
+    const float vol_new = static_cast<float>(std::pow(static_cast<double>(volSize), 3));
     float vol_int = 1.f;
     for (int k = 0; k < 3; ++k) {
         const float d = std::min(high[k], high_new[k]) - std::max(low[k], low_new[k]);
