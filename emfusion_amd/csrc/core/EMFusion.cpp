@@ -525,8 +525,9 @@ int EMFusion::initNewObjVolume(const emf_image_t& mask) {
     const Vec3f p90(world_stats.p90[0], world_stats.p90[1], world_stats.p90[2]);
     const Vec3f center = (p10 + p90) / 2.f;
     const Vec3f off = center - pose.translation();
-    if (std::sqrt(off[0] * off[0] + off[1] * off[1] + off[2] * off[2]) > params.distanceThresh)
-        return -1;  // EMFusion.cpp:531-533
+    // cv::norm accumulates the squares in double (EMFusion.cpp:531-533)
+    const double o0 = off[0], o1 = off[1], o2 = off[2];
+    if (std::sqrt(o0 * o0 + o1 * o1 + o2 * o2) > static_cast<double>(params.distanceThresh)) return -1;
     const Vec3f dims = p90 - p10;
     const float volSize = params.volPad * std::max(dims[0], std::max(dims[1], dims[2]));
     return addObject(center, volSize);
