@@ -581,6 +581,7 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
     for (const auto& m : meshes) io::writeMesh(dir + "/mesh_" + std::to_string(m.first) + ".ply", m.second);
     dump("bg_tsdf", background.getTSDF(), background);
     for (auto& obj : objects) {
+        if (ignorePerson && isPerson(obj)) continue;  // the same `continue` skips them (EMFusion.cpp:274-277)
         const std::string id = std::to_string(obj.getID());
         dump("tsdf_" + id, obj.getTSDF(), obj);
         dump("weights_" + id, obj.getWeightsVol(), obj);

@@ -521,6 +521,6 @@ def test_class_scores_accumulate_and_ignore_person_hides_the_object(oracle, dev,
     assert np.array_equal(hidden[~was], shown[~was]) and not np.array_equal(hidden[was], shown[was])
     fus.write_results(str(tmp_path), volumes=True)
     assert (tmp_path / "mesh_1.ply").exists() and not (tmp_path / "mesh_2.ply").exists()
-    assert (tmp_path / "tsdfs" / "tsdf_2.bin").exists()  # volumes are still dumped (EMFusion.cpp:1187-1218)
+    assert (tmp_path / "tsdfs" / "tsdf_1.bin").exists() and not (tmp_path / "tsdfs" / "tsdf_2.bin").exists()
     fus.close()
     synth.close()
