@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
         std::vector<emf::DeviceImage<uint8_t>> maskDev;
         for (int k = 0; k < objects; ++k) maskDev.emplace_back(params.frameSize);
         emf.enableTimings(true);
-        if (!outDir.empty()) emf.enablePoseLog(true);
+        if (!outDir.empty()) emf.setupOutput(false, true);  // apps/EM-Fusion.cpp:112
 
         double gpuMs = 0;
         int spawned = 0;
@@ -129,7 +129,7 @@ int main(int argc, char** argv) {
                     t.points, t.estep, t.raycast, t.composite, t.integrate, t.masks,
                     emf.visibleObjects().size(), emf.usesBatchedLaunches() ? "yes" : "no");
         if (!outDir.empty()) {
-            emf.writeResults(outDir, true);
+            emf.writeResults(outDir, false);  // volumes follow setupOutput, as in the reference
             const emf::Mesh bg = emf.getMesh(0);
             std::printf("results in %s: background mesh %zu vertices, %zu triangles\n", outDir.c_str(),
                         bg.vertices(), bg.triangles());

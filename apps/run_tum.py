@@ -67,7 +67,7 @@ def main():
     fus.set_ignore_person(args.ignore_person)
     fus.set_preprocess(True)
     fus.set_cleanup(True)
-    fus.enable_pose_log(True)
+    fus.setup_output(False, args.volumes)  # EMFusion::setupOutput of the reference app (apps/EM-Fusion.cpp:112)
     eye, zero = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)
     t0 = time.time()
     for f in range(n):

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace emf {
@@ -184,7 +185,7 @@ int EMFusion::addObject(const Vec3f& center, float volSize) {
 
 int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
     if (static_cast<int>(allIds.size()) >= EMF_MAX_MODELS - 1)
-        throw HipError("EMFusion::addObject: too many objects", EMF_E_LIMIT);
+        throw HipError("EMFusion::addObject: too many live objects", EMF_E_LIMIT);
     synchronize();  // object creation is rare and changes the model table
     refreshVisibleFromDevice();
     const int id = nextId++;
@@ -530,6 +531,13 @@ int EMFusion::initNewObjVolume(const emf_image_t& mask) {
     if (std::sqrt(o0 * o0 + o1 * o1 + o2 * o2) > static_cast<double>(params.distanceThresh)) return -1;
     const Vec3f dims = p90 - p10;
     const float volSize = params.volPad * std::max(dims[0], std::max(dims[1], dims[2]));
+    if (static_cast<int>(allIds.size()) >= EMF_MAX_MODELS - 1) {
+        // every slot of the model table is live: this mask gets no volume (the frame loop goes on,
+        // as the reference's would); addObject() itself keeps rejecting the explicit call
+        std::fprintf(stderr, "EMFusion::initNewObjVolume: %d live objects, no new volume for this mask\n",
+                     static_cast<int>(allIds.size()));
+        return -1;
+    }
     return addObject(center, volSize);
 }
 
@@ -565,28 +573,41 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
         io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + ".txt", op.second);
     for (const auto& op : addPoseOffsets(obj_poses, obj_pose_offsets))  // EMFusion.cpp:1000-1006
         io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + "-corrected.txt", op.second);
-    if (!volumes) return;
-    const std::string t = dir + "/tsdfs";
-    if (mkdir(t.c_str(), 0777) != 0 && errno != EEXIST)
-        throw std::runtime_error("EMFusion::writeResults: cannot create " + t);
-    auto dump = [&](const std::string& name, const std::vector<float>& v, const TSDF& vol) {
-        io::writeVolume(t + "/" + name + ".bin", v.data(), sizeof(float), vol.getVolumeRes(),
-                        vol.getVoxelSize());
-    };
-    // writeMeshes (EMFusion.cpp:1147-1156): the background, the live objects, and the objects that
-    // were deleted while the log was on (their last mesh, EMFusion.cpp:966)
+    // writeMeshes (EMFusion.cpp:1147-1156) runs whether or not volumes are exported: the background,
+    // the live objects, and the objects that were deleted while the log was on (their last mesh,
+    // EMFusion.cpp:966)
     io::writeMesh(dir + "/mesh_bg.ply", background.getMesh());
     for (auto& obj : objects)
         if (!(ignorePerson && isPerson(obj))) meshes[obj.getID()] = obj.getMesh();
     for (const auto& m : meshes) io::writeMesh(dir + "/mesh_" + std::to_string(m.first) + ".ply", m.second);
-    dump("bg_tsdf", background.getTSDF(), background);
+    if (!(volumes || expVols)) return;  // `if ( expVols ) writeTSDFs ( p )` (EMFusion.cpp:290-291)
+    const std::string t = dir + "/tsdfs";
+    if (mkdir(t.c_str(), 0777) != 0 && errno != EEXIST)
+        throw std::runtime_error("EMFusion::writeResults: cannot create " + t);
+    auto dump = [&](const std::string& name, const std::vector<float>& v, const Vec3i& res, float vox) {
+        io::writeVolume(t + "/" + name + ".bin", v.data(), sizeof(float), res, vox);
+    };
+    dump("bg_tsdf", background.getTSDF(), background.getVolumeRes(), background.getVoxelSize());
     for (auto& obj : objects) {
         if (ignorePerson && isPerson(obj)) continue;  // the same `continue` skips them (EMFusion.cpp:274-277)
-        const std::string id = std::to_string(obj.getID());
-        dump("tsdf_" + id, obj.getTSDF(), obj);
-        dump("weights_" + id, obj.getWeightsVol(), obj);
-        dump("fgProbs_" + id, obj.getFgProbVol(), obj);
+        savedVolumes[obj.getID()] = saveVolumes(obj);
     }
+    for (const auto& sv : savedVolumes) {  // writeTSDFs (EMFusion.cpp:1195-1216): live and deleted objects
+        const std::string id = std::to_string(sv.first);
+        dump("tsdf_" + id, sv.second.tsdf, sv.second.res, sv.second.voxelSize);
+        dump("weights_" + id, sv.second.weights, sv.second.res, sv.second.voxelSize);
+        dump("fgProbs_" + id, sv.second.fgProbs, sv.second.res, sv.second.voxelSize);
+    }
+}
+
+EMFusion::SavedVolumes EMFusion::saveVolumes(ObjTSDF& obj) {  // EMFusion.cpp:279-285, 967-973
+    SavedVolumes sv;
+    sv.tsdf = obj.getTSDF();
+    sv.weights = obj.getWeightsVol();
+    sv.fgProbs = obj.getFgProbVol();
+    sv.res = obj.getVolumeRes();
+    sv.voxelSize = obj.getVoxelSize();
+    return sv;
 }
 
 std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& segs,
@@ -613,8 +634,12 @@ std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& s
             float new_iou = 0.f;
             matched = matchSegmentation(segs[i], new_iou);
             if (matched >= 0 && matches.count(matched)) {
-                // a second mask for the same model: keep the better one; THIS mask goes on as
-                // unmatched either way, as in the reference
+                // a second mask for the same model: the better one becomes the match; THIS mask goes
+                // on as unmatched either way (EMFusion.cpp:424-437).  Quirk Q20: when it replaced the
+                // earlier match it is carved below against the match of that model -- itself, the
+                // reference's matches[id] being a shallow GpuMat copy of seg_gpus[i] -- so the model
+                // ends up matched to an all-zero mask.  Reproduced: matches[] holds views of the same
+                // device buffers.
                 const uint32_t* c = overlapCounts(matches[matched]);
                 const float prev_iou = static_cast<float>(c[1 + matched]) /
                                        static_cast<float>(c[0] + c[257 + matched] - c[1 + matched]);
@@ -636,7 +661,6 @@ std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& s
     }
     // ---- initObjsFromUnmatched (EMFusion.cpp:446-494) ----
     for (int i : unmatched) {
-        if (assigned[i] >= 0) continue;  // it replaced an earlier match above: already in use
         for (const auto& obj : objects) {
             const int id = obj.getID();
             if (id > 255) continue;
@@ -657,8 +681,8 @@ std::map<int, emf_image_t> EMFusion::initOrMatchObjs(std::vector<emf_image_t>& s
         }
         const int id = initNewObjVolume(segs[i]);
         lastCreated.push_back(id);
-        matches[id] = segs[i];  // the reference inserts even id == -1; callers drop that key
-        assigned[i] = id;
+        matches.insert(std::make_pair(id, segs[i]));  // even id == -1 (EMFusion.cpp:491); callers drop that key
+        if (assigned[i] < 0) assigned[i] = id;        // a replacing mask keeps scoring its model (score_matches)
     }
     bool resized = false;
     for (auto& obj : objects) {  // EMFusion.cpp:358-369
@@ -711,6 +735,7 @@ Vec3f EMFusion::updateObject(int id, const emf_image_t& mask) {
     for (auto& obj : objects)
         if (obj.getID() == id) {
             synchronize();
+            refreshVisibleFromDevice();  // rebuildModelTable below uploads the gate from the host set
             const Vec3f offset = updateObj(obj, mask);
             if (poseLog) {  // several calls between two frames add up
                 Vec3f& logged = obj_pose_offsets[id][frameCount];
@@ -743,6 +768,9 @@ std::map<int, std::map<int, Affine3f>> EMFusion::addPoseOffsets(
 }
 
 void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989
+    // the slot of a deleted object is free again: EMF_MAX_MODELS bounds the LIVE models, not the
+    // number ever created (a long run spawns and cleans up spurious objects all the time)
+    allIds.erase(std::remove(allIds.begin(), allIds.end(), id), allIds.end());
     streams.erase(id);
     objImages.erase(id);
     vis_objs.erase(id);
@@ -780,8 +808,10 @@ std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_i
             deleted.push_back(id);
             synchronize();  // nothing in flight may still use the volume
             deleteObj(id);
-            if (poseLog && !(ignorePerson && isPerson(*it)))
+            if (poseLog && !(ignorePerson && isPerson(*it))) {
                 meshes[id] = it->getMesh();  // saveOutput: EMFusion.cpp:962-966
+                if (expVols) savedVolumes[id] = saveVolumes(*it);  // EMFusion.cpp:967-973
+            }
             it = objects.erase(it);
         } else {
             ++it;

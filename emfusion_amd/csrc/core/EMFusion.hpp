@@ -155,6 +155,21 @@ public:
      * <dir>/tsdfs/{bg_tsdf,tsdf_<id>,weights_<id>,fgProbs_<id>}.bin (writeTSDFs, EMFusion.cpp:1187-1218).
      */
     void enablePoseLog(bool on) { poseLog = on; }
+    /**
+     * Reference EMFusion::setupOutput (EMFusion.cpp:243-247): turns the log on (saveOutput) and
+     * chooses whether the volumes are exported too.  With exp_vols the volumes of objects deleted
+     * during the run are kept on the host like their mesh (EMFusion.cpp:966-973).  The per-frame
+     * mesh export of exp_frame_meshes belongs to the viz path and is not kept.
+     */
+    void setupOutput(bool expFrameMeshes, bool exp_vols) {
+        (void)expFrameMeshes;
+        poseLog = true;
+        expVols = exp_vols;
+    }
+    /**
+     * Reference EMFusion::writeResults (EMFusion.cpp:248-292): pose files and meshes always, the
+     * tsdfs/ dumps only with `volumes` (or setupOutput's exp_vols).
+     */
     void writeResults(const std::string& dir, bool volumes);
     /** Ids returned by initNewObjVolume for FrameInputs::newObjectMasks of the last frame (-1: none). */
     const std::vector<int>& lastCreatedObjects() const { return lastCreated; }
@@ -313,6 +328,14 @@ private:
     std::array<uint8_t, 768> colorMap = io::randomColors();
     DeviceImage<uint8_t, 3> image;  // rendering
     std::map<int, Mesh> meshes;                            // id -> last mesh (deleted objects keep theirs)
+    bool expVols = false;                                  // setupOutput: keep / dump volumes too
+    struct SavedVolumes {                                  // tsdfs / intWeights / fgProbs / meta of the reference
+        std::vector<float> tsdf, weights, fgProbs;
+        Vec3i res;
+        float voxelSize = 0.f;
+    };
+    static SavedVolumes saveVolumes(ObjTSDF& obj);
+    std::map<int, SavedVolumes> savedVolumes;              // id -> volumes of objects deleted while the log was on
     DeviceBuffer massDev;
     void deleteObj(int id);
     void ensureLifecycleBuffers();

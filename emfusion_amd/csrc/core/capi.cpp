@@ -321,6 +321,11 @@ int emf_fusion_enable_pose_log(emf_fusion_t* h, int on) {
     return guarded([&] { h->impl->enablePoseLog(on != 0); });
 }
 
+int emf_fusion_setup_output(emf_fusion_t* h, int exp_frame_meshes, int exp_vols) {
+    REQ(h);
+    return guarded([&] { h->impl->setupOutput(exp_frame_meshes != 0, exp_vols != 0); });
+}
+
 int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes) {
     REQ(h);
     REQ(dir);
@@ -350,6 +355,37 @@ int emf_io_write_pose_file(const char* filename, int n, const int32_t* frames, c
             poses[frames[i]] = Affine3f(m33(R + 9 * i), Vec3f(t[3 * i], t[3 * i + 1], t[3 * i + 2]));
         io::writePoseFile(filename, poses);
     });
+}
+
+int emf_io_png_unfilter(const uint8_t* rows, int height, int stride, int bpp, uint8_t* out) {
+    REQ(rows);
+    REQ(out);
+    if (height < 0 || stride <= 0 || (bpp != 1 && bpp != 2)) return EMF_E_ARG;
+    // PNG specification 9.2: each scan line is preceded by its filter type; Sub / Average / Paeth
+    // predict from the reconstructed byte bpp positions to the left (a), above (b), above-left (c)
+    const uint8_t* prev = nullptr;
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* in = rows + static_cast<size_t>(y) * (stride + 1);
+        uint8_t* cur = out + static_cast<size_t>(y) * stride;
+        const int f = in[0];
+        if (f > 4) return EMF_E_ARG;
+        for (int x = 0; x < stride; ++x) {
+            const int a = x >= bpp ? cur[x - bpp] : 0;
+            const int b = prev ? prev[x] : 0;
+            const int c = (prev && x >= bpp) ? prev[x - bpp] : 0;
+            int pred = 0;
+            if (f == 1) pred = a;
+            else if (f == 2) pred = b;
+            else if (f == 3) pred = (a + b) >> 1;
+            else if (f == 4) {
+                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            cur[x] = static_cast<uint8_t>(in[1 + x] + pred);
+        }
+        prev = cur;
+    }
+    return EMF_OK;
 }
 
 int emf_fusion_set_cleanup(emf_fusion_t* h, int on) {
@@ -569,6 +605,18 @@ int emf_fusion_visible_objects(emf_fusion_t* h, int32_t* ids, int cap, int* n) {
     REQ(n);
     int c = 0;
     for (int id : h->impl->visibleObjects()) {
+        if (c < cap && ids) ids[c] = id;
+        ++c;
+    }
+    *n = c < cap ? c : cap;
+    return EMF_OK;
+}
+
+int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n) {
+    REQ(h);
+    REQ(n);
+    int c = 0;
+    for (int id : h->impl->objectIds()) {
         if (c < cap && ids) ids[c] = id;
         ++c;
     }

@@ -99,7 +99,9 @@ def load() -> C.CDLL:
         "emf_fusion_set_preprocess": [vp, C.c_int],
         "emf_fusion_set_cleanup": [vp, C.c_int],
         "emf_fusion_enable_pose_log": [vp, C.c_int],
+        "emf_fusion_setup_output": [vp, C.c_int, C.c_int],
         "emf_fusion_write_results": [vp, C.c_char_p, C.c_int],
+        "emf_io_png_unfilter": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
         "emf_io_write_volume": [C.c_char_p, fp, ip, C.c_float],
         "emf_io_write_pose_file": [C.c_char_p, C.c_int, ip, fp, fp],
         "emf_fusion_last_deleted": [vp, ip, C.c_int, ip],
@@ -135,6 +137,7 @@ def load() -> C.CDLL:
         "emf_fusion_get_image": [vp, C.c_int, C.c_int, img],
         "emf_fusion_get_volume": [vp, C.c_int, C.c_int, C.POINTER(vp), ip],
         "emf_fusion_visible_objects": [vp, ip, C.c_int, C.POINTER(C.c_int)],
+        "emf_fusion_object_ids": [vp, ip, C.c_int, C.POINTER(C.c_int)],
         "emf_fusion_frame_index": [vp],
         "emf_fusion_owns_object": [vp, C.c_int],
         "emf_comm_unique_id": [vp],
@@ -443,8 +446,13 @@ class Fusion:
     def enable_pose_log(self, on=True):
         _check("emf_fusion_enable_pose_log", load().emf_fusion_enable_pose_log(self._h, int(on)))
 
+    def setup_output(self, exp_frame_meshes=False, exp_vols=False):
+        """Reference EMFusion::setupOutput: log on; exp_vols keeps deleted objects' volumes too."""
+        _check("emf_fusion_setup_output",
+               load().emf_fusion_setup_output(self._h, int(exp_frame_meshes), int(exp_vols)))
+
     def write_results(self, directory: str, volumes: bool = True):
-        """poses-cam.txt, poses-<id>.txt and tsdfs/*.bin in the reference's formats."""
+        """poses-*.txt, mesh_bg.ply, mesh_<id>.ply always; tsdfs/*.bin with `volumes` (reference formats)."""
         _check("emf_fusion_write_results",
                load().emf_fusion_write_results(self._h, os.fspath(directory).encode(), int(volumes)))
 
@@ -554,6 +562,13 @@ class Fusion:
         out = np.empty((res[2], res[1], res[0]), dt)
         devmem.memcpy_d2h(out, ptr.value)
         return out
+
+    def object_ids(self):
+        """Live objects of the job in creation order."""
+        ids = (C.c_int32 * 256)()
+        n = C.c_int()
+        _check("emf_fusion_object_ids", load().emf_fusion_object_ids(self._h, ids, 256, C.byref(n)))
+        return [ids[i] for i in range(n.value)]
 
     def visible_objects(self):
         ids = (C.c_int32 * 256)()

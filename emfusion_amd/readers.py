@@ -45,44 +45,90 @@ def read_png_gray(path) -> np.ndarray:
     bpp = depth // 8
     stride = w * bpp
     data = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, stride + 1)
+    out = _unfilter(np.ascontiguousarray(data), h, stride, bpp, path)
+    if bpp == 1:
+        return out
+    return out.reshape(h, w, 2).astype(np.uint16) @ np.array([256, 1], np.uint16)  # big endian
+
+
+def _unfilter(data: np.ndarray, h: int, stride: int, bpp: int, path) -> np.ndarray:
+    """Undo the scan-line filters.  libpng writes adaptive filters (Sub / Average / Paeth on most rows
+    of a TUM depth image), whose recurrence runs along x: the host library does it in C
+    (emf_io_png_unfilter); without the library, numpy handles None / Sub / Up per row and only
+    Average / Paeth rows fall back to a Python loop."""
+    if (data[:, 0] > 4).any():
+        raise ValueError(f"{path}: bad filter type {int(data[:, 0].max())}")
     out = np.zeros((h, stride), np.uint8)
+    try:
+        from . import pipeline
+        lib = pipeline.load()
+    except (RuntimeError, OSError):
+        lib = None
+    if lib is not None:
+        rc = lib.emf_io_png_unfilter(data.ctypes.data, h, stride, bpp, out.ctypes.data)
+        if rc != 0:
+            raise ValueError(f"{path}: emf_io_png_unfilter failed ({rc})")
+        return out
     prev = np.zeros(stride, np.int32)
     for y in range(h):
         f, line = int(data[y, 0]), data[y, 1:].astype(np.int32)
         if f == 0:
             cur = line
+        elif f == 1:  # Sub: running sum mod 256 per byte lane
+            cur = np.empty(stride, np.int32)
+            for c in range(bpp):
+                cur[c::bpp] = np.cumsum(line[c::bpp]) & 255
         elif f == 2:  # Up
             cur = (line + prev) & 255
-        elif f in (1, 3, 4):  # Sub, Average, Paeth: sequential in x
+        else:  # Average, Paeth: sequential in x
             cur = np.zeros(stride, np.int32)
             for x in range(stride):
                 a = cur[x - bpp] if x >= bpp else 0
                 b = prev[x]
                 c = prev[x - bpp] if x >= bpp else 0
-                if f == 1:
-                    pred = a
-                elif f == 3:
+                if f == 3:
                     pred = (a + b) >> 1
                 else:
                     p = a + b - c
                     pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
                     pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
                 cur[x] = (line[x] + pred) & 255
-        else:
-            raise ValueError(f"{path}: bad filter type {f}")
         out[y] = cur
         prev = cur
-    if bpp == 1:
-        return out
-    return out.reshape(h, w, 2).astype(np.uint16) @ np.array([256, 1], np.uint16)  # big endian
+    return out
 
 
-def write_png_gray16(path, image: np.ndarray) -> None:
-    """Minimal writer (filter 0) -- used by the tests and to stage synthetic sequences."""
+def write_png_gray16(path, image: np.ndarray, filters=None) -> None:
+    """Minimal writer -- used by the tests and to stage synthetic sequences.  filters: None (type 0
+    everywhere) or one filter type 0..4 per row (adaptive filtering as libpng writes it)."""
     img = np.ascontiguousarray(image, np.uint16)
     h, w = img.shape
     rows = np.zeros((h, 1 + 2 * w), np.uint8)
     rows[:, 1::2], rows[:, 2::2] = (img >> 8).astype(np.uint8), (img & 255).astype(np.uint8)
+    if filters is not None:
+        raw = rows[:, 1:].astype(np.int32)
+        enc = np.zeros_like(raw)
+        zero = np.zeros(2 * w, np.int32)
+        for y in range(h):
+            f = int(filters[y])
+            a = np.concatenate([zero[:2], raw[y, :-2]])
+            b = raw[y - 1] if y else zero
+            c = np.concatenate([zero[:2], b[:-2]])
+            if f == 0:
+                pred = zero
+            elif f == 1:
+                pred = a
+            elif f == 2:
+                pred = b
+            elif f == 3:
+                pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+            enc[y] = (raw[y] - pred) & 255
+            rows[y, 0] = f
+        rows[:, 1:] = enc.astype(np.uint8)
 
     def chunk(kind, body):
         return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))

@@ -143,10 +143,19 @@ int emf_fusion_render(emf_fusion_t* h, uint8_t* rgb, uint8_t* color_map);
  * before anything else runs.  root < 0 (default): every rank is handed the frame itself. */
 int emf_fusion_set_depth_broadcast(emf_fusion_t* h, int root);
 int emf_fusion_enable_pose_log(emf_fusion_t* h, int on);
+/* EMFusion::setupOutput (EMFusion.cpp:243-247): log on; exp_vols != 0 also keeps the volumes of
+ * objects deleted during the run for write_results.  exp_frame_meshes is accepted and ignored. */
+int emf_fusion_setup_output(emf_fusion_t* h, int exp_frame_meshes, int exp_vols);
+/* EMFusion::writeResults (EMFusion.cpp:248-292): pose files, mesh_bg.ply and mesh_<id>.ply always;
+ * tsdfs/ *.bin only if volumes != 0 or setup_output asked for them. */
 int emf_fusion_write_results(emf_fusion_t* h, const char* dir, int volumes);
 int emf_io_write_volume(const char* filename, const float* voxels, const int32_t res[3], float voxel_size);
 int emf_io_write_pose_file(const char* filename, int n, const int32_t* frames, const float* R,
                            const float* t);
+/* Undo the PNG scan-line filters (PNG specification 9.2; what cv::imread does inside
+ * TUMRGBDReader.cpp for the depth images): rows = height x (1 + stride) bytes, each line preceded by
+ * its filter type 0..4; out = height x stride reconstructed bytes; bpp = bytes per pixel (1 or 2). */
+int emf_io_png_unfilter(const uint8_t* rows, int height, int stride, int bpp, uint8_t* out);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);
@@ -192,6 +201,8 @@ int emf_fusion_get_image(emf_fusion_t* h, int which, int obj_id, emf_image_t* vi
 int emf_fusion_get_volume(emf_fusion_t* h, int which, int obj_id, void** dev_ptr, int32_t res[3]);
 /* ids of the objects classified visible by the last raycast; returns count in *n (<= cap) */
 int emf_fusion_visible_objects(emf_fusion_t* h, int32_t* ids, int cap, int* n);
+/* ids of all live objects of the job in creation order (deleted ones are gone); count in *n (<= cap) */
+int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n);
 int emf_fusion_frame_index(emf_fusion_t* h);
 /* 1 if this rank holds object id's volume */
 int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);

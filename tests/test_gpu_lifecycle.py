@@ -167,8 +167,12 @@ def test_mask_association_mass(ops, dev):
         assert abs(total - float(assoc[inside].astype(np.float64).sum())) < 1e-9 * n
 
 
-def test_invisible_objects_are_cleaned_up(oracle, dev):
-    """cleanUpObjs: an object that the raycast no longer sees is deleted (EMFusion.cpp:951-976)."""
+@pytest.mark.parametrize("exp_vols", [False, True])
+def test_invisible_objects_are_cleaned_up(oracle, dev, tmp_path, exp_vols):
+    """cleanUpObjs: an object that the raycast no longer sees is deleted (EMFusion.cpp:951-976).  With
+    the log on its last mesh is kept, and with setupOutput's exp_vols its volumes too (EMFusion.cpp:
+    962-973); writeResults writes the meshes in either case and tsdfs/ only with exp_vols
+    (EMFusion.cpp:273-291)."""
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
     Wf, Hf = 320, 240
@@ -176,6 +180,8 @@ def test_invisible_objects_are_cleaned_up(oracle, dev):
     synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 2, seed=0xE3F5)
     fus = pipeline.Fusion(prm, None)
     fus.set_cleanup(True)
+    fus.setup_output(False, exp_vols)
+    last_tsdf2 = None
     centers, keep = {}, []
     for f in range(5):
         depth, sid = synth.render(f)
@@ -190,6 +196,8 @@ def test_invisible_objects_are_cleaned_up(oracle, dev):
             new = [to_dev((sid == k).astype(np.uint8)) for k in (1, 2)]
             keep.append(new)
             fus.queue_new_object_masks([image_view(m) for m in new])
+        if f == 3:
+            last_tsdf2 = fus.volume("tsdf", 2)
         fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, True)
         fus.synchronize()
         if f == 0:
@@ -202,6 +210,49 @@ def test_invisible_objects_are_cleaned_up(oracle, dev):
             del centers[2]
         else:
             assert fus.last_deleted() == [] and sorted(fus.visible_objects()) == [1]
+    fus.write_results(tmp_path, volumes=False)
+    for name in ("poses-cam.txt", "poses-1.txt", "poses-2.txt", "mesh_bg.ply", "mesh_1.ply", "mesh_2.ply"):
+        assert (tmp_path / name).stat().st_size > 0, name
+    if exp_vols:
+        import struct
+        names = sorted(p.name for p in (tmp_path / "tsdfs").iterdir())
+        assert names == sorted(["bg_tsdf.bin"] + [f"{k}_{i}.bin" for k in ("tsdf", "weights", "fgProbs") for i in (1, 2)])
+        raw = (tmp_path / "tsdfs" / "tsdf_2.bin").read_bytes()
+        assert struct.unpack_from("<3i", raw, 0) == (32, 32, 32)
+        # the deleted object's volume as it was when cleanUpObjs dropped it: frame 3 integrated nothing
+        # into it (invisible), so it is the volume read back before that frame
+        assert np.array_equal(np.frombuffer(raw, np.float32, offset=24).reshape(32, 32, 32), last_tsdf2)
+    else:
+        assert not (tmp_path / "tsdfs").exists()
+    fus.close()
+    synth.close()
+
+
+def test_model_table_slots_are_reused_after_clean_up(oracle, dev):
+    """EMF_MAX_MODELS bounds the LIVE objects, not the number ever created: a long run that keeps
+    spawning spurious objects and cleaning them up (the normal flow on TUM walking sequences) goes
+    past 255 creations without trouble."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    Wf, Hf = 80, 60
+    prm = pipeline.make_params(Wf, Hf, 32, 0.08, 8, visibility_thresh=50, boundary=2)
+    synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 1, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    fus.set_cleanup(True)
+    depth, _ = synth.render(0)
+    R, t = synth.camera_pose(0)
+    d = to_dev(depth)
+    eye = np.eye(3, dtype=np.float32).reshape(-1)
+    behind = np.array([0, 0, -30], np.float32)
+    created = 0
+    for f in range(270):
+        oid = fus.add_object(behind, 0.5)  # never visible: cleaned up at the end of the frame
+        created += 1
+        fus.process_frame(image_view(d), R, t, {oid: (eye, behind)}, {}, False)
+        fus.synchronize()
+        # frame 0 has no raycast (EMFusion.cpp:78-95), so its object lives one frame longer
+        assert fus.last_deleted() == ([] if f == 0 else [1, 2] if f == 1 else [oid]), f
+    assert created == 270 and fus.object_ids() == []
     fus.close()
     synth.close()
 
@@ -222,7 +273,10 @@ def test_carve_mask(ops, dev):
 
 def test_instance_masks_run_the_reference_control_flow(oracle, dev):
     """initOrMatchObjs inside the frame: spawn on frame 0, match afterwards, a second mask on the
-    same model goes through the unmatched path, is carved to (almost) nothing and spawns nothing."""
+    same model goes through the unmatched path, is carved to (almost) nothing and spawns nothing.
+    Frame 3 pins quirk Q20 (EMFusion.cpp:424-437, 462-478): a second mask that matches BETTER replaces
+    the first in matches[] but still continues as unmatched; matches[id] being a shallow copy of it, it
+    is carved against itself, so the model ends up matched to an all-zero mask."""
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
     Wf, Hf = 320, 240
@@ -240,6 +294,12 @@ def test_instance_masks_run_the_reference_control_flow(oracle, dev):
             dup = (sid == 1).astype(np.uint8)
             dup[:, : Wf // 2 - 10] = 0
             inst.append(to_dev(dup))
+        if f == 3:  # ... and once more with the worse mask first: the full one replaces it
+            full = (sid == 1).astype(np.uint8)
+            rows = np.flatnonzero(full.any(axis=1))
+            worse = full.copy()
+            worse[: rows[0] + len(rows) // 4] = 0  # top quarter missing: IoU ~ 0.8 < IoU of the full mask
+            inst = [to_dev(worse), inst[1], to_dev(full)]
         keep += [d, inst]
         fus.queue_instance_masks([image_view(m) for m in inst])
         poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), c) for i, c in centers.items()}
@@ -252,6 +312,10 @@ def test_instance_masks_run_the_reference_control_flow(oracle, dev):
         elif f == 2:
             assert a[:2] == [1, 2] and a[2] == -1 and fus.last_created() == [-1]
             assert inst[2].numpy().sum() < 0.5 * ((sid == 1).sum())  # carved in place
+        elif f == 3:
+            assert a == [-1, 2, 1] and fus.last_created() == [-1], (a, fus.last_created())
+            assert inst[2].numpy().sum() == 0           # carved against its own alias
+            assert inst[0].numpy().sum() == worse.sum()  # the replaced mask is simply dropped
         else:
             assert a == [1, 2] and fus.last_created() == []
         assert fus.last_deleted() == []

@@ -59,6 +59,31 @@ def test_png16_roundtrip_all_filters(tmp_path):
         readers.read_png_gray(tmp_path / "bad.png")
 
 
+def test_png16_full_frame_with_adaptive_filters_is_fast_and_both_decoders_agree(tmp_path, monkeypatch):
+    """A 640 x 480 TUM-sized depth image whose rows use Sub / Average / Paeth (what libpng writes):
+    the C unfilter of the host library decodes it in milliseconds; the numpy / Python path used
+    when the library is missing gives the same pixels."""
+    import time
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = (5000 * (1.5 + 0.001 * xx + 0.0005 * yy) + rng.integers(0, 30, (480, 640))).astype(np.uint16)
+    img[rng.uniform(size=img.shape) < 0.02] = 0
+    readers.write_png_gray16(tmp_path / "d.png", img, filters=rng.choice([1, 3, 4, 2, 0], 480))
+    t0 = time.time()
+    got = readers.read_png_gray(tmp_path / "d.png")
+    dt = time.time() - t0
+    assert np.array_equal(got, img)
+    assert dt < 0.5, dt
+    small = img[:12, :40]
+    readers.write_png_gray16(tmp_path / "s.png", small, filters=[1, 3, 4, 2, 0, 4, 3, 1, 4, 4, 3, 3])
+    from emfusion_amd import pipeline
+
+    def missing():
+        raise RuntimeError("no library")
+    monkeypatch.setattr(pipeline, "load", missing)
+    assert np.array_equal(readers.read_png_gray(tmp_path / "s.png"), small)
+
+
 @pytest.mark.parametrize("rgb_first", [True, False])
 def test_tum_sequence(tmp_path, rgb_first):
     (tmp_path / "depth").mkdir()
