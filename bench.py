@@ -209,7 +209,7 @@ def main():
     if not args.no_kernel_events:
         fus.kernel_timers_enable(launches_per_frame * args.steps + 64)
         if not args.all_kernel_events:
-            fus.kernel_timers_select(["raycast", "integrate", "track"])
+            fus.kernel_timers_select(["raycast", "integrate", "integrate_bg", "track"])
     fus.enable_raycast_stats(True)
     if args.track:
         fus.set_tracking(camera=True, objects=True)
@@ -312,6 +312,7 @@ def main():
 # kernel kind -> (HIP kernel symbol for the rocprof cross-check, per-unit algorithmic bytes note)
 KERNEL_NAMES = {
     "integrate": "k_integrate_cull + k_integrate_listed",
+    "integrate_bg": "k_integrate_cull + k_integrate_listed<out of place> (background, beside k_raycast)",
     "raycast": "k_raycast",
     "assoc": "k_assoc",
     "normalize": "k_assoc_normalize",
@@ -327,7 +328,7 @@ def algorithmic_bytes(kind, summ, stats, P):
     """Algorithmic bytes summed over all launches of one kernel kind -- SURVEY.md section 8(d),
     restated in DESIGN.md "Byte model".  `units` = voxels (sweeps) or pixels (image kernels)."""
     u, n = summ["units"], max(summ["launches"], 1)
-    if kind == "integrate":   # B_int: read tsdf + weight, write tsdf + weight per voxel
+    if kind in ("integrate", "integrate_bg"):   # B_int: read tsdf + weight, write tsdf + weight per voxel
         return 16.0 * u
     if kind == "grads":       # B_grad: 4 B read + 12 B written per voxel
         return 16.0 * u

@@ -86,6 +86,9 @@ SIGNATURES = {
     "emf_hip_integrateCullScratchBytes": [_I3, C.c_int],
     "emf_hip_integrateBatchedCulled": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, C.c_uint32, _FP, _FP,
                                        _STREAM],
+    "emf_hip_integrateDirtyMapBytes": [_I3],
+    "emf_hip_integrateBatchedCulledOut": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_void_p, _FP, C.c_uint32,
+                                          _FP, _FP, _STREAM],
     "emf_hip_visibilityFlags": [_FP, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_resetBrickFlags": [_FP, _I3, _STREAM],
     "emf_hip_packHitKeys": [C.c_int, _I3, _IMG, _IMG, _FP, C.c_int, C.c_int, _STREAM],
@@ -94,6 +97,11 @@ SIGNATURES = {
                                   _STREAM],
     "emf_hip_visibilityFlagsIndexed": [_FP, C.c_int, _I3, C.c_int, _FP, _STREAM],
 }
+
+
+class EmfVolumeOut(C.Structure):
+    """Mirror of emf_volume_out_t (second copy of a double-buffered volume + its dirty maps)."""
+    _fields_ = [("tsdf", C.c_void_p), ("weights", C.c_void_p), ("dirtyPrev", C.c_void_p), ("dirtyNext", C.c_void_p)]
 
 
 class EmfModel(C.Structure):
@@ -165,6 +173,7 @@ def load() -> C.CDLL:
     lib.emf_hip_pointStatsScratchBytes.restype = C.c_size_t
     lib.emf_hip_meshScratchBytes.restype = C.c_size_t
     lib.emf_hip_integrateCullScratchBytes.restype = C.c_size_t
+    lib.emf_hip_integrateDirtyMapBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

@@ -345,12 +345,32 @@ __global__ __launch_bounds__(256) void k_integrate_batched_linear(const Integrat
 constexpr int kBoxX = EMF_INT_BOX_X * kTileX, kBoxY = EMF_INT_BOX_Y * kTileY, kBoxZ = EMF_INT_BOX_Z * kTileZ;
 constexpr unsigned kBoxTiles = EMF_INT_BOX_X * EMF_INT_BOX_Y * EMF_INT_BOX_Z;
 
+// Out-of-place integration (emf_hip_integrateBatchedCulledOut): per model the second copy of the
+// volume that receives the result, and one byte per 32 x 8 x 8 tile saying whether the two copies
+// differ there (`dirtyPrev`: left by the previous call, `dirtyNext`: written by this one).
+struct IntegrateOutTable {
+    float* tsdf[EMF_MAX_BATCH];
+    float* weights[EMF_MAX_BATCH];
+    const uint8_t* dirtyPrev[EMF_MAX_BATCH];
+    uint8_t* dirtyNext[EMF_MAX_BATCH];
+};
+
 struct IntegrateCullArgs {
     IntegrateBatchArgs b;
     int boxStart[EMF_MAX_BATCH + 1];  // prefix sum of boxes per model (0 boxes for untiled models)
     unsigned* list;                    // entries: model << 24 | box index within the model
     unsigned* count;                   // survivors appended so far (zeroed by the caller's memset)
+    IntegrateOutTable out;             // second copies (haveOut != 0), by value like the poses
+    int haveOut;
 };
+
+__device__ __forceinline__ size_t tile_count(const I3& n) {
+    return static_cast<size_t>((n.x + kTileX - 1) / kTileX) * ((n.y + kTileY - 1) / kTileY) * ((n.z + kTileZ - 1) / kTileZ);
+}
+__device__ __forceinline__ size_t tile_index(const I3& n, int x0, int y0, int z0) {
+    const int ntx = (n.x + kTileX - 1) / kTileX, nty = (n.y + kTileY - 1) / kTileY;
+    return (static_cast<size_t>(z0 / kTileZ) * nty + y0 / kTileY) * ntx + x0 / kTileX;
+}
 
 __device__ __forceinline__ IntegrateGeom geom_of(const IntegrateBatchArgs& a, int m) {
     const emf_model_t& md = a.models[m];
@@ -378,10 +398,12 @@ __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs 
     if (i < a.boxStart[a.b.nmodels]) {
         int m = 0;
         while (m + 1 < a.b.nmodels && i >= a.boxStart[m + 1]) ++m;
-        if (!a.b.visible || a.b.visible[m] != 0) {
+        const bool open = !a.b.visible || a.b.visible[m] != 0;  // the gate of EMFusion.cpp:869-872
+        if (open || a.haveOut) {
             const IntegrateGeom g = geom_of(a.b, m);
             const int box = i - a.boxStart[m];
-            if (a.b.stats && box == 0) atomicAdd(a.b.stats, static_cast<unsigned long long>(g.n.x) * g.n.y * g.n.z);
+            if (open && a.b.stats && box == 0)
+                atomicAdd(a.b.stats, static_cast<unsigned long long>(g.n.x) * g.n.y * g.n.z);
             const int nbx = (g.n.x + kBoxX - 1) / kBoxX, nby = (g.n.y + kBoxY - 1) / kBoxY;
             const int bx = box % nbx, by = (box / nbx) % nby, bz = box / (nbx * nby);
             const int x0 = bx * kBoxX, y0 = by * kBoxY, z0 = bz * kBoxZ;
@@ -400,7 +422,21 @@ __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs 
                 up = up && v < -1.5f;
                 down = down && v > static_cast<float>(g.h) + 0.5f;
             }
-            keep = !(front && (left || right || up || down));
+            keep = open && !(front && (left || right || up || down));
+            if (!keep && a.haveOut) {
+                // out of place: a box outside the view cone still gets its workgroups if the previous
+                // integration changed one of its tiles -- the other copy has to catch up there
+                const uint8_t* dirty = a.out.dirtyPrev[m];
+                for (unsigned sub = 0; sub < kBoxTiles; ++sub) {
+                    const int tx0 = x0 + static_cast<int>(sub % EMF_INT_BOX_X) * kTileX,
+                              ty0 = y0 + static_cast<int>((sub / EMF_INT_BOX_X) % EMF_INT_BOX_Y) * kTileY,
+                              tz0 = z0 + static_cast<int>(sub / (EMF_INT_BOX_X * EMF_INT_BOX_Y)) * kTileZ;
+                    if (tx0 < g.n.x && ty0 < g.n.y && tz0 < g.n.z) {
+                        const size_t t = tile_index(g.n, tx0, ty0, tz0);
+                        keep = keep || (dirty[t] | dirty[tile_count(g.n) + t]) != 0;
+                    }
+                }
+            }
             entry = (static_cast<unsigned>(m) << 24) | static_cast<unsigned>(box);
         }
     }
@@ -415,6 +451,7 @@ __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs 
 }
 
 // tile `sub` (0..7) of list entry e
+template <bool OUT>
 __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a, unsigned e, unsigned sub,
                                                       unsigned* lds) {
     const unsigned entry = a.list[e];
@@ -427,25 +464,37 @@ __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a
               dz = static_cast<int>(sub / (EMF_INT_BOX_X * EMF_INT_BOX_Y));
     const int x0 = (EMF_INT_BOX_X * bx + dx) * kTileX, y0 = (EMF_INT_BOX_Y * by + dy) * kTileY,
               z0 = (EMF_INT_BOX_Z * bz + dz) * kTileZ;
-    if (x0 < g.n.x && y0 < g.n.y && z0 < g.n.z)  // block-uniform
-        integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds);
+    if (x0 < g.n.x && y0 < g.n.y && z0 < g.n.z) {  // block-uniform
+        if constexpr (OUT) {
+            const size_t t = tile_index(g.n, x0, y0, z0), nt = tile_count(g.n);
+            const uint8_t* dp = a.out.dirtyPrev[m];
+            const int force = (dp[t] ? 1 : 0) | (dp[nt + t] ? 2 : 0);
+            integrate_tile<true>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
+                                 a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
+                                 a.b.visible && a.b.visible[m] == 0);
+        } else {
+            integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds);
+        }
+    }
 }
 
 // one workgroup per (entry, tile): entries [0, min(count, grid / 8))
+template <bool OUT>
 __attribute__((amdgpu_waves_per_eu(EMF_INT_WPE, EMF_INT_WPE)))
 __global__ __launch_bounds__(256) void k_integrate_listed(const IntegrateCullArgs a) {
     __shared__ unsigned lds[32];
     const unsigned e = blockIdx.x / kBoxTiles;
     if (e >= *a.count) return;
-    integrate_listed_tile(a, e, blockIdx.x % kBoxTiles, lds);
+    integrate_listed_tile<OUT>(a, e, blockIdx.x % kBoxTiles, lds);
 }
 
 // the entries a too-small grid left over: a few workgroups stride over [first, count)
+template <bool OUT>
 __global__ __launch_bounds__(256) void k_integrate_listed_rest(const IntegrateCullArgs a, unsigned first) {
     __shared__ unsigned lds[32];
     const unsigned todo = *a.count;
     for (unsigned e = first + blockIdx.x / kBoxTiles; e < todo; e += gridDim.x / kBoxTiles) {
-        integrate_listed_tile(a, e, blockIdx.x % kBoxTiles, lds);
+        integrate_listed_tile<OUT>(a, e, blockIdx.x % kBoxTiles, lds);
         __syncthreads();
     }
 }
@@ -656,11 +705,28 @@ size_t emf_hip_integrateCullScratchBytes(const int32_t* res_host, int nmodels) {
     return (boxes + 4) * sizeof(unsigned);
 }
 
+size_t emf_hip_integrateDirtyMapBytes(const int32_t res[3]) {
+    if (!res || res[0] < 1 || res[1] < 1 || res[2] < 1) return 0;
+    // one byte per tile for the tsdf array, then one per tile for the weights
+    return 2 * static_cast<size_t>(ceil_div(res[0], kTileX)) * ceil_div(res[1], kTileY) * ceil_div(res[2], kTileZ);
+}
+
 int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                                    const int32_t* res_host, int nmodels, const int32_t* visible_dev,
                                    const emf_image_t* depth, const emf_image_t* invLambda,
                                    const float K[9], void* scratch_dev, uint32_t launchBoxes,
                                    uint32_t* survivors_out_dev, uint64_t* stats, emf_stream_t stream) {
+    return emf_hip_integrateBatchedCulledOut(models_dev, poseOC_host, res_host, nmodels, visible_dev, depth,
+                                             invLambda, K, nullptr, scratch_dev, launchBoxes, survivors_out_dev,
+                                             stats, stream);
+}
+
+int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                                      const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                                      const emf_image_t* depth, const emf_image_t* invLambda,
+                                      const float K[9], const emf_volume_out_t* out_host, void* scratch_dev,
+                                      uint32_t launchBoxes, uint32_t* survivors_out_dev, uint64_t* stats,
+                                      emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseOC_host, nmodels, "integrateBatchedCulled"));
     EMF_REQUIRE_PTR(res_host);
     EMF_REQUIRE_PTR(scratch_dev);
@@ -696,17 +762,44 @@ int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose
     a.b.pinhole = is_pinhole(a.b.K);
     a.count = static_cast<unsigned*>(scratch_dev);
     a.list = a.count + 4;
+    a.out = IntegrateOutTable{};
+    a.haveOut = out_host ? 1 : 0;
     const unsigned total = static_cast<unsigned>(a.boxStart[nmodels]);
     const hipError_t e = hipMemsetAsync(a.count, 0, sizeof(unsigned), as_stream(stream));
     if (e != hipSuccess) {
         set_error("integrateBatchedCulled: memset: %s", hipGetErrorString(e));
         return static_cast<int>(e);
     }
+    if (out_host) {
+        // the next-dirty maps start out clean
+        for (int m = 0; m < nmodels; ++m) {
+            const emf_volume_out_t& o = out_host[m];
+            if (!o.tsdf || !o.weights || !o.dirtyPrev || !o.dirtyNext)
+                return fail(EMF_E_NULL, "integrateBatchedCulledOut: model %d: tsdf / weights / dirtyPrev / dirtyNext "
+                            "of the second copy are all required", m);
+            a.out.tsdf[m] = o.tsdf;
+            a.out.weights[m] = o.weights;
+            a.out.dirtyPrev[m] = o.dirtyPrev;
+            a.out.dirtyNext[m] = o.dirtyNext;
+            const hipError_t c = hipMemsetAsync(o.dirtyNext, 0, emf_hip_integrateDirtyMapBytes(res_host + 3 * m),
+                                                as_stream(stream));
+            if (c != hipSuccess) {
+                set_error("integrateBatchedCulledOut: memset: %s", hipGetErrorString(c));
+                return static_cast<int>(c);
+            }
+        }
+    }
     hipLaunchKernelGGL(k_integrate_cull, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), a);
     const unsigned boxes = launchBoxes == 0 || launchBoxes > total ? total : launchBoxes;
-    hipLaunchKernelGGL(k_integrate_listed, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
-    if (boxes < total)  // an estimate: whatever it missed is swept by a small strided grid
-        hipLaunchKernelGGL(k_integrate_listed_rest, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+    if (out_host) {
+        hipLaunchKernelGGL(k_integrate_listed<true>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
+        if (boxes < total)
+            hipLaunchKernelGGL(k_integrate_listed_rest<true>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+    } else {
+        hipLaunchKernelGGL(k_integrate_listed<false>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
+        if (boxes < total)  // an estimate: whatever it missed is swept by a small strided grid
+            hipLaunchKernelGGL(k_integrate_listed_rest<false>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+    }
     if (survivors_out_dev) {
         const hipError_t c = hipMemcpyAsync(survivors_out_dev, a.count, sizeof(unsigned), hipMemcpyDeviceToDevice,
                                             as_stream(stream));

@@ -62,7 +62,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
       occludedMask(_params.frameSize),
       visCounts(sizeof(int32_t) * EMF_MAX_MODELS),
       raycastStatsDev(4 * sizeof(uint64_t)),
-      modelTable(sizeof(emf_model_t) * EMF_MAX_BATCH),
+      modelTable(2 * sizeof(emf_model_t) * EMF_MAX_BATCH),
       visibleDev(sizeof(int32_t) * EMF_MAX_MODELS),
       integrateStatsDev(sizeof(uint64_t)) {
     if (comm) {
@@ -81,6 +81,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     cullBoxes = !(ic && ic[0] == '0');
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
+    // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
+    const char* bo = std::getenv("EMF_BG_OVERLAP");
+    bgOverlap = !(bo && bo[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -146,6 +149,8 @@ void EMFusion::reset() {
         it = it->first == 0 ? std::next(it) : streams.erase(it);
     frameCount = 0;
     nextId = 1;
+    bgInFlight = false;
+    bgBackStale = false;
     Stream& s = Stream::Null();
     bg_associationWeights.setTo(1.f, s);
     diffRaylengths.setZero(s);
@@ -261,10 +266,26 @@ void EMFusion::rebuildModelTable() {
             resHost.data(), static_cast<int>(modelsHost.size())));
     batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly &&
               static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
+    if (bgInFlight) aux.waitForCompletion();  // it reads slot 0 of the table uploaded below
+    if (batched && !integrateCullScratch.empty() && bgOverlap && bgCullScratch.empty()) {
+        // the background gets its second copy the first time the two-level launch is usable
+        background.enableDoubleBuffer();
+        bgCullScratch = DeviceBuffer(emf_hip_integrateCullScratchBytes(resHost.data(), 1));
+    }
+    tableSel = 0;
     if (batched) {
         hipCheck(hipMemcpy(modelTable.data(), modelsHost.data(),
                            modelsHost.size() * sizeof(emf_model_t), hipMemcpyHostToDevice),
                  "model table upload");
+        if (background.doubleBuffered()) {
+            std::vector<emf_model_t> alt = modelsHost;
+            const emf_volume_out_t back = background.backBuffers();
+            alt[0].tsdf = back.tsdf;
+            alt[0].weights = back.weights;
+            hipCheck(hipMemcpy(modelTable.as<emf_model_t>() + EMF_MAX_BATCH, alt.data(),
+                               alt.size() * sizeof(emf_model_t), hipMemcpyHostToDevice),
+                     "model table upload");
+        }
         // device gate: keep what the last raycast decided, new slots start visible
         std::vector<int32_t> vis(modelsHost.size(), 0);
         vis[0] = 1;
@@ -400,6 +421,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         else applyObjectPoses();
         computeAssociationWeights();
         stamp(kEstep);
+        integrateBackgroundAsync();  // runs beside the raycast (see there)
         raycast();
     } else {
         pose = in.cam_pose;
@@ -431,6 +453,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         for (const auto& obj : objects) obj_poses[obj.getID()][frameCount] = obj.getPose();
     }
 
+    integrateBackgroundAsync();  // frame 0 (no raycast): same path, nothing to overlap with
     integrateDepth();
     stamp(kIntegrate);
 
@@ -888,7 +911,7 @@ void EMFusion::trackModels(int first, int count) {
         const int chunk = trackChunk > 0 ? trackChunk : params.maxTrackingIter;
         for (int done = 0; done < params.maxTrackingIter;) {
             const int n = std::min(chunk, params.maxTrackingIter - done);
-            emfCheck(emf_hip_trackIterate(modelTable.as<emf_model_t>() + first, states, count, &pv,
+            emfCheck(emf_hip_trackIterate(currentTable() + first, states, count, &pv,
                                           &tp, static_cast<char*>(trackScratch.data()) + per * first,
                                           per, n, main.abi()),
                      "trackIterate");
@@ -1007,7 +1030,7 @@ void EMFusion::estepBatched() {
     posesCO(co);
     const int n = static_cast<int>(co.size());
     const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
-    const emf_model_t* table = modelTable.as<emf_model_t>();
+    const emf_model_t* table = currentTable();
     if (!sharded) {
         auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
         emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 1, &nv, nullptr, main.abi()),
@@ -1038,7 +1061,7 @@ void EMFusion::raycastBatched() {
     uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
     {
         auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
-        const emf_model_t* table = modelTable.as<emf_model_t>();
+        const emf_model_t* table = currentTable();
         const int w = params.frameSize.width, h = params.frameSize.height;
         const int flags = TSDF::brickFlagMode() != 0;
         // One grid for all models.  (Measured alternative: the objects' grid on a second stream so
@@ -1062,30 +1085,76 @@ void EMFusion::raycastBatched() {
     compositeAndVisibility(true);
 }
 
+bool EMFusion::overlapUsable() const {
+    return batched && bgOverlap && background.doubleBuffered() && !bgCullScratch.empty();
+}
+
+// Fork: the background's integration of this frame needs the pose, the depth map and the background
+// association weights of the last E-step -- all known BEFORE the raycast -- and nothing the raycast
+// produces (only object volumes are gated by its visibility counts, EMFusion.cpp:869-872).  With the
+// background kept twice it runs out of place on `aux` while `main` ray-marches the front copy: the
+// raycast is a latency chain of its longest rays that leaves most of the chip idle, the integration
+// is a streaming sweep that fills it.  Same values as the reference's raycast -> integrate sequence.
+void EMFusion::integrateBackgroundAsync() {
+    if (!overlapUsable() || bgInFlight) return;
+    if (bgBackStale) {  // an in-place integration (other path) in between: re-equalise the copies
+        synchronize();
+        background.resyncBack();
+        bgBackStale = false;
+    }
+    aux.waitFor(main);
+    const emf_pose_t oc = toPose(pose.inv() * background.getPose());  // reference TSDF.cpp:112
+    const double vox = static_cast<double>(resHost[0]) * resHost[1] * resHost[2];
+    auto kt = ktimers.scope(KernelTimers::IntegrateBg, vox, aux);
+    const emf_image_t il = invLambda.view();
+    const emf_volume_out_t out = background.backBuffers();
+    emfCheck(emf_hip_integrateBatchedCulledOut(currentTable(), &oc, resHost.data(), 1, nullptr, &depth,
+                                               useLambdaTable ? &il : nullptr, params.intr.val, &out,
+                                               bgCullScratch.data(), 0, nullptr,
+                                               integrateStatsDev.as<uint64_t>(), aux.abi()),
+             "integrateBatchedCulledOut");
+    bgInFlight = true;
+}
+
+// Join: the frame's later stages (and the next frame) see the integrated background.
+void EMFusion::joinBackground() {
+    if (!bgInFlight) return;
+    main.waitFor(aux);
+    background.flip();
+    tableSel ^= 1;
+    bgInFlight = false;
+}
+
 void EMFusion::integrateBatched() {
     std::vector<emf_pose_t> oc;
     posesOC(oc);
     const int n = static_cast<int>(oc.size());
-    double vox = 0;
-    for (int m = 0; m < n; ++m)
-        vox += static_cast<double>(resHost[3 * m]) * resHost[3 * m + 1] * resHost[3 * m + 2];
-    auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
-    const emf_image_t il = invLambda.view();
-    const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
-    if (cullBoxes && !integrateCullScratch.empty()) {
-        // two-level launch: the boxes of tiles outside the view cone never get a workgroup
-        emfCheck(emf_hip_integrateBatchedCulled(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
-                                                visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
-                                                integrateCullScratch.data(), 0, nullptr,
-                                                integrateStatsDev.as<uint64_t>(), main.abi()),
-                 "integrateBatchedCulled");
-        return;
+    const int first = bgInFlight ? 1 : 0;  // the background is already on its way
+    if (!bgInFlight && background.doubleBuffered()) bgBackStale = true;  // in place below
+    if (n > first) {
+        double vox = 0;
+        for (int m = first; m < n; ++m)
+            vox += static_cast<double>(resHost[3 * m]) * resHost[3 * m + 1] * resHost[3 * m + 2];
+        auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
+        const emf_image_t il = invLambda.view();
+        const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
+        const emf_model_t* table = currentTable() + first;
+        const int32_t* vis = visibleDev.as<int32_t>() + first;
+        if (cullBoxes && !integrateCullScratch.empty()) {
+            // two-level launch: the boxes of tiles outside the view cone never get a workgroup
+            emfCheck(emf_hip_integrateBatchedCulled(table, oc.data() + first, resHost.data() + 3 * first, n - first,
+                                                    vis, &depth, ilp, params.intr.val,
+                                                    integrateCullScratch.data(), 0, nullptr,
+                                                    integrateStatsDev.as<uint64_t>(), main.abi()),
+                     "integrateBatchedCulled");
+        } else {
+            emfCheck(emf_hip_integrateBatched(table, oc.data() + first, resHost.data() + 3 * first, n - first, vis,
+                                              &depth, ilp, params.intr.val, TSDF::brickFlagMode() != 0,
+                                              integrateStatsDev.as<uint64_t>(), main.abi()),
+                     "integrateBatched");
+        }
     }
-    emfCheck(emf_hip_integrateBatched(modelTable.as<emf_model_t>(), oc.data(), resHost.data(), n,
-                                      visibleDev.as<int32_t>(), &depth, ilp, params.intr.val,
-                                      TSDF::brickFlagMode() != 0,
-                                      integrateStatsDev.as<uint64_t>(), main.abi()),
-             "integrateBatched");
+    joinBackground();
 }
 
 // Compositing in list (creation) order + visibility counts (reference EMFusion.cpp:760-794).
@@ -1285,6 +1354,7 @@ void EMFusion::raycastPerVolume() {
 }
 
 void EMFusion::integratePerVolume() {
+    if (background.doubleBuffered()) bgBackStale = true;  // integrated in place below
     refreshVisibleFromDevice();
     forkVolumeStreams();
     const bool grads = gradMode == TSDF::Gradients::Materialized;

@@ -363,7 +363,20 @@ private:
     bool batched = true;            // false: per-volume launches (see EMFusion.cpp)
     bool forceLegacy = false;
     bool sharded = false;           // objects sharded over ranks: use the cross-rank exchanges
-    DeviceBuffer modelTable;        // emf_model_t[EMF_MAX_BATCH]
+    DeviceBuffer modelTable;        // 2 x emf_model_t[EMF_MAX_BATCH]: [1] has the background's two copies swapped
+    int tableSel = 0;               // which of the two describes the background's current front copy
+    const emf_model_t* currentTable() const { return modelTable.as<emf_model_t>() + tableSel * EMF_MAX_BATCH; }
+    // Background kept twice (TSDF::enableDoubleBuffer): its integration runs out of place on `aux`,
+    // concurrently with the raycast of the same frame, and the copies are flipped at the join.
+    // EMF_BG_OVERLAP=0 keeps the reference's sequence raycast -> integrate (A/B measurements).
+    bool bgOverlap = true;
+    bool bgInFlight = false;        // the out-of-place integration of this frame has been enqueued
+    bool bgBackStale = false;       // the background was integrated in place: the copies differ
+    Stream aux;
+    DeviceBuffer bgCullScratch;     // box list of the background's own launch
+    bool overlapUsable() const;
+    void integrateBackgroundAsync();  // fork: enqueue on aux what integrateDepth() would do for slot 0
+    void joinBackground();
     std::vector<emf_model_t> modelsHost;
     std::vector<int32_t> resHost;   // 3 per model
     DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device

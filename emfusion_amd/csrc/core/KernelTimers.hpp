@@ -26,6 +26,7 @@ public:
         Grads,        // computeTSDFGrads (materialised mode only)
         FgBg,         // updateFgBgProbs + computeFgProbs
         Track,        // one tracking stage (prepare + maxTrackingIter LM iterations)
+        IntegrateBg,  // the background's out-of-place integration, concurrent with the raycast
         kNumKinds
     };
     struct Summary {

@@ -34,8 +34,59 @@ void TSDF::reset(const Affine3f& _pose) {
     if (!tsdfGrads.empty()) tsdfGrads.setZero(s);
     emfCheck(emf_hip_resetBrickFlags(brickFlags.as<uint8_t>(), volumeRes.val, s.abi()),
              "TSDF::reset");
+    if (doubleBuffered()) {  // equal copies, clean maps
+        tsdfBack.setZero(s);
+        weightsBack.setZero(s);
+        dirtyMaps[0].setZero(s);
+        dirtyMaps[1].setZero(s);
+    }
     s.waitForCompletion();  // per-volume streams are non-blocking: do not race the clears
     pose = _pose;
+}
+
+void TSDF::enableDoubleBuffer() {
+    if (doubleBuffered()) return;
+    hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    tsdfBack = DeviceBuffer(voxels() * sizeof(float));
+    weightsBack = DeviceBuffer(voxels() * sizeof(float));
+    hipCheck(hipMemcpy(tsdfBack.data(), tsdfVol.data(), voxels() * sizeof(float), hipMemcpyDeviceToDevice),
+             "TSDF::enableDoubleBuffer");
+    hipCheck(hipMemcpy(weightsBack.data(), tsdfWeights.data(), voxels() * sizeof(float), hipMemcpyDeviceToDevice),
+             "TSDF::enableDoubleBuffer");
+    const size_t bytes = emf_hip_integrateDirtyMapBytes(volumeRes.val);
+    for (auto& d : dirtyMaps) {
+        d = DeviceBuffer(bytes);
+        d.setZero(Stream::Null());
+    }
+    Stream::Null().waitForCompletion();
+    dirtyPrev = 0;
+}
+
+emf_volume_out_t TSDF::backBuffers() const {
+    emf_volume_out_t o;
+    o.tsdf = tsdfBack.as<float>();
+    o.weights = weightsBack.as<float>();
+    o.dirtyPrev = dirtyMaps[dirtyPrev].as<uint8_t>();
+    o.dirtyNext = dirtyMaps[1 - dirtyPrev].as<uint8_t>();
+    return o;
+}
+
+void TSDF::resyncBack() {
+    if (!doubleBuffered()) return;
+    hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    hipCheck(hipMemcpy(tsdfBack.data(), tsdfVol.data(), voxels() * sizeof(float), hipMemcpyDeviceToDevice),
+             "TSDF::resyncBack");
+    hipCheck(hipMemcpy(weightsBack.data(), tsdfWeights.data(), voxels() * sizeof(float), hipMemcpyDeviceToDevice),
+             "TSDF::resyncBack");
+    dirtyMaps[0].setZero(Stream::Null());
+    dirtyMaps[1].setZero(Stream::Null());
+    Stream::Null().waitForCompletion();
+}
+
+void TSDF::flip() {
+    std::swap(tsdfVol, tsdfBack);
+    std::swap(tsdfWeights, weightsBack);
+    dirtyPrev = 1 - dirtyPrev;
 }
 
 void TSDF::getCorners(Vec3f& low, Vec3f& high) const {

@@ -94,6 +94,22 @@ public:
     Gradients gradientMode() const { return gradMode; }
 
     /**
+     * Keep the volume twice (MI355X has the memory: 1 GB more for a 512^3 background) so that a
+     * frame's integration can run out of place, concurrently with the same frame's raycast
+     * (emf_hip_integrateBatchedCulledOut; EMFusion::integrateBatched).  Everything else keeps reading
+     * tsdfPtr() / weightsPtr(), the FRONT copy; after an out-of-place integration into backBuffers()
+     * the owner calls flip().  Allocates the second copy (equal to the first) and the two dirty maps.
+     */
+    void enableDoubleBuffer();
+    bool doubleBuffered() const { return !tsdfBack.empty(); }
+    /** Second copy + dirty maps in the roles emf_hip_integrateBatchedCulledOut expects now. */
+    emf_volume_out_t backBuffers() const;
+    /** The back copy holds the newly integrated state: make it the front. */
+    void flip();
+    /** After an IN-PLACE integration of a double-buffered volume: make the copies equal again. */
+    void resyncBack();
+
+    /**
      * Static part of this volume's entry in the device model table used by the batched launches
      * (emf_model_t, include/emf_hip.h); image pointers are filled in by the owner of the images.
      */
@@ -116,6 +132,10 @@ protected:
     DeviceBuffer tsdfWeights;  // N^3 f32
     DeviceBuffer tsdfGrads;    // N^3 x 3 f32, only in Materialized mode
     DeviceBuffer brickFlags;   // ceil(N/8)^3 u8 uniformity flags kept by integrate(), read by raycast()
+    // double buffering (enableDoubleBuffer): the other copy, and per 32x8x8 tile "the copies differ"
+    DeviceBuffer tsdfBack, weightsBack;
+    DeviceBuffer dirtyMaps[2];
+    int dirtyPrev = 0;  // index of the map the last out-of-place integration wrote
 };
 
 }  // namespace emf

@@ -308,6 +308,30 @@ __device__ __forceinline__ int classify_shot(const IntegrateGeom& a, const Voxel
     return kNegIfUnseen;
 }
 
+// 16-byte volume accesses of the out-of-place sweep: streamed once, never re-read by this kernel, and
+// the raycast running beside it lives on what stays in L2 -- mark them non-temporal (EMF_INT_NT=0: plain)
+#ifndef EMF_INT_NT
+#define EMF_INT_NT 1
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store4(float* p, const float4& v) {
+    if (NT && EMF_INT_NT) {
+        f4v t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ float4 load4(const float* p) {
+    if (NT && EMF_INT_NT) {
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
 // Process the tile at voxel origin (x0, y0, z0) with the 256 lanes of the workgroup.
 // lds: 32 unsigned words.  All lanes of the block must call this (it contains barriers).
 //
@@ -324,12 +348,51 @@ __device__ __forceinline__ int classify_shot(const IntegrateGeom& a, const Voxel
 // to fuse -- put the VALU floor of the bench workload at ~0.30 ms; removing the load dependencies,
 // staging the pixel window in LDS, persistent tile scheduling were all measured and gave nothing
 // or lost, the 1 / lambda table and 6 waves per SIMD gave 9 %.
+//
+// OUT = true is the out-of-place form behind emf_hip_integrateBatchedCulledOut: (tsdf, weights) are
+// only READ, the integrated state goes to (tsdfOut, weightsOut), a second copy of the volume that
+// already equals the first one wherever the previous integration changed nothing.  `force` (block-
+// uniform; bit 0: tsdf, bit 1: weights) = "the previous integration changed that array in this
+// tile": then every voxel of the array in the tile is written (integrated or copied), otherwise only
+// the voxels that change now.  dirtyT / dirtyW are set when this call changes a tsdf / weight of the
+// tile, i.e. they are the next call's `force`.  (Free space below the weight cap changes its weight
+// every frame and its tsdf never: tracking the arrays apart halves what has to be stored there.)
+// Same arithmetic, same values: only where they are stored differs.
+template <bool OUT = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __restrict__ tsdf,
                                                float* __restrict__ weights,
                                                uint8_t* __restrict__ bricks, int x0, int y0,
-                                               int z0, unsigned* lds) {
+                                               int z0, unsigned* lds,
+                                               float* __restrict__ tsdfOut = nullptr,
+                                               float* __restrict__ weightsOut = nullptr,
+                                               int force = 0, uint8_t* dirtyT = nullptr,
+                                               uint8_t* dirtyW = nullptr, bool copyOnly = false) {
     const V3 half = half_extent(a.n);
-    if (tile_culled(a, half, x0, y0, z0)) return;  // block-uniform: no divergent barrier
+    // copyOnly (OUT, block-uniform): the model is not integrated this frame (visibility gate closed),
+    // its second copy only has to catch up
+    if ((OUT && copyOnly) || tile_culled(a, half, x0, y0, z0)) {  // block-uniform: no divergent barrier
+        if (OUT && force) {  // nothing to integrate, but the other copy is one integration behind here
+            const int xg = threadIdx.x & 7, yy = (threadIdx.x >> 3) & 7, zs = threadIdx.x >> 6;
+            const int x = x0 + 4 * xg, y = y0 + yy;
+            if (x < a.n.x && y < a.n.y) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int z = z0 + zs + 4 * i;
+                    if (z < a.n.z) {
+                        const size_t b = (static_cast<size_t>(z) * a.n.y + y) * a.n.x + x;
+                        if (force & 1) store4<OUT>(tsdfOut + b, load4<OUT>(tsdf + b));
+                        if (force & 2) store4<OUT>(weightsOut + b, load4<OUT>(weights + b));
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if (!OUT) {  // in place: stores go where the loads came from
+        tsdfOut = tsdf;
+        weightsOut = weights;
+    }
+    int anyChanged = 0;
     const int tid = threadIdx.x;
     const bool haveIl = a.invLambda.data != nullptr;
     // 32 x 8 x 8 voxels = 8 x 2 x 2 bricks of 4^3: lds[bx + 8 * (by + 2 * bz)]
@@ -380,16 +443,17 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 tl = make_float4(0.f, 0.f, 0.f, 0.f), wl = tl;
-            if ((bricks && live[i]) || touch[i]) tl = *reinterpret_cast<const float4*>(tsdf + base[i]);
-            if (touch[i]) wl = *reinterpret_cast<const float4*>(weights + base[i]);
+            if ((bricks && live[i]) || touch[i] || (OUT && (force & 1) && live[i]))
+                tl = load4<OUT>(tsdf + base[i]);
+            if (touch[i] || (OUT && (force & 2) && live[i])) wl = load4<OUT>(weights + base[i]);
             tv[i][0] = tl.x; tv[i][1] = tl.y; tv[i][2] = tl.z; tv[i][3] = tl.w;
             wv[i][0] = wl.x; wv[i][1] = wl.y; wv[i][2] = wl.z; wv[i][3] = wl.w;
         }
         // ---- phase C: classify, fuse, store ---------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            int changed = 0;
             if (touch[i]) {
-                int changed = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     VoxelShot s;
@@ -405,16 +469,22 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                     const float aw = band ? a.assoc.row(s.py)[s.px] : 1.f;
                     changed |= apply_voxel(kind, samp, aw, a.maxWeight, tv[i][e], wv[i][e]);
                 }
-                if (changed & 1)
-                    *reinterpret_cast<float4*>(tsdf + base[i]) =
-                        make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]);
-                if (changed & 2)
-                    *reinterpret_cast<float4*>(weights + base[i]) =
-                        make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
+                anyChanged |= changed;
             }
+            if ((changed & 1) || (OUT && (force & 1) && live[i]))
+                store4<OUT>(tsdfOut + base[i], make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]));
+            if ((changed & 2) || (OUT && (force & 2) && live[i]))
+                store4<OUT>(weightsOut + base[i], make_float4(wv[i][0], wv[i][1], wv[i][2], wv[i][3]));
             if (bricks && live[i])  // the lane's 4 voxels are one x-row of brick (xg, yy >> 2, i)
                 bits[i] = uniform_bits(tv[i][0]) & uniform_bits(tv[i][1]) &
                           uniform_bits(tv[i][2]) & uniform_bits(tv[i][3]);
+        }
+    }
+    if (OUT && dirtyT) {  // one store per wave that changed something (same value from all)
+        const bool t = __ballot((anyChanged & 1) != 0) != 0ull, w = __ballot((anyChanged & 2) != 0) != 0ull;
+        if ((tid & 63) == 0) {
+            if (t) *dirtyT = 1;
+            if (w) *dirtyW = 1;
         }
     }
     if (bricks) {

@@ -330,6 +330,29 @@ def integrate_batched_culled(models_dev, poses_oc, res_list, visible, depth, K, 
     return scratch
 
 
+def integrate_dirty_map_bytes(res) -> int:
+    return int(_L.emf_hip_integrateDirtyMapBytes((C.c_int32 * 3)(*[int(v) for v in res])))
+
+
+def integrate_batched_culled_out(models_dev, poses_oc, res_list, visible, depth, K, outs, launch_boxes=0,
+                                 stats=None, stream=None, inv_lambda=None, scratch=None):
+    """emf_hip_integrateBatchedCulledOut: model m is read from the table and written to outs[m] =
+    (tsdf_back, weights_back, dirty_prev, dirty_next) device arrays; returns the scratch buffer."""
+    from ._lib import EmfVolumeOut
+    res = (C.c_int32 * (3 * len(poses_oc)))(*[int(v) for r in res_list for v in r])
+    if scratch is None:
+        scratch = DeviceArray.zeros((int(_L.emf_hip_integrateCullScratchBytes(res, len(poses_oc))) // 4,), np.uint32)
+    table = (EmfVolumeOut * len(outs))()
+    for o, (t, w, dp, dn) in zip(table, outs):
+        o.tsdf, o.weights, o.dirtyPrev, o.dirtyNext = t.ptr, w.ptr, dp.ptr, dn.ptr
+    check("emf_hip_integrateBatchedCulledOut",
+          _L.emf_hip_integrateBatchedCulledOut(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc), _ptr(visible),
+                                               C.byref(image_view(depth)), _opt_view(inv_lambda), _f(K, 9),
+                                               C.cast(table, C.c_void_p), _ptr(scratch), int(launch_boxes), None,
+                                               _ptr(stats), _stream(stream)))
+    return scratch
+
+
 def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):
     check("emf_hip_visibilityFlags",
           _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible),

@@ -47,7 +47,7 @@ class KernelSummary(C.Structure):
 
 
 KERNEL_KINDS = ("points", "assoc", "normalize", "raycast", "composite", "integrate", "grads", "fgbg",
-                "track")
+                "track", "integrate_bg")
 
 IMG = dict(points=0, bg_assoc=1, obj_assoc=2, assoc_norm=3, raylengths=4, vertices=5, normals=6,
            segmentation=7, bg_raylengths=8, obj_raylengths=9)

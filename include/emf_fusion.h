@@ -181,7 +181,7 @@ int emf_fusion_raycast_stats(emf_fusion_t* h, uint64_t counters[4]);
  * must be called with the device idle (after emf_fusion_synchronize). */
 enum emf_kernel_kind {
     EMF_K_POINTS = 0, EMF_K_ASSOC, EMF_K_NORMALIZE, EMF_K_RAYCAST, EMF_K_COMPOSITE,
-    EMF_K_INTEGRATE, EMF_K_GRADS, EMF_K_FGBG, EMF_K_TRACK, EMF_K_NUM_KINDS
+    EMF_K_INTEGRATE, EMF_K_GRADS, EMF_K_FGBG, EMF_K_TRACK, EMF_K_INTEGRATE_BG, EMF_K_NUM_KINDS
 };
 typedef struct emf_kernel_summary {
     uint64_t launches;

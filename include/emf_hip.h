@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 3
+#define EMF_HIP_ABI_VERSION 4
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -333,6 +333,35 @@ int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose
                                    const emf_image_t* depth, const emf_image_t* invLambda,
                                    const float K[9], void* scratch_dev, uint32_t launchBoxes,
                                    uint32_t* survivors_out_dev, uint64_t* stats, emf_stream_t stream);
+
+/* Out-of-place form of the same launch, for volumes that are kept TWICE (double-buffered) so that the
+ * integration of a frame can run concurrently with the raycast of the same frame -- both read the state
+ * the previous frame left; the reference runs them back to back (EMFusion.cpp:94, 103) -- and the
+ * raycast never sees a half-integrated volume.  Model m is READ from models_dev[m].tsdf / .weights
+ * and the integrated state is written to out_host[m].tsdf / .weights, the volume's second copy.  The
+ * two copies are equal wherever the previous integration changed nothing, which the dirty maps track
+ * per array at tile granularity (one byte per 32 x 8 x 8 voxel tile for the tsdf, then one per tile for
+ * the weights: emf_hip_integrateDirtyMapBytes(res) bytes in all).  A set byte of dirtyPrev -- the
+ * copies of that array differ in that tile -- makes this call write every voxel of the array in the
+ * tile (integrated or copied), elsewhere it writes only what changes; dirtyNext (cleared by the call)
+ * receives what this call changed and is the next call's dirtyPrev, with the roles of the copies
+ * swapped.  A model whose visible_dev gate is closed is not integrated but still brought up to date.
+ * Start with equal copies and clean maps.  Values are those of the in-place launch, bit for bit.
+ * out_host == NULL: in place (= emf_hip_integrateBatchedCulled); otherwise every model of the call
+ * needs its four pointers. */
+typedef struct emf_volume_out {
+    float* tsdf;
+    float* weights;
+    const uint8_t* dirtyPrev;
+    uint8_t* dirtyNext;
+} emf_volume_out_t;
+size_t emf_hip_integrateDirtyMapBytes(const int32_t res[3]);
+int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
+                                      const int32_t* res_host, int nmodels, const int32_t* visible_dev,
+                                      const emf_image_t* depth, const emf_image_t* invLambda,
+                                      const float K[9], const emf_volume_out_t* out_host, void* scratch_dev,
+                                      uint32_t launchBoxes, uint32_t* survivors_out_dev, uint64_t* stats,
+                                      emf_stream_t stream);
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */

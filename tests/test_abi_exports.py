@@ -27,7 +27,7 @@ def test_dynamic_symbol_table_matches_header():
 
 
 def test_abi_version():
-    assert _lib.load().emf_hip_abi_version() == 3
+    assert _lib.load().emf_hip_abi_version() == 4
 
 
 def test_null_and_shape_arguments_are_rejected_before_any_launch():

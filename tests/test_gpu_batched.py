@@ -408,6 +408,56 @@ def test_integrate_culled_launch_equals_the_plain_batched_one(ops, oracle, dev, 
     assert int(to_np(stats_a)[0]) == int(to_np(stats_b)[0]) > 0
 
 
+def test_integrate_out_of_place_equals_in_place_over_a_swinging_camera(ops, oracle, dev):
+    """emf_hip_integrateBatchedCulledOut on double-buffered volumes: after every frame the copy that was
+    written equals the in-place result bit for bit -- also where the camera has swung away from what it
+    integrated a frame earlier (boxes outside the view cone whose tiles are still dirty get copied), with
+    frames in which nothing at all is seen, and with the visibility gate closing a model for a frame."""
+    shapes = [((128, 96, 80), 0.03, Pose(t=[0, 0, 1.28]), False), ((32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True),
+              ((40, 24, 36), 0.025, Pose(rot([0, 1, 0], 9), SPHERES[1][0]), True)]
+    twins = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    front = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    back = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    for m in twins + front + back:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    maps = [[dev_full((ops.integrate_dirty_map_bytes(r),), 0, np.uint8) for _ in range(2)] for r, _, _, _ in shapes]
+    rng = np.random.default_rng(77)
+    visible = dev_full((3,), 1, np.int32)
+    # yaw in degrees per frame: look ahead, swing far right, back, far left + up, ahead, away (sees nothing), ahead
+    swings = [(0, 0), (35, 0), (0, 0), (-40, 12), (5, -3), (170, 0), (0, 0), (2, 1)]
+    copied_only = 0
+    for i, (yaw, pitch) in enumerate(swings):
+        base, depth, _ = frame(i)
+        cam = Pose(base.R @ rot([0, 1, 0], yaw) @ rot([1, 0, 0], pitch), base.t)
+        if i >= 3:  # the depth image need not match the view: only determinism matters here
+            depth = np.roll(depth, 17 * i, axis=1)
+        visible.copy_from(np.array([1, 1, 0 if i == 2 else 1], np.int32))
+        poses = []
+        for a, b, c in zip(twins, front, back):
+            assoc = rng.uniform(0, 1, (H, W)).astype(np.float32)
+            for m in (a, b, c):
+                m.d_assoc.copy_from(assoc)
+            oc = rel_OC(cam, a.pose)
+            poses.append((oc.R32, oc.t32))
+        d_depth = to_dev(depth)
+        res = [m.res for m in twins]
+        ops.integrate_batched_culled(ops.upload_models([m.table_entry() for m in twins]), poses, res, visible, d_depth, K)
+        outs = [(b.d_tsdf, b.d_wts, mp[i % 2], mp[1 - i % 2]) for b, mp in zip(back, maps)]
+        before = [to_np(b.d_tsdf).copy() for b in back]
+        ops.integrate_batched_culled_out(ops.upload_models([m.table_entry() for m in front]), poses, res, visible,
+                                         d_depth, K, outs)
+        dev.synchronize()
+        for a, f, b, old in zip(twins, front, back, before):
+            assert_parity(to_np(b.d_tsdf), to_np(a.d_tsdf), f"frame {i} tsdf model {a.id}", exact=True)
+            assert_parity(to_np(b.d_wts), to_np(a.d_wts), f"frame {i} weights model {a.id}", exact=True)
+            # tiles that were only brought up to date (the front copy already held these values)
+            copied_only += int(((to_np(b.d_tsdf) != old) & (to_np(b.d_tsdf) == to_np(f.d_tsdf))).sum())
+        front, back = back, front  # flip
+    assert copied_only > 1000, copied_only
+    # a gated model is left alone in BOTH copies: its next-dirty map stays clean and nothing is lost
+    assert int(to_np(maps[0][0]).sum()) + int(to_np(maps[0][1]).sum()) > 0
+
+
 def test_visibility_flags(ops, dev):
     counts = to_dev(np.array([1601, 1600, 0, 99999], np.int32))
     vis = dev_full((5,), -1, np.int32)

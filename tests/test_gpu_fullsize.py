@@ -129,8 +129,11 @@ def test_full_size_frame_is_repeatable_and_path_independent(bench_scene):
     again = bench_scene["run"]()
     per_volume = bench_scene["run"]({"EMF_PER_VOLUME": "1"})
     divide = bench_scene["run"]({"EMF_VOXEL_RCP": "0", "EMF_LAMBDA_TABLE": "0"})
+    in_place = bench_scene["run"]({"EMF_BG_OVERLAP": "0"})
     for other, what in ((again, "second run"), (per_volume, "per-volume launches"),
-                        (divide, "IEEE divisions, inline 1/lambda")):
+                        (divide, "IEEE divisions, inline 1/lambda"),
+                        (in_place, "background integrated in place after the raycast instead of out of "
+                                   "place beside it")):
         for key in ("bg_t", "bg_w", "ray", "seg"):
             assert base[key].tobytes() == other[key].tobytes(), (what, key)
         for i in base["ids"]:

@@ -15,7 +15,7 @@ BG_RES, BG_VOX, OBJ_RES = 64, 0.04, 32
 NOBJ, NFRAMES, MASK_EVERY = 2, 6, 3
 
 
-@pytest.fixture(scope="module", params=["batched", "per_volume", "sharded_1rank",
+@pytest.fixture(scope="module", params=["batched", "batched_in_place", "per_volume", "sharded_1rank",
                                          "sharded_1rank_per_volume"])
 def run(request, oracle, dev):
     """Execution paths of emf::EMFusion: batched model-table launches (default), the
@@ -29,6 +29,9 @@ def run(request, oracle, dev):
     from emfusion_amd.ops import image_view
 
     os.environ["EMF_PER_VOLUME"] = "1" if request.param.endswith("per_volume") else "0"
+    # default: the background is kept twice and integrated out of place beside the raycast;
+    # "in_place": the reference's sequence raycast -> integrate on one copy
+    os.environ["EMF_BG_OVERLAP"] = "0" if request.param.endswith("in_place") else "1"
     comm = None
     if request.param.startswith("sharded"):
         os.environ["EMF_FORCE_SHARDED"] = "1"
@@ -68,6 +71,7 @@ def run(request, oracle, dev):
                           masks, run_masks)
         history.append(dict(vis=sorted(fus.visible_objects()), ovis=sorted(orc.vis)))
     os.environ.pop("EMF_PER_VOLUME", None)
+    os.environ.pop("EMF_BG_OVERLAP", None)
     os.environ.pop("EMF_FORCE_SHARDED", None)
     yield fus, orc, ids, history
     fus.close()
