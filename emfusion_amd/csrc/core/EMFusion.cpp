@@ -84,6 +84,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
+    // EMF_FAR_BOUNDS=0: no far bounds for the raycast (A/B measurements; same results)
+    const char* fb = std::getenv("EMF_FAR_BOUNDS");
+    useFarBounds = !(fb && fb[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -234,6 +237,11 @@ void EMFusion::createObj(int id) {
 void EMFusion::rebuildModelTable() {
     modelsHost.clear();
     resHost.clear();
+    if (bgInFlight) aux.waitForCompletion();
+    if (useFarBounds) {  // sign maps that something other than the tile integration made stale
+        background.refreshSignMaps();
+        for (auto& obj : objects) obj.refreshSignMaps();
+    }
     emf_model_t m{};
     background.describe(m);
     m.assoc = bg_associationWeights.ptr();
@@ -266,7 +274,10 @@ void EMFusion::rebuildModelTable() {
             resHost.data(), static_cast<int>(modelsHost.size())));
     batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly &&
               static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
-    if (bgInFlight) aux.waitForCompletion();  // it reads slot 0 of the table uploaded below
+    farBounds = DeviceBuffer();
+    if (batched && useFarBounds)
+        farBounds = DeviceBuffer(emf_hip_raycastFarBoundBytes(static_cast<int>(modelsHost.size()),
+                                                              params.frameSize.width, params.frameSize.height));
     if (batched && !integrateCullScratch.empty() && bgOverlap && bgCullScratch.empty()) {
         // the background gets its second copy the first time the two-level launch is usable
         background.enableDoubleBuffer();
@@ -1072,9 +1083,16 @@ void EMFusion::raycastBatched() {
         // the bands are then gathered (1.5 MB at VGA).  Background vertices / normals stay
         // band-local: like the remote objects' they only feed rendering.
         const int band = sharded && bgBands ? bgBandRows(h, world) : 0;
+        const float* far = nullptr;
+        if (!farBounds.empty() && !flags) {
+            emfCheck(emf_hip_raycastFarBounds(table, co.data(), resHost.data(), n, w, h, params.intr.val,
+                                              farBounds.as<float>(), main.abi()),
+                     "raycastFarBounds");
+            far = farBounds.as<float>();
+        }
         emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
                                         flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
-                                        band, stats, main.abi()),
+                                        band, far, stats, main.abi()),
                  "raycastBatched");
         if (band) {
             comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), band, h, main);

@@ -373,6 +373,10 @@ private:
     bool bgInFlight = false;        // the out-of-place integration of this frame has been enqueued
     bool bgBackStale = false;       // the background was integrated in place: the copies differ
     Stream aux;
+    // Raycast far bounds (emf_hip_raycastFarBounds): per model and 8x8-pixel cell, where a march may
+    // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
+    bool useFarBounds = true;
+    DeviceBuffer farBounds;
     DeviceBuffer bgCullScratch;     // box list of the background's own launch
     bool overlapUsable() const;
     void integrateBackgroundAsync();  // fork: enqueue on aux what integrateDepth() would do for slot 0

@@ -125,6 +125,8 @@ Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& 
     const size_t nb = static_cast<size_t>((n + 3) / 4) * ((n + 3) / 4) * ((n + 3) / 4);
     brickFlags = DeviceBuffer(2 * nb);
     brickFlags.setZero(stream);  // every brick "mixed": always correct; integrate() refines them
+    signMaps = DeviceBuffer();   // new resolution, shifted values: rebuilt by refreshSignMaps()
+    signMapsValid = false;
     computeFgProbs(stream);
     return newCenter;
 }

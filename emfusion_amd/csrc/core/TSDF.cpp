@@ -34,6 +34,14 @@ void TSDF::reset(const Affine3f& _pose) {
     if (!tsdfGrads.empty()) tsdfGrads.setZero(s);
     emfCheck(emf_hip_resetBrickFlags(brickFlags.as<uint8_t>(), volumeRes.val, s.abi()),
              "TSDF::reset");
+    if (volumeRes[0] % 4 == 0) {  // an all-zero volume has neither sign anywhere
+        if (signMaps.empty()) signMaps = DeviceBuffer(emf_hip_signMapBytes(volumeRes.val));
+        signMaps.setZero(s);
+        signMapsValid = true;
+    } else {
+        signMaps = DeviceBuffer();
+        signMapsValid = false;
+    }
     if (doubleBuffered()) {  // equal copies, clean maps
         tsdfBack.setZero(s);
         weightsBack.setZero(s);
@@ -42,6 +50,15 @@ void TSDF::reset(const Affine3f& _pose) {
     }
     s.waitForCompletion();  // per-volume streams are non-blocking: do not race the clears
     pose = _pose;
+}
+
+void TSDF::refreshSignMaps(Stream& stream) {
+    if (signMapsValid || volumeRes[0] % 4 != 0) return;
+    const size_t bytes = emf_hip_signMapBytes(volumeRes.val);
+    if (signMaps.empty() || signMaps.bytes() != bytes) signMaps = DeviceBuffer(bytes);
+    emfCheck(emf_hip_rebuildSignMaps(tsdfVol.as<float>(), volumeRes.val, signMaps.as<uint8_t>(), stream.abi()),
+             "TSDF::refreshSignMaps");
+    signMapsValid = true;
 }
 
 void TSDF::enableDoubleBuffer() {
@@ -108,6 +125,7 @@ void TSDF::integrate(const emf_image_t& depth, const emf_image_t& weights,
                      const Affine3f& cam_pose, const Matx33f& intr, Stream& stream,
                      const emf_image_t* invLambda) {
     const Affine3f rel_pose_OC = cam_pose.inv() * pose;  // volume -> camera
+    signMapsValid = false;  // the per-volume launch does not keep them
     emfCheck(emf_hip_updateTSDF(&depth, &weights, tsdfVol.as<float>(), tsdfWeights.as<float>(),
                                 brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr,
                                 rel_pose_OC.rotation().val, rel_pose_OC.translation().val,
@@ -181,6 +199,7 @@ void TSDF::describe(emf_model_t& m) const {
     m.brickFlags = mode ? brickFlags.as<uint8_t>() : nullptr;
     m.reserved = mode == 2 ? 2 : 0;
     m.rcpVoxel = rcpVoxel;
+    m.signMaps = signMapsValid && !signMaps.empty() ? signMaps.as<uint8_t>() : nullptr;
     m.pad_ = 0;
 }
 

@@ -110,6 +110,15 @@ public:
     void resyncBack();
 
     /**
+     * Sign maps (emf_model_t.signMaps, include/emf_hip.h): kept by the tile integration launches through
+     * the model table, read by emf_hip_raycastFarBounds.  Anything else that writes the tsdf volume
+     * calls invalidateSignMaps(); refreshSignMaps() rebuilds them from the values when they are stale
+     * (the owner calls it before describe()).  Volumes with Nx % 4 != 0 have none (no tile launches).
+     */
+    void invalidateSignMaps() { signMapsValid = false; }
+    void refreshSignMaps(Stream& stream = Stream::Null());
+
+    /**
      * Static part of this volume's entry in the device model table used by the batched launches
      * (emf_model_t, include/emf_hip.h); image pointers are filled in by the owner of the images.
      */
@@ -135,6 +144,8 @@ protected:
     // double buffering (enableDoubleBuffer): the other copy, and per 32x8x8 tile "the copies differ"
     DeviceBuffer tsdfBack, weightsBack;
     DeviceBuffer dirtyMaps[2];
+    DeviceBuffer signMaps;      // per 32x8x8 tile: holds a positive tsdf / holds a negative tsdf
+    bool signMapsValid = false;
     int dirtyPrev = 0;  // index of the map the last out-of-place integration wrote
 };
 

@@ -366,7 +366,8 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                                                float* __restrict__ tsdfOut = nullptr,
                                                float* __restrict__ weightsOut = nullptr,
                                                int force = 0, uint8_t* dirtyT = nullptr,
-                                               uint8_t* dirtyW = nullptr, bool copyOnly = false) {
+                                               uint8_t* dirtyW = nullptr, bool copyOnly = false,
+                                               uint8_t* signPos = nullptr, uint8_t* signNeg = nullptr) {
     const V3 half = half_extent(a.n);
     // copyOnly (OUT, block-uniform): the model is not integrated this frame (visibility gate closed),
     // its second copy only has to catch up
@@ -393,6 +394,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
         weightsOut = weights;
     }
     int anyChanged = 0;
+    bool sawPos = false, sawNeg = false;  // signs among the tsdf values this lane holds at the end
     const int tid = threadIdx.x;
     const bool haveIl = a.invLambda.data != nullptr;
     // 32 x 8 x 8 voxels = 8 x 2 x 2 bricks of 4^3: lds[bx + 8 * (by + 2 * bz)]
@@ -471,6 +473,10 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                 }
                 anyChanged |= changed;
             }
+            if (signPos && (touch[i] || (OUT && (force & 1) && live[i]))) {  // values that were loaded
+                sawPos = sawPos || tv[i][0] > 0.f || tv[i][1] > 0.f || tv[i][2] > 0.f || tv[i][3] > 0.f;
+                sawNeg = sawNeg || tv[i][0] < 0.f || tv[i][1] < 0.f || tv[i][2] < 0.f || tv[i][3] < 0.f;
+            }
             if ((changed & 1) || (OUT && (force & 1) && live[i]))
                 store4<OUT>(tsdfOut + base[i], make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]));
             if ((changed & 2) || (OUT && (force & 2) && live[i]))
@@ -478,6 +484,16 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
             if (bricks && live[i])  // the lane's 4 voxels are one x-row of brick (xg, yy >> 2, i)
                 bits[i] = uniform_bits(tv[i][0]) & uniform_bits(tv[i][1]) &
                           uniform_bits(tv[i][2]) & uniform_bits(tv[i][3]);
+        }
+    }
+    // Sign maps (raycast far bounds, batched.hip): "this tile holds a positive / a negative tsdf".
+    // Sticky and conservative: a voxel's value only ever changes in a lane that has it loaded, and
+    // that lane reports the sign it leaves behind; a bit is never cleared here.
+    if (signPos) {
+        const bool p = __ballot(sawPos) != 0ull, n = __ballot(sawNeg) != 0ull;
+        if ((tid & 63) == 0) {
+            if (p) *signPos = 1;
+            if (n) *signNeg = 1;
         }
     }
     if (OUT && dirtyT) {  // one store per wave that changed something (same value from all)

@@ -139,7 +139,7 @@ struct RayState {
 // Everything before the main loop of the reference kernel (TSDF.cu:476-521).
 __device__ __forceinline__ void ray_setup(const RayVolume& v, const V3& half, const V3& nf, int x,
                                           int y, float fx, float fy, float cx, float cy,
-                                          float oldRaylength, RayState& r) {
+                                          float oldRaylength, float cut, RayState& r) {
     r.active = false;
     const V3 unproj = v3((static_cast<float>(x) - cx) / fx, (static_cast<float>(y) - cy) / fy, 1.f);
     const V3 rayv = mul(v.R, unproj);
@@ -168,6 +168,12 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, const V3& half, co
     if (fabsf(r.tsdf) < 1.f) r.raystep = v.voxelSize;
     if (fabsf(r.tsdf) < .8f) r.raystep = 0.5f * v.voxelSize;
     r.active = true;
+    // Far bound (k_far_bounds in batched.hip): past `cut` no sample can complete a hit, PROVIDED the
+    // positive sample a hit compares with is the one taken an iteration earlier.  That holds once the
+    // march is inside [0, N - 2)^3 -- a convex region the ray cannot re-enter, in which every iteration
+    // samples; if this first sample lies in the volume's outer shell the loop may skip iterations
+    // (TSDF.cu:525-528) while still comparing with it, arbitrarily far back: such a ray keeps its range.
+    if (!outside_flat(p, 2.f, nf)) r.maxRay = fminf(r.maxRay, cut);
 }
 
 // One iteration of `while ((raylength += raystep) <= maxRaylength)` (TSDF.cu:523-572) for the
@@ -212,12 +218,118 @@ __device__ __forceinline__ void ray_step(const RayVolume& v, const V3& half, con
     r.tsdf = next;
 }
 
+// ---- the march, second form: one divergent loop per lane ---------------------------------------------
+// scripts/probes/march_probe.hip: a wave that is alone on its SIMD issues ONE instruction every 8
+// clocks, whatever the instruction (VALU, SALU, branch, s_nop, s_waitcnt) and however independent --
+// gfx950 needs four waves per SIMD to fill the VALU.  The march is 4800 waves of ~250..600 strictly
+// sequential steps, about five per SIMD at the start and ever fewer as the short rays finish: its
+// duration is (steps of the longest rays) x (instructions per step) x 8 clocks, plus the memory round
+// trip where the lines are cold.  So the step below is written for the instruction COUNT of its common
+// path (a sample with no sign change against the previous one):
+//   * the loop is the lane's own (exec-masked) loop: no `active` flag to test, set and vote on;
+//   * the four x-pairs of the 8 corners are fetched at ONE 32-bit offset from four wave-uniform row
+//     bases (y, y + 1 at z and z + 1) instead of four offsets from one base;
+//   * offset = lz * strideZ + ly * strideY + 4 lx with two 24-bit multiply-adds (full rate);
+//   * fraction = v_fract_f32 (x - floor(x): the bits of x - float(int(x)) for x >= 0);
+//   * the two crossing tests (TSDF.cu:533, 541) hide behind one integer test "the sign bits of the
+//     previous and the new sample differ"; only then the exact tests, the weights and a possible hit run.
+// Arithmetic and its order are those of ray_step above (the reference's): same bits.
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+
+//   * the loop has ONE exit, at its top: a lane that is done (back-side crossing, hit) sets its range
+//     to -inf and leaves at the next range test -- breaks out of nested branches cost a dozen scalar
+//     instructions of exec-mask bookkeeping per iteration, in every iteration;
+//   * bounds (TSDF.cu:525-528): lx = floor(x) as an integer, and 0 <= lx < Nx - 3 (one unsigned
+//     comparison per axis) means 0 <= x and x + 2 < Nx whatever the rounding of x + 2; only a sample
+//     in the outermost cells takes the six float comparisons;
+//   * x / voxelSize by multiplication or by division is decided once per wave, not once per sample.
+template <bool RCP, class Sink>
+__device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, const V3& nf, RayState& r,
+                                           MarchCount& out, Sink& sink) {
+    const unsigned sy = 4u * static_cast<unsigned>(v.n.x), sz = sy * static_cast<unsigned>(v.n.y);
+    const float* const row00 = v.tsdf;
+    const float* const row01 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sy);
+    const float* const row10 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz);
+    const float* const row11 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz + sy);
+    const float vs = v.voxelSize, hvs = 0.5f * v.voxelSize, rcp = v.rcpVoxel;
+    // cells [0, lim) are inside whatever the rounding (lim may be <= 0 for tiny volumes: nothing is)
+    const unsigned limx = static_cast<unsigned>(max(v.n.x - 3, 0)), limy = static_cast<unsigned>(max(v.n.y - 3, 0)),
+                   limz = static_cast<unsigned>(max(v.n.z - 3, 0));
+    const V3 dir = r.dir;
+    float tmax = r.maxRay;
+    float t = r.raylength, step = r.raystep, tsdf = r.tsdf;
+    unsigned samples = 0;
+    for (;;) {
+        t += step;
+        if (!(t <= tmax)) break;
+        const V3 pm = v.cam + dir * t;
+        V3 p;
+        if (RCP) {
+            p = v3(div_voxel(pm.x, vs, rcp), div_voxel(pm.y, vs, rcp), div_voxel(pm.z, vs, rcp)) + half;
+        } else {
+            p = pm / vs + half;
+        }
+        const int lx = static_cast<int>(floorf(p.x)), ly = static_cast<int>(floorf(p.y)),
+                  lz = static_cast<int>(floorf(p.z));
+        bool inside = (static_cast<unsigned>(lx) < limx) & (static_cast<unsigned>(ly) < limy) &
+                      (static_cast<unsigned>(lz) < limz);
+        if (!inside) inside = !outside_flat(p, 2.f, nf);  // outermost cells, outside, NaN: the reference's test
+        if (inside) {
+            ++samples;
+            const float fx = __builtin_amdgcn_fractf(p.x), fy = __builtin_amdgcn_fractf(p.y),
+                        fz = __builtin_amdgcn_fractf(p.z);
+            const unsigned off = mad24(static_cast<unsigned>(lz), sz,
+                                       mad24(static_cast<unsigned>(ly), sy, static_cast<unsigned>(lx) << 2));
+            const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off),
+                         e = gload2(row11, off);
+            const float next = blend8(a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, fx, fy, fz);
+            bool advance = true;  // reference: `tsdf = next_tsdf` at the end of the iteration
+            if ((__float_as_int(tsdf) ^ __float_as_int(next)) < 0) {
+                // the signs differ (counting -0 as negative): the reference's two crossing tests
+                const Cell32 c{off, fx, fy, fz};
+                if (tsdf < 0 && next > 0 && trilinear_weights_g(v, c) > 0.f) {
+                    tmax = -__builtin_inff();  // crossing from behind: `break`
+                    advance = false;
+                } else if (tsdf > 0 && next < 0) {
+                    // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:537-543)
+                    float st = step;
+                    if (fabsf(next) < 1.f) st = vs;
+                    if (fabsf(next) < .8f) st = hvs;
+                    const float tstar = t - st * tsdf / (next - tsdf);
+                    const V3 ps = to_voxel(v.cam + dir * tstar, v, half);
+                    if (outside_flat(ps, 2.f, nf)) {
+                        advance = false;  // reference `continue`: the step is updated, tsdf is NOT
+                    } else {
+                        const Cell32 cs = cell32_of(ps, v.n);
+                        if (trilinear_weights_g(v, cs) > 0.f) {
+                            const V3 g = gradient_at(v, widen(cs));
+                            const M33 Rt = transpose(v.R);
+                            out.hit = true;
+                            sink(tstar, mul(Rt, dir * tstar), mul(Rt, g / norm(g)));  // 0/0 -> NaN like the reference
+                            tmax = -__builtin_inff();  // `break`
+                        }
+                    }
+                }
+            }
+            if (fabsf(next) < 1.f) step = vs;  // (harmless for a lane that is done)
+            if (fabsf(next) < .8f) step = hvs;
+            if (advance) tsdf = next;
+        }
+    }
+    out.samples = samples;
+}
+
+#ifndef EMF_MARCH_LANE
+#define EMF_MARCH_LANE 1  // 0: the wave-voted loop over ray_step (A/B builds)
+#endif
+
 // March the ray of pixel (x, y); `valid` = the pixel exists.  All 64 lanes of the wave call this.
 // The volume must fit 32-bit byte offsets (Nx Ny Nz <= 2^30): the caller checks.
 template <class Sink>
 __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid, int x, int y,
                                                  float fx, float fy, float cx, float cy,
-                                                 float oldRaylength, Sink& sink) {
+                                                 float oldRaylength, Sink& sink,
+                                                 float cut = __builtin_inff()) {
     MarchCount out;
     out.hit = false;
     out.samples = 0;
@@ -227,10 +339,19 @@ __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid,
     r.dir = v3(0.f, 0.f, 1.f);
     r.raylength = r.maxRay = r.raystep = r.tsdf = 0.f;
     r.active = false;
-    if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, r);
+    if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, cut, r);
+#if EMF_MARCH_LANE
+    if (r.active) {
+        if (v.rcpVoxel != 0.f)  // wave-uniform
+            march_lane<true>(v, half, nf, r, out, sink);
+        else
+            march_lane<false>(v, half, nf, r, out, sink);
+    }
+#else
     while (__ballot(r.active) != 0) {
         if (r.active) ray_step(v, half, nf, r, out, sink);
     }
+#endif
     return out;
 }
 

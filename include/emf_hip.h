@@ -249,6 +249,9 @@ typedef struct emf_model {
     float* vertices;        /* f32x3 */
     float* normals;         /* f32x3 */
     uint8_t* hitMask;       /* u8 0/1 */
+    uint8_t* signMaps;      /* emf_hip_signMapBytes(res) bytes or NULL: per 32x8x8 tile "holds a positive
+                             * tsdf", then per tile "holds a negative tsdf"; kept by the tile integration
+                             * launches (sticky), read by emf_hip_raycastFarBounds */
     int32_t res[3];
     int32_t id;             /* 0 = background */
     float voxelSize, truncdist, maxWeight;
@@ -295,7 +298,26 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
-                           uint64_t* stats, emf_stream_t stream);
+                           const float* farBounds_dev, uint64_t* stats, emf_stream_t stream);
+
+/* Far bounds for emf_hip_raycastBatched (farBounds_dev; NULL = none).  A hit of the reference's march
+ * (TSDF.cu:533-568) is a negative sample following a positive one, so it needs a negative and a positive
+ * voxel close together.  From the models' sign maps (emf_model_t.signMaps) this call computes, per model
+ * and per 8x8-pixel cell of the image, the largest raylength at which a ray of the cell can still
+ * complete a hit (0: it cannot at all; +inf for models without sign maps); the march of a ray is cut
+ * there.  Every sample still taken is taken exactly as before, the ones dropped could not have written
+ * an output: results are bit-identical, the rays that used to run on through unseen space to the far
+ * side of the volume -- the longest of the image -- stop behind the last surface.
+ *   bounds_dev: emf_hip_raycastFarBoundBytes(nmodels, width, height) bytes
+ * emf_hip_rebuildSignMaps recomputes a volume's maps from its values (needed after anything but the
+ * tile integration launches wrote the tsdf: uploads, emf_hip_copyValues, the one-voxel-per-lane
+ * kernels, emf_hip_updateTSDF). */
+size_t emf_hip_signMapBytes(const int32_t res[3]);
+int emf_hip_rebuildSignMaps(const float* tsdf, const int32_t res[3], uint8_t* signMaps, emf_stream_t stream);
+size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height);
+int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                             const int32_t* res_host, int nmodels, int width, int height, const float K[9],
+                             float* bounds_dev, emf_stream_t stream);
 
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera

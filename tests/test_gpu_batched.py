@@ -92,6 +92,7 @@ class Model:
         self.d_vert = dev_full((H, W, 3), 0.0)
         self.d_nrm = dev_full((H, W, 3), 0.0)
         self.d_hit = dev_full((H, W), 0, np.uint8)
+        self.d_sign = None  # sign maps (far bounds of the raycast), set by the tests that use them
 
     @property
     def trunc(self):
@@ -118,7 +119,7 @@ class Model:
             float(self.vox), float(self.trunc), MAXW, SIGMA, ALPHA, PRIOR, model_id=self.id,
             fg_probs=self.d_probs if self.is_obj else None,
             fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags,
-            rcp_voxel=self.ops.voxel_reciprocal(self.vox))
+            rcp_voxel=self.ops.voxel_reciprocal(self.vox), sign_maps=self.d_sign)
 
 
 @pytest.fixture(scope="module")
@@ -253,6 +254,101 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
                                  ["ray", "vert", "normal", "mask"]):
             assert_parity(to_np(got), w_, f"{name} model {m.id}", exact=True)
     assert int(to_np(st)[0]) == total
+
+
+def tile_sign_maps(tsdf):
+    """numpy restatement of the sign maps: per 32 x 8 x 8 tile, any tsdf > 0 / any tsdf < 0."""
+    nz, ny, nx = tsdf.shape
+    tz, ty, tx = -(-nz // 8), -(-ny // 8), -(-nx // 32)
+    pad = np.zeros((tz * 8, ty * 8, tx * 32), np.float32)
+    pad[:nz, :ny, :nx] = tsdf
+    t = pad.reshape(tz, 8, ty, 8, tx, 32)
+    return np.concatenate([(t > 0).any(axis=(1, 3, 5)).reshape(-1), (t < 0).any(axis=(1, 3, 5)).reshape(-1)]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("view", ["path", "turned", "inside", "far_side", "grazing"])
+def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, scene, dev, view):
+    """emf_hip_raycastFarBounds + the cut in the march: every output equals the oracle's full march bit
+    for bit from all kinds of viewpoints, with fewer samples taken; the rebuilt sign maps equal their
+    numpy restatement."""
+    cam = {"path": camera_path(4),
+           "turned": Pose(rot([0, 1, 0], 38) @ rot([1, 0, 0], -11), [0.35, -0.1, 0.2]),
+           "inside": Pose(rot([0.3, 1, 0], 160), [0.1, 0.05, 1.1]),       # inside the background volume, looking back
+           "far_side": Pose(rot([0, 1, 0], 180), [0.0, 0.0, 3.2]),         # behind everything, looking at the back sides
+           "grazing": Pose(rot([0, 1, 0], 89.5), [-1.2, 0.0, 1.0])}[view]  # along the volume's faces
+    for m in scene:
+        m.d_sign = dev_full((ops.sign_map_bytes(m.res),), 7, np.uint8)
+        ops.rebuild_sign_maps(m.d_tsdf, m.d_sign)
+        assert np.array_equal(to_np(m.d_sign), tile_sign_maps(m.tsdf)), m.id
+    try:
+        table = ops.upload_models([m.table_entry() for m in scene])
+        poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
+        res = [m.res for m in scene]
+        bounds = ops.raycast_far_bounds(table, poses, res, W, H, K)
+        st_cut, st_full = dev_full((4,), 0, np.uint64), dev_full((4,), 0, np.uint64)
+        ops.raycast_batched(table, poses, res, W, H, K, stats=st_full)
+        full = [[to_np(a).copy() for a in (m.d_ray, m.d_vert, m.d_nrm, m.d_hit)] for m in scene]
+        ops.raycast_batched(table, poses, res, W, H, K, stats=st_cut, far_bounds=bounds)
+        hits = 0
+        for m, (R, t), f in zip(scene, poses, full):
+            want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t, K, m.vox, m.trunc)
+            hits += int(want[3].sum())
+            for got, w_, f_, name in zip([m.d_ray, m.d_vert, m.d_nrm, m.d_hit], want, f, ["ray", "vert", "normal", "mask"]):
+                assert_parity(to_np(got), w_, f"{view}: {name} model {m.id}", exact=True)
+                assert to_np(got).tobytes() == f_.tobytes()
+        b = to_np(bounds)
+        assert b.shape == (len(scene), 2 * ((H + 15) // 16), 2 * ((W + 15) // 16)) and np.isfinite(b).all() and (b >= 0).all()
+        cut, whole = int(to_np(st_cut)[0]), int(to_np(st_full)[0])
+        assert cut <= whole
+        if view in ("path", "turned"):
+            assert hits > 1000  # (volumes this small lie within reach of their surfaces almost everywhere:
+            #                      the saving is checked at full size, tests/test_gpu_fullsize.py)
+        # a model without sign maps keeps its whole range
+        scene[1].d_sign = None
+        table = ops.upload_models([m.table_entry() for m in scene])
+        b2 = to_np(ops.raycast_far_bounds(table, poses, res, W, H, K))
+        assert np.isinf(b2[1]).all() and np.array_equal(b2[0], b[0]) and np.array_equal(b2[2], b[2])
+    finally:
+        for m in scene:
+            m.d_sign = None
+
+
+def test_sign_maps_kept_by_the_integration_cover_the_exact_ones(ops, oracle, dev):
+    """The tile integration launches (in place and out of place) leave sticky sign maps behind that are
+    never short of a sign that is in the volume."""
+    shapes = [((96, 64, 72), 0.035, Pose(t=[0, 0, 1.28]), False), ((32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True)]
+    a = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    b = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    b2 = [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    for m in a + b + b2:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    for m in a + b:
+        m.d_sign = dev_full((ops.sign_map_bytes(m.res),), 0, np.uint8)
+    for x, y in zip(b, b2):
+        y.d_sign = x.d_sign  # the two copies of a volume share one pair of maps
+    maps = [[dev_full((ops.integrate_dirty_map_bytes(r),), 0, np.uint8) for _ in range(2)] for r, _, _, _ in shapes]
+    visible = dev_full((2,), 1, np.int32)
+    front, back = b, b2
+    for i in range(5):
+        base, depth, _ = frame(i)
+        cam = Pose(base.R @ rot([0, 1, 0], [0, 25, -20, 0, 8][i]), base.t)
+        poses = []
+        for k, m in enumerate(a):
+            oc = rel_OC(cam, m.pose)
+            poses.append((oc.R32, oc.t32))
+        d_depth = to_dev(depth)
+        res = [m.res for m in a]
+        ops.integrate_batched_culled(ops.upload_models([m.table_entry() for m in a]), poses, res, visible, d_depth, K)
+        outs = [(bk.d_tsdf, bk.d_wts, mp[i % 2], mp[1 - i % 2]) for bk, mp in zip(back, maps)]
+        ops.integrate_batched_culled_out(ops.upload_models([m.table_entry() for m in front]), poses, res, visible, d_depth, K, outs)
+        dev.synchronize()
+        front, back = back, front
+        for m, f in zip(a, front):
+            exact = tile_sign_maps(to_np(m.d_tsdf))
+            assert exact.sum() > 0
+            for got, name in ((to_np(m.d_sign), "in place"), (to_np(f.d_sign), "out of place")):
+                assert ((got != 0) | (exact == 0)).all(), (i, m.id, name)  # got covers exact
+                assert got.sum() <= exact.sum() + 0.2 * exact.size       # ... without being everything
 
 
 @pytest.mark.parametrize("table", [False, True], ids=["inline", "table"])

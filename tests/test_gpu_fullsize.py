@@ -101,6 +101,7 @@ def bench_scene(dev):
         for k, v in (env or {}).items():
             os.environ[k] = v
         fus = pipeline.Fusion(prm, None)
+        fus.enable_raycast_stats(True)
         ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(4)]
         for f in range(6):
             depth, sid = synth.render(f)
@@ -110,7 +111,8 @@ def bench_scene(dev):
             d = to_dev(depth)
             fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, f == 0)
             fus.synchronize()
-        out = dict(bg_t=fus.volume("tsdf", 0), bg_w=fus.volume("weights", 0),
+        out = dict(samples=fus.raycast_stats()[0],
+                   bg_t=fus.volume("tsdf", 0), bg_w=fus.volume("weights", 0),
                    obj_t={i: fus.volume("tsdf", i) for i in ids}, ray=fus.image("raylengths"),
                    seg=fus.image("segmentation"), norm=fus.image("assoc_norm"), bg_a=fus.image("bg_assoc"),
                    obj_a={i: fus.image("obj_assoc", i) for i in ids},
@@ -130,10 +132,15 @@ def test_full_size_frame_is_repeatable_and_path_independent(bench_scene):
     per_volume = bench_scene["run"]({"EMF_PER_VOLUME": "1"})
     divide = bench_scene["run"]({"EMF_VOXEL_RCP": "0", "EMF_LAMBDA_TABLE": "0"})
     in_place = bench_scene["run"]({"EMF_BG_OVERLAP": "0"})
+    no_bounds = bench_scene["run"]({"EMF_FAR_BOUNDS": "0"})
+    # the far bounds drop march samples, never an output
+    assert base["samples"] < no_bounds["samples"], (base["samples"], no_bounds["samples"])
+    assert per_volume["samples"] == no_bounds["samples"]
     for other, what in ((again, "second run"), (per_volume, "per-volume launches"),
                         (divide, "IEEE divisions, inline 1/lambda"),
                         (in_place, "background integrated in place after the raycast instead of out of "
-                                   "place beside it")):
+                                   "place beside it"),
+                        (no_bounds, "every ray marched to the end of its range (no far bounds)")):
         for key in ("bg_t", "bg_w", "ray", "seg"):
             assert base[key].tobytes() == other[key].tobytes(), (what, key)
         for i in base["ids"]:
