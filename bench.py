@@ -415,17 +415,23 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
     if copy_gbs:
         roof["frac_of_copy"] = round(dom["achieved_GBs"] / copy_gbs, 4)
     # SURVEY 8(d) headline for the streaming part: algorithmic integrate bytes over integrate time
-    integ = next((r for r in rows if r["kind"] == "integrate"), None)
+    integ = next((r for r in rows if r["kind"] == "integrate_bg"), None)
+    overlapped = integ is not None  # the background's integration runs beside the raycast on a second stream
+    if integ is None:
+        integ = next((r for r in rows if r["kind"] == "integrate"), None)
     if integ:
         roof["integrate_stream"] = {
+            "kernel": integ["kernel"], "concurrent_with_raycast": overlapped,
             "achieved": integ["achieved_GBs"], "unit": "GB/s",
             "frac": round(integ["achieved_GBs"] / HBM_PEAK_GBS, 4),
             "frac_of_copy": round(integ["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
             "avg_launch_ms": integ["avg_ms"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"],
-            "traffic": measured_traffic("integrate") if profiled else None,
+            "traffic": measured_traffic(integ["kind"]) if profiled else None,
             "note": "alg_bytes = 16 B x every voxel of the integrated volumes (SURVEY 8d); boxes outside "
                     "the view cone are culled before they are touched, so the model rate can exceed the "
-                    "HBM peak -- `traffic` is what really moves",
+                    "HBM peak -- `traffic` is what really moves.  With concurrent_with_raycast the launch "
+                    "shares the chip with k_raycast (its duration is that of the contended run; alone it "
+                    "takes ~0.23 ms, EMF_BG_OVERLAP=0)",
         }
     if dom["kind"] == "raycast":
         roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)

@@ -12,7 +12,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_integrate_listed_rest", "integrate_rest"),
+                     ("k_integrate_listed<true>", "integrate_bg"), ("k_integrate_listed<(bool)1>", "integrate_bg"),
                      ("k_integrate_listed", "integrate"), ("k_integrate_cull", "integrate_cull"),
+                     ("k_far_bounds", "far_bounds"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
+                     ("k_deep_ones", "deep_ones"),
                      ("k_integrate_batched", "integrate"),
                      ("k_estep", "assoc"), ("k_composite", "composite"), ("k_vis_counts", "vis_counts"),
                      ("k_vis_flags", "vis_flags"), ("k_dilate_batched", "dilate_flags"),
