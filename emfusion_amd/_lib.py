@@ -64,7 +64,9 @@ SIGNATURES = {
     "emf_hip_signMapBytes": [_I3],
     "emf_hip_rebuildSignMaps": [_FP, _I3, _FP, _STREAM],
     "emf_hip_raycastFarBoundBytes": [C.c_int, C.c_int, C.c_int],
-    "emf_hip_raycastFarBounds": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, _FP, _STREAM],
+    "emf_hip_raycastFarBounds": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _STREAM],
+    "emf_hip_relevantTileBytes": [_I3],
+    "emf_hip_updateRelevantTiles": [_FP, _I3, C.c_int, _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
     "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],
@@ -115,7 +117,7 @@ class EmfModel(C.Structure):
                 ("fgProbs", C.c_void_p), ("fgVolMask", C.c_void_p), ("brickFlags", C.c_void_p),
                 ("assoc", C.c_void_p), ("raylengths", C.c_void_p), ("vertices", C.c_void_p),
                 ("normals", C.c_void_p), ("hitMask", C.c_void_p), ("signMaps", C.c_void_p),
-                ("res", C.c_int32 * 3),
+                ("relevantTiles", C.c_void_p), ("res", C.c_int32 * 3),
                 ("id", C.c_int32), ("voxelSize", C.c_float), ("truncdist", C.c_float),
                 ("maxWeight", C.c_float), ("assocC1", C.c_float), ("assocC2", C.c_float),
                 ("alpha", C.c_float), ("assocC3", C.c_float), ("reserved", C.c_int32),
@@ -181,6 +183,7 @@ def load() -> C.CDLL:
     lib.emf_hip_integrateDirtyMapBytes.restype = C.c_size_t
     lib.emf_hip_signMapBytes.restype = C.c_size_t
     lib.emf_hip_raycastFarBoundBytes.restype = C.c_size_t
+    lib.emf_hip_relevantTileBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     _lib = lib

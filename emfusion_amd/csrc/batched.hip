@@ -326,17 +326,10 @@ __global__ __launch_bounds__(256) void k_far_init(const FarBoundArgs a) {
     a.bounds[i] = a.models[i / cells].signMaps ? 0.f : __builtin_inff();
 }
 
-__global__ __launch_bounds__(256) void k_far_bounds(const FarBoundArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.tileStart[a.nmodels]) return;
-    int m = 0;
-    while (m + 1 < a.nmodels && i >= a.tileStart[m + 1]) ++m;
-    const emf_model_t& md = a.models[m];
-    if (!md.signMaps) return;
-    const I3 n = I3{md.res[0], md.res[1], md.res[2]};
-    const int ntx = (n.x + kTileX - 1) / kTileX, nty = (n.y + kTileY - 1) / kTileY, ntz = (n.z + kTileZ - 1) / kTileZ;
-    const int t = i - a.tileStart[m];
-    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+// Is tile (tx, ty, tz) of model md one in which a hit can be completed?  (see above)
+__device__ __forceinline__ bool tile_relevant(const emf_model_t& md, int tx, int ty, int tz) {
+    const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY,
+              ntz = (md.res[2] + kTileZ - 1) / kTileZ;
     const uint8_t* pos = md.signMaps;
     const uint8_t* neg = pos + static_cast<size_t>(ntx) * nty * ntz;
     auto any_in = [&](const uint8_t* map, int rx, int ry, int rz) {
@@ -349,11 +342,16 @@ __global__ __launch_bounds__(256) void k_far_bounds(const FarBoundArgs a) {
     };
     // the negative corner is in the sample's own cell (base voxel in this tile, corners up to +1): this
     // tile or a direct neighbour
-    if (!any_in(neg, 1, 1, 1)) return;
+    if (!any_in(neg, 1, 1, 1)) return false;
     // the positive corner belongs to the previous sample: one step back (<= truncdist), two where the
     // hit test re-used an older sample (march_wave.hpp), plus the cells' own extent
     const int reach = 2 * static_cast<int>(ceilf(md.truncdist / md.voxelSize)) + 4;
-    if (!any_in(pos, (reach + kTileX - 1) / kTileX, (reach + kTileY - 1) / kTileY, (reach + kTileZ - 1) / kTileZ)) return;
+    return any_in(pos, (reach + kTileX - 1) / kTileX, (reach + kTileY - 1) / kTileY, (reach + kTileZ - 1) / kTileZ);
+}
+
+// Project tile (tx, ty, tz) into the image and raise the far bound of the cells it may cover.
+__device__ __forceinline__ void raise_far_bounds(const FarBoundArgs& a, int m, const emf_model_t& md, int tx, int ty, int tz) {
+    const I3 n = I3{md.res[0], md.res[1], md.res[2]};
     // the tile's sample positions in the camera frame: voxel box widened by 1.5 voxels (a cell's far
     // corners, rounding of the march's position arithmetic)
     const M33 R = pose_R(a.poses.p[m]);
@@ -394,7 +392,130 @@ __global__ __launch_bounds__(256) void k_far_bounds(const FarBoundArgs a) {
     const unsigned bits = __float_as_uint(far * 1.0001f + 2.f * md.voxelSize);
     unsigned* cells = reinterpret_cast<unsigned*>(a.bounds) + static_cast<size_t>(m) * a.cellsX * a.cellsY;
     for (int y = cy0; y <= cy1; ++y)
-        for (int x = cx0; x <= cx1; ++x) atomicMax(&cells[y * a.cellsX + x], bits);  // positive floats order as integers
+        for (int x = cx0; x <= cx1; ++x) {
+            unsigned* c = &cells[y * a.cellsX + x];
+            // positive floats order as integers; most tiles raise nothing (plain read first: an atomic
+            // is a trip to L2 and back whether or not it changes the value)
+            if (__builtin_nontemporal_load(c) < bits) atomicMax(c, bits);
+        }
+}
+
+// one thread per tile of every model WITHOUT a relevant-tile list (emf_model_t.relevantTiles == NULL)
+__global__ __launch_bounds__(256) void k_far_bounds(const FarBoundArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.tileStart[a.nmodels]) return;
+    int m = 0;
+    while (m + 1 < a.nmodels && i >= a.tileStart[m + 1]) ++m;
+    const emf_model_t& md = a.models[m];
+    if (!md.signMaps || md.relevantTiles) return;
+    const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY;
+    const int t = i - a.tileStart[m];
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    if (tile_relevant(md, tx, ty, tz)) raise_far_bounds(a, m, md, tx, ty, tz);
+}
+
+// models WITH a list (emf_hip_updateRelevantTiles, after each integration): one WAVE per listed tile -- a few
+// thousand tiles instead of a neighbourhood scan around every tile of the volume.  Lanes 0..7 project the
+// tile's corners, then the 64 lanes share the cells of its footprint (a tile covers some tens of cells:
+// one lane walking them alone pays an L2 round trip per cell, 260 us per launch when 8 workgroups did it).
+constexpr int kFarListBlocks = 512;  // x 4 waves per model; the list is walked with that stride (64: 36 us for 3300 tiles)
+__global__ __launch_bounds__(256) void k_far_bounds_listed(const FarBoundArgs a) {
+    const int m = blockIdx.x / kFarListBlocks;
+    const emf_model_t& md = a.models[m];
+    if (!md.signMaps || !md.relevantTiles) return;
+    const unsigned count = md.relevantTiles[0];
+    const I3 n = I3{md.res[0], md.res[1], md.res[2]};
+    const int ntx = (n.x + kTileX - 1) / kTileX, nty = (n.y + kTileY - 1) / kTileY;
+    const M33 R = pose_R(a.poses.p[m]);
+    const V3 cam = pose_t(a.poses.p[m]);
+    const V3 half = half_extent(n);
+    const int lane = threadIdx.x & 63;
+    unsigned* cells = reinterpret_cast<unsigned*>(a.bounds) + static_cast<size_t>(m) * a.cellsX * a.cellsY;
+    for (unsigned e = (blockIdx.x % kFarListBlocks) * 4u + (threadIdx.x >> 6); e < count; e += kFarListBlocks * 4u) {
+        const int t = static_cast<int>(md.relevantTiles[1 + e]);
+        const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+        // corner (lane & 7) of the tile's voxel box widened by 1.5 voxels (a cell's far corners, rounding
+        // of the march's position arithmetic), in the camera frame; all lanes compute one (lanes 8.. repeat)
+        const int k = lane & 7;
+        const float ix = (k & 1) ? static_cast<float>(min((tx + 1) * kTileX, n.x)) + 1.5f : static_cast<float>(tx * kTileX) - 1.5f;
+        const float iy = (k & 2) ? static_cast<float>(min((ty + 1) * kTileY, n.y)) + 1.5f : static_cast<float>(ty * kTileY) - 1.5f;
+        const float iz = (k & 4) ? static_cast<float>(min((tz + 1) * kTileZ, n.z)) + 1.5f : static_cast<float>(tz * kTileZ) - 1.5f;
+        const V3 q = v3((ix - half.x) * md.voxelSize, (iy - half.y) * md.voxelSize, (iz - half.z) * md.voxelSize);
+        const V3 d = v3(q.x - cam.x, q.y - cam.y, q.z - cam.z);
+        const V3 c = v3(R.r0.x * d.x + R.r1.x * d.y + R.r2.x * d.z, R.r0.y * d.x + R.r1.y * d.y + R.r2.y * d.z,
+                        R.r0.z * d.x + R.r1.z * d.y + R.r2.z * d.z);  // R^T d
+        const bool behind = !(c.z > 1e-2f * md.voxelSize);  // at or behind the camera plane: cover the whole image
+        float far = norm(d);
+        float umin = behind ? 3e38f : a.fx * c.x / c.z + a.cx, umax = behind ? -3e38f : umin;
+        float vmin = behind ? 3e38f : a.fy * c.y / c.z + a.cy, vmax = behind ? -3e38f : vmin;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {  // over the 8 corners (every group of 8 lanes holds all of them)
+            far = fmaxf(far, __shfl_xor(far, o));
+            umin = fminf(umin, __shfl_xor(umin, o));
+            umax = fmaxf(umax, __shfl_xor(umax, o));
+            vmin = fminf(vmin, __shfl_xor(vmin, o));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        }
+        const bool wide = __ballot(behind) != 0ull;
+        int cx0 = 0, cx1 = a.cellsX - 1, cy0 = 0, cy1 = a.cellsY - 1;
+        if (!wide) {
+            if (!(umax >= -2.f && vmax >= -2.f && umin <= static_cast<float>(a.w) + 1.f && vmin <= static_cast<float>(a.h) + 1.f))
+                continue;  // projects beside the image (wave-uniform)
+            cx0 = max(static_cast<int>(floorf((umin - 2.f) / 8.f)), 0);
+            cy0 = max(static_cast<int>(floorf((vmin - 2.f) / 8.f)), 0);
+            cx1 = min(static_cast<int>(floorf((fminf(umax, 1e6f) + 2.f) / 8.f)), a.cellsX - 1);
+            cy1 = min(static_cast<int>(floorf((fminf(vmax, 1e6f) + 2.f) / 8.f)), a.cellsY - 1);
+        }
+        // raylength of a sample = its distance from the camera (unit direction): a relative and an absolute margin
+        const unsigned bits = __float_as_uint(far * 1.0001f + 2.f * md.voxelSize);
+        const int wdt = cx1 - cx0 + 1, cnt = wdt * (cy1 - cy0 + 1);
+        for (int i = lane; i < cnt; i += 64) {
+            unsigned* cp = &cells[(cy0 + i / wdt) * a.cellsX + cx0 + i % wdt];
+            if (__builtin_nontemporal_load(cp) < bits) atomicMax(cp, bits);  // positive floats order as integers
+        }
+    }
+}
+
+// (re)build the relevant-tile lists from the sign maps; the counts must be zero (emf_hip_updateRelevantTiles)
+struct RelevantArgs {
+    const emf_model_t* models;
+    int nmodels;
+    int tileStart[EMF_MAX_BATCH + 1];
+};
+__global__ __launch_bounds__(256) void k_relevant_tiles(const RelevantArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    int m = 0, t = 0;
+    if (i < a.tileStart[a.nmodels]) {
+        while (m + 1 < a.nmodels && i >= a.tileStart[m + 1]) ++m;
+        const emf_model_t& md = a.models[m];
+        if (md.signMaps && md.relevantTiles) {
+            const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY;
+            t = i - a.tileStart[m];
+            keep = tile_relevant(md, t % ntx, (t / ntx) % nty, t / (ntx * nty));
+        }
+    }
+    // a wave may straddle two models: append per lane group with one atomic per (wave, model)
+    while (true) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask == 0ull) break;
+        const int lead = __ffsll(static_cast<long long>(mask)) - 1;
+        const int mLead = __shfl(m, lead);
+        const bool mineNow = keep && m == mLead;
+        const unsigned long long grp = __ballot(mineNow);
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == lead) base = atomicAdd(&a.models[mLead].relevantTiles[0], static_cast<unsigned>(__popcll(grp)));
+        base = __shfl(base, lead);
+        if (mineNow) {
+            a.models[m].relevantTiles[1 + base + __popcll(grp & ((1ull << lane) - 1ull))] = static_cast<unsigned>(t);
+            keep = false;
+        }
+    }
+}
+__global__ void k_relevant_reset(const emf_model_t* models, int nmodels) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nmodels && models[m].relevantTiles) models[m].relevantTiles[0] = 0;
 }
 
 // exact rebuild of a volume's sign maps from its values (after anything but the tile integration wrote them)
@@ -787,7 +908,7 @@ size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height) {
 }
 
 int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, const int32_t* res_host,
-                             int nmodels, int width, int height, const float K[9], float* bounds_dev,
+                             int nmodels, int width, int height, const float K[9], int scanAll, float* bounds_dev,
                              emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastFarBounds"));
     EMF_REQUIRE_PTR(res_host);
@@ -815,8 +936,34 @@ int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* po
     a.cy = K[5];
     a.bounds = bounds_dev;
     hipLaunchKernelGGL(k_far_init, dim3(ceil_div(nmodels * a.cellsX * a.cellsY, 256)), dim3(256), 0, as_stream(stream), a);
-    hipLaunchKernelGGL(k_far_bounds, dim3(ceil_div(a.tileStart[nmodels], 256)), dim3(256), 0, as_stream(stream), a);
+    if (scanAll)  // some model has sign maps but no relevant-tile list (the caller knows; the kernel checks per model)
+        hipLaunchKernelGGL(k_far_bounds, dim3(ceil_div(a.tileStart[nmodels], 256)), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_far_bounds_listed, dim3(nmodels * kFarListBlocks), dim3(256), 0, as_stream(stream), a);
     return launch_status("raycastFarBounds");
+}
+
+size_t emf_hip_relevantTileBytes(const int32_t res[3]) {
+    if (!res || res[0] < 1 || res[1] < 1 || res[2] < 1) return 0;
+    return (1 + emf_hip_signMapBytes(res) / 2) * sizeof(uint32_t);
+}
+
+int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* res_host, int nmodels, emf_stream_t stream) {
+    if (!models_dev) return fail(EMF_E_NULL, "updateRelevantTiles: models_dev is NULL");
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH) return fail(EMF_E_LIMIT, "updateRelevantTiles: nmodels = %d", nmodels);
+    EMF_REQUIRE_PTR(res_host);
+    RelevantArgs a;
+    a.models = models_dev;
+    a.nmodels = nmodels;
+    a.tileStart[0] = 0;
+    for (int m = 0; m < nmodels; ++m) {
+        EMF_TRY(check_res(res_host + 3 * m));
+        const size_t tiles = emf_hip_signMapBytes(res_host + 3 * m) / 2;
+        if (tiles > static_cast<size_t>(0x7fffffff - a.tileStart[m])) return fail(EMF_E_LIMIT, "updateRelevantTiles: too many tiles");
+        a.tileStart[m + 1] = a.tileStart[m] + static_cast<int>(tiles);
+    }
+    hipLaunchKernelGGL(k_relevant_reset, dim3(1), dim3(64), 0, as_stream(stream), models_dev, nmodels);
+    hipLaunchKernelGGL(k_relevant_tiles, dim3(ceil_div(a.tileStart[nmodels], 256)), dim3(256), 0, as_stream(stream), a);
+    return launch_status("updateRelevantTiles");
 }
 
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,

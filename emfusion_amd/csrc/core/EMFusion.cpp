@@ -237,7 +237,8 @@ void EMFusion::createObj(int id) {
 void EMFusion::rebuildModelTable() {
     modelsHost.clear();
     resHost.clear();
-    if (bgInFlight) aux.waitForCompletion();
+    aux.waitForCompletion();  // the background's integration / the list rebuild may still be running there
+    listsOnAux = false;
     if (useFarBounds) {  // sign maps that something other than the tile integration made stale
         background.refreshSignMaps();
         for (auto& obj : objects) obj.refreshSignMaps();
@@ -305,6 +306,12 @@ void EMFusion::rebuildModelTable() {
         hipCheck(hipMemcpy(visibleDev.data(), vis.data(), vis.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice),
                  "visibility upload");
+        if (useFarBounds) {  // lists of new / rebuilt sign maps
+            emfCheck(emf_hip_updateRelevantTiles(modelTable.as<emf_model_t>(), resHost.data(),
+                                                 static_cast<int>(modelsHost.size()), Stream::Null().abi()),
+                     "updateRelevantTiles");
+            Stream::Null().waitForCompletion();
+        }
     }
 }
 
@@ -432,6 +439,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         else applyObjectPoses();
         computeAssociationWeights();
         stamp(kEstep);
+        computeFarBounds();
         integrateBackgroundAsync();  // runs beside the raycast (see there)
         raycast();
     } else {
@@ -1083,13 +1091,8 @@ void EMFusion::raycastBatched() {
         // the bands are then gathered (1.5 MB at VGA).  Background vertices / normals stay
         // band-local: like the remote objects' they only feed rendering.
         const int band = sharded && bgBands ? bgBandRows(h, world) : 0;
-        const float* far = nullptr;
-        if (!farBounds.empty() && !flags) {
-            emfCheck(emf_hip_raycastFarBounds(table, co.data(), resHost.data(), n, w, h, params.intr.val,
-                                              farBounds.as<float>(), main.abi()),
-                     "raycastFarBounds");
-            far = farBounds.as<float>();
-        }
+        const float* far = farBoundsReady && !flags ? farBounds.as<float>() : nullptr;
+        farBoundsReady = false;
         emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
                                         flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
                                         band, far, stats, main.abi()),
@@ -1101,6 +1104,24 @@ void EMFusion::raycastBatched() {
     }
     stamp(kRaycast);
     compositeAndVisibility(true);
+}
+
+// Far bounds of this frame's raycast (poses are final): BEFORE the background's integration is forked --
+// that one ends by rebuilding the background's relevant-tile list, which this launch reads.
+void EMFusion::computeFarBounds() {
+    farBoundsReady = false;
+    if (!batched || farBounds.empty() || TSDF::brickFlagMode() != 0) return;
+    if (listsOnAux) {  // last frame's list rebuild
+        main.waitFor(aux);
+        listsOnAux = false;
+    }
+    std::vector<emf_pose_t> co;
+    posesCO(co);
+    emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
+                                      params.frameSize.width, params.frameSize.height, params.intr.val, 0,
+                                      farBounds.as<float>(), main.abi()),
+             "raycastFarBounds");
+    farBoundsReady = true;
 }
 
 bool EMFusion::overlapUsable() const {
@@ -1131,13 +1152,14 @@ void EMFusion::integrateBackgroundAsync() {
                                                bgCullScratch.data(), 0, nullptr,
                                                integrateStatsDev.as<uint64_t>(), aux.abi()),
              "integrateBatchedCulledOut");
+    aux.record();  // what joinBackground() waits for
     bgInFlight = true;
 }
 
 // Join: the frame's later stages (and the next frame) see the integrated background.
 void EMFusion::joinBackground() {
     if (!bgInFlight) return;
-    main.waitFor(aux);
+    main.waitOn(aux);  // the record() after the integration kernels
     background.flip();
     tableSel ^= 1;
     bgInFlight = false;
@@ -1172,7 +1194,17 @@ void EMFusion::integrateBatched() {
                      "integrateBatched");
         }
     }
+    const bool overlapped = bgInFlight;
     joinBackground();
+    if (useFarBounds && !farBounds.empty()) {
+        // The sign maps may have grown: rebuild the relevant-tile lists the NEXT frame's far bounds read.
+        // Nothing of this frame needs them, so with the second stream in use they go there -- behind
+        // both integrations -- and the next computeFarBounds() waits for that stream.
+        Stream& s = overlapped ? aux : main;
+        if (overlapped) aux.waitFor(main);
+        emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), n, s.abi()), "updateRelevantTiles");
+        listsOnAux = overlapped;
+    }
 }
 
 // Compositing in list (creation) order + visibility counts (reference EMFusion.cpp:760-794).

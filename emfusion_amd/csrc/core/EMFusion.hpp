@@ -377,6 +377,9 @@ private:
     // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
     bool useFarBounds = true;
     DeviceBuffer farBounds;
+    bool farBoundsReady = false;
+    bool listsOnAux = false;  // the relevant-tile lists are being rebuilt on `aux` (wait before reading them)
+    void computeFarBounds();
     DeviceBuffer bgCullScratch;     // box list of the background's own launch
     bool overlapUsable() const;
     void integrateBackgroundAsync();  // fork: enqueue on aux what integrateDepth() would do for slot 0

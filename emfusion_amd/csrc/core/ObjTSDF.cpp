@@ -127,6 +127,7 @@ Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& 
     brickFlags.setZero(stream);  // every brick "mixed": always correct; integrate() refines them
     signMaps = DeviceBuffer();   // new resolution, shifted values: rebuilt by refreshSignMaps()
     signMapsValid = false;
+    relevantTiles = DeviceBuffer();
     computeFgProbs(stream);
     return newCenter;
 }

@@ -38,9 +38,12 @@ void TSDF::reset(const Affine3f& _pose) {
         if (signMaps.empty()) signMaps = DeviceBuffer(emf_hip_signMapBytes(volumeRes.val));
         signMaps.setZero(s);
         signMapsValid = true;
+        if (relevantTiles.empty()) relevantTiles = DeviceBuffer(emf_hip_relevantTileBytes(volumeRes.val));
+        relevantTiles.setZero(s);  // count 0: nothing can be hit in an empty volume
     } else {
         signMaps = DeviceBuffer();
         signMapsValid = false;
+        relevantTiles = DeviceBuffer();
     }
     if (doubleBuffered()) {  // equal copies, clean maps
         tsdfBack.setZero(s);
@@ -59,6 +62,9 @@ void TSDF::refreshSignMaps(Stream& stream) {
     emfCheck(emf_hip_rebuildSignMaps(tsdfVol.as<float>(), volumeRes.val, signMaps.as<uint8_t>(), stream.abi()),
              "TSDF::refreshSignMaps");
     signMapsValid = true;
+    const size_t rb = emf_hip_relevantTileBytes(volumeRes.val);
+    if (relevantTiles.empty() || relevantTiles.bytes() != rb) relevantTiles = DeviceBuffer(rb);
+    relevantTiles.setZero(stream);  // the owner rebuilds the list (emf_hip_updateRelevantTiles) before it is used
 }
 
 void TSDF::enableDoubleBuffer() {
@@ -200,6 +206,7 @@ void TSDF::describe(emf_model_t& m) const {
     m.reserved = mode == 2 ? 2 : 0;
     m.rcpVoxel = rcpVoxel;
     m.signMaps = signMapsValid && !signMaps.empty() ? signMaps.as<uint8_t>() : nullptr;
+    m.relevantTiles = m.signMaps && !relevantTiles.empty() ? relevantTiles.as<uint32_t>() : nullptr;
     m.pad_ = 0;
 }
 

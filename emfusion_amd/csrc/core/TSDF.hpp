@@ -146,6 +146,7 @@ protected:
     DeviceBuffer dirtyMaps[2];
     DeviceBuffer signMaps;      // per 32x8x8 tile: holds a positive tsdf / holds a negative tsdf
     bool signMapsValid = false;
+    DeviceBuffer relevantTiles; // count + indices of the tiles in which a raycast hit can be completed
     int dirtyPrev = 0;  // index of the map the last out-of-place integration wrote
 };
 

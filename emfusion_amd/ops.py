@@ -240,7 +240,7 @@ def device_info():
 
 def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, voxel_size,
                truncdist, max_weight, sigma, alpha, uni_prior, model_id=0, grads=None,
-               fg_probs=None, fg_mask=None, brick_flags=None, rcp_voxel=0.0, sign_maps=None) -> "_lib.EmfModel":
+               fg_probs=None, fg_mask=None, brick_flags=None, rcp_voxel=0.0, sign_maps=None, relevant_tiles=None) -> "_lib.EmfModel":
     """Fill an emf_model_t from device arrays (images must be unpadded)."""
     f32 = np.float32
     m = _lib.EmfModel()
@@ -250,6 +250,7 @@ def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, vo
     m.fgVolMask = fg_mask.ptr if fg_mask is not None else None
     m.brickFlags = brick_flags.ptr if brick_flags is not None else None
     m.signMaps = sign_maps.ptr if sign_maps is not None else None
+    m.relevantTiles = relevant_tiles.ptr if relevant_tiles is not None else None
     for name, im in (("assoc", assoc), ("raylengths", raylengths), ("vertices", vertices),
                      ("normals", normals), ("hitMask", hit_mask)):
         assert not im.padded
@@ -327,9 +328,19 @@ def raycast_far_bounds(models_dev, poses_co, res_list, width, height, K, bounds=
         assert int(_L.emf_hip_raycastFarBoundBytes(n, width, height)) == 4 * n * cy * cx
         bounds = DeviceArray.zeros((n, cy, cx), np.float32)
     check("emf_hip_raycastFarBounds",
-          _L.emf_hip_raycastFarBounds(_ptr(models_dev), _poses(poses_co), res, n, width, height, _f(K, 9),
+          _L.emf_hip_raycastFarBounds(_ptr(models_dev), _poses(poses_co), res, n, width, height, _f(K, 9), 1,
                                       _ptr(bounds), _stream(stream)))
     return bounds
+
+
+def relevant_tile_words(res) -> int:
+    return int(_L.emf_hip_relevantTileBytes((C.c_int32 * 3)(*[int(v) for v in res]))) // 4
+
+
+def update_relevant_tiles(models_dev, res_list, stream=None):
+    n = len(res_list)
+    res = (C.c_int32 * (3 * n))(*[int(v) for r in res_list for v in r])
+    check("emf_hip_updateRelevantTiles", _L.emf_hip_updateRelevantTiles(_ptr(models_dev), res, n, _stream(stream)))
 
 
 def integrate_batched(models_dev, poses_oc, res_list, visible, depth, K, stats=None, stream=None,

@@ -252,6 +252,7 @@ typedef struct emf_model {
     uint8_t* signMaps;      /* emf_hip_signMapBytes(res) bytes or NULL: per 32x8x8 tile "holds a positive
                              * tsdf", then per tile "holds a negative tsdf"; kept by the tile integration
                              * launches (sticky), read by emf_hip_raycastFarBounds */
+    uint32_t* relevantTiles; /* emf_hip_relevantTileBytes(res) bytes or NULL (emf_hip_updateRelevantTiles) */
     int32_t res[3];
     int32_t id;             /* 0 = background */
     float voxelSize, truncdist, maxWeight;
@@ -315,9 +316,20 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
 size_t emf_hip_signMapBytes(const int32_t res[3]);
 int emf_hip_rebuildSignMaps(const float* tsdf, const int32_t res[3], uint8_t* signMaps, emf_stream_t stream);
 size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height);
+/* scanAll != 0: models without a relevant-tile list (emf_model_t.relevantTiles == NULL) have every tile of
+ * their sign maps examined (a neighbourhood scan per tile: ~50 us for a 512^3 volume); 0: the caller
+ * guarantees that every model with sign maps also has a list. */
 int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                              const int32_t* res_host, int nmodels, int width, int height, const float K[9],
-                             float* bounds_dev, emf_stream_t stream);
+                             int scanAll, float* bounds_dev, emf_stream_t stream);
+/* The tiles in which a hit can be completed, as a list per model (emf_model_t.relevantTiles:
+ * emf_hip_relevantTileBytes(res) bytes: a count, then tile indices): rebuilt from the sign maps after an
+ * integration -- off the frame's critical path -- so that emf_hip_raycastFarBounds, which needs the
+ * camera pose of the frame and therefore sits right in front of the raycast, only has to project a
+ * few thousand tiles.  Models whose relevantTiles is NULL are skipped. */
+size_t emf_hip_relevantTileBytes(const int32_t res[3]);
+int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* res_host, int nmodels,
+                                emf_stream_t stream);
 
 /* Integration of all models in one launch (TSDF.cu:327-427 per model, EMFusion.cpp:865-875).
  *   poseOC_host[m]: volume m -> camera

@@ -93,6 +93,7 @@ class Model:
         self.d_nrm = dev_full((H, W, 3), 0.0)
         self.d_hit = dev_full((H, W), 0, np.uint8)
         self.d_sign = None  # sign maps (far bounds of the raycast), set by the tests that use them
+        self.d_rel = None   # relevant-tile list built from them
 
     @property
     def trunc(self):
@@ -119,7 +120,7 @@ class Model:
             float(self.vox), float(self.trunc), MAXW, SIGMA, ALPHA, PRIOR, model_id=self.id,
             fg_probs=self.d_probs if self.is_obj else None,
             fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags,
-            rcp_voxel=self.ops.voxel_reciprocal(self.vox), sign_maps=self.d_sign)
+            rcp_voxel=self.ops.voxel_reciprocal(self.vox), sign_maps=self.d_sign, relevant_tiles=self.d_rel)
 
 
 @pytest.fixture(scope="module")
@@ -298,6 +299,16 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
                 assert to_np(got).tobytes() == f_.tobytes()
         b = to_np(bounds)
         assert b.shape == (len(scene), 2 * ((H + 15) // 16), 2 * ((W + 15) // 16)) and np.isfinite(b).all() and (b >= 0).all()
+        # the same bounds from relevant-tile lists (what the host classes keep up to date after every integration)
+        for m in scene:
+            m.d_rel = dev_full((ops.relevant_tile_words(m.res),), 0xdead, np.uint32)
+        table = ops.upload_models([m.table_entry() for m in scene])
+        ops.update_relevant_tiles(table, res)
+        assert np.array_equal(to_np(ops.raycast_far_bounds(table, poses, res, W, H, K)), b)
+        counts = [int(to_np(m.d_rel)[0]) for m in scene]
+        assert all(0 < c <= ops.sign_map_bytes(m.res) // 2 for c, m in zip(counts, scene)), counts
+        for m in scene:
+            m.d_rel = None
         cut, whole = int(to_np(st_cut)[0]), int(to_np(st_full)[0])
         assert cut <= whole
         if view in ("path", "turned"):
@@ -310,7 +321,7 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
         assert np.isinf(b2[1]).all() and np.array_equal(b2[0], b[0]) and np.array_equal(b2[2], b[2])
     finally:
         for m in scene:
-            m.d_sign = None
+            m.d_sign = m.d_rel = None
 
 
 def test_sign_maps_kept_by_the_integration_cover_the_exact_ones(ops, oracle, dev):
