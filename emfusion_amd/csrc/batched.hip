@@ -833,10 +833,11 @@ __global__ __launch_bounds__(256) void k_dilate_batched(const DilateBatchArgs a)
 }
 
 __global__ void k_vis_flags(const int32_t* __restrict__ counts, int nmodels, int thresh,
-                            int32_t* __restrict__ visible) {
+                            int32_t* __restrict__ visible, int32_t* __restrict__ mirror) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nmodels) return;
     visible[s] = s == 0 ? 1 : (counts[s - 1] > thresh ? 1 : 0);
+    if (mirror && s > 0) mirror[s - 1] = counts[s - 1];  // host-visible copy: no copy kernel, no copy engine
 }
 
 int check_batch(const emf_model_t* models, const emf_pose_t* poses, int nmodels, const char* fn) {
@@ -1204,13 +1205,13 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
 }
 
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,
-                            int32_t* visible_dev, emf_stream_t stream) {
+                            int32_t* visible_dev, int32_t* countsMirror, emf_stream_t stream) {
     EMF_REQUIRE_PTR(visible_dev);
     if (nmodels < 1 || nmodels > EMF_MAX_MODELS)
         return fail(EMF_E_LIMIT, "visibilityFlags: nmodels = %d", nmodels);
     if (nmodels > 1) EMF_REQUIRE_PTR(visCounts);
     hipLaunchKernelGGL(k_vis_flags, dim3(ceil_div(nmodels, 64)), dim3(64), 0, as_stream(stream),
-                       visCounts, nmodels, visibilityThresh, visible_dev);
+                       visCounts, nmodels, visibilityThresh, visible_dev, countsMirror);
     return launch_status("visibilityFlags");
 }
 

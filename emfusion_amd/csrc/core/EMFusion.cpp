@@ -1153,6 +1153,12 @@ void EMFusion::integrateBackgroundAsync() {
                                                integrateStatsDev.as<uint64_t>(), aux.abi()),
              "integrateBatchedCulledOut");
     aux.record();  // what joinBackground() waits for
+    if (useFarBounds && !farBounds.empty()) {
+        // its sign maps may have grown: rebuild the list the NEXT frame's far bounds read, right here,
+        // behind the integration and beside the rest of the raycast -- nobody waits for it this frame
+        emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), 1, aux.abi()), "updateRelevantTiles");
+        listsOnAux = true;
+    }
     bgInFlight = true;
 }
 
@@ -1180,8 +1186,10 @@ void EMFusion::integrateBatched() {
         const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
         const emf_model_t* table = currentTable() + first;
         const int32_t* vis = visibleDev.as<int32_t>() + first;
-        if (cullBoxes && !integrateCullScratch.empty()) {
-            // two-level launch: the boxes of tiles outside the view cone never get a workgroup
+        // two-level launch: the boxes of tiles outside the view cone never get a workgroup -- what the
+        // background needs; object volumes alone are small and mostly in view, and the list's counter
+        // reset + cull kernel cost them more (24 us of the frame) than the culled tiles would
+        if (first == 0 && cullBoxes && !integrateCullScratch.empty()) {
             emfCheck(emf_hip_integrateBatchedCulled(table, oc.data() + first, resHost.data() + 3 * first, n - first,
                                                     vis, &depth, ilp, params.intr.val,
                                                     integrateCullScratch.data(), 0, nullptr,
@@ -1200,10 +1208,15 @@ void EMFusion::integrateBatched() {
         // The sign maps may have grown: rebuild the relevant-tile lists the NEXT frame's far bounds read.
         // Nothing of this frame needs them, so with the second stream in use they go there -- behind
         // both integrations -- and the next computeFarBounds() waits for that stream.
+        // (the background's own list was rebuilt behind its integration already when that ran on aux)
         Stream& s = overlapped ? aux : main;
-        if (overlapped) aux.waitFor(main);
-        emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), n, s.abi()), "updateRelevantTiles");
-        listsOnAux = overlapped;
+        const int from = overlapped ? 1 : 0;
+        if (n > from) {
+            if (overlapped) aux.waitFor(main);
+            emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, s.abi()),
+                     "updateRelevantTiles");
+        }
+        listsOnAux = listsOnAux || overlapped;
     }
 }
 
@@ -1239,10 +1252,10 @@ void EMFusion::compositeAndVisibility(bool deviceGate) {
                                           &v_diff, &v_noObj, params.boundary,
                                           visCounts.as<int32_t>(), main.abi()),
                  "compositeRaycast");
-        if (deviceGate)
+        if (deviceGate)  // the counts also go to pinned host memory straight from the kernel
             emfCheck(emf_hip_visibilityFlags(visCounts.as<int32_t>(), nobj + 1,
                                              params.visibilityThresh, visibleDev.as<int32_t>(),
-                                             main.abi()),
+                                             visibleHost, main.abi()),
                      "visibilityFlags");
     }
     stamp(kComposite);
@@ -1250,9 +1263,6 @@ void EMFusion::compositeAndVisibility(bool deviceGate) {
     visPending = false;
     if (nobj == 0) return;
     if (deviceGate) {
-        hipCheck(hipMemcpyAsync(visibleHost, visCounts.data(), sizeof(int32_t) * nobj,
-                                hipMemcpyDeviceToHost, main.get()),
-                 "visCounts D2H");
         hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
         visIds = ids;
         visPending = true;

@@ -392,7 +392,7 @@ def integrate_batched_culled_out(models_dev, poses_oc, res_list, visible, depth,
 
 def visibility_flags(vis_counts, nmodels, thresh, visible, stream=None):
     check("emf_hip_visibilityFlags",
-          _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible),
+          _L.emf_hip_visibilityFlags(_ptr(vis_counts), nmodels, thresh, _ptr(visible), None,
                                      _stream(stream)))
 
 

@@ -398,9 +398,11 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
                                       emf_stream_t stream);
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
- * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above. */
+ * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above.
+ * countsMirror: NULL, or nmodels - 1 int32 in device-visible HOST memory (hipHostMalloc) that receive
+ * the counts as well -- the host's view of the visible set without a copy command in the stream. */
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,
-                            int32_t* visible_dev, emf_stream_t stream);
+                            int32_t* visible_dev, int32_t* countsMirror, emf_stream_t stream);
 
 /* Fill a brick flag buffer (2 * B bytes) for a freshly zeroed volume (all EMF_BRICK_ALL_ZERO). */
 int emf_hip_resetBrickFlags(uint8_t* brickFlags, const int32_t res[3], emf_stream_t stream);
