@@ -1110,16 +1110,34 @@ int emf_hip_integrateBatchedCulled(const emf_model_t* models_dev, const emf_pose
                                    const float K[9], void* scratch_dev, uint32_t launchBoxes,
                                    uint32_t* survivors_out_dev, uint64_t* stats, emf_stream_t stream) {
     return emf_hip_integrateBatchedCulledOut(models_dev, poseOC_host, res_host, nmodels, visible_dev, depth,
-                                             invLambda, K, nullptr, scratch_dev, launchBoxes, survivors_out_dev,
+                                             invLambda, K, nullptr, 0, scratch_dev, launchBoxes, survivors_out_dev,
                                              stats, stream);
+}
+
+int emf_hip_integratePrepareOut(const emf_volume_out_t* out_host, const int32_t* res_host, int nmodels,
+                                void* scratch_dev, emf_stream_t stream) {
+    EMF_REQUIRE_PTR(res_host);
+    EMF_REQUIRE_PTR(scratch_dev);
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH) return fail(EMF_E_LIMIT, "integratePrepareOut: nmodels = %d", nmodels);
+    hipError_t e = hipMemsetAsync(scratch_dev, 0, sizeof(unsigned), as_stream(stream));
+    for (int m = 0; e == hipSuccess && out_host && m < nmodels; ++m) {
+        if (!out_host[m].dirtyNext) return fail(EMF_E_NULL, "integratePrepareOut: model %d has no dirtyNext map", m);
+        EMF_TRY(check_res(res_host + 3 * m));
+        e = hipMemsetAsync(out_host[m].dirtyNext, 0, emf_hip_integrateDirtyMapBytes(res_host + 3 * m), as_stream(stream));
+    }
+    if (e != hipSuccess) {
+        set_error("integratePrepareOut: memset: %s", hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    return EMF_OK;
 }
 
 int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                                       const int32_t* res_host, int nmodels, const int32_t* visible_dev,
                                       const emf_image_t* depth, const emf_image_t* invLambda,
-                                      const float K[9], const emf_volume_out_t* out_host, void* scratch_dev,
-                                      uint32_t launchBoxes, uint32_t* survivors_out_dev, uint64_t* stats,
-                                      emf_stream_t stream) {
+                                      const float K[9], const emf_volume_out_t* out_host, int prepared,
+                                      void* scratch_dev, uint32_t launchBoxes, uint32_t* survivors_out_dev,
+                                      uint64_t* stats, emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseOC_host, nmodels, "integrateBatchedCulled"));
     EMF_REQUIRE_PTR(res_host);
     EMF_REQUIRE_PTR(scratch_dev);
@@ -1158,7 +1176,7 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
     a.out = IntegrateOutTable{};
     a.haveOut = out_host ? 1 : 0;
     const unsigned total = static_cast<unsigned>(a.boxStart[nmodels]);
-    const hipError_t e = hipMemsetAsync(a.count, 0, sizeof(unsigned), as_stream(stream));
+    const hipError_t e = prepared ? hipSuccess : hipMemsetAsync(a.count, 0, sizeof(unsigned), as_stream(stream));
     if (e != hipSuccess) {
         set_error("integrateBatchedCulled: memset: %s", hipGetErrorString(e));
         return static_cast<int>(e);
@@ -1174,8 +1192,9 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
             a.out.weights[m] = o.weights;
             a.out.dirtyPrev[m] = o.dirtyPrev;
             a.out.dirtyNext[m] = o.dirtyNext;
-            const hipError_t c = hipMemsetAsync(o.dirtyNext, 0, emf_hip_integrateDirtyMapBytes(res_host + 3 * m),
-                                                as_stream(stream));
+            const hipError_t c = prepared ? hipSuccess
+                                          : hipMemsetAsync(o.dirtyNext, 0, emf_hip_integrateDirtyMapBytes(res_host + 3 * m),
+                                                           as_stream(stream));
             if (c != hipSuccess) {
                 set_error("integrateBatchedCulledOut: memset: %s", hipGetErrorString(c));
                 return static_cast<int>(c);

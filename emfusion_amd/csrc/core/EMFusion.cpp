@@ -154,6 +154,9 @@ void EMFusion::reset() {
     nextId = 1;
     bgInFlight = false;
     bgBackStale = false;
+    bgPrepared = false;
+    bgListPending = false;
+    listsPending = false;
     Stream& s = Stream::Null();
     bg_associationWeights.setTo(1.f, s);
     diffRaylengths.setZero(s);
@@ -237,8 +240,9 @@ void EMFusion::createObj(int id) {
 void EMFusion::rebuildModelTable() {
     modelsHost.clear();
     resHost.clear();
-    aux.waitForCompletion();  // the background's integration / the list rebuild may still be running there
-    listsOnAux = false;
+    aux.waitForCompletion();  // the background's integration / the list rebuilds may still be running
+    lists.waitForCompletion();
+    listsPending = false;
     if (useFarBounds) {  // sign maps that something other than the tile integration made stale
         background.refreshSignMaps();
         for (auto& obj : objects) obj.refreshSignMaps();
@@ -439,8 +443,8 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         else applyObjectPoses();
         computeAssociationWeights();
         stamp(kEstep);
+        integrateBackgroundAsync();  // runs beside the far bounds and the raycast (see there)
         computeFarBounds();
-        integrateBackgroundAsync();  // runs beside the raycast (see there)
         raycast();
     } else {
         pose = in.cam_pose;
@@ -1106,22 +1110,38 @@ void EMFusion::raycastBatched() {
     compositeAndVisibility(true);
 }
 
-// Far bounds of this frame's raycast (poses are final): BEFORE the background's integration is forked --
-// that one ends by rebuilding the background's relevant-tile list, which this launch reads.
+// Far bounds of this frame's raycast (poses are final).  They read the relevant-tile lists, which are
+// rebuilt on the `lists` stream: last frame's rebuild has to be through, and this frame's rebuild of the
+// background's list -- its integration has been forked already -- is enqueued behind this launch.
 void EMFusion::computeFarBounds() {
     farBoundsReady = false;
-    if (!batched || farBounds.empty() || TSDF::brickFlagMode() != 0) return;
-    if (listsOnAux) {  // last frame's list rebuild
-        main.waitFor(aux);
-        listsOnAux = false;
+    if (batched && !farBounds.empty() && TSDF::brickFlagMode() == 0) {
+        if (listsPending) {
+            main.waitFor(lists);
+            listsPending = false;
+        }
+        std::vector<emf_pose_t> co;
+        posesCO(co);
+        emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
+                                          params.frameSize.width, params.frameSize.height, params.intr.val, 0,
+                                          farBounds.as<float>(), main.abi()),
+                 "raycastFarBounds");
+        farBoundsReady = true;
     }
-    std::vector<emf_pose_t> co;
-    posesCO(co);
-    emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
-                                      params.frameSize.width, params.frameSize.height, params.intr.val, 0,
-                                      farBounds.as<float>(), main.abi()),
-             "raycastFarBounds");
-    farBoundsReady = true;
+    rebuildBackgroundList();
+}
+
+// The background's sign maps may have grown in the integration just forked: rebuild the list the NEXT
+// frame's far bounds read -- behind that integration and behind whatever of this frame still reads the
+// list, on a stream nobody waits for this frame.
+void EMFusion::rebuildBackgroundList() {
+    if (!bgListPending) return;
+    bgListPending = false;
+    if (!useFarBounds || farBounds.empty()) return;
+    lists.waitOn(aux);    // the record() behind the integration kernels
+    lists.waitFor(main);  // this frame's far bounds
+    emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), 1, lists.abi()), "updateRelevantTiles");
+    listsPending = true;
 }
 
 bool EMFusion::overlapUsable() const {
@@ -1134,38 +1154,46 @@ bool EMFusion::overlapUsable() const {
 // background kept twice it runs out of place on `aux` while `main` ray-marches the front copy: the
 // raycast is a latency chain of its longest rays that leaves most of the chip idle, the integration
 // is a streaming sweep that fills it.  Same values as the reference's raycast -> integrate sequence.
+// It is forked as soon as the last E-step is enqueued, before the far bounds: its box cull then runs
+// beside them instead of fighting the raycast's workgroup dispatch (8 us instead of 40).
 void EMFusion::integrateBackgroundAsync() {
     if (!overlapUsable() || bgInFlight) return;
     if (bgBackStale) {  // an in-place integration (other path) in between: re-equalise the copies
         synchronize();
         background.resyncBack();
         bgBackStale = false;
+        bgPrepared = false;
     }
     aux.waitFor(main);
     const emf_pose_t oc = toPose(pose.inv() * background.getPose());  // reference TSDF.cpp:112
     const double vox = static_cast<double>(resHost[0]) * resHost[1] * resHost[2];
-    auto kt = ktimers.scope(KernelTimers::IntegrateBg, vox, aux);
     const emf_image_t il = invLambda.view();
     const emf_volume_out_t out = background.backBuffers();
-    emfCheck(emf_hip_integrateBatchedCulledOut(currentTable(), &oc, resHost.data(), 1, nullptr, &depth,
-                                               useLambdaTable ? &il : nullptr, params.intr.val, &out,
-                                               bgCullScratch.data(), 0, nullptr,
-                                               integrateStatsDev.as<uint64_t>(), aux.abi()),
-             "integrateBatchedCulledOut");
-    aux.record();  // what joinBackground() waits for
-    if (useFarBounds && !farBounds.empty()) {
-        // its sign maps may have grown: rebuild the list the NEXT frame's far bounds read, right here,
-        // behind the integration and beside the rest of the raycast -- nobody waits for it this frame
-        emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), 1, aux.abi()), "updateRelevantTiles");
-        listsOnAux = true;
+    {
+        auto kt = ktimers.scope(KernelTimers::IntegrateBg, vox, aux);
+        emfCheck(emf_hip_integrateBatchedCulledOut(currentTable(), &oc, resHost.data(), 1, nullptr, &depth,
+                                                   useLambdaTable ? &il : nullptr, params.intr.val, &out,
+                                                   bgPrepared ? 1 : 0, bgCullScratch.data(), 0, nullptr,
+                                                   integrateStatsDev.as<uint64_t>(), aux.abi()),
+                 "integrateBatchedCulledOut");
     }
+    aux.record();  // what joinBackground() and the list rebuild wait for
+    // clear, behind this call and off everybody's path, what the NEXT call wants clean: the box counter
+    // and the map that will be its dirtyNext (this call's dirtyPrev: the copies swap roles)
+    emf_volume_out_t next = out;
+    next.dirtyNext = const_cast<uint8_t*>(out.dirtyPrev);
+    emfCheck(emf_hip_integratePrepareOut(&next, resHost.data(), 1, bgCullScratch.data(), aux.abi()),
+             "integratePrepareOut");
+    bgPrepared = true;
     bgInFlight = true;
+    bgListPending = true;
 }
 
 // Join: the frame's later stages (and the next frame) see the integrated background.
 void EMFusion::joinBackground() {
     if (!bgInFlight) return;
-    main.waitOn(aux);  // the record() after the integration kernels
+    rebuildBackgroundList();  // (a frame without far bounds: frame 0)
+    main.waitOn(aux);  // the record() behind the integration kernels
     background.flip();
     tableSel ^= 1;
     bgInFlight = false;
@@ -1206,17 +1234,16 @@ void EMFusion::integrateBatched() {
     joinBackground();
     if (useFarBounds && !farBounds.empty()) {
         // The sign maps may have grown: rebuild the relevant-tile lists the NEXT frame's far bounds read.
-        // Nothing of this frame needs them, so with the second stream in use they go there -- behind
-        // both integrations -- and the next computeFarBounds() waits for that stream.
-        // (the background's own list was rebuilt behind its integration already when that ran on aux)
-        Stream& s = overlapped ? aux : main;
+        // Nothing of this frame needs them: with the streams in use they go to `lists`, behind the
+        // integration above (the background's own list went there behind its integration already).
         const int from = overlapped ? 1 : 0;
         if (n > from) {
-            if (overlapped) aux.waitFor(main);
+            Stream& s = overlapped ? lists : main;
+            if (overlapped) lists.waitFor(main);
             emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, s.abi()),
                      "updateRelevantTiles");
+            listsPending = listsPending || overlapped;
         }
-        listsOnAux = listsOnAux || overlapped;
     }
 }
 

@@ -378,7 +378,11 @@ private:
     bool useFarBounds = true;
     DeviceBuffer farBounds;
     bool farBoundsReady = false;
-    bool listsOnAux = false;  // the relevant-tile lists are being rebuilt on `aux` (wait before reading them)
+    Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
+    bool listsPending = false;  // ... something is enqueued there that the next computeFarBounds() must wait for
+    bool bgListPending = false; // the background was forked; its list rebuild is not enqueued yet
+    bool bgPrepared = false;    // bgCullScratch's counter and the next dirtyNext map are already cleared
+    void rebuildBackgroundList();
     void computeFarBounds();
     DeviceBuffer bgCullScratch;     // box list of the background's own launch
     bool overlapUsable() const;

@@ -371,8 +371,19 @@ def integrate_dirty_map_bytes(res) -> int:
     return int(_L.emf_hip_integrateDirtyMapBytes((C.c_int32 * 3)(*[int(v) for v in res])))
 
 
+def integrate_prepare_out(outs, res_list, scratch, stream=None):
+    """emf_hip_integratePrepareOut: clear the survivor counter and the dirtyNext maps of outs ahead of time."""
+    from ._lib import EmfVolumeOut
+    res = (C.c_int32 * (3 * len(res_list)))(*[int(v) for r in res_list for v in r])
+    table = (EmfVolumeOut * len(outs))()
+    for o, (t, w, dp, dn) in zip(table, outs):
+        o.tsdf, o.weights, o.dirtyPrev, o.dirtyNext = t.ptr, w.ptr, dp.ptr, dn.ptr
+    check("emf_hip_integratePrepareOut",
+          _L.emf_hip_integratePrepareOut(C.cast(table, C.c_void_p), res, len(outs), _ptr(scratch), _stream(stream)))
+
+
 def integrate_batched_culled_out(models_dev, poses_oc, res_list, visible, depth, K, outs, launch_boxes=0,
-                                 stats=None, stream=None, inv_lambda=None, scratch=None):
+                                 stats=None, stream=None, inv_lambda=None, scratch=None, prepared=False):
     """emf_hip_integrateBatchedCulledOut: model m is read from the table and written to outs[m] =
     (tsdf_back, weights_back, dirty_prev, dirty_next) device arrays; returns the scratch buffer."""
     from ._lib import EmfVolumeOut
@@ -385,7 +396,7 @@ def integrate_batched_culled_out(models_dev, poses_oc, res_list, visible, depth,
     check("emf_hip_integrateBatchedCulledOut",
           _L.emf_hip_integrateBatchedCulledOut(_ptr(models_dev), _poses(poses_oc), res, len(poses_oc), _ptr(visible),
                                                C.byref(image_view(depth)), _opt_view(inv_lambda), _f(K, 9),
-                                               C.cast(table, C.c_void_p), _ptr(scratch), int(launch_boxes), None,
+                                               C.cast(table, C.c_void_p), int(prepared), _ptr(scratch), int(launch_boxes), None,
                                                _ptr(stats), _stream(stream)))
     return scratch
 

@@ -393,9 +393,16 @@ size_t emf_hip_integrateDirtyMapBytes(const int32_t res[3]);
 int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_pose_t* poseOC_host,
                                       const int32_t* res_host, int nmodels, const int32_t* visible_dev,
                                       const emf_image_t* depth, const emf_image_t* invLambda,
-                                      const float K[9], const emf_volume_out_t* out_host, void* scratch_dev,
-                                      uint32_t launchBoxes, uint32_t* survivors_out_dev, uint64_t* stats,
-                                      emf_stream_t stream);
+                                      const float K[9], const emf_volume_out_t* out_host, int prepared,
+                                      void* scratch_dev, uint32_t launchBoxes, uint32_t* survivors_out_dev,
+                                      uint64_t* stats, emf_stream_t stream);
+/* prepared != 0: the caller has cleared the survivor counter (first word of scratch_dev) and the
+ * dirtyNext maps already -- emf_hip_integratePrepareOut does exactly that and can be enqueued as soon as
+ * the previous call on that scratch / those maps has run, i.e. off the frame's critical path (two fill
+ * commands in front of the launch cost it ~40 us while the raycast's workgroups are being dispatched).
+ * out_host may be NULL here (counter only). */
+int emf_hip_integratePrepareOut(const emf_volume_out_t* out_host, const int32_t* res_host, int nmodels,
+                                void* scratch_dev, emf_stream_t stream);
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above.

@@ -515,7 +515,8 @@ def test_integrate_culled_launch_equals_the_plain_batched_one(ops, oracle, dev, 
     assert int(to_np(stats_a)[0]) == int(to_np(stats_b)[0]) > 0
 
 
-def test_integrate_out_of_place_equals_in_place_over_a_swinging_camera(ops, oracle, dev):
+@pytest.mark.parametrize("prepared", [False, True], ids=["self_clearing", "prepared_ahead"])
+def test_integrate_out_of_place_equals_in_place_over_a_swinging_camera(ops, oracle, dev, prepared):
     """emf_hip_integrateBatchedCulledOut on double-buffered volumes: after every frame the copy that was
     written equals the in-place result bit for bit -- also where the camera has swung away from what it
     integrated a frame earlier (boxes outside the view cone whose tiles are still dirty get copied), with
@@ -533,6 +534,7 @@ def test_integrate_out_of_place_equals_in_place_over_a_swinging_camera(ops, orac
     # yaw in degrees per frame: look ahead, swing far right, back, far left + up, ahead, away (sees nothing), ahead
     swings = [(0, 0), (35, 0), (0, 0), (-40, 12), (5, -3), (170, 0), (0, 0), (2, 1)]
     copied_only = 0
+    scratch = None
     for i, (yaw, pitch) in enumerate(swings):
         base, depth, _ = frame(i)
         cam = Pose(base.R @ rot([0, 1, 0], yaw) @ rot([1, 0, 0], pitch), base.t)
@@ -551,8 +553,13 @@ def test_integrate_out_of_place_equals_in_place_over_a_swinging_camera(ops, orac
         ops.integrate_batched_culled(ops.upload_models([m.table_entry() for m in twins]), poses, res, visible, d_depth, K)
         outs = [(b.d_tsdf, b.d_wts, mp[i % 2], mp[1 - i % 2]) for b, mp in zip(back, maps)]
         before = [to_np(b.d_tsdf).copy() for b in back]
-        ops.integrate_batched_culled_out(ops.upload_models([m.table_entry() for m in front]), poses, res, visible,
-                                         d_depth, K, outs)
+        # prepared: the counter and the next-dirty maps were cleared behind the previous call
+        # (emf_hip_integratePrepareOut), as the host classes do to keep the fills off the frame's path
+        scratch = ops.integrate_batched_culled_out(ops.upload_models([m.table_entry() for m in front]), poses, res,
+                                                   visible, d_depth, K, outs, scratch=scratch, prepared=prepared and i > 0)
+        if prepared:  # the copies swap roles: the next call's dirtyNext is this call's dirtyPrev
+            ops.integrate_prepare_out([(f.d_tsdf, f.d_wts, mp[1 - i % 2], mp[i % 2]) for f, mp in zip(front, maps)],
+                                      res, scratch)
         dev.synchronize()
         for a, f, b, old in zip(twins, front, back, before):
             assert_parity(to_np(b.d_tsdf), to_np(a.d_tsdf), f"frame {i} tsdf model {a.id}", exact=True)
