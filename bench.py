@@ -209,7 +209,7 @@ def main():
     if not args.no_kernel_events:
         fus.kernel_timers_enable(launches_per_frame * args.steps + 64)
         if not args.all_kernel_events:
-            fus.kernel_timers_select(["raycast", "integrate", "integrate_bg", "track"])
+            fus.kernel_timers_select(["raycast", "integrate_bg", "track"] if fus.background_overlap() else ["raycast", "integrate", "track"])
     fus.enable_raycast_stats(True)
     if args.track:
         fus.set_tracking(camera=True, objects=True)

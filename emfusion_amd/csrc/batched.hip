@@ -109,7 +109,12 @@ struct RaycastBatchArgs {
     int bandTile0, bandTiles;  // slot 0 only: tile rows this rank marches (bandTiles == 0: all)
     unsigned long long* stats;
     const float* farBounds;    // [model][2 tilesY][2 tilesX] per 8x8-pixel cell, or nullptr (see k_far_bounds)
+    // objects (slots 1..): the tiles their volume box can project to (host-computed from the pose); only
+    // those get a marching workgroup, the rest of the object's images is zero-filled 16 tiles per workgroup
+    short rect[EMF_MAX_BATCH][4];      // tx0, ty0, width, height in tiles (slot 0 unused)
+    int objStart[EMF_MAX_BATCH + 1];   // prefix sum of width * height over slots 1..; [m] = first block of slot m
 };
+constexpr int kZeroTiles = 16;  // tiles per zero-fill workgroup
 
 // 4 waves (8x8-pixel sub-tiles) per workgroup = a 16x16 tile; 1-wave workgroups measured the same
 constexpr int kRbWaves = 4;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     {
         const int ring = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
         const int b = blockIdx.x;
-        const int objBlocks = (a.nmodels - 1) * perModel;
+        const int objBlocks = a.objStart[a.nmodels];
         if (b < ring) {
             m = 0;
             if (b < a.tilesX) tile = b;                                              // top row
@@ -180,21 +185,47 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
                 const int k = b - 2 * a.tilesX;                                       // left / right columns
                 tile = (1 + (k >> 1)) * a.tilesX + ((k & 1) ? a.tilesX - 1 : 0);
             }
-        } else if (b < ring + objBlocks) {
+        } else if (b < ring + objBlocks) {  // a tile of an object's footprint
             const int o = b - ring;
-            m = 1 + o / perModel;
-            const int i = o - (m - 1) * perModel;
-            tile = (i & 7) * a.chunk + (i >> 3);
+            m = 1;
+            while (m + 1 < a.nmodels && o >= a.objStart[m + 1]) ++m;
+            const int i = o - a.objStart[m], rw = a.rect[m][2];
+            tile = (a.rect[m][1] + i / rw) * a.tilesX + a.rect[m][0] + i % rw;
         } else {
             m = 0;
-            const int i = b - ring - objBlocks;
+            int i = b - ring - objBlocks;
+            const int bgBlocks = ring ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : perModel;
+            if (i >= bgBlocks) {
+                // zero-fill of the objects' images outside their footprints: kZeroTiles tiles per workgroup
+                i -= bgBlocks;
+                const int perObj = (a.tilesX * a.tilesY + kZeroTiles - 1) / kZeroTiles;
+                const int mz = 1 + i / perObj;
+                if (mz >= a.nmodels) return;
+                const emf_model_t& mo = a.models[mz];
+                const int tx0 = a.rect[mz][0], ty0 = a.rect[mz][1], tx1 = tx0 + a.rect[mz][2], ty1 = ty0 + a.rect[mz][3];
+                const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+                for (int t = (i % perObj) * kZeroTiles; t < min((i % perObj + 1) * kZeroTiles, a.tilesX * a.tilesY); ++t) {
+                    const int tyz = t / a.tilesX, txz = t - tyz * a.tilesX;
+                    if (txz >= tx0 && txz < tx1 && tyz >= ty0 && tyz < ty1) continue;  // marched above
+                    const int x = txz * kRbTile + px, y = tyz * kRbTile + py;
+                    if (x < a.w && y < a.h) {
+                        const size_t pix = static_cast<size_t>(y) * a.w + x;
+                        mo.raylengths[pix] = 0.f;
+                        float* pv = mo.vertices + 3 * pix;
+                        float* pn = mo.normals + 3 * pix;
+                        pv[0] = pv[1] = pv[2] = 0.f;
+                        pn[0] = pn[1] = pn[2] = 0.f;
+                        mo.hitMask[pix] = 0;
+                    }
+                }
+                return;
+            }
             if (ring) {  // interior tiles, XCD-banded like the full image
                 const int inX = a.tilesX - 2, inY = a.tilesY - 2, chunkIn = (inX * inY + 7) / 8;
                 const int t = (i & 7) * chunkIn + (i >> 3);
-                if (i >= 8 * chunkIn || t >= inX * inY) return;
+                if (t >= inX * inY) return;
                 tile = (1 + t / inX) * a.tilesX + 1 + t % inX;
             } else {
-                if (i >= perModel) return;
                 tile = (i & 7) * a.chunk + (i >> 3);
             }
         }
@@ -970,7 +1001,8 @@ int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* re
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
-                           const float* farBounds_dev, uint64_t* stats, emf_stream_t stream) {
+                           const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
+                           emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
     if (bgBandRows < 0 || bgBandRow0 < 0 || bgBandRow0 % kRbTile || bgBandRows % kRbTile)
         return fail(EMF_E_ARG, "raycastBatched: band [%d, +%d) must be non-negative multiples of %d rows",
@@ -1003,8 +1035,59 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.farBounds = farBounds_dev;
     a.bandTile0 = bgBandRow0 / kRbTile;
     a.bandTiles = bgBandRows / kRbTile;
-    // (+ 8: the border-first order of the background rounds its interior up to whole XCD chunks)
-    const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk + 8u);
+    // footprints of the objects: the tiles the (slightly enlarged) volume box projects to
+    a.objStart[0] = a.objStart[1] = 0;
+    for (int m = 1; m < nmodels; ++m) {
+        const int32_t* r = res_host + 3 * m;
+        const emf_pose_t& p = poseCO_host[m];
+        // (the voxel size lives in the device table: without the host's copy the object keeps the whole image)
+        const float vs = voxelSizes_host ? voxelSizes_host[m] : 0.f;
+        int tx0 = 0, ty0 = 0, tx1 = a.tilesX, ty1 = a.tilesY;
+        if (vs > 0.f) {
+            float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f;
+            bool wide = false;
+            for (int k = 0; k < 8 && !wide; ++k) {
+                const float q[3] = {((k & 1) ? .5f : -.5f) * (r[0] + 2) * vs, ((k & 2) ? .5f : -.5f) * (r[1] + 2) * vs,
+                                    ((k & 4) ? .5f : -.5f) * (r[2] + 2) * vs};
+                const float d[3] = {q[0] - p.t[0], q[1] - p.t[1], q[2] - p.t[2]};
+                const float c[3] = {p.R[0] * d[0] + p.R[3] * d[1] + p.R[6] * d[2], p.R[1] * d[0] + p.R[4] * d[1] + p.R[7] * d[2],
+                                    p.R[2] * d[0] + p.R[5] * d[1] + p.R[8] * d[2]};  // R^T d
+                if (!(c[2] > 1e-2f * vs)) {
+                    wide = true;
+                } else {
+                    const float u = a.fx * c[0] / c[2] + a.cx, v = a.fy * c[1] / c[2] + a.cy;
+                    umin = std::fmin(umin, u); umax = std::fmax(umax, u);
+                    vmin = std::fmin(vmin, v); vmax = std::fmax(vmax, v);
+                }
+            }
+            if (!wide) {
+                if (!(umax >= -2.f && vmax >= -2.f && umin <= width + 1.f && vmin <= height + 1.f)) {
+                    tx1 = tx0 = ty1 = ty0 = 0;  // beside the image: nothing to march
+                } else {
+                    tx0 = std::max(static_cast<int>(std::floor((umin - 2.f) / kRbTile)), 0);
+                    ty0 = std::max(static_cast<int>(std::floor((vmin - 2.f) / kRbTile)), 0);
+                    tx1 = std::min(static_cast<int>(std::floor((std::fmin(umax, 1e6f) + 2.f) / kRbTile)) + 1, a.tilesX);
+                    ty1 = std::min(static_cast<int>(std::floor((std::fmin(vmax, 1e6f) + 2.f) / kRbTile)) + 1, a.tilesY);
+                }
+            }
+        }
+        a.rect[m][0] = static_cast<short>(tx0);
+        a.rect[m][1] = static_cast<short>(ty0);
+        a.rect[m][2] = static_cast<short>(std::max(tx1 - tx0, 0));
+        a.rect[m][3] = static_cast<short>(std::max(ty1 - ty0, 0));
+        a.objStart[m + 1] = a.objStart[m] + a.rect[m][2] * a.rect[m][3];
+    }
+    a.rect[0][0] = a.rect[0][1] = a.rect[0][2] = a.rect[0][3] = 0;
+#if EMF_RAY_ORDER == 2
+    // background: border ring + interior rounded up to whole XCD chunks (or all of it when banded);
+    // objects: footprint tiles, and ceil(tiles / kZeroTiles) zero-fill workgroups each
+    const int ringTiles = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
+    const int bgBlocks = ringTiles ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : 8 * a.chunk;
+    const int zeroBlocks = (nmodels - 1) * static_cast<int>(ceil_div(a.tilesX * a.tilesY, kZeroTiles));
+    const dim3 grid(static_cast<unsigned>(ringTiles + a.objStart[nmodels] + bgBlocks + zeroBlocks));
+#else
+    const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk);
+#endif
     if (useBrickFlags || !offsets32)  // the wave march addresses with 32-bit byte offsets
         hipLaunchKernelGGL(k_raycast_batched<false>, grid, dim3(64 * kRbWaves), 0,
                            as_stream(stream), a);

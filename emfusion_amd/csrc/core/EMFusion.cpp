@@ -87,6 +87,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_FAR_BOUNDS=0: no far bounds for the raycast (A/B measurements; same results)
     const char* fb = std::getenv("EMF_FAR_BOUNDS");
     useFarBounds = !(fb && fb[0] == '0');
+    // EMF_RAY_FOOTPRINTS=0: every object gets a marching workgroup for every tile of the image
+    const char* rf = std::getenv("EMF_RAY_FOOTPRINTS");
+    useFootprints = !(rf && rf[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -267,7 +270,9 @@ void EMFusion::rebuildModelTable() {
         modelsHost.push_back(o);
     }
     bool tiled = true;
+    voxelHost.clear();
     for (const auto& md : modelsHost) {
+        voxelHost.push_back(md.voxelSize);
         resHost.insert(resHost.end(), md.res, md.res + 3);
         tiled &= md.res[0] % 4 == 0;
     }
@@ -1099,7 +1104,7 @@ void EMFusion::raycastBatched() {
         farBoundsReady = false;
         emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
                                         flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
-                                        band, far, stats, main.abi()),
+                                        band, far, useFootprints ? voxelHost.data() : nullptr, stats, main.abi()),
                  "raycastBatched");
         if (band) {
             comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), band, h, main);

@@ -234,6 +234,8 @@ public:
     /** Voxels swept by the batched integration since the counter was last read (and reset). */
     uint64_t takeIntegratedVoxels();
     bool usesBatchedLaunches() const { return batched; }
+    /** The background is integrated out of place on a second stream, beside the raycast. */
+    bool overlapsBackground() const { return overlapUsable(); }
     std::vector<int> objectIds() const { return allIds; }
     bool ownsObject(int id) const;
     const FrameTimings& lastTimings() const { return timings; }
@@ -375,6 +377,7 @@ private:
     Stream aux;
     // Raycast far bounds (emf_hip_raycastFarBounds): per model and 8x8-pixel cell, where a march may
     // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
+    bool useFootprints = true;  // objects are marched only where their volume box projects to
     bool useFarBounds = true;
     DeviceBuffer farBounds;
     bool farBoundsReady = false;
@@ -390,6 +393,7 @@ private:
     void joinBackground();
     std::vector<emf_model_t> modelsHost;
     std::vector<int32_t> resHost;   // 3 per model
+    std::vector<float> voxelHost;   // voxel size per model (object footprints of the batched raycast)
     DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device
     DeviceBuffer integrateStatsDev; // u64: voxels swept by integrateBatched
     int32_t* visibleHost = nullptr; // pinned mirror of visCounts for visibleObjects()

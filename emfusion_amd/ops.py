@@ -299,14 +299,16 @@ def voxel_reciprocal(voxel_size) -> float:
 
 
 def raycast_batched(models_dev, poses_co, res_list, width, height, K, stats=None,
-                    use_brick_flags=False, stream=None, bg_band=(0, 0), far_bounds=None):
+                    use_brick_flags=False, stream=None, bg_band=(0, 0), far_bounds=None, voxel_sizes=None):
     """bg_band = (row0, rows): march only that row band of table slot 0 (multi-GPU background split).
     far_bounds: raycast_far_bounds()'s array for the same table, poses and image (same results, shorter marches)."""
     res = (C.c_int32 * (3 * len(poses_co)))(*[int(v) for r in res_list for v in r])
     check("emf_hip_raycastBatched",
           _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width,
                                     height, _f(K, 9), int(use_brick_flags), int(bg_band[0]),
-                                    int(bg_band[1]), _ptr(far_bounds), _ptr(stats), _stream(stream)))
+                                    int(bg_band[1]), _ptr(far_bounds),
+                                    None if voxel_sizes is None else _f(voxel_sizes, len(poses_co)), _ptr(stats),
+                                    _stream(stream)))
 
 
 def sign_map_bytes(res) -> int:

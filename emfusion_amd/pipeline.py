@@ -139,6 +139,7 @@ def load() -> C.CDLL:
         "emf_fusion_visible_objects": [vp, ip, C.c_int, C.POINTER(C.c_int)],
         "emf_fusion_object_ids": [vp, ip, C.c_int, C.POINTER(C.c_int)],
         "emf_fusion_frame_index": [vp],
+        "emf_fusion_background_overlap": [vp],
         "emf_fusion_owns_object": [vp, C.c_int],
         "emf_comm_unique_id": [vp],
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
@@ -562,6 +563,9 @@ class Fusion:
         out = np.empty((res[2], res[1], res[0]), dt)
         devmem.memcpy_d2h(out, ptr.value)
         return out
+
+    def background_overlap(self) -> bool:
+        return load().emf_fusion_background_overlap(self._h) == 1
 
     def object_ids(self):
         """Live objects of the job in creation order."""

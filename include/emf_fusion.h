@@ -204,6 +204,8 @@ int emf_fusion_visible_objects(emf_fusion_t* h, int32_t* ids, int cap, int* n);
 /* ids of all live objects of the job in creation order (deleted ones are gone); count in *n (<= cap) */
 int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n);
 int emf_fusion_frame_index(emf_fusion_t* h);
+/* 1 if the background's integration runs out of place beside the raycast (double-buffered background) */
+int emf_fusion_background_overlap(emf_fusion_t* h);
 /* 1 if this rank holds object id's volume */
 int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);
 

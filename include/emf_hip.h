@@ -299,7 +299,13 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
-                           const float* farBounds_dev, uint64_t* stats, emf_stream_t stream);
+                           const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
+                           emf_stream_t stream);
+/* voxelSizes_host: NULL, or HOST float[nmodels], the voxel sizes stored in the table.  With them the
+ * objects (slots 1..) get marching workgroups only for the 16x16-pixel tiles their volume box can project
+ * to under poseCO_host; the rest of their images is zero-filled sixteen tiles per workgroup -- same
+ * output, but four objects no longer put 4 x 1200 nearly empty workgroups in front of the background's
+ * (whose dispatch alone took the first 200 us of the launch). */
 
 /* Far bounds for emf_hip_raycastBatched (farBounds_dev; NULL = none).  A hit of the reference's march
  * (TSDF.cu:533-568) is a negative sample following a positive one, so it needs a negative and a positive

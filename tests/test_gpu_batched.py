@@ -232,8 +232,11 @@ def test_estep_batched_matches_per_model_calls(ops, oracle, scene, dev):
         assert_parity(to_np(m.d_assoc), wv, f"map {m.id} vs oracle", rtol=4e-6)
 
 
-@pytest.mark.parametrize("use_flags", [False, True])
-def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, use_flags):
+@pytest.mark.parametrize("use_flags,footprints", [(False, False), (True, False), (False, True)],
+                         ids=["plain", "brick_flags", "object_footprints"])
+def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, use_flags, footprints):
+    """footprints: with the voxel sizes on the host, objects get marching workgroups only where their box
+    projects to, and zero-fill workgroups elsewhere -- every pixel of every image is still written."""
     cam = camera_path(4)
     table = ops.upload_models([m.table_entry() for m in scene])
     poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
@@ -244,7 +247,7 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
         m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
     st = dev_full((4,), 0, np.uint64)
     ops.raycast_batched(table, poses, [m.res for m in scene], W, H, K, stats=st,
-                        use_brick_flags=use_flags)
+                        use_brick_flags=use_flags, voxel_sizes=[m.vox for m in scene] if footprints else None)
     total = 0
     for m, (R, t) in zip(scene, poses):
         want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t,
@@ -289,7 +292,8 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
         st_cut, st_full = dev_full((4,), 0, np.uint64), dev_full((4,), 0, np.uint64)
         ops.raycast_batched(table, poses, res, W, H, K, stats=st_full)
         full = [[to_np(a).copy() for a in (m.d_ray, m.d_vert, m.d_nrm, m.d_hit)] for m in scene]
-        ops.raycast_batched(table, poses, res, W, H, K, stats=st_cut, far_bounds=bounds)
+        ops.raycast_batched(table, poses, res, W, H, K, stats=st_cut, far_bounds=bounds,
+                            voxel_sizes=[m.vox for m in scene])  # + object footprints from all these viewpoints
         hits = 0
         for m, (R, t), f in zip(scene, poses, full):
             want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t, K, m.vox, m.trunc)
