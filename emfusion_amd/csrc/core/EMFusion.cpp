@@ -90,6 +90,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_RAY_FOOTPRINTS=0: every object gets a marching workgroup for every tile of the image
     const char* rf = std::getenv("EMF_RAY_FOOTPRINTS");
     useFootprints = !(rf && rf[0] == '0');
+    // the background's sweep yields to the raycast when both have workgroups to place (its long chains
+    // should start as early as they can): lowest queue priority for the second stream (+1 % frames/s)
+    aux = Stream(-1);
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a

@@ -18,6 +18,12 @@ void emfCheck(int rc, const char* what) {
 Stream::Stream() : owned_(true) {
     hipCheck(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking), "hipStreamCreate");
 }
+Stream::Stream(int priority) : owned_(true) {
+    int least = 0, greatest = 0;  // numerically lower = higher priority
+    hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    const int p = priority > 0 ? greatest : (priority < 0 ? least : (least + greatest) / 2);
+    hipCheck(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, p), "hipStreamCreateWithPriority");
+}
 Stream::Stream(hipStream_t s) : s_(s), owned_(false) {}
 Stream::~Stream() {
     if (ev_) (void)hipEventDestroy(ev_);

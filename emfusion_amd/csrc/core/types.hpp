@@ -136,6 +136,7 @@ void emfCheck(int rc, const char* what);
 class Stream {
 public:
     Stream();                       // creates a non-blocking stream
+    explicit Stream(int priority);  // > 0: highest, < 0: lowest, 0: middle of the device's priority range
     explicit Stream(hipStream_t s); // borrows (never destroyed); nullptr = the null stream
     ~Stream();
     Stream(Stream&& o) noexcept;
