@@ -15,7 +15,7 @@ SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_integrate_listed_rest
                      ("k_integrate_listed<true>", "integrate_bg"), ("k_integrate_listed<(bool)1>", "integrate_bg"),
                      ("k_integrate_listed", "integrate"), ("k_integrate_cull", "integrate_cull"),
                      ("k_far_bounds", "far_bounds"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
-                     ("k_deep_ones", "deep_ones"),
+                     ("k_relevant_tiles", "relevant_tiles"), ("k_relevant_reset", "relevant_reset"),
                      ("k_integrate_batched", "integrate"),
                      ("k_estep", "assoc"), ("k_composite", "composite"), ("k_vis_counts", "vis_counts"),
                      ("k_vis_flags", "vis_flags"), ("k_dilate_batched", "dilate_flags"),
