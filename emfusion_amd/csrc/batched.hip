@@ -364,12 +364,12 @@ __device__ __forceinline__ bool tile_relevant(const emf_model_t& md, int tx, int
     const uint8_t* pos = md.signMaps;
     const uint8_t* neg = pos + static_cast<size_t>(ntx) * nty * ntz;
     auto any_in = [&](const uint8_t* map, int rx, int ry, int rz) {
-        bool any = false;
+        unsigned any = 0;  // OR of plain loads: no short-circuit, so the loads are independent and pipeline
         for (int z = max(tz - rz, 0); z <= min(tz + rz, ntz - 1); ++z)
             for (int y = max(ty - ry, 0); y <= min(ty + ry, nty - 1); ++y)
                 for (int x = max(tx - rx, 0); x <= min(tx + rx, ntx - 1); ++x)
-                    any = any || map[(static_cast<size_t>(z) * nty + y) * ntx + x] != 0;
-        return any;
+                    any |= map[(static_cast<size_t>(z) * nty + y) * ntx + x];
+        return any != 0;
     };
     // the negative corner is in the sample's own cell (base voxel in this tile, corners up to +1): this
     // tile or a direct neighbour

@@ -162,7 +162,6 @@ void EMFusion::reset() {
     bgBackStale = false;
     bgPrepared = false;
     bgListPending = false;
-    listsPending = false;
     Stream& s = Stream::Null();
     bg_associationWeights.setTo(1.f, s);
     diffRaylengths.setZero(s);
@@ -248,7 +247,6 @@ void EMFusion::rebuildModelTable() {
     resHost.clear();
     aux.waitForCompletion();  // the background's integration / the list rebuilds may still be running
     lists.waitForCompletion();
-    listsPending = false;
     if (useFarBounds) {  // sign maps that something other than the tile integration made stale
         background.refreshSignMaps();
         for (auto& obj : objects) obj.refreshSignMaps();
@@ -443,16 +441,34 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         // Q17: the E-step runs three times per frame around the two tracking stages
         // (reference EMFusion.cpp:79, 687, 87).  The stages either run here (trackCamera /
         // trackObjects) or their results arrive as in.cam_pose / in.obj_poses.
+        // The far bounds of this frame's raycast need the frame's FINAL poses and nothing else of it:
+        // with both poses supplied they are known now and the bounds are computed beside the E-steps,
+        // otherwise as soon as the object tracking is through (beside the last E-step).
+        const bool posesKnown = !in.trackCamera && !in.trackObjects;
+        if (posesKnown) {
+            std::vector<emf_pose_t> co;
+            co.push_back(toPose(background.getPose().inv() * in.cam_pose));
+            for (const auto& obj : objects) {
+                const auto it = in.obj_poses.find(obj.getID());
+                co.push_back(toPose((it != in.obj_poses.end() ? it->second : obj.getPose()).inv() * in.cam_pose));
+            }
+            computeFarBounds(co);
+        }
         computeAssociationWeights();
         if (in.trackCamera) trackCamera();  // EMFusion.cpp:673-685
         else pose = in.cam_pose;            // ... or its result, supplied
         computeAssociationWeights();
         if (in.trackObjects) trackObjects();  // EMFusion.cpp:689-723
         else applyObjectPoses();
+        if (!posesKnown) {
+            std::vector<emf_pose_t> co;
+            posesCO(co);
+            computeFarBounds(co);
+        }
         computeAssociationWeights();
         stamp(kEstep);
-        integrateBackgroundAsync();  // runs beside the far bounds and the raycast (see there)
-        computeFarBounds();
+        integrateBackgroundAsync();  // runs beside the raycast (see there)
+        joinFarBounds();
         raycast();
     } else {
         pose = in.cam_pose;
@@ -1118,24 +1134,23 @@ void EMFusion::raycastBatched() {
     compositeAndVisibility(true);
 }
 
-// Far bounds of this frame's raycast (poses are final).  They read the relevant-tile lists, which are
-// rebuilt on the `lists` stream: last frame's rebuild has to be through, and this frame's rebuild of the
-// background's list -- its integration has been forked already -- is enqueued behind this launch.
-void EMFusion::computeFarBounds() {
+// Far bounds of this frame's raycast for its final camera -> volume poses `co`.  They read the relevant-tile
+// lists, which are rebuilt on the `lists` stream behind the integrations -- so that is where the bounds are
+// computed too, in order behind last frame's rebuilds and beside whatever `main` is doing (E-steps);
+// joinFarBounds() makes `main` wait for them in front of the raycast.
+void EMFusion::computeFarBounds(const std::vector<emf_pose_t>& co) {
     farBoundsReady = false;
-    if (batched && !farBounds.empty() && TSDF::brickFlagMode() == 0) {
-        if (listsPending) {
-            main.waitFor(lists);
-            listsPending = false;
-        }
-        std::vector<emf_pose_t> co;
-        posesCO(co);
-        emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
-                                          params.frameSize.width, params.frameSize.height, params.intr.val, 0,
-                                          farBounds.as<float>(), main.abi()),
-                 "raycastFarBounds");
-        farBoundsReady = true;
-    }
+    if (!batched || farBounds.empty() || TSDF::brickFlagMode() != 0) return;
+    lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
+    emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
+                                      params.frameSize.width, params.frameSize.height, params.intr.val, 0,
+                                      farBounds.as<float>(), lists.abi()),
+             "raycastFarBounds");
+    farBoundsReady = true;
+}
+
+void EMFusion::joinFarBounds() {
+    if (farBoundsReady) main.waitFor(lists);  // before this frame's list rebuild is enqueued there
     rebuildBackgroundList();
 }
 
@@ -1146,10 +1161,8 @@ void EMFusion::rebuildBackgroundList() {
     if (!bgListPending) return;
     bgListPending = false;
     if (!useFarBounds || farBounds.empty()) return;
-    lists.waitOn(aux);    // the record() behind the integration kernels
-    lists.waitFor(main);  // this frame's far bounds
+    lists.waitOn(aux);  // the record() behind the integration kernels (this frame's far bounds ran on `lists`)
     emfCheck(emf_hip_updateRelevantTiles(currentTable(), resHost.data(), 1, lists.abi()), "updateRelevantTiles");
-    listsPending = true;
 }
 
 bool EMFusion::overlapUsable() const {
@@ -1246,11 +1259,9 @@ void EMFusion::integrateBatched() {
         // integration above (the background's own list went there behind its integration already).
         const int from = overlapped ? 1 : 0;
         if (n > from) {
-            Stream& s = overlapped ? lists : main;
-            if (overlapped) lists.waitFor(main);
-            emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, s.abi()),
+            lists.waitFor(main);
+            emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, lists.abi()),
                      "updateRelevantTiles");
-            listsPending = listsPending || overlapped;
         }
     }
 }

@@ -382,11 +382,11 @@ private:
     DeviceBuffer farBounds;
     bool farBoundsReady = false;
     Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
-    bool listsPending = false;  // ... something is enqueued there that the next computeFarBounds() must wait for
     bool bgListPending = false; // the background was forked; its list rebuild is not enqueued yet
     bool bgPrepared = false;    // bgCullScratch's counter and the next dirtyNext map are already cleared
     void rebuildBackgroundList();
-    void computeFarBounds();
+    void computeFarBounds(const std::vector<emf_pose_t>& co);
+    void joinFarBounds();
     DeviceBuffer bgCullScratch;     // box list of the background's own launch
     bool overlapUsable() const;
     void integrateBackgroundAsync();  // fork: enqueue on aux what integrateDepth() would do for slot 0
