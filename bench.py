@@ -414,6 +414,15 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
     }
     if copy_gbs:
         roof["frac_of_copy"] = round(dom["achieved_GBs"] / copy_gbs, 4)
+    if roof["traffic"]:  # what the PMC pass saw moving at the HBM side, at this launch's duration
+        roof["traffic_GBs"] = round(roof["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9, 1)
+    if dom["kind"] == "raycast":
+        roof["note"] = ("achieved = SURVEY 8(d)'s gather-byte model (64 B per march sample + 96 B per hit + 29 B per "
+                        "pixel and model) over the launch duration: an upper bound on the bytes that, as 8(d) says, "
+                        "caches beat -- the 8 corners of consecutive samples and neighbouring rays are served by L1 / "
+                        "L2 (hit rate 0.85-0.90), so frac can pass 1 while the HBM side moves only `traffic`. The "
+                        "kernel is bound by the latency chain of its longest marches and the CU's gather path "
+                        "(DESIGN.md 5.3), not by HBM; the streaming kernel of the path is integrate_stream.")
     # SURVEY 8(d) headline for the streaming part: algorithmic integrate bytes over integrate time
     integ = next((r for r in rows if r["kind"] == "integrate_bg"), None)
     overlapped = integ is not None  # the background's integration runs beside the raycast on a second stream
@@ -427,6 +436,8 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
             "frac_of_copy": round(integ["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
             "avg_launch_ms": integ["avg_ms"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"],
             "traffic": measured_traffic(integ["kind"]) if profiled else None,
+            "traffic_GBs": (round(measured_traffic(integ["kind"]) / (integ["avg_ms"] * 1e-3) / 1e9, 1)
+                            if profiled and measured_traffic(integ["kind"]) else None),
             "note": "alg_bytes = 16 B x every voxel of the integrated volumes (SURVEY 8d); boxes outside "
                     "the view cone are culled before they are touched, so the model rate can exceed the "
                     "HBM peak -- `traffic` is what really moves.  With concurrent_with_raycast the launch "
