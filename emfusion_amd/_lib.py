@@ -64,7 +64,7 @@ SIGNATURES = {
     "emf_hip_signMapBytes": [_I3],
     "emf_hip_rebuildSignMaps": [_FP, _I3, _FP, _STREAM],
     "emf_hip_raycastFarBoundBytes": [C.c_int, C.c_int, C.c_int],
-    "emf_hip_raycastFarBounds": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _STREAM],
+    "emf_hip_raycastFarBounds": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_uint32, _FP, _STREAM],
     "emf_hip_relevantTileBytes": [_I3],
     "emf_hip_updateRelevantTiles": [_FP, _I3, C.c_int, _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],

@@ -353,8 +353,12 @@ struct FarBoundArgs {
 __global__ __launch_bounds__(256) void k_far_init(const FarBoundArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x, cells = a.cellsX * a.cellsY;
     if (i >= a.nmodels * cells) return;
-    // a model without sign maps is marched to the end as before
-    a.bounds[i] = a.models[i / cells].signMaps ? 0.f : __builtin_inff();
+    // a model without sign maps -- or with maps that nobody looks at: no list and not in the scan mask --
+    // is marched to the end as before
+    const int m = i / cells;
+    const emf_model_t& md = a.models[m];
+    const bool bounded = md.signMaps && (md.relevantTiles || a.tileStart[m + 1] != a.tileStart[m]);
+    a.bounds[i] = bounded ? 0.f : __builtin_inff();
 }
 
 // Is tile (tx, ty, tz) of model md one in which a hit can be completed?  (see above)
@@ -380,40 +384,43 @@ __device__ __forceinline__ bool tile_relevant(const emf_model_t& md, int tx, int
     return any_in(pos, (reach + kTileX - 1) / kTileX, (reach + kTileY - 1) / kTileY, (reach + kTileZ - 1) / kTileZ);
 }
 
-// Project tile (tx, ty, tz) into the image and raise the far bound of the cells it may cover.
-__device__ __forceinline__ void raise_far_bounds(const FarBoundArgs& a, int m, const emf_model_t& md, int tx, int ty, int tz) {
+// The 64 lanes of a wave project tile (tx, ty, tz) and raise the far bounds of the cells it may cover:
+// lanes 0..7 (and their copies) take the corners, then all lanes share the cells (a tile covers some tens
+// of cells: one lane walking them alone pays an L2 round trip per cell).  Wave-uniform arguments.
+__device__ __forceinline__ void raise_far_bounds_wave(const FarBoundArgs& a, int m, const emf_model_t& md, int tx, int ty,
+                                                      int tz) {
     const I3 n = I3{md.res[0], md.res[1], md.res[2]};
-    // the tile's sample positions in the camera frame: voxel box widened by 1.5 voxels (a cell's far
-    // corners, rounding of the march's position arithmetic)
     const M33 R = pose_R(a.poses.p[m]);
     const V3 cam = pose_t(a.poses.p[m]);
     const V3 half = half_extent(n);
-    const float lo[3] = {static_cast<float>(tx * kTileX) - 1.5f, static_cast<float>(ty * kTileY) - 1.5f,
-                         static_cast<float>(tz * kTileZ) - 1.5f};
-    const float hi[3] = {static_cast<float>(min((tx + 1) * kTileX, n.x)) + 1.5f,
-                         static_cast<float>(min((ty + 1) * kTileY, n.y)) + 1.5f,
-                         static_cast<float>(min((tz + 1) * kTileZ, n.z)) + 1.5f};
-    float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f, far = 0.f;
-    bool wide = false;  // a corner at or behind the camera plane: cover the whole image
-    for (int k = 0; k < 8; ++k) {
-        const V3 q = v3((((k & 1) ? hi[0] : lo[0]) - half.x) * md.voxelSize, (((k & 2) ? hi[1] : lo[1]) - half.y) * md.voxelSize,
-                        (((k & 4) ? hi[2] : lo[2]) - half.z) * md.voxelSize);
-        const V3 d = v3(q.x - cam.x, q.y - cam.y, q.z - cam.z);
-        const V3 c = v3(R.r0.x * d.x + R.r1.x * d.y + R.r2.x * d.z, R.r0.y * d.x + R.r1.y * d.y + R.r2.y * d.z,
-                        R.r0.z * d.x + R.r1.z * d.y + R.r2.z * d.z);  // R^T d
-        far = fmaxf(far, norm(d));
-        if (!(c.z > 1e-2f * md.voxelSize)) {
-            wide = true;
-        } else {
-            const float u = a.fx * c.x / c.z + a.cx, v = a.fy * c.y / c.z + a.cy;
-            umin = fminf(umin, u); umax = fmaxf(umax, u);
-            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-        }
+    const int lane = threadIdx.x & 63;
+    // corner (lane & 7) of the tile's voxel box widened by 1.5 voxels (a cell's far corners, rounding of the
+    // march's position arithmetic), in the camera frame
+    const int k = lane & 7;
+    const float ix = (k & 1) ? static_cast<float>(min((tx + 1) * kTileX, n.x)) + 1.5f : static_cast<float>(tx * kTileX) - 1.5f;
+    const float iy = (k & 2) ? static_cast<float>(min((ty + 1) * kTileY, n.y)) + 1.5f : static_cast<float>(ty * kTileY) - 1.5f;
+    const float iz = (k & 4) ? static_cast<float>(min((tz + 1) * kTileZ, n.z)) + 1.5f : static_cast<float>(tz * kTileZ) - 1.5f;
+    const V3 q = v3((ix - half.x) * md.voxelSize, (iy - half.y) * md.voxelSize, (iz - half.z) * md.voxelSize);
+    const V3 d = v3(q.x - cam.x, q.y - cam.y, q.z - cam.z);
+    const V3 c = v3(R.r0.x * d.x + R.r1.x * d.y + R.r2.x * d.z, R.r0.y * d.x + R.r1.y * d.y + R.r2.y * d.z,
+                    R.r0.z * d.x + R.r1.z * d.y + R.r2.z * d.z);  // R^T d
+    const bool behind = !(c.z > 1e-2f * md.voxelSize);  // at or behind the camera plane: cover the whole image
+    float far = norm(d);
+    float umin = behind ? 3e38f : a.fx * c.x / c.z + a.cx, umax = behind ? -3e38f : umin;
+    float vmin = behind ? 3e38f : a.fy * c.y / c.z + a.cy, vmax = behind ? -3e38f : vmin;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {  // over the 8 corners (every group of 8 lanes holds all of them)
+        far = fmaxf(far, __shfl_xor(far, o));
+        umin = fminf(umin, __shfl_xor(umin, o));
+        umax = fmaxf(umax, __shfl_xor(umax, o));
+        vmin = fminf(vmin, __shfl_xor(vmin, o));
+        vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     }
+    const bool wide = __ballot(behind) != 0ull;
     int cx0 = 0, cx1 = a.cellsX - 1, cy0 = 0, cy1 = a.cellsY - 1;
     if (!wide) {
         if (!(umax >= -2.f && vmax >= -2.f && umin <= static_cast<float>(a.w) + 1.f && vmin <= static_cast<float>(a.h) + 1.f))
-            return;  // projects beside the image
+            return;  // projects beside the image (wave-uniform)
         cx0 = max(static_cast<int>(floorf((umin - 2.f) / 8.f)), 0);
         cy0 = max(static_cast<int>(floorf((vmin - 2.f) / 8.f)), 0);
         cx1 = min(static_cast<int>(floorf((fminf(umax, 1e6f) + 2.f) / 8.f)), a.cellsX - 1);
@@ -422,88 +429,63 @@ __device__ __forceinline__ void raise_far_bounds(const FarBoundArgs& a, int m, c
     // raylength of a sample = its distance from the camera (unit direction): a relative and an absolute margin
     const unsigned bits = __float_as_uint(far * 1.0001f + 2.f * md.voxelSize);
     unsigned* cells = reinterpret_cast<unsigned*>(a.bounds) + static_cast<size_t>(m) * a.cellsX * a.cellsY;
-    for (int y = cy0; y <= cy1; ++y)
-        for (int x = cx0; x <= cx1; ++x) {
-            unsigned* c = &cells[y * a.cellsX + x];
-            // positive floats order as integers; most tiles raise nothing (plain read first: an atomic
-            // is a trip to L2 and back whether or not it changes the value)
-            if (__builtin_nontemporal_load(c) < bits) atomicMax(c, bits);
-        }
+    const int wdt = cx1 - cx0 + 1, cnt = wdt * (cy1 - cy0 + 1);
+    for (int i = lane; i < cnt; i += 64) {
+        unsigned* cp = &cells[(cy0 + i / wdt) * a.cellsX + cx0 + i % wdt];
+        // positive floats order as integers; most tiles raise nothing (plain read first: an atomic is a
+        // trip to L2 and back whether or not it changes the value)
+        if (__builtin_nontemporal_load(cp) < bits) atomicMax(cp, bits);
+    }
 }
 
-// one thread per tile of every model WITHOUT a relevant-tile list (emf_model_t.relevantTiles == NULL)
+// The relevance test of tile_relevant with the neighbourhood spread over the lanes of a wave.
+__device__ __forceinline__ bool tile_relevant_wave(const emf_model_t& md, int tx, int ty, int tz) {
+    const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY,
+              ntz = (md.res[2] + kTileZ - 1) / kTileZ;
+    const uint8_t* pos = md.signMaps;
+    const uint8_t* neg = pos + static_cast<size_t>(ntx) * nty * ntz;
+    const int lane = threadIdx.x & 63;
+    auto any_in = [&](const uint8_t* map, int rx, int ry, int rz) {
+        const int wx = 2 * rx + 1, wy = 2 * ry + 1, cnt = wx * wy * (2 * rz + 1);
+        bool any = false;
+        for (int i = lane; i < cnt; i += 64) {
+            const int x = tx - rx + i % wx, y = ty - ry + (i / wx) % wy, z = tz - rz + i / (wx * wy);
+            if (x >= 0 && x < ntx && y >= 0 && y < nty && z >= 0 && z < ntz)
+                any = any || map[(static_cast<size_t>(z) * nty + y) * ntx + x] != 0;
+        }
+        return __ballot(any) != 0ull;
+    };
+    if (!any_in(neg, 1, 1, 1)) return false;
+    const int reach = 2 * static_cast<int>(ceilf(md.truncdist / md.voxelSize)) + 4;
+    return any_in(pos, (reach + kTileX - 1) / kTileX, (reach + kTileY - 1) / kTileY, (reach + kTileZ - 1) / kTileZ);
+}
+
+// models WITHOUT a relevant-tile list (object volumes): one wave per tile of their sign maps
 __global__ __launch_bounds__(256) void k_far_bounds(const FarBoundArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.tileStart[a.nmodels]) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.tileStart[a.nmodels]) return;  // wave-uniform
     int m = 0;
-    while (m + 1 < a.nmodels && i >= a.tileStart[m + 1]) ++m;
+    while (m + 1 < a.nmodels && i >= a.tileStart[m + 1]) ++m;  // (models outside the scan mask have no tiles here)
     const emf_model_t& md = a.models[m];
-    if (!md.signMaps || md.relevantTiles) return;
+    if (!md.signMaps) return;
     const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY;
     const int t = i - a.tileStart[m];
     const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
-    if (tile_relevant(md, tx, ty, tz)) raise_far_bounds(a, m, md, tx, ty, tz);
+    if (tile_relevant_wave(md, tx, ty, tz)) raise_far_bounds_wave(a, m, md, tx, ty, tz);
 }
 
 // models WITH a list (emf_hip_updateRelevantTiles, after each integration): one WAVE per listed tile -- a few
-// thousand tiles instead of a neighbourhood scan around every tile of the volume.  Lanes 0..7 project the
-// tile's corners, then the 64 lanes share the cells of its footprint (a tile covers some tens of cells:
-// one lane walking them alone pays an L2 round trip per cell, 260 us per launch when 8 workgroups did it).
+// thousand tiles instead of a neighbourhood scan around every tile of a 512^3 volume
 constexpr int kFarListBlocks = 512;  // x 4 waves per model; the list is walked with that stride (64: 36 us for 3300 tiles)
 __global__ __launch_bounds__(256) void k_far_bounds_listed(const FarBoundArgs a) {
     const int m = blockIdx.x / kFarListBlocks;
     const emf_model_t& md = a.models[m];
-    if (!md.signMaps || !md.relevantTiles) return;
+    if (!md.signMaps || !md.relevantTiles || a.tileStart[m + 1] != a.tileStart[m]) return;  // no maps / scanned instead
     const unsigned count = md.relevantTiles[0];
-    const I3 n = I3{md.res[0], md.res[1], md.res[2]};
-    const int ntx = (n.x + kTileX - 1) / kTileX, nty = (n.y + kTileY - 1) / kTileY;
-    const M33 R = pose_R(a.poses.p[m]);
-    const V3 cam = pose_t(a.poses.p[m]);
-    const V3 half = half_extent(n);
-    const int lane = threadIdx.x & 63;
-    unsigned* cells = reinterpret_cast<unsigned*>(a.bounds) + static_cast<size_t>(m) * a.cellsX * a.cellsY;
+    const int ntx = (md.res[0] + kTileX - 1) / kTileX, nty = (md.res[1] + kTileY - 1) / kTileY;
     for (unsigned e = (blockIdx.x % kFarListBlocks) * 4u + (threadIdx.x >> 6); e < count; e += kFarListBlocks * 4u) {
         const int t = static_cast<int>(md.relevantTiles[1 + e]);
-        const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
-        // corner (lane & 7) of the tile's voxel box widened by 1.5 voxels (a cell's far corners, rounding
-        // of the march's position arithmetic), in the camera frame; all lanes compute one (lanes 8.. repeat)
-        const int k = lane & 7;
-        const float ix = (k & 1) ? static_cast<float>(min((tx + 1) * kTileX, n.x)) + 1.5f : static_cast<float>(tx * kTileX) - 1.5f;
-        const float iy = (k & 2) ? static_cast<float>(min((ty + 1) * kTileY, n.y)) + 1.5f : static_cast<float>(ty * kTileY) - 1.5f;
-        const float iz = (k & 4) ? static_cast<float>(min((tz + 1) * kTileZ, n.z)) + 1.5f : static_cast<float>(tz * kTileZ) - 1.5f;
-        const V3 q = v3((ix - half.x) * md.voxelSize, (iy - half.y) * md.voxelSize, (iz - half.z) * md.voxelSize);
-        const V3 d = v3(q.x - cam.x, q.y - cam.y, q.z - cam.z);
-        const V3 c = v3(R.r0.x * d.x + R.r1.x * d.y + R.r2.x * d.z, R.r0.y * d.x + R.r1.y * d.y + R.r2.y * d.z,
-                        R.r0.z * d.x + R.r1.z * d.y + R.r2.z * d.z);  // R^T d
-        const bool behind = !(c.z > 1e-2f * md.voxelSize);  // at or behind the camera plane: cover the whole image
-        float far = norm(d);
-        float umin = behind ? 3e38f : a.fx * c.x / c.z + a.cx, umax = behind ? -3e38f : umin;
-        float vmin = behind ? 3e38f : a.fy * c.y / c.z + a.cy, vmax = behind ? -3e38f : vmin;
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {  // over the 8 corners (every group of 8 lanes holds all of them)
-            far = fmaxf(far, __shfl_xor(far, o));
-            umin = fminf(umin, __shfl_xor(umin, o));
-            umax = fmaxf(umax, __shfl_xor(umax, o));
-            vmin = fminf(vmin, __shfl_xor(vmin, o));
-            vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        }
-        const bool wide = __ballot(behind) != 0ull;
-        int cx0 = 0, cx1 = a.cellsX - 1, cy0 = 0, cy1 = a.cellsY - 1;
-        if (!wide) {
-            if (!(umax >= -2.f && vmax >= -2.f && umin <= static_cast<float>(a.w) + 1.f && vmin <= static_cast<float>(a.h) + 1.f))
-                continue;  // projects beside the image (wave-uniform)
-            cx0 = max(static_cast<int>(floorf((umin - 2.f) / 8.f)), 0);
-            cy0 = max(static_cast<int>(floorf((vmin - 2.f) / 8.f)), 0);
-            cx1 = min(static_cast<int>(floorf((fminf(umax, 1e6f) + 2.f) / 8.f)), a.cellsX - 1);
-            cy1 = min(static_cast<int>(floorf((fminf(vmax, 1e6f) + 2.f) / 8.f)), a.cellsY - 1);
-        }
-        // raylength of a sample = its distance from the camera (unit direction): a relative and an absolute margin
-        const unsigned bits = __float_as_uint(far * 1.0001f + 2.f * md.voxelSize);
-        const int wdt = cx1 - cx0 + 1, cnt = wdt * (cy1 - cy0 + 1);
-        for (int i = lane; i < cnt; i += 64) {
-            unsigned* cp = &cells[(cy0 + i / wdt) * a.cellsX + cx0 + i % wdt];
-            if (__builtin_nontemporal_load(cp) < bits) atomicMax(cp, bits);  // positive floats order as integers
-        }
+        raise_far_bounds_wave(a, m, md, t % ntx, (t / ntx) % nty, t / (ntx * nty));
     }
 }
 
@@ -940,7 +922,7 @@ size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height) {
 }
 
 int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, const int32_t* res_host,
-                             int nmodels, int width, int height, const float K[9], int scanAll, float* bounds_dev,
+                             int nmodels, int width, int height, const float K[9], uint32_t scanMask, float* bounds_dev,
                              emf_stream_t stream) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastFarBounds"));
     EMF_REQUIRE_PTR(res_host);
@@ -954,7 +936,8 @@ int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* po
     for (int m = 0; m < nmodels; ++m) {
         EMF_TRY(check_res(res_host + 3 * m));
         a.poses.p[m] = poseCO_host[m];
-        const size_t tiles = emf_hip_signMapBytes(res_host + 3 * m) / 2;
+        // the scan kernel's grid only covers the models the caller asks it to scan
+        const size_t tiles = ((scanMask >> m) & 1u) ? emf_hip_signMapBytes(res_host + 3 * m) / 2 : 0;
         if (tiles > static_cast<size_t>(0x7fffffff - a.tileStart[m])) return fail(EMF_E_LIMIT, "raycastFarBounds: too many tiles");
         a.tileStart[m + 1] = a.tileStart[m] + static_cast<int>(tiles);
     }
@@ -968,8 +951,8 @@ int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* po
     a.cy = K[5];
     a.bounds = bounds_dev;
     hipLaunchKernelGGL(k_far_init, dim3(ceil_div(nmodels * a.cellsX * a.cellsY, 256)), dim3(256), 0, as_stream(stream), a);
-    if (scanAll)  // some model has sign maps but no relevant-tile list (the caller knows; the kernel checks per model)
-        hipLaunchKernelGGL(k_far_bounds, dim3(ceil_div(a.tileStart[nmodels], 256)), dim3(256), 0, as_stream(stream), a);
+    if (a.tileStart[nmodels] > 0)  // models with sign maps but no relevant-tile list
+        hipLaunchKernelGGL(k_far_bounds, dim3(ceil_div(a.tileStart[nmodels], 4)), dim3(256), 0, as_stream(stream), a);
     hipLaunchKernelGGL(k_far_bounds_listed, dim3(nmodels * kFarListBlocks), dim3(256), 0, as_stream(stream), a);
     return launch_status("raycastFarBounds");
 }

@@ -272,7 +272,12 @@ void EMFusion::rebuildModelTable() {
     }
     bool tiled = true;
     voxelHost.clear();
+    scanMask = 0;
+    listMask = 0;
     for (const auto& md : modelsHost) {
+        const unsigned bit = 1u << (voxelHost.size() & 31);
+        if (md.signMaps && !md.relevantTiles) scanMask |= bit;
+        if (md.signMaps && md.relevantTiles) listMask |= bit;
         voxelHost.push_back(md.voxelSize);
         resHost.insert(resHost.end(), md.res, md.res + 3);
         tiled &= md.res[0] % 4 == 0;
@@ -1143,7 +1148,7 @@ void EMFusion::computeFarBounds(const std::vector<emf_pose_t>& co) {
     if (!batched || farBounds.empty() || TSDF::brickFlagMode() != 0) return;
     lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
     emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
-                                      params.frameSize.width, params.frameSize.height, params.intr.val, 0,
+                                      params.frameSize.width, params.frameSize.height, params.intr.val, scanMask,
                                       farBounds.as<float>(), lists.abi()),
              "raycastFarBounds");
     farBoundsReady = true;
@@ -1258,7 +1263,7 @@ void EMFusion::integrateBatched() {
         // Nothing of this frame needs them: with the streams in use they go to `lists`, behind the
         // integration above (the background's own list went there behind its integration already).
         const int from = overlapped ? 1 : 0;
-        if (n > from) {
+        if (n > from && (listMask >> from) != 0) {
             lists.waitFor(main);
             emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, lists.abi()),
                      "updateRelevantTiles");

@@ -394,6 +394,7 @@ private:
     std::vector<emf_model_t> modelsHost;
     std::vector<int32_t> resHost;   // 3 per model
     std::vector<float> voxelHost;   // voxel size per model (object footprints of the batched raycast)
+    uint32_t scanMask = 0, listMask = 0;  // far bounds: models whose sign maps are scanned / that keep a relevant-tile list
     DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device
     DeviceBuffer integrateStatsDev; // u64: voxels swept by integrateBatched
     int32_t* visibleHost = nullptr; // pinned mirror of visCounts for visibleObjects()

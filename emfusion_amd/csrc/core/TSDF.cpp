@@ -206,7 +206,11 @@ void TSDF::describe(emf_model_t& m) const {
     m.reserved = mode == 2 ? 2 : 0;
     m.rcpVoxel = rcpVoxel;
     m.signMaps = signMapsValid && !signMaps.empty() ? signMaps.as<uint8_t>() : nullptr;
-    m.relevantTiles = m.signMaps && !relevantTiles.empty() ? relevantTiles.as<uint32_t>() : nullptr;
+    // a list pays for large volumes (the far bounds then project a few thousand tiles instead of scanning
+    // 65 536 neighbourhoods); an object volume's thousand tiles are scanned faster than a list is kept
+    m.relevantTiles = m.signMaps && !relevantTiles.empty() && emf_hip_signMapBytes(volumeRes.val) / 2 >= 8192
+                          ? relevantTiles.as<uint32_t>()
+                          : nullptr;
     m.pad_ = 0;
 }
 

@@ -321,7 +321,7 @@ def rebuild_sign_maps(tsdf, sign_maps, stream=None):
           _L.emf_hip_rebuildSignMaps(_ptr(tsdf), (C.c_int32 * 3)(nx, ny, nz), _ptr(sign_maps), _stream(stream)))
 
 
-def raycast_far_bounds(models_dev, poses_co, res_list, width, height, K, bounds=None, stream=None):
+def raycast_far_bounds(models_dev, poses_co, res_list, width, height, K, bounds=None, stream=None, scan_mask=0xffffffff):
     """emf_hip_raycastFarBounds -> float32 (nmodels, cellsY, cellsX) device array."""
     n = len(poses_co)
     res = (C.c_int32 * (3 * n))(*[int(v) for r in res_list for v in r])
@@ -330,7 +330,7 @@ def raycast_far_bounds(models_dev, poses_co, res_list, width, height, K, bounds=
         assert int(_L.emf_hip_raycastFarBoundBytes(n, width, height)) == 4 * n * cy * cx
         bounds = DeviceArray.zeros((n, cy, cx), np.float32)
     check("emf_hip_raycastFarBounds",
-          _L.emf_hip_raycastFarBounds(_ptr(models_dev), _poses(poses_co), res, n, width, height, _f(K, 9), 1,
+          _L.emf_hip_raycastFarBounds(_ptr(models_dev), _poses(poses_co), res, n, width, height, _f(K, 9), int(scan_mask),
                                       _ptr(bounds), _stream(stream)))
     return bounds
 

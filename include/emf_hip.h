@@ -322,12 +322,12 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
 size_t emf_hip_signMapBytes(const int32_t res[3]);
 int emf_hip_rebuildSignMaps(const float* tsdf, const int32_t res[3], uint8_t* signMaps, emf_stream_t stream);
 size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height);
-/* scanAll != 0: models without a relevant-tile list (emf_model_t.relevantTiles == NULL) have every tile of
- * their sign maps examined (a neighbourhood scan per tile: ~50 us for a 512^3 volume); 0: the caller
- * guarantees that every model with sign maps also has a list. */
+/* scanMask: bit m set = model m has every tile of its sign maps examined (a neighbourhood scan per tile:
+ * fine for an object volume, ~50 us for a 512^3 one); clear = its relevant-tile list is walked
+ * (emf_model_t.relevantTiles; a model with neither bit nor list keeps its whole range). */
 int emf_hip_raycastFarBounds(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                              const int32_t* res_host, int nmodels, int width, int height, const float K[9],
-                             int scanAll, float* bounds_dev, emf_stream_t stream);
+                             uint32_t scanMask, float* bounds_dev, emf_stream_t stream);
 /* The tiles in which a hit can be completed, as a list per model (emf_model_t.relevantTiles:
  * emf_hip_relevantTileBytes(res) bytes: a count, then tile indices): rebuilt from the sign maps after an
  * integration -- off the frame's critical path -- so that emf_hip_raycastFarBounds, which needs the

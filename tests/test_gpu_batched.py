@@ -308,7 +308,8 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
             m.d_rel = dev_full((ops.relevant_tile_words(m.res),), 0xdead, np.uint32)
         table = ops.upload_models([m.table_entry() for m in scene])
         ops.update_relevant_tiles(table, res)
-        assert np.array_equal(to_np(ops.raycast_far_bounds(table, poses, res, W, H, K)), b)
+        assert np.array_equal(to_np(ops.raycast_far_bounds(table, poses, res, W, H, K, scan_mask=0)), b)
+        assert np.array_equal(to_np(ops.raycast_far_bounds(table, poses, res, W, H, K, scan_mask=0b010)), b)  # mixed
         counts = [int(to_np(m.d_rel)[0]) for m in scene]
         assert all(0 < c <= ops.sign_map_bytes(m.res) // 2 for c, m in zip(counts, scene)), counts
         for m in scene:
@@ -323,6 +324,9 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
         table = ops.upload_models([m.table_entry() for m in scene])
         b2 = to_np(ops.raycast_far_bounds(table, poses, res, W, H, K))
         assert np.isinf(b2[1]).all() and np.array_equal(b2[0], b[0]) and np.array_equal(b2[2], b[2])
+        # ... and so does one with maps that is neither scanned nor listed
+        b3 = to_np(ops.raycast_far_bounds(table, poses, res, W, H, K, scan_mask=0b001))
+        assert np.isinf(b3[1]).all() and np.isinf(b3[2]).all() and np.array_equal(b3[0], b[0])
     finally:
         for m in scene:
             m.d_sign = m.d_rel = None
