@@ -160,3 +160,46 @@ def test_march_sample_count_close_to_oracle(run):
     # the oracle marches every ray to the end of its range; the batched path cuts a march where nothing
     # can be hit any more (far bounds): never more samples than the oracle, and not wildly fewer
     assert 0.5 * orc.march_samples <= samples <= 1.01 * orc.march_samples
+
+
+def test_reset_in_the_middle_of_a_run_starts_over_exactly(dev):
+    """EMFusion::reset (reference EMFusion.cpp:58-68) with everything the native path keeps beside the
+    volumes -- second copy of the background and its dirty maps, fills done a frame ahead, sign maps,
+    relevant-tile lists, streams with work in flight: a run after reset() equals a run on a fresh instance
+    byte for byte."""
+    from emfusion_amd import pipeline
+    from emfusion_amd.ops import image_view
+    prm = pipeline.make_params(W, H, 128, 0.02, OBJ_RES, visibility_thresh=100, boundary=5, mask_frames=MASK_EVERY)
+    K = np.array(prm.K, np.float32)
+    synth = pipeline.SyntheticStream(W, H, K, NOBJ, seed=0xE3F5)
+    keep = []
+
+    def run(fus, frames):
+        ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(NOBJ)]
+        for f in frames:
+            depth, sid = synth.render(f)
+            R, t = synth.camera_pose(f)
+            poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
+            masks = {i: to_dev((sid == i).astype(np.uint8)) for i in ids} if f % MASK_EVERY == 0 else {}
+            d = to_dev(depth)
+            keep.append((d, masks))
+            fus.process_frame(image_view(d), R, t, poses, {i: image_view(m) for i, m in masks.items()}, bool(masks))
+        fus.synchronize()
+        return dict(t=fus.volume("tsdf", 0), w=fus.volume("weights", 0), ray=fus.image("raylengths"),
+                    seg=fus.image("segmentation"), obj={i: fus.volume("tsdf", i) for i in ids},
+                    assoc=fus.image("bg_assoc"))
+
+    fresh = pipeline.Fusion(prm, None)
+    want = run(fresh, range(5))
+    fresh.close()
+    fus = pipeline.Fusion(prm, None)
+    run(fus, range(2, 6))  # another stretch of the stream first, left without waiting for anything
+    fus.reset()
+    got = run(fus, range(5))
+    fus.close()
+    synth.close()
+    for k in ("t", "w", "ray", "seg", "assoc"):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    for i in want["obj"]:
+        assert got["obj"][i].tobytes() == want["obj"][i].tobytes(), i
+    assert (want["w"] > 0).sum() > 10000 and (want["seg"] > 0).sum() > 100
