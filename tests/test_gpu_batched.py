@@ -332,6 +332,62 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
             m.d_sign = m.d_rel = None
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_far_bounds_are_conservative_on_adversarial_volumes(ops, oracle, dev, seed):
+    """Volumes no integration would produce -- isolated positive and negative blobs in unseen space, thin
+    sheets, sign noise, a surface hugging the volume's outer shell -- seen from random poses (outside,
+    inside, grazing): the batched raycast with far bounds, relevant-tile lists and object footprints equals
+    the oracle's full march bit for bit (a bound that is too tight anywhere would lose a hit)."""
+    rng = np.random.default_rng(1000 + seed)
+    res, vox = (96, 64, 80), 0.02
+    nz, ny, nx = res[2], res[1], res[0]
+    zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    t = np.zeros((nz, ny, nx), np.float32)
+    w = np.zeros((nz, ny, nx), np.float32)
+    for _ in range(6):  # blobs: positive outside, negative inside, observed
+        c = rng.uniform([8, 8, 8], [nz - 8, ny - 8, nx - 8])
+        r = rng.uniform(3, 14)
+        d = (np.sqrt((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) - r) / 6.0
+        near = np.abs(d) < 1.5
+        t[near] = np.clip(d[near], -1, 1)
+        w[near] = rng.integers(1, 64)
+    if seed % 2:  # a thin sheet and sign noise
+        t[nz // 2] = np.where(xx[nz // 2] % 7 < 3, -0.4, 0.6)
+        w[nz // 2] = 5
+        noisy = rng.uniform(size=t.shape) < 0.002
+        t[noisy] = rng.choice([-1.0, 1.0, -0.3, 0.9], noisy.sum()).astype(np.float32)
+        w[noisy] = 1
+    else:  # a surface in the outermost cells of the volume
+        t[:, :, :3] = np.array([0.8, 0.1, -0.7], np.float32)
+        w[:, :, :3] = 9
+        t[-3:] = np.array([-0.9, 0.2, 0.9], np.float32)[:, None, None]
+        w[-3:] = 3
+    m = Model(ops, oracle, res, vox, Pose(rot([0.1, 1, 0.2], 11 * seed), [0.1, -0.05, 1.4]), False, 0)
+    m.tsdf[:], m.wts[:] = t, w
+    m.d_tsdf.copy_from(t)
+    m.d_wts.copy_from(w)
+    m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    m.d_sign = dev_full((ops.sign_map_bytes(res),), 9, np.uint8)
+    ops.rebuild_sign_maps(m.d_tsdf, m.d_sign)
+    m.d_rel = dev_full((ops.relevant_tile_words(res),), 0, np.uint32)
+    table = ops.upload_models([m.table_entry()])
+    ops.update_relevant_tiles(table, [res])
+    hits = 0
+    for k in range(6):
+        axis, ang = rng.normal(size=3), rng.uniform(0, 360)
+        cam = Pose(rot(axis, ang), m.pose.t + rng.uniform(-1.6, 1.6, 3) * (0.35 if k % 3 == 0 else 1.0))
+        co = rel_CO(cam, m.pose)
+        poses = [(co.R32, co.t32)]
+        want = oracle.raycast_tsdf(m.tsdf, None, m.wts, None, W, H, co.R32, co.t32, K, m.vox, m.trunc)
+        hits += int(want[3].sum())
+        for mask in (0, 1):  # list walked / maps scanned
+            bounds = ops.raycast_far_bounds(table, poses, [res], W, H, K, scan_mask=mask)
+            ops.raycast_batched(table, poses, [res], W, H, K, far_bounds=bounds, voxel_sizes=[m.vox])
+            for got, w_, name in zip([m.d_ray, m.d_vert, m.d_nrm, m.d_hit], want, ["ray", "vert", "normal", "mask"]):
+                assert_parity(to_np(got), w_, f"seed {seed} pose {k} scan {mask}: {name}", exact=True)
+    assert hits > 2000, hits
+
+
 def test_sign_maps_kept_by_the_integration_cover_the_exact_ones(ops, oracle, dev):
     """The tile integration launches (in place and out of place) leave sticky sign maps behind that are
     never short of a sign that is in the volume."""
