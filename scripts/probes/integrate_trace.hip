@@ -22,13 +22,11 @@ struct Rec {
 __global__ __launch_bounds__(256) void k_probe(const IntegrateGeom a, float* tsdf, float* weights,
                                                int ntx, int nty, Rec* rec) {
     __shared__ unsigned lds[32];
-    __shared__ float4 win4[kWinFloats / 4];
     const unsigned long long t0 = wall_clock64();
     const int b = blockIdx.x;
     const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
-    const TileWindow tw = tile_window(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
-    integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds,
-                   reinterpret_cast<float*>(win4));
+    const bool culledTile = tile_culled(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
+    integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds);
     __syncthreads();
     if (threadIdx.x == 0 && rec) {
         Rec r;
@@ -36,7 +34,7 @@ __global__ __launch_bounds__(256) void k_probe(const IntegrateGeom a, float* tsd
         r.t1 = wall_clock64();
         r.hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_ID
         r.xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
-        r.cls = tw.culled ? 0 : (tw.staged ? 1 : 2);
+        r.cls = culledTile ? 0 : 2;
         r.pad = 0;
         rec[b] = r;
     }
@@ -49,7 +47,6 @@ __global__ __launch_bounds__(256) void k_probe_persistent(const IntegrateGeom a,
                                                           int ntiles, int chunk, unsigned* tickets,
                                                           Rec* rec) {
     __shared__ unsigned lds[32];
-    __shared__ float4 win4[kWinFloats / 4];
     __shared__ unsigned s_next;
     const int nchunks = (ntiles + chunk - 1) / chunk;
     if (threadIdx.x == 0) s_next = atomicAdd(&tickets[0], 1u);
@@ -61,9 +58,8 @@ __global__ __launch_bounds__(256) void k_probe_persistent(const IntegrateGeom a,
         for (int b = cur * chunk; b < min((int)(cur + 1) * chunk, ntiles); ++b) {
             const unsigned long long t0 = wall_clock64();
             const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
-            const TileWindow tw = tile_window(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
-            integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds,
-                           reinterpret_cast<float*>(win4));
+            const bool culledTile = tile_culled(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
+            integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds);
             __syncthreads();
             if (threadIdx.x == 0 && rec) {
                 Rec r;
@@ -71,7 +67,7 @@ __global__ __launch_bounds__(256) void k_probe_persistent(const IntegrateGeom a,
                 r.t1 = wall_clock64();
                 r.hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
                 r.xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-                r.cls = tw.culled ? 0 : (tw.staged ? 1 : 2);
+                r.cls = culledTile ? 0 : 2;
                 r.pad = 0;
                 rec[b] = r;
             }
@@ -96,14 +92,12 @@ __global__ __launch_bounds__(256) void k_probe_list(const IntegrateGeom a, float
                                                     float* weights, int ntx, int nty,
                                                     const unsigned* list, int count, Rec* rec) {
     __shared__ unsigned lds[32];
-    __shared__ float4 win4[kWinFloats / 4];
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
         const unsigned long long t0 = wall_clock64();
         const int b = list[i];
         const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
-        const TileWindow tw = tile_window(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
-        integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds,
-                       reinterpret_cast<float*>(win4));
+        const bool culledTile = tile_culled(a, half_extent(a.n), tx * kTileX, ty * kTileY, tz * kTileZ);
+        integrate_tile(a, tsdf, weights, nullptr, tx * kTileX, ty * kTileY, tz * kTileZ, lds);
         __syncthreads();
         if (threadIdx.x == 0 && rec) {
             Rec r;
@@ -111,7 +105,7 @@ __global__ __launch_bounds__(256) void k_probe_list(const IntegrateGeom a, float
             r.t1 = wall_clock64();
             r.hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
             r.xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-            r.cls = tw.culled ? 0 : (tw.staged ? 1 : 2);
+            r.cls = culledTile ? 0 : 2;
             r.pad = 0;
             rec[b] = r;
         }
