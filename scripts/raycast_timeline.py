@@ -79,3 +79,11 @@ print(f" background waves with > 400 samples: {len(lw)}; tile columns {np.bincou
 print(f"   tile rows {np.bincount(ty, minlength=30).tolist()}")
 order = np.argsort(-r["smax"][lw])[:12]
 print("   longest:", [(int(tx[i]), int(ty[i]), int(r["wave"][lw][i]), int(r["smax"][lw][i])) for i in order])
+
+# the last waves to finish: who are they?
+order = np.argsort(r["t1"])[::-1][:24]
+print(" last waves to finish (end us, start us, model, tile x, tile y, sub-tile, max samples, ns/step):")
+tilesX = (W + 15) // 16
+for k in order:
+    print(f"   {(r['t1'][k] - t0) / 100.0:7.1f} {(r['t0'][k] - t0) / 100.0:7.1f}  m{r['model'][k]} ({r['tile'][k] % tilesX:2d},{r['tile'][k] // tilesX:2d}) w{r['wave'][k]} "
+          f"{r['smax'][k]:4d} {1e3 * dur[k] / max(r['smax'][k], 1):6.0f}")
