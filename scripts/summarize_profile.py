@@ -14,7 +14,7 @@ dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_integrate_listed_rest", "integrate_rest"),
                      ("k_integrate_listed<true>", "integrate_bg"), ("k_integrate_listed<(bool)1>", "integrate_bg"),
                      ("k_integrate_listed", "integrate"), ("k_integrate_cull", "integrate_cull"),
-                     ("k_far_bounds", "far_bounds"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
+                     ("k_far_bounds_listed", "far_bounds_listed"), ("k_far_bounds", "far_bounds_scan"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
                      ("k_relevant_tiles", "relevant_tiles"), ("k_relevant_reset", "relevant_reset"),
                      ("k_integrate_batched", "integrate"),
                      ("k_estep", "assoc"), ("k_composite", "composite"), ("k_vis_counts", "vis_counts"),
