@@ -142,6 +142,44 @@ __device__ __forceinline__ double wave_strided_sum(const float* p, int n, int st
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     return acc;
 }
+// The sums of 32 per-lane values over the wave, with 32 cross-lane moves instead of 32 x 6: at the
+// level that pairs lane L with L ^ o each lane keeps the half of the values its bit `o` selects,
+// adds the partner's copy of those and hands the other half over.  Every value still goes through
+// the xor tree of wave_sum (32, 16, ..., 1; a + b on one side is b + a on the other), so the
+// results are bit-identical to it; afterwards lane L holds the total of value L >> 1 in s[0].
+#ifndef EMF_TRACK_XPOSE
+#define EMF_TRACK_XPOSE 1
+#endif
+__device__ __forceinline__ void wave_sum32(float (&s)[32], int lane) {
+    // lane ^ 32 and lane ^ 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half
+    // (the odd 16-lane rows) of the first register with the lower half (the even rows) of the second
+    // in the VALU -- afterwards the two registers hold, lane by lane, the two addends
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 16]), false, false);
+        s[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 8]), false, false);
+        s[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int half = 4, o = 8; half >= 1; half >>= 1, o >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            float a = s[k], b = s[k + half];
+            // (opaque: otherwise the two selects become one dynamically indexed read of s[], which
+            // the backend expands into a compare chain over every register of the array)
+            asm("" : "+v"(a), "+v"(b));
+            const float keep = up ? b : a;
+            const float send = up ? a : b;
+            s[k] = keep + __shfl_xor(send, o);
+        }
+    }
+    s[0] += __shfl_xor(s[0], 1);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f)
         scratch_w(f, m)[pix] = w;
     }
     // As = (g_j * g_k) * w, bs = (r * g_j) * w: the products of computeAb / multSingletonCol
-    float s[kSums];
+    float s[32];
     int q = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j)
@@ -217,12 +255,18 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f)
 #pragma unroll
     for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
     s[27] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
+    s[28] = s[29] = s[30] = s[31] = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if EMF_TRACK_XPOSE
+    wave_sum32(s, lane);
+    if (!(lane & 1) && (lane >> 1) < kSums) red[wave][lane >> 1] = s[0];
+#else
 #pragma unroll
     for (int k = 0; k < kSums; ++k) {
         const float v = wave_sum(s[k]);
         if (lane == 0) red[wave][k] = v;
     }
+#endif
     __syncthreads();
     if (threadIdx.x < kSums) {
         float v = red[0][threadIdx.x];

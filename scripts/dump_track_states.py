@@ -1,0 +1,20 @@
+"""Dump the LM states (A, b, err, pose, mu ...) of tests/test_gpu_tracking.py's world after 1, 2, 5 and 100
+iterations to gpurun_out/<name>.npy -- to compare two builds of the tracking kernels byte by byte
+(python scripts/dump_track_states.py NAME; test infrastructure: uses the oracle to integrate the scene)."""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, ".")
+from oracle import binding
+from emfusion_amd import devmem, ops
+import tests.test_gpu_tracking as T
+
+binding.lib(); binding.set_threads(8); devmem.set_device(0)
+world = T.world.__wrapped__(binding)
+out = []
+for n in (1, 2, 5, 100):
+    tr = T.DeviceTracker(ops, world, [0, 1])
+    tr.iterate(n)
+    raw = T.to_np(tr.states).copy()
+    out.append(raw)
+np.save("gpurun_out/%s.npy" % sys.argv[1], np.stack(out))
+print(sys.argv[1], [int(x.view(np.uint32).sum()) for x in out])
