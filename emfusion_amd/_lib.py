@@ -150,7 +150,10 @@ class EmfTrackState(C.Structure):
                 ("maxIwTrialBits", C.c_uint32),
                 ("converged", C.c_int32), ("firstIteration", C.c_int32),
                 ("evaluateGradient", C.c_int32), ("haveTrial", C.c_int32),
-                ("iterations", C.c_int32), ("accepted", C.c_int32), ("iwSel", C.c_int32)]
+                ("iterations", C.c_int32), ("accepted", C.c_int32), ("iwSel", C.c_int32),
+                ("wSel", C.c_int32), ("needAccum", C.c_int32), ("haveSpec", C.c_int32),
+                ("spec", C.c_float * 28), ("checkB", C.c_int32),
+                ("pending", C.c_int32), ("body", C.c_int32), ("iterTarget", C.c_int32)]
 
 _lib = None
 

@@ -162,6 +162,7 @@ void EMFusion::reset() {
     bgBackStale = false;
     bgPrepared = false;
     bgListPending = false;
+    trackPredicted[0] = trackPredicted[1] = 0;
     Stream& s = Stream::Null();
     bg_associationWeights.setTo(1.f, s);
     diffRaylengths.setZero(s);
@@ -955,28 +956,41 @@ void EMFusion::trackModels(int first, int count) {
                                 pixels() * count * params.maxTrackingIter, main);
         emfCheck(emf_hip_trackPrepare(states, co.data() + first, count, tp.nuInit, main.abi()),
                  "trackPrepare");
-        // The loop itself needs no host: iterations are enqueued in chunks and the device-side
-        // `converged` flags are polled once per chunk, only to stop enqueuing launches that would
-        // return at once (LM converges in 20-40 of the 100 iterations; a no-op iteration still
-        // costs five launches).  The states come back with the last poll: the E-step and raycast
-        // that follow take the poses by value.
+        // The loop itself needs no host: iterations are enqueued in chunks (one launch each) and the
+        // device-side states are polled once per chunk, only to stop enqueuing launches that would
+        // return at once (LM converges in 20-40 of the 100 iterations).  A chunk normally advances
+        // every model by its n iterations; after more than one speculation miss (see
+        // emf_hip_trackIterate) by fewer -- the iteration counts come back with the poll.  The
+        // E-step and raycast that follow take the poses by value.
+        // The first chunk is as long as the stage was in the last frame (+2): consecutive frames
+        // take about the same number of steps, and an idle launch costs ~5 us, a poll ~30.
         const int chunk = trackChunk > 0 ? trackChunk : params.maxTrackingIter;
+        int& predicted = trackPredicted[first == 0 ? 0 : 1];
+        int taken = 0;
         for (int done = 0; done < params.maxTrackingIter;) {
-            const int n = std::min(chunk, params.maxTrackingIter - done);
+            const int want = done == 0 && predicted > 0 && trackChunk > 0 ? std::max(chunk, predicted + 2) : chunk;
+            const int n = std::min(want, params.maxTrackingIter - done);
             emfCheck(emf_hip_trackIterate(currentTable() + first, states, count, &pv,
                                           &tp, static_cast<char*>(trackScratch.data()) + per * first,
                                           per, n, main.abi()),
                      "trackIterate");
-            done += n;
             hipCheck(hipMemcpyAsync(trackStatesHost + first, states,
                                     sizeof(emf_track_state_t) * count, hipMemcpyDeviceToHost,
                                     main.get()),
                      "hipMemcpyAsync");
             main.waitForCompletion();
             bool all = true;
-            for (int m = first; m < first + count; ++m) all = all && trackStatesHost[m].converged;
+            done = params.maxTrackingIter;
+            for (int m = first; m < first + count; ++m) {
+                const emf_track_state_t& st = trackStatesHost[m];
+                taken = std::max(taken, st.iterations);
+                if (st.converged) continue;
+                all = false;
+                done = std::min(done, st.iterations);  // (judged steps; a pending trial is not counted yet)
+            }
             if (all) break;
         }
+        predicted = taken;
     }
 }
 

@@ -346,6 +346,7 @@ private:
     // ---- tracking (SURVEY f-1) ----
     void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)
     int trackChunk = 8;                        // iterations per convergence poll (0: never poll)
+    int trackPredicted[2] = {0, 0};            // iterations the camera / object stage took last frame
     DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_BATCH]
     DeviceBuffer trackScratch;                 // EMF_MAX_BATCH x emf_hip_trackScratchBytes
     emf_track_state_t* trackStatesHost = nullptr;  // pinned mirror

@@ -32,6 +32,8 @@
 // but fixed, run-to-run deterministic -- order than cv::cuda::reduce's unspecified one, and the
 // SE(3) exponential / QR re-orthonormalisation restate Sophus / Eigen (absent from the reference
 // tree, versions unpinned): these agree with the oracle to float rounding, not bit for bit.
+#include <atomic>
+
 #include "device_core.hpp"
 
 namespace emf_hip {
@@ -41,7 +43,9 @@ namespace {
 #define EMF_TRACK_BLOCK 1024  // 256: 1.64 ms per stage, 512: 1.51, 1024: 1.45 (fewer, fatter workgroups; 300 partial rows)
 #endif
 constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // pixels per workgroup
-constexpr int kSums = 28;          // 21 (upper triangle of A) + 6 (b) + 1 (error)
+constexpr int kCols = 30;          // partial-sum columns per workgroup: 21 (upper triangle of A) + 6 (b) + 1
+                                   // (error), + the trial step's error + max |integration weight| at the
+                                   // trial pose (k_track_step)
 
 struct TrackFrame {
     const emf_model_t* models;
@@ -50,22 +54,33 @@ struct TrackFrame {
     Img<const float> points;
     int w, h, nblocks;
     emf_track_params_t prm;
-    char* scratch;          // per model: [w image][iw image 0][iw image 1][partials 28 x nblocks][err nblocks]
+    char* scratch;          // per model: [w images 0, 1][iw images 0, 1][partials 2 x 30 x nblocks][shadow state]
     size_t scratchStride;   // bytes per model
+    int launch;             // index of the launch within the trackIterate call (parity of the double buffers)
+    int iterations;         // LM iterations the call asks for
 };
 
-__device__ __forceinline__ float* scratch_w(const TrackFrame& f, int m) {
+__device__ __forceinline__ float* scratch_base(const TrackFrame& f, int m) {
     return reinterpret_cast<float*>(f.scratch + f.scratchStride * m);
 }
-// two clamped-weight images: [sel] belongs to the current pose, [1 - sel] is filled at the trial pose
+// two per-pixel weight images (Huber x normalised integration weight x association): [wSel] belongs to
+// the current pose, the other one is filled at the trial pose
+__device__ __forceinline__ float* scratch_w(const TrackFrame& f, int m, int sel) {
+    return scratch_base(f, m) + static_cast<size_t>(f.w) * f.h * sel;
+}
+// two clamped integration-weight images, likewise ([iwSel])
 __device__ __forceinline__ float* scratch_iw(const TrackFrame& f, int m, int sel) {
-    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h * (1 + sel);
+    return scratch_base(f, m) + static_cast<size_t>(f.w) * f.h * (2 + sel);
 }
-__device__ __forceinline__ float* scratch_partials(const TrackFrame& f, int m) {
-    return scratch_w(f, m) + static_cast<size_t>(f.w) * f.h * 3;
+// two sets of partial sums, by launch parity
+__device__ __forceinline__ float* scratch_partials(const TrackFrame& f, int m, int parity) {
+    return scratch_base(f, m) + static_cast<size_t>(f.w) * f.h * 4 + static_cast<size_t>(f.nblocks) * kCols * parity;
 }
-__device__ __forceinline__ float* scratch_err(const TrackFrame& f, int m) {
-    return scratch_partials(f, m) + static_cast<size_t>(f.nblocks) * kSums;
+// the state, by launch parity: [0] is the caller's array, [1] a shadow in the scratch
+__device__ __forceinline__ emf_track_state_t* state_buf(const TrackFrame& f, int m, int parity) {
+    if (parity == 0) return f.states + m;
+    return reinterpret_cast<emf_track_state_t*>(scratch_base(f, m) + static_cast<size_t>(f.w) * f.h * 4 +
+                                                static_cast<size_t>(f.nblocks) * kCols * 2);
 }
 
 __device__ __forceinline__ M33 state_R(const float* R) {
@@ -73,8 +88,8 @@ __device__ __forceinline__ M33 state_R(const float* R) {
 }
 
 // pixel of this lane: blockIdx.x covers the image in runs of kTrackBlock pixels, blockIdx.y = model
-__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc) {
-    pix = static_cast<size_t>(blockIdx.x) * kTrackBlock + threadIdx.x;
+__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc, unsigned block = blockIdx.x) {
+    pix = static_cast<size_t>(block) * kTrackBlock + threadIdx.x;
     pc = v3(0.f, 0.f, 0.f);
     if (pix >= static_cast<size_t>(f.w) * f.h) return false;
     const int y = static_cast<int>(pix / f.w), x = static_cast<int>(pix - static_cast<size_t>(y) * f.w);
@@ -116,11 +131,6 @@ __device__ __forceinline__ void pose_gradient(const float* tsdf, const float* gr
     g[3] = gr.x; g[4] = gr.y; g[5] = gr.z;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 // sum of p[i * stride], i < n, over the 64 lanes of the calling wave: lane-strided partial sums in
 // double, then a fixed xor tree -- the same order on every run.  The loads of a lane are issued in
 // batches of 8 before any of them is added: a plain `acc += p[i]` loop is not pipelined by the
@@ -142,30 +152,54 @@ __device__ __forceinline__ double wave_strided_sum(const float* p, int n, int st
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     return acc;
 }
-// The sums of 32 per-lane values over the wave, with 32 cross-lane moves instead of 32 x 6: at the
+// two columns at once (same order of additions per column; their loads and shuffles overlap)
+__device__ __forceinline__ void wave_strided_sum2(const float* p0, const float* p1, int n, int lane,
+                                                  double& r0, double& r1) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + 64 * j;
+            v0[j] = i < n ? p0[i] : 0.f;
+            v1[j] = i < n ? p1[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a0 += static_cast<double>(v0[j]);
+            a1 += static_cast<double>(v1[j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+    }
+    r0 = a0;
+    r1 = a1;
+}
+// The sums of 16 per-lane values over the wave, with 17 cross-lane moves instead of 16 x 6: at the
 // level that pairs lane L with L ^ o each lane keeps the half of the values its bit `o` selects,
 // adds the partner's copy of those and hands the other half over.  Every value still goes through
-// the xor tree of wave_sum (32, 16, ..., 1; a + b on one side is b + a on the other), so the
-// results are bit-identical to it; afterwards lane L holds the total of value L >> 1 in s[0].
-#ifndef EMF_TRACK_XPOSE
-#define EMF_TRACK_XPOSE 1
-#endif
-__device__ __forceinline__ void wave_sum32(float (&s)[32], int lane) {
+// the plain xor tree `v += shfl_xor(v, o)`, o = 32, 16, ..., 1 (a + b on one side is b + a on the
+// other), so the results are bit-identical to it; afterwards lane L holds the total of value L >> 2
+// in s[0].  (16 at a time, not all 29 sums of a pixel at once: that many live registers spill.)
+__device__ __forceinline__ void wave_sum16(float (&s)[16], int lane) {
     // lane ^ 32 and lane ^ 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half
     // (the odd 16-lane rows) of the first register with the lower half (the even rows) of the second
     // in the VALU -- afterwards the two registers hold, lane by lane, the two addends
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 16]), false, false);
-        s[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 8]), false, false);
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 8]), false, false);
         s[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int half = 4, o = 8; half >= 1; half >>= 1, o >>= 1) {
+    for (int k = 0; k < 4; ++k) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[k]), __float_as_uint(s[k + 4]), false, false);
+        s[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int half = 2, o = 8; half >= 1; half >>= 1, o >>= 1) {
         const bool up = (lane & o) != 0;
 #pragma unroll
         for (int k = 0; k < half; ++k) {
@@ -178,6 +212,7 @@ __device__ __forceinline__ void wave_sum32(float (&s)[32], int lane) {
             s[k] = keep + __shfl_xor(send, o);
         }
     }
+    s[0] += __shfl_xor(s[0], 2);
     s[0] += __shfl_xor(s[0], 1);
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -192,7 +227,7 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) 
     const int m = blockIdx.y;
     emf_track_state_t& st = f.states[m];
     // only the first iteration of a stage: afterwards the weights of an accepted pose were already
-    // looked up by k_track_error when that pose was the trial (TSDF.cpp:212-214, 234)
+    // looked up by k_track_step when that pose was the trial (TSDF.cpp:212-214, 234)
     if (st.converged || !st.firstIteration) return;
     const emf_model_t& md = f.models[m];
     size_t pix;
@@ -215,103 +250,6 @@ __global__ __launch_bounds__(kTrackBlock) void k_track_maxw(const TrackFrame f) 
         // (the weight cap, after a few frames) already there and skip the same-address atomic
         const unsigned bits = __float_as_uint(mx);
         if (bits > __atomic_load_n(&st.maxIwBits, __ATOMIC_RELAXED)) atomicMax(&st.maxIwBits, bits);
-    }
-}
-
-__global__ __launch_bounds__(kTrackBlock) void k_track_accum(const TrackFrame f) {
-    __shared__ float red[kTrackBlock / 64][kSums];
-    const int m = blockIdx.y;
-    emf_track_state_t& st = f.states[m];
-    if (st.converged || !st.evaluateGradient) return;
-    const emf_model_t& md = f.models[m];
-    const M33 R = state_R(st.R);
-    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
-    const I3 n{md.res[0], md.res[1], md.res[2]};
-    // cv::cuda::normalize(NORM_INF, alpha = 1): scale = norm > DBL_EPSILON ? 1 / norm : 0
-    const float mx = __uint_as_float(st.maxIwBits);
-    const float scale = static_cast<double>(mx) > 2.220446049250313e-16
-                            ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f;
-    size_t pix;
-    V3 pc;
-    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f;
-    if (load_point(f, pix, pc)) {
-        pose_gradient(md.tsdf, md.grads, R, t, pc, n, md.voxelSize, g);
-        r = lookup1(md.tsdf, R, t, pc, n, md.voxelSize);
-        const float a = fabsf(r);
-        float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
-        tw = fminf(tw, 1.0f);
-        w = scratch_iw(f, m, st.iwSel)[pix] * scale;
-        w = tw * w;               // multiply(trackWeights, intWeights)
-        w = w * md.assoc[pix];    // multiply(intWeights, associationWeights)
-        scratch_w(f, m)[pix] = w;
-    }
-    // As = (g_j * g_k) * w, bs = (r * g_j) * w: the products of computeAb / multSingletonCol
-    float s[32];
-    int q = 0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int k = j; k < 6; ++k) s[q++] = (g[j] * g[k]) * w;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
-    s[27] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
-    s[28] = s[29] = s[30] = s[31] = 0.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#if EMF_TRACK_XPOSE
-    wave_sum32(s, lane);
-    if (!(lane & 1) && (lane >> 1) < kSums) red[wave][lane >> 1] = s[0];
-#else
-#pragma unroll
-    for (int k = 0; k < kSums; ++k) {
-        const float v = wave_sum(s[k]);
-        if (lane == 0) red[wave][k] = v;
-    }
-#endif
-    __syncthreads();
-    if (threadIdx.x < kSums) {
-        float v = red[0][threadIdx.x];
-        for (int i = 1; i < kTrackBlock / 64; ++i) v += red[i][threadIdx.x];
-        // component-major: the final reduction reads each component contiguously
-        scratch_partials(f, m)[static_cast<size_t>(threadIdx.x) * f.nblocks + blockIdx.x] = v;
-    }
-}
-
-__global__ __launch_bounds__(kTrackBlock) void k_track_error(const TrackFrame f) {
-    __shared__ float red[kTrackBlock / 64], redMax[kTrackBlock / 64];
-    const int m = blockIdx.y;
-    emf_track_state_t& st = f.states[m];
-    if (st.converged || !st.haveTrial) return;
-    const emf_model_t& md = f.models[m];
-    size_t pix;
-    V3 pc;
-    float e = 0.f, iw = 0.f;
-    if (load_point(f, pix, pc)) {
-        const M33 R = state_R(st.Rtrial);
-        const V3 t = v3(st.ttrial[0], st.ttrial[1], st.ttrial[2]);
-        const I3 n{md.res[0], md.res[1], md.res[2]};
-        const float r = lookup1(md.tsdf, R, t, pc, n, md.voxelSize);
-        e = (r * r) * scratch_w(f, m)[pix];
-        // the clamped integration weights at the trial pose: if the step is accepted they are the
-        // next iteration's (same lookup, same values), so that iteration needs no extra pass
-        iw = fminf(lookup1(md.weights, R, t, pc, n, md.voxelSize), f.prm.maxWeight);
-        scratch_iw(f, m, 1 - st.iwSel)[pix] = iw;
-    }
-    e = wave_sum(e);
-    const float wmx = wave_max(fabsf(iw));
-    if ((threadIdx.x & 63) == 0) {
-        red[threadIdx.x >> 6] = e;
-        redMax[threadIdx.x >> 6] = wmx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float v = red[0], mx = redMax[0];
-        for (int i = 1; i < kTrackBlock / 64; ++i) {
-            v += red[i];
-            mx = fmaxf(mx, redMax[i]);
-        }
-        scratch_err(f, m)[blockIdx.x] = v;
-        const unsigned bits = __float_as_uint(mx);
-        if (bits > __atomic_load_n(&st.maxIwTrialBits, __ATOMIC_RELAXED)) atomicMax(&st.maxIwTrialBits, bits);
     }
 }
 
@@ -413,109 +351,65 @@ __host__ __device__ inline bool solve6(float M[6][6], float rhs[6], float x[6]) 
     return ok;
 }
 
-// ---- per-model kernels (one wave each) -----------------------------------------------------------
+// ---- the Levenberg-Marquardt step: one launch per iteration -------------------------------------
+//
+// A launch is [prologue | per-pixel body].  The prologue is the scalar LM logic (what used to be two
+// one-workgroup kernels between the per-pixel ones): EVERY workgroup of a model runs it on its own
+// LDS copy of the state -- same inputs, same code, same result everywhere -- so nobody waits for a
+// grid-wide reduction other than through the kernel boundary: the partial sums the previous launch
+// left are added (fixed order, double), the pending trial step is judged, the next one is solved
+// for; workgroup 0 stores the state.  The state and the partial sums are double-buffered by launch
+// parity (a fast workgroup's body must not overwrite what a slow one's prologue still reads).
+// The body then evaluates the new trial pose: the error of the step under the current weights, the
+// integration weights and their maximum there, and -- speculatively, they are the same gathers --
+// the Hessian sums the NEXT iteration needs if this step is accepted.  An accepted step with an
+// unchanged weight maximum (the normaliser of the weights) adopts them; otherwise the next launch
+// re-makes them at the accepted pose (body 1) and the iteration after it costs one launch more.
 
-constexpr int kSolveWaves = 16;  // 28 columns of partials: at most two per wave
+constexpr int kBodyNone = 0, kBodyAccum = 1, kBodyTrial = 2;
 
-// The two per-model kernels run their scalar Levenberg-Marquardt logic on a copy of the state in
-// LDS: on the global-memory struct every access of the single working lane was a dependent ~0.5 us
-// round trip (22 us per launch); the state is copied in and out cooperatively instead.
+// The scalar logic runs on a copy of the state in LDS: on the global-memory struct every access of
+// the single working lane was a dependent ~0.5 us round trip; the state is copied cooperatively.
 constexpr int kStateWords = sizeof(emf_track_state_t) / 4;
-
 __device__ __forceinline__ void state_copy(unsigned* dst, const unsigned* src, int tid, int nthreads) {
     for (int i = tid; i < kStateWords; i += nthreads) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(64 * kSolveWaves) void k_track_solve(const TrackFrame f) {
-    __shared__ double sums[kSums];
-    __shared__ emf_track_state_t st;
-    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (f.states[m].converged) return;
-    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(&f.states[m]),
-               threadIdx.x, 64 * kSolveWaves);
-    if (f.states[m].evaluateGradient) {  // reduceHessians (TSDF.cpp:264-279); else A, b, err are kept
-        for (int c = wave; c < kSums; c += kSolveWaves) {
-            const double v = wave_strided_sum(scratch_partials(f, m) + static_cast<size_t>(c) * f.nblocks,
-                                              f.nblocks, 1, lane);
-            if (lane == 0) sums[c] = v;
+// TSDF::reduceHessians' results (TSDF.cpp:264-279) from the 28 sums
+__device__ __forceinline__ void adopt_sums(emf_track_state_t& st, const float* sums) {
+    int q = 0;
+    for (int j = 0; j < 6; ++j)
+        for (int k = j; k < 6; ++k) {
+            const float v = sums[q++];
+            st.A[6 * j + k] = v;
+            st.A[6 * k + j] = v;
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (st.evaluateGradient) {
-            int q = 0;
-            for (int j = 0; j < 6; ++j)
-                for (int k = j; k < 6; ++k) {
-                    const float v = static_cast<float>(sums[q++]);
-                    st.A[6 * j + k] = v;
-                    st.A[6 * k + j] = v;
-                }
-            float maxB = 0.f;
-            for (int j = 0; j < 6; ++j) {
-                st.b[j] = static_cast<float>(sums[21 + j]);
-                maxB = fmaxf(maxB, fabsf(st.b[j]));
-            }
-            st.err = static_cast<float>(sums[27]);
-            if (maxB < f.prm.eps1) st.converged = 1;  // TSDF.cpp:276-278
-        }
-        if (!st.converged) {
-            // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
-            if (st.firstIteration) {
-                float maxA = st.A[0];
-                for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
-                st.mu = f.prm.tau * maxA;
-                st.firstIteration = 0;
-            }
-            float M[6][6], rhs[6], x[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
-                rhs[j] = st.b[j];
-            }
-            solve6(M, rhs, x);
-            float nx = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                st.x[j] = x[j];
-                nx += x[j] * x[j];
-            }
-            nx = sqrtf(nx);
-            const M33 R = state_R(st.R);
-            const V3 t = v3(st.t[0], st.t[1], st.t[2]);
-            if (nx < f.prm.eps2 * (se3_log_norm(R, t) + f.prm.eps2)) {
-                st.converged = 1;
-            } else {
-                float mx[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) mx[j] = -x[j];
-                const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
-                const M33 Rn = mat_mul(inc.R, R);
-                const V3 tn = mul(inc.R, t) + inc.t;
-                st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
-                st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
-                st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
-                st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
-                st.maxIwTrialBits = 0u;
-                st.haveTrial = 1;
-            }
-        }
-    }
-    __syncthreads();
-    state_copy(reinterpret_cast<unsigned*>(&f.states[m]), reinterpret_cast<const unsigned*>(&st),
-               threadIdx.x, 64 * kSolveWaves);
+    for (int j = 0; j < 6; ++j) st.b[j] = sums[21 + j];
+    st.err = sums[27];
+    st.needAccum = st.haveSpec = 0;
+    st.checkB = 1;
 }
 
-__global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
-    __shared__ emf_track_state_t st;
-    const int m = blockIdx.x, lane = threadIdx.x;
-    if (f.states[m].converged || !f.states[m].haveTrial) return;
-    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(&f.states[m]), lane, 64);
-    const double total = wave_strided_sum(scratch_err(f, m), f.nblocks, 1, lane);
-    __syncthreads();
-    if (lane == 0) {
-        const float errNew = static_cast<float>(total);
+// One lane: everything between two per-pixel passes.  Sets st.body (what this launch does per
+// pixel) and st.pending (what the next launch will find in the partial sums).
+// logNorm: |log| of the current and of the trial pose as the launch found them (made by another wave
+// while the sums were added: the step-size test needs the one of the pose the verdict leaves current).
+__device__ void lm_advance(emf_track_state_t& st, const double* sums, const float* logNorm, const TrackFrame& f) {
+    if (f.launch == 0) st.iterTarget = st.iterations + f.iterations;
+    st.body = kBodyNone;
+    if (st.converged) {
+        st.pending = 0;
+        return;
+    }
+    if (st.pending == kBodyAccum) {
+        for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
+        st.needAccum = 0;
+        st.haveSpec = 1;
+    } else if (st.pending == kBodyTrial) {
+        // ---- computePoseUpdate, second half (TSDF.cpp:315-337) ----
+        const float errNew = static_cast<float>(sums[28]);
         st.errNew = errNew;
+        st.maxIwTrialBits = __float_as_uint(static_cast<float>(sums[29]));
         // gain = 0.5 * -x^T (mu * -x - b)  (TSDF.cpp:319)
         float gain = 0.f;
         for (int j = 0; j < 6; ++j) gain += -st.x[j] * (st.mu * -st.x[j] - st.b[j]);
@@ -532,7 +426,14 @@ __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
             st.nu = f.prm.nuInit;
             st.evaluateGradient = 1;
             st.accepted += 1;
-            st.iwSel ^= 1;  // the trial pose's weights (k_track_error) become the current ones
+            st.iwSel ^= 1;  // the trial pose's integration weights become the current ones
+            if (st.maxIwTrialBits == st.maxIwBits) {  // the body's weights were normalised correctly
+                for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
+                st.haveSpec = 1;
+                st.wSel ^= 1;
+            } else {
+                st.needAccum = 1;
+            }
             st.maxIwBits = st.maxIwTrialBits;
         } else {  // reject (TSDF.cpp:328-336)
             st.mu *= st.nu;
@@ -541,8 +442,247 @@ __global__ __launch_bounds__(64) void k_track_update(const TrackFrame f) {
         }
         st.haveTrial = 0;
     }
+    const bool stepped = st.pending == kBodyTrial && st.rho > 0;  // the trial pose became the current one
+    st.pending = 0;
+    if (st.iterations >= st.iterTarget) return;
+    if (st.needAccum) {
+        st.body = st.pending = kBodyAccum;
+        return;
+    }
+    // the iteration proper starts here: its A, b, err (TSDF.cpp:264-275) are the sums made ahead of it
+    if (st.haveSpec) adopt_sums(st, st.spec);
+    if (st.checkB) {  // TSDF.cpp:276-278, on freshly reduced sums only
+        st.checkB = 0;
+        float maxB = 0.f;
+        for (int j = 0; j < 6; ++j) maxB = fmaxf(maxB, fabsf(st.b[j]));
+        if (maxB < f.prm.eps1) {
+            st.converged = 1;
+            return;
+        }
+    }
+    // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
+    if (st.firstIteration) {
+        float maxA = st.A[0];
+        for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
+        st.mu = f.prm.tau * maxA;
+        st.firstIteration = 0;
+    }
+    float M[6][6], rhs[6], x[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
+        rhs[j] = st.b[j];
+    }
+    solve6(M, rhs, x);
+    float nx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        st.x[j] = x[j];
+        nx += x[j] * x[j];
+    }
+    nx = sqrtf(nx);
+    const M33 R = state_R(st.R);
+    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
+    if (nx < f.prm.eps2 * (logNorm[stepped ? 1 : 0] + f.prm.eps2)) {  // se3_log_norm(R, t)
+        st.converged = 1;
+        return;
+    }
+    float mx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) mx[j] = -x[j];
+    const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
+    const M33 Rn = mat_mul(inc.R, R);
+    const V3 tn = mul(inc.R, t) + inc.t;
+    st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
+    st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
+    st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
+    st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
+    st.haveTrial = 1;
+    st.body = st.pending = kBodyTrial;
+}
+
+__global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame f) {  // 8 waves per SIMD: two workgroups per CU
+    constexpr int kWaves = kTrackBlock / 64;
+    __shared__ double sums[kCols];
+    __shared__ emf_track_state_t st;
+    __shared__ float red[kWaves][32], redMax[kWaves], logNorm[2];
+    const int m = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef EMF_TRACK_TRACE  // timing probe: 10 ns stamps of workgroup (EMF_TRACK_TRACE) of model 0, per launch
+    long long* stamps = reinterpret_cast<long long*>(state_buf(f, 0, 1) + 1) + 8 * f.launch;
+    const bool tracer = blockIdx.x == EMF_TRACK_TRACE && m == 0 && threadIdx.x == 0 && f.launch < 24;
+#define STAMP(i) do { if (tracer) stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    STAMP(0);
+    const emf_track_state_t* in = state_buf(f, m, f.launch & 1);
+    // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
+    if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
+        if (blockIdx.x == 0)
+            state_copy(reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1)),
+                       reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
+        return;
+    }
+    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
+    const emf_model_t& md = f.models[m];
+    const I3 n{md.res[0], md.res[1], md.res[2]};
+    const float voxelSize = md.voxelSize;
+    const float* const tsdf = md.tsdf;
+    const float* const weights = md.weights;
+    size_t pix;
+    V3 pc;
+    bool valid = load_point(f, pix, pc);  // (the first block's points: fetched under the prologue)
+    // ---- prologue ----
+    if (in->pending != 0 && !in->converged) {  // (uniform: read from global memory, not from the copy in flight)
+        const float* prev = scratch_partials(f, m, (f.launch + 1) & 1);
+        for (int c = wave; c < kCols; c += 2 * kWaves) {  // columns c and c + kWaves: the last one is the maximum
+            const float* col = prev + static_cast<size_t>(c) * f.nblocks;
+            const int c1 = c + kWaves;
+            if (c1 < kCols - 1) {
+                double v0, v1;
+                wave_strided_sum2(col, col + static_cast<size_t>(kWaves) * f.nblocks, f.nblocks, lane, v0, v1);
+                if (lane == 0) {
+                    sums[c] = v0;
+                    sums[c1] = v1;
+                }
+            } else {
+                float mx = 0.f;
+                if (c1 == kCols - 1)
+                    for (int i = lane; i < f.nblocks; i += 64)
+                        mx = fmaxf(mx, col[static_cast<size_t>(kWaves) * f.nblocks + i]);
+                if (c < kCols - 1) {
+                    const double v = wave_strided_sum(col, f.nblocks, 1, lane);
+                    if (lane == 0) sums[c] = v;
+                }
+                mx = wave_max(mx);
+                if (lane == 0 && c1 == kCols - 1) sums[c1] = static_cast<double>(mx);
+            }
+        }
+    }
+    // the last wave has the fewest columns: two of its lanes take the poses' |log| off the solver's path
+    if (wave == kWaves - 1 && lane < 2) {
+        const float* Rp = lane ? in->Rtrial : in->R;
+        const float* tp = lane ? in->ttrial : in->t;
+        logNorm[lane] = se3_log_norm(state_R(Rp), v3(tp[0], tp[1], tp[2]));
+    }
+    STAMP(1);
     __syncthreads();
-    state_copy(reinterpret_cast<unsigned*>(&f.states[m]), reinterpret_cast<const unsigned*>(&st), lane, 64);
+    STAMP(2);
+    if (threadIdx.x == 0) lm_advance(st, sums, logNorm, f);
+    STAMP(3);
+    __syncthreads();
+    if (blockIdx.x == 0)
+        state_copy(reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1)),
+                   reinterpret_cast<const unsigned*>(&st), threadIdx.x, kTrackBlock);
+    // (what comes out of the LDS copy of the state is the same in every lane: kept in scalar registers)
+    const auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+    const int body = __builtin_amdgcn_readfirstlane(st.body);
+    STAMP(4);
+    if (body == kBodyNone) return;
+    // ---- body ----
+    const bool trial = body == kBodyTrial;
+    const float* Rp = trial ? st.Rtrial : st.R;
+    const float* tp = trial ? st.ttrial : st.t;
+    const M33 R{{uni(Rp[0]), uni(Rp[1]), uni(Rp[2])}, {uni(Rp[3]), uni(Rp[4]), uni(Rp[5])}, {uni(Rp[6]), uni(Rp[7]), uni(Rp[8])}};
+    const V3 t = v3(uni(tp[0]), uni(tp[1]), uni(tp[2]));
+    // cv::cuda::normalize(NORM_INF, alpha = 1): scale = norm > DBL_EPSILON ? 1 / norm : 0
+    // (trial: the current pose's maximum, assumed to hold at the trial pose as well -- checked by
+    // the next prologue)
+    const float mx = __uint_as_float(__builtin_amdgcn_readfirstlane(st.maxIwBits));
+    const float scale = uni(static_cast<double>(mx) > 2.220446049250313e-16
+                                ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f);
+    const int iwSel = __builtin_amdgcn_readfirstlane(st.iwSel), wSel = __builtin_amdgcn_readfirstlane(st.wSel);
+    float* const wOut = scratch_w(f, m, trial ? 1 - wSel : wSel);
+    float* const mine = scratch_partials(f, m, f.launch & 1);
+    // The image in blocks of kTrackBlock pixels, one row of partial sums each -- however many of them
+    // a workgroup takes (the launch sizes the grid so that all workgroups are resident at once and
+    // the prologue is paid once per workgroup): the sums do not depend on the grid.
+    for (unsigned blk = blockIdx.x; blk < static_cast<unsigned>(f.nblocks); blk += gridDim.x) {
+    if (blk != blockIdx.x) {
+        __syncthreads();  // red[] of the previous block has been read
+        valid = load_point(f, pix, pc, blk);
+    }
+    // A pixel whose point is invalid or falls outside the volume's interpolation range contributes
+    // exact zeros to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such
+    // pixels -- most of the image, for an object -- stores its zeros and skips the arithmetic.
+    const bool alive = valid && pc.z > 0 && !outside(to_voxel(mul(R, pc) + t, voxelSize, half_extent(n)), 1.f, n);
+    if (__ballot(alive) == 0ull) {
+        if (valid) {
+            if (trial) scratch_iw(f, m, 1 - iwSel)[pix] = 0.f;
+            wOut[pix] = 0.f;
+        }
+        if (lane < kCols - 1) red[wave][lane] = 0.f;
+        if (lane == 0) redMax[wave] = 0.f;
+    } else {
+        float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f, e = 0.f, iw = 0.f;
+        if (valid) {
+            pose_gradient(tsdf, md.grads, R, t, pc, n, voxelSize, g);
+            r = lookup1(tsdf, R, t, pc, n, voxelSize);
+            if (trial) {
+                // computeError at the trial pose under the current weights (TSDF.cpp:390-394) ...
+                e = (r * r) * scratch_w(f, m, wSel)[pix];
+                // ... and the clamped integration weights there: the next iteration's if the step is accepted
+                iw = fminf(lookup1(weights, R, t, pc, n, voxelSize), f.prm.maxWeight);  // TSDF.cpp:234
+                scratch_iw(f, m, 1 - iwSel)[pix] = iw;
+            } else {
+                iw = scratch_iw(f, m, iwSel)[pix];
+            }
+            const float a = fabsf(r);
+            float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
+            tw = fminf(tw, 1.0f);
+            w = iw * scale;
+            w = tw * w;        // multiply(trackWeights, intWeights)
+            w = w * md.assoc[pix];  // multiply(intWeights, associationWeights)
+            wOut[pix] = w;
+        }
+        STAMP(5);
+        // As = (g_j * g_k) * w, bs = (r * g_j) * w: the products of computeAb / multSingletonCol;
+        // column order: the upper triangle of A row by row (21), b (6), err, the trial step's error
+        {
+            float s[16];
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = j; k < 6; ++k)
+                    if (6 * j - j * (j - 1) / 2 + (k - j) < 16) s[q++] = (g[j] * g[k]) * w;
+            wave_sum16(s, lane);
+            if (!(lane & 3)) red[wave][lane >> 2] = s[0];
+        }
+        {
+            float s[16];
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = j; k < 6; ++k)
+                    if (6 * j - j * (j - 1) / 2 + (k - j) >= 16) s[q++] = (g[j] * g[k]) * w;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
+            s[q++] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
+            s[q++] = e;
+            s[13] = s[14] = s[15] = 0.f;
+            wave_sum16(s, lane);
+            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) red[wave][16 + (lane >> 2)] = s[0];
+        }
+        const float wmx = wave_max(fabsf(iw));
+        if (lane == 0) redMax[wave] = wmx;
+    }
+    __syncthreads();
+    if (threadIdx.x < kCols - 1) {
+        float v = red[0][threadIdx.x];
+        for (int i = 1; i < kWaves; ++i) v += red[i][threadIdx.x];
+        // component-major: the next prologue reads each component contiguously
+        mine[static_cast<size_t>(threadIdx.x) * f.nblocks + blk] = v;
+    } else if (threadIdx.x == kCols - 1) {
+        float v = redMax[0];
+        for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
+        mine[static_cast<size_t>(kCols - 1) * f.nblocks + blk] = v;
+    }
+    }
+    STAMP(6);
+#undef STAMP
 }
 
 struct PrepareArgs {
@@ -571,6 +711,13 @@ __global__ void k_track_prepare(const PrepareArgs a) {
     st.haveTrial = 0;
     st.iterations = 0;
     st.accepted = 0;
+    st.wSel = 0;
+    st.needAccum = 1;
+    st.haveSpec = 0;
+    for (int k = 0; k < 28; ++k) st.spec[k] = 0.f;
+    st.checkB = 0;
+    st.pending = st.body = 0;
+    st.iterTarget = 0;
     a.states[m] = st;
 }
 
@@ -597,6 +744,19 @@ __global__ __launch_bounds__(kTrackBlock) void k_pose_gradients(const PoseGradAr
     float* o = a.out + 6 * pix;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = g[k];  // every pixel written: the setTo(0) is folded in
+}
+
+// CUs of the current device (looked up once per device: an immutable property, not state)
+int compute_units() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* states_dev,
@@ -632,7 +792,10 @@ extern "C" {
 size_t emf_hip_trackScratchBytes(int width, int height) {
     const size_t px = static_cast<size_t>(width) * height;
     const size_t nblocks = ceil_div(px, kTrackBlock);
-    const size_t bytes = (3 * px + nblocks * (kSums + 1)) * sizeof(float);
+    size_t bytes = (4 * px + 2 * nblocks * kCols) * sizeof(float) + sizeof(emf_track_state_t);
+#ifdef EMF_TRACK_TRACE
+    bytes += 24 * 8 * sizeof(long long);
+#endif
     return (bytes + 255) / 256 * 256;
 }
 
@@ -660,14 +823,21 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     if (iterations < 0) return fail(EMF_E_ARG, "trackIterate: iterations = %d", iterations);
     const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
     hipStream_t s = as_stream(stream);
-    for (int i = 0; i < iterations; ++i) {
-        // the weight maximum is looked up at the first pose of a stage only (device flag): later
-        // iterations of this call cannot need it, the first of a later call returns at once
-        if (i == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
-        hipLaunchKernelGGL(k_track_accum, px, dim3(kTrackBlock), 0, s, f);
-        hipLaunchKernelGGL(k_track_solve, dim3(nmodels), dim3(64 * kSolveWaves), 0, s, f);
-        hipLaunchKernelGGL(k_track_error, px, dim3(kTrackBlock), 0, s, f);
-        hipLaunchKernelGGL(k_track_update, dim3(nmodels), dim3(64), 0, s, f);
+    if (iterations == 0) return EMF_OK;
+    // the weight maximum is looked up at the first pose of a stage only (device flag); in a later
+    // call of the stage the kernel returns at once
+    hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
+    // sums at the first pose + one launch per iteration + the last step's verdict + one spare for a
+    // speculation miss; an even number, so that the state ends in the caller's array
+    const int launches = (iterations + 3 + 1) & ~1;
+    f.iterations = iterations;
+    // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
+    const int cus = compute_units();
+    const int perModel = std::max(1, std::min(f.nblocks, 2 * cus / nmodels));
+    const dim3 grid(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels));
+    for (int i = 0; i < launches; ++i) {
+        f.launch = i;
+        hipLaunchKernelGGL(k_track_step, grid, dim3(kTrackBlock), 0, s, f);
     }
     return launch_status("trackIterate");
 }
@@ -701,5 +871,5 @@ int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const em
 
 }  // extern "C"
 
-static_assert(sizeof(emf_track_state_t) == 344, "emf_track_state_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_track_state_t) == 484, "emf_track_state_t layout is mirrored in _lib.py");
 static_assert(sizeof(emf_model_t) == 160, "emf_model_t layout is mirrored in _lib.py");

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 4
+#define EMF_HIP_ABI_VERSION 5
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -612,6 +612,16 @@ typedef struct emf_track_state {
     int32_t iterations;        /* trial steps evaluated */
     int32_t accepted;          /* ... of which accepted (rho > 0) */
     int32_t iwSel;             /* which of the two weight images belongs to the current pose */
+    /* bookkeeping of the fused step kernel (one launch per LM iteration, see emf_hip_trackIterate) */
+    int32_t wSel;              /* which of the two per-pixel weight images belongs to the current pose */
+    int32_t needAccum;         /* A, b, err must be summed at the current pose before the next solve */
+    int32_t haveSpec;          /* spec[] holds them already (summed speculatively at the accepted trial pose) */
+    float spec[28];            /* upper triangle of A (21), b (6), err -- moved into A, b, err by the next solve */
+    int32_t checkB;            /* A, b are fresh: the max|b| < eps1 test is still to be made */
+    int32_t pending;           /* what the last launch left in the partial sums: 0 nothing, 1 A/b/err at the
+                                  current pose, 2 the trial step's error + A/b/err at the trial pose */
+    int32_t body;              /* what the current launch does per pixel (same codes) */
+    int32_t iterTarget;        /* `iterations` at which the current trackIterate call stops */
 } emf_track_state_t;
 
 /* bytes of scratch per model for emf_hip_trackIterate on a width x height image */
@@ -623,10 +633,18 @@ size_t emf_hip_trackScratchBytes(int width, int height);
 int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO_host, int nmodels,
                          float nuInit, emf_stream_t stream);
 
-/* `iterations` LM iterations of every model in lock-step, as EMFusion::performTracking runs them
- * (EMFusion.cpp:673-684, 692-720): five launches per iteration, no host synchronisation; models
- * that have converged, and iterations that must not re-evaluate the gradient, are skipped on
- * device-side flags.  Each model's `assoc` map supplies the association weights.
+/* `iterations` more LM iterations of every model in lock-step, as EMFusion::performTracking runs them
+ * (EMFusion.cpp:673-684, 692-720), without host synchronisation: ONE launch per iteration.  Every
+ * workgroup of a launch first finishes the previous launch in its own LDS copy of the state (adds the
+ * partial sums in a fixed order, judges the pending trial step, solves for the next one -- the same
+ * arithmetic in every workgroup, workgroup 0 stores the state), then evaluates the new trial pose per
+ * pixel: its error under the current weights AND, speculatively, the Hessian sums the next iteration
+ * needs if the step is accepted.  That speculation assumes the maximum integration weight seen from
+ * the trial pose equals the current one (it is the weight cap after a few frames); when it does not,
+ * the sums are re-made at the accepted pose by one extra launch.  The call enqueues iterations + 3
+ * launches (rounded up to even): one spare for such a miss -- read `iterations` / `haveTrial` from the
+ * state to see how far a model got; launches with nothing left to do return at once, as do converged
+ * models.  Each model's `assoc` map supplies the association weights.
  * scratch_dev: nmodels * scratchBytesPerModel bytes (>= emf_hip_trackScratchBytes). */
 int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                          const emf_image_t* points, const emf_track_params_t* params,

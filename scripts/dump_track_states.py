@@ -18,3 +18,11 @@ for n in (1, 2, 5, 100):
     out.append(raw)
 np.save("gpurun_out/%s.npy" % sys.argv[1], np.stack(out))
 print(sys.argv[1], [int(x.view(np.uint32).sum()) for x in out])
+if len(sys.argv) > 2:  # compare the legacy fields (first 344 bytes of a state) with another dump
+    a, b = np.load("gpurun_out/%s.npy" % sys.argv[2]), np.stack(out)
+    sa, sb = a.shape[1] // 2, b.shape[1] // 2
+    for i, n in enumerate((1, 2, 5, 100)):
+        for m in range(2):
+            x, y = a[i, m * sa:m * sa + 344], b[i, m * sb:m * sb + 344]
+            diff = np.nonzero(x.view(np.uint32) != y.view(np.uint32))[0]
+            print("iterations", n, "model", m, "identical" if diff.size == 0 else "DIFFERENT words %s" % diff[:12])

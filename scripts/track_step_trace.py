@@ -1,0 +1,23 @@
+"""Where a k_track_step launch spends its time (build with EXTRA=-DEMF_TRACK_TRACE=<workgroup>): stamps of one
+workgroup of model 0 for the first launches of a 20-iteration call on tests/test_gpu_tracking.py's world
+scaled to 640x480.  Columns: us from kernel entry to [reduce done, barrier, lm_advance done, state stored,
+per-pixel loads done, end]."""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, ".")
+from oracle import binding
+from emfusion_amd import devmem, ops, _lib
+import tests.test_gpu_tracking as T
+binding.lib(); binding.set_threads(8); devmem.set_device(0)
+T.W, T.H = 640, 480
+T.K = T.intrinsics(T.W, T.H)
+world = T.world.__wrapped__(binding)
+tr = T.DeviceTracker(ops, world, [0, 1])
+tr.iterate(20)
+raw = T.to_np(tr.scratch)[:tr.per_model]
+px, nb = T.W * T.H, -(-T.W * T.H // 1024)
+off = (4 * px + 2 * nb * 30) * 4 + C.sizeof(_lib.EmfTrackState)
+st = raw[off:off + 24 * 64].view(np.int64).reshape(24, 8)
+for i, r in enumerate(st):
+    if r[0] == 0: continue
+    print(i, " ".join("%6.2f" % ((x - r[0]) / 100.0) if x else "   -  " for x in r[1:7]))

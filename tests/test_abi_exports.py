@@ -27,7 +27,7 @@ def test_dynamic_symbol_table_matches_header():
 
 
 def test_abi_version():
-    assert _lib.load().emf_hip_abi_version() == 4
+    assert _lib.load().emf_hip_abi_version() == 5
 
 
 def test_null_and_shape_arguments_are_rejected_before_any_launch():
@@ -55,8 +55,8 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_struct_mirrors_have_the_sizes_the_library_asserts():
     """emf_model_t / emf_track_state_t are mirrored by ctypes structures; csrc/tracking.hip holds the
-    matching static_asserts (160 and 344 bytes)."""
+    matching static_asserts (160 and 484 bytes)."""
     import ctypes as C
     assert C.sizeof(_lib.EmfModel) == 160
-    assert C.sizeof(_lib.EmfTrackState) == 344
+    assert C.sizeof(_lib.EmfTrackState) == 484
     assert C.sizeof(_lib.EmfVolumeOut) == 32
