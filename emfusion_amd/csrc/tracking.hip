@@ -131,53 +131,6 @@ __device__ __forceinline__ void pose_gradient(const float* tsdf, const float* gr
     g[3] = gr.x; g[4] = gr.y; g[5] = gr.z;
 }
 
-// sum of p[i * stride], i < n, over the 64 lanes of the calling wave: lane-strided partial sums in
-// double, then a fixed xor tree -- the same order on every run.  The loads of a lane are issued in
-// batches of 8 before any of them is added: a plain `acc += p[i]` loop is not pipelined by the
-// compiler (the double add is a dependency chain) and exposes one memory latency per element --
-// that alone made the per-model kernels take 22 us.
-__device__ __forceinline__ double wave_strided_sum(const float* p, int n, int stride, int lane) {
-    double acc = 0.0;
-    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = i0 + 64 * j;
-            v[j] = i < n ? p[static_cast<size_t>(i) * stride] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += static_cast<double>(v[j]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return acc;
-}
-// two columns at once (same order of additions per column; their loads and shuffles overlap)
-__device__ __forceinline__ void wave_strided_sum2(const float* p0, const float* p1, int n, int lane,
-                                                  double& r0, double& r1) {
-    double a0 = 0.0, a1 = 0.0;
-    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
-        float v0[8], v1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int i = i0 + 64 * j;
-            v0[j] = i < n ? p0[i] : 0.f;
-            v1[j] = i < n ? p1[i] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a0 += static_cast<double>(v0[j]);
-            a1 += static_cast<double>(v1[j]);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a0 += __shfl_xor(a0, o);
-        a1 += __shfl_xor(a1, o);
-    }
-    r0 = a0;
-    r1 = a1;
-}
 // The sums of 16 per-lane values over the wave, with 17 cross-lane moves instead of 16 x 6: at the
 // level that pairs lane L with L ^ o each lane keeps the half of the values its bit `o` selects,
 // adds the partner's copy of those and hands the other half over.  Every value still goes through
@@ -517,6 +470,13 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #endif
     STAMP(0);
     const emf_track_state_t* in = state_buf(f, m, f.launch & 1);
+    // this wave's two columns of the previous launch's partial sums (c1: a sum, the maximum, or none)
+    static_assert(2 * kWaves >= kCols, "k_track_step: two columns of partial sums per wave");
+    const int c0 = wave, c1 = wave + kWaves;
+    const bool sum0 = c0 < kCols - 1, sum1 = c1 < kCols - 1, max1 = c1 == kCols - 1;
+    const float* const prev = scratch_partials(f, m, (f.launch + 1) & 1);
+    const float* const col0 = prev + static_cast<size_t>(sum0 ? c0 : 0) * f.nblocks;
+    const float* const col1 = prev + static_cast<size_t>(sum1 || max1 ? c1 : 0) * f.nblocks;
     // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
         if (blockIdx.x == 0)
@@ -534,30 +494,38 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     V3 pc;
     bool valid = load_point(f, pix, pc);  // (the first block's points: fetched under the prologue)
     // ---- prologue ----
-    if (in->pending != 0 && !in->converged) {  // (uniform: read from global memory, not from the copy in flight)
-        const float* prev = scratch_partials(f, m, (f.launch + 1) & 1);
-        for (int c = wave; c < kCols; c += 2 * kWaves) {  // columns c and c + kWaves: the last one is the maximum
-            const float* col = prev + static_cast<size_t>(c) * f.nblocks;
-            const int c1 = c + kWaves;
-            if (c1 < kCols - 1) {
-                double v0, v1;
-                wave_strided_sum2(col, col + static_cast<size_t>(kWaves) * f.nblocks, f.nblocks, lane, v0, v1);
-                if (lane == 0) {
-                    sums[c] = v0;
-                    sums[c1] = v1;
-                }
-            } else {
-                float mx = 0.f;
-                if (c1 == kCols - 1)
-                    for (int i = lane; i < f.nblocks; i += 64)
-                        mx = fmaxf(mx, col[static_cast<size_t>(kWaves) * f.nblocks + i]);
-                if (c < kCols - 1) {
-                    const double v = wave_strided_sum(col, f.nblocks, 1, lane);
-                    if (lane == 0) sums[c] = v;
-                }
-                mx = wave_max(mx);
-                if (lane == 0 && c1 == kCols - 1) sums[c1] = static_cast<double>(mx);
+    if (in->pending != 0) {  // (uniform: read from global memory, not from the copy in flight)
+        // lane-strided partial sums in double, then a fixed xor tree -- the same order on every run.
+        // The rows of a lane are loaded in batches of 8 before any of them is added: a plain
+        // `acc += p[i]` loop is not pipelined by the compiler (the double add is a dependency chain)
+        // and exposes one memory latency per element.  The maximum column likewise.
+        double a0 = 0.0, a1 = 0.0;
+        float mx = 0.f;
+        for (int i0 = lane; i0 < f.nblocks; i0 += 64 * 8) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 64 * j;
+                v0[j] = i < f.nblocks ? col0[i] : 0.f;
+                v1[j] = i < f.nblocks ? col1[i] : 0.f;
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0 += static_cast<double>(v0[j]);
+                a1 += static_cast<double>(v1[j]);
+                mx = fmaxf(mx, v1[j]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o);
+            a1 += __shfl_xor(a1, o);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) {
+            if (sum0) sums[c0] = a0;
+            if (sum1) sums[c1] = a1;
+            if (max1) sums[c1] = static_cast<double>(mx);
         }
     }
     // the last wave has the fewest columns: two of its lanes take the poses' |log| off the solver's path

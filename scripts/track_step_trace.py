@@ -12,7 +12,7 @@ binding.lib(); binding.set_threads(8); devmem.set_device(0)
 T.W, T.H = 640, 480
 T.K = T.intrinsics(T.W, T.H)
 world = T.world.__wrapped__(binding)
-tr = T.DeviceTracker(ops, world, [0, 1])
+tr = T.DeviceTracker(ops, world, [int(a) for a in sys.argv[1:]] or [0])
 tr.iterate(20)
 raw = T.to_np(tr.scratch)[:tr.per_model]
 px, nb = T.W * T.H, -(-T.W * T.H // 1024)

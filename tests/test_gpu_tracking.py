@@ -179,3 +179,63 @@ def test_converged_models_do_nothing(ops, dev, world):
     st = dt.iterate(3)[0]
     assert st.converged == 1 and st.iterations == 0 and st.accepted == 0
     assert list(st.R) == list(dt.iterate(1)[0].R)
+
+
+LEGACY = ("R", "t", "Rtrial", "ttrial", "A", "b", "x", "mu", "nu", "rho", "err", "errNew", "maxIwBits",
+          "converged", "firstIteration", "evaluateGradient", "haveTrial", "iterations", "accepted", "iwSel")
+
+
+def _fields(st):
+    return {k: (list(v) if hasattr(v, "__len__") else v) for k in LEGACY for v in [getattr(st, k)]}
+
+
+def test_split_calls_equal_one_call(ops, dev, world):
+    """The state carries everything across trackIterate calls (pending sums, buffer parity): 3 + 1 + 6
+    iterations leave the state 10 in one call leave, bit for bit."""
+    one = DeviceTracker(ops, world, [0, 1]).iterate(10)
+    dt = DeviceTracker(ops, world, [0, 1])
+    dt.iterate(3)
+    dt.iterate(1)
+    dt.iterate(0)  # nothing enqueued
+    parts = dt.iterate(6)
+    for k in (0, 1):
+        assert one[k].iterations == 10 and parts[k].iterations == 10
+        assert _fields(one[k]) == _fields(parts[k]), k
+
+
+def _ramped(world):
+    """The same world with integration weights that grow along x: their maximum over the image
+    changes with the pose, so the speculative Hessian sums of every accepted step are normalised
+    with the wrong maximum and have to be re-made (emf_hip_trackIterate's extra launch)."""
+    w2 = dict(world)
+    vols = []
+    for v in world["vols"]:
+        nx = v["wts"].shape[2]
+        ramp = (1.0 + np.arange(nx, dtype=np.float32) / nx)[None, None, :]
+        vols.append(dict(v, wts=(v["wts"] * ramp).astype(np.float32)))
+    w2["vols"] = vols
+    return w2
+
+
+def test_speculation_miss_takes_the_extra_launch_and_stays_exact(oracle, ops, dev, world):
+    w2 = _ramped(world)
+    iters = 12
+    dt = DeviceTracker(ops, w2, [0])
+    st = dt.iterate(iters)[0]
+    calls = 1
+    # every accepted step costs a launch more than the call provides for: fewer iterations per call
+    assert 0 < st.iterations < iters
+    while st.iterations < iters and not st.converged:
+        st = dt.iterate(iters - st.iterations)[0]
+        calls += 1
+        assert calls < 40
+    assert st.iterations == iters and st.haveTrial == 0
+    ot = _oracle_tracker(oracle, w2, 0)
+    for _ in range(iters):
+        ot.iterate(w2["points"], w2["assoc"][0])
+    assert st.accepted == ot.accepted and ot.accepted >= 3
+    assert np.abs(np.array(st.R, np.float32).reshape(3, 3) - ot.R).max() < 1e-5
+    assert np.abs(np.array(st.t, np.float32) - ot.t).max() < 1e-5
+    assert abs(st.mu - float(ot.mu)) <= 1e-3 * float(ot.mu)
+    # and with weights whose maximum does not move (the common case) one call is enough
+    assert DeviceTracker(ops, world, [0]).iterate(iters)[0].iterations == iters
