@@ -16,6 +16,7 @@
 #include "Output.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cmath>
 #include <cstdio>
@@ -81,6 +82,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     cullBoxes = !(ic && ic[0] == '0');
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
+    if (const char* tw = std::getenv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
@@ -142,6 +144,7 @@ EMFusion::~EMFusion() {
     if (visCountsHost) (void)hipHostFree(visCountsHost);
     if (visibleHost) (void)hipHostFree(visibleHost);
     if (trackStatesHost) (void)hipHostFree(trackStatesHost);
+    if (trackWatch) (void)hipHostFree(trackWatch);
     if (lifecycleHost) (void)hipHostFree(lifecycleHost);
 }
 
@@ -935,6 +938,12 @@ void EMFusion::trackModels(int first, int count) {
         hipCheck(hipHostMalloc(reinterpret_cast<void**>(&trackStatesHost),
                                sizeof(emf_track_state_t) * EMF_MAX_BATCH, hipHostMallocDefault),
                  "hipHostMalloc");
+        // progress words the step kernel writes while the stream runs (emf_hip_trackStep)
+        hipCheck(hipHostMalloc(reinterpret_cast<void**>(&trackWatch), sizeof(uint32_t) * (1 + EMF_MAX_BATCH),
+                               hipHostMallocCoherent | hipHostMallocMapped),
+                 "hipHostMalloc");
+        hipCheck(hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0),
+                 "hipHostGetDevicePointer");
     }
     std::vector<emf_pose_t> co;
     posesCO(co);
@@ -956,23 +965,56 @@ void EMFusion::trackModels(int first, int count) {
                                 pixels() * count * params.maxTrackingIter, main);
         emfCheck(emf_hip_trackPrepare(states, co.data() + first, count, tp.nuInit, main.abi()),
                  "trackPrepare");
-        // The loop itself needs no host: iterations are enqueued in chunks (one launch each) and the
+        char* const scratch = static_cast<char*>(trackScratch.data()) + per * first;
+        if (trackWindow > 0) {
+            // The loop needs the host only to stop enqueuing: one launch per LM iteration, kept
+            // `trackWindow` launches ahead of the device, which reports -- into host memory, while the
+            // stream runs -- how far it is and which models are done (LM converges in 20-60 of the
+            // 100 iterations, differently in every frame).  The launches already enqueued when the
+            // last model finishes return at once (~2 us each); the states are read back once.
+            volatile uint32_t* watch = trackWatch;
+            for (int i = 0; i <= count; ++i) watch[i] = 0u;
+            const int maxLaunches = 2 * params.maxTrackingIter + 4;  // (every step a speculation miss)
+            const auto t0 = std::chrono::steady_clock::now();
+            int launch = 0;
+            for (; launch < maxLaunches; ++launch) {
+                for (unsigned spins = 0; launch - static_cast<int>(watch[0]) >= trackWindow; ++spins)
+                    if ((spins & 0xffffu) == 0xffffu &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+                        throw HipError("EMFusion: the tracking launches make no progress", EMF_E_ARG);
+                bool all = launch > 0;
+                for (int m = 0; m < count && all; ++m) all = watch[1 + m] != 0u;
+                if (all) break;
+                emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
+                                           params.maxTrackingIter, trackWatchDev, static_cast<uint32_t>(launch + 1),
+                                           main.abi()),
+                         "trackStep");
+            }
+            if (launch & 1)  // an even number of launches leaves the state in `states`
+                emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
+                                           params.maxTrackingIter, nullptr, 0u, main.abi()),
+                         "trackStep");
+            hipCheck(hipMemcpyAsync(trackStatesHost + first, states, sizeof(emf_track_state_t) * count,
+                                    hipMemcpyDeviceToHost, main.get()),
+                     "hipMemcpyAsync");
+            main.waitForCompletion();
+            return;
+        }
+        // Without the progress words (EMF_TRACK_WINDOW=0): iterations are enqueued in chunks and the
         // device-side states are polled once per chunk, only to stop enqueuing launches that would
-        // return at once (LM converges in 20-40 of the 100 iterations).  A chunk normally advances
-        // every model by its n iterations; after more than one speculation miss (see
-        // emf_hip_trackIterate) by fewer -- the iteration counts come back with the poll.  The
-        // E-step and raycast that follow take the poses by value.
-        // The first chunk is as long as the stage was in the last frame (+2): consecutive frames
-        // take about the same number of steps, and an idle launch costs ~5 us, a poll ~30.
+        // return at once.  A chunk normally advances every model by its n iterations; after more
+        // than one speculation miss (see emf_hip_trackIterate) by fewer -- the iteration counts come
+        // back with the poll.
+        // The first chunk is as long as the stage was in the last frame (+8): an idle launch costs
+        // ~2 us, a poll ~50.
         const int chunk = trackChunk > 0 ? trackChunk : params.maxTrackingIter;
         int& predicted = trackPredicted[first == 0 ? 0 : 1];
         int taken = 0;
         for (int done = 0; done < params.maxTrackingIter;) {
-            const int want = done == 0 && predicted > 0 && trackChunk > 0 ? std::max(chunk, predicted + 2) : chunk;
+            const int want = done == 0 && predicted > 0 && trackChunk > 0 ? std::max(chunk, predicted + 8) : chunk;
             const int n = std::min(want, params.maxTrackingIter - done);
-            emfCheck(emf_hip_trackIterate(currentTable() + first, states, count, &pv,
-                                          &tp, static_cast<char*>(trackScratch.data()) + per * first,
-                                          per, n, main.abi()),
+            emfCheck(emf_hip_trackIterate(currentTable() + first, states, count, &pv, &tp, scratch, per, n,
+                                          main.abi()),
                      "trackIterate");
             hipCheck(hipMemcpyAsync(trackStatesHost + first, states,
                                     sizeof(emf_track_state_t) * count, hipMemcpyDeviceToHost,

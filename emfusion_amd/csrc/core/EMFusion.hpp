@@ -347,6 +347,9 @@ private:
     void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)
     int trackChunk = 8;                        // iterations per convergence poll (0: never poll)
     int trackPredicted[2] = {0, 0};            // iterations the camera / object stage took last frame
+    int trackWindow = 6;                       // launches kept ahead of the device's progress report (0: poll in chunks)
+    uint32_t* trackWatch = nullptr;            // pinned host words the step kernel reports to
+    uint32_t* trackWatchDev = nullptr;         // ... as the device addresses them
     DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_BATCH]
     DeviceBuffer trackScratch;                 // EMF_MAX_BATCH x emf_hip_trackScratchBytes
     emf_track_state_t* trackStatesHost = nullptr;  // pinned mirror

@@ -58,6 +58,8 @@ struct TrackFrame {
     size_t scratchStride;   // bytes per model
     int launch;             // index of the launch within the trackIterate call (parity of the double buffers)
     int iterations;         // LM iterations the call asks for
+    uint32_t* watch;        // host memory (or null): [0] <- seq, [1 + m] <- model m is done (emf_hip_trackStep)
+    uint32_t seq;
 };
 
 __device__ __forceinline__ float* scratch_base(const TrackFrame& f, int m) {
@@ -455,6 +457,15 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const floa
     st.body = st.pending = kBodyTrial;
 }
 
+// progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
+// go to the host's memory while the kernel runs
+__device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st) {
+    if (!f.watch) return;
+    const uint32_t done = st.converged ? 1u : (st.pending == 0 && st.iterations >= st.iterTarget ? 2u : 0u);
+    __hip_atomic_store(f.watch + 1 + m, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame f) {  // 8 waves per SIMD: two workgroups per CU
     constexpr int kWaves = kTrackBlock / 64;
     __shared__ double sums[kCols];
@@ -479,9 +490,11 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     const float* const col1 = prev + static_cast<size_t>(sum1 || max1 ? c1 : 0) * f.nblocks;
     // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
-        if (blockIdx.x == 0)
+        if (blockIdx.x == 0) {
             state_copy(reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1)),
                        reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
+            if (threadIdx.x == 0) report(f, m, *in);
+        }
         return;
     }
     state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
@@ -537,7 +550,10 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    if (threadIdx.x == 0) lm_advance(st, sums, logNorm, f);
+    if (threadIdx.x == 0) {
+        lm_advance(st, sums, logNorm, f);
+        if (blockIdx.x == 0) report(f, m, st);
+    }
     STAMP(3);
     __syncthreads();
     if (blockIdx.x == 0)
@@ -781,6 +797,21 @@ int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO
     return launch_status("trackPrepare");
 }
 
+namespace {
+// launch `launch` of a stage (see emf_hip_trackStep)
+void enqueue_step(TrackFrame& f, int nmodels, int launch, hipStream_t s) {
+    const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
+    // the weight maximum is looked up at the first pose of a stage only (device flag); in a later
+    // call of the stage the kernel returns at once
+    if (launch == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
+    // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
+    const int perModel = std::max(1, std::min(f.nblocks, 2 * compute_units() / nmodels));
+    f.launch = launch;
+    hipLaunchKernelGGL(k_track_step, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
+                       dim3(kTrackBlock), 0, s, f);
+}
+}  // namespace
+
 int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                          const emf_image_t* points, const emf_track_params_t* params,
                          void* scratch_dev, size_t scratchBytesPerModel, int iterations,
@@ -789,25 +820,30 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     EMF_TRY(fill_frame(f, models_dev, states_dev, nmodels, points, params, scratch_dev,
                        scratchBytesPerModel, "trackIterate"));
     if (iterations < 0) return fail(EMF_E_ARG, "trackIterate: iterations = %d", iterations);
-    const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
-    hipStream_t s = as_stream(stream);
     if (iterations == 0) return EMF_OK;
-    // the weight maximum is looked up at the first pose of a stage only (device flag); in a later
-    // call of the stage the kernel returns at once
-    hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
     // sums at the first pose + one launch per iteration + the last step's verdict + one spare for a
     // speculation miss; an even number, so that the state ends in the caller's array
     const int launches = (iterations + 3 + 1) & ~1;
     f.iterations = iterations;
-    // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
-    const int cus = compute_units();
-    const int perModel = std::max(1, std::min(f.nblocks, 2 * cus / nmodels));
-    const dim3 grid(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels));
-    for (int i = 0; i < launches; ++i) {
-        f.launch = i;
-        hipLaunchKernelGGL(k_track_step, grid, dim3(kTrackBlock), 0, s, f);
-    }
+    f.watch = nullptr;
+    f.seq = 0;
+    for (int i = 0; i < launches; ++i) enqueue_step(f, nmodels, i, as_stream(stream));
     return launch_status("trackIterate");
+}
+
+int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
+                      const emf_image_t* points, const emf_track_params_t* params,
+                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
+                      uint32_t* watch, uint32_t seq, emf_stream_t stream) {
+    TrackFrame f;
+    EMF_TRY(fill_frame(f, models_dev, states_dev, nmodels, points, params, scratch_dev,
+                       scratchBytesPerModel, "trackStep"));
+    if (launch < 0 || iterations < 0) return fail(EMF_E_ARG, "trackStep: launch = %d, iterations = %d", launch, iterations);
+    f.iterations = iterations;
+    f.watch = watch;
+    f.seq = seq;
+    enqueue_step(f, nmodels, launch, as_stream(stream));
+    return launch_status("trackStep");
 }
 
 int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const emf_image_t* points,

@@ -477,6 +477,15 @@ def track_iterate(models_dev, states_dev, nmodels, points, params, scratch, scra
                                   scratch_per_model, iterations, _stream(stream)))
 
 
+def track_step(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model, launch,
+               iterations, watch=None, seq=0, stream=None):
+    """One launch of the LM step kernel (emf_hip_trackStep); watch: address of host-pinned uint32s or None."""
+    check("emf_hip_trackStep",
+          _L.emf_hip_trackStep(_ptr(models_dev), _ptr(states_dev), nmodels, C.byref(image_view(points)),
+                               C.byref(params), _ptr(scratch), scratch_per_model, launch, iterations,
+                               watch, seq, _stream(stream)))
+
+
 def read_track_states(states_dev, nmodels):
     """Synchronise and return the device LM states as a list of EmfTrackState."""
     raw = states_dev.numpy().tobytes()

@@ -651,6 +651,23 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
                          void* scratch_dev, size_t scratchBytesPerModel, int iterations,
                          emf_stream_t stream);
 
+/* The same loop, launch by launch, for a host that does not want to guess how many iterations a
+ * stage needs: emf_hip_trackStep enqueues launch number `launch` (0, 1, 2, ... since the stage's
+ * emf_hip_trackPrepare or since the last call of emf_hip_trackIterate; launch 0 also runs the weight-
+ * maximum pass and lets every model do `iterations` more iterations) and has the device report to
+ * `watch`, which must be host memory the device can write (hipHostMalloc, coherent):
+ *   watch[0]      <- seq when the launch has begun (any nonzero number the caller increases per launch),
+ *   watch[1 + m]  <- 1 when model m has converged, 2 when it has done its iterations, else 0.
+ * These are hints to stop enqueuing (written with system-scope stores while the stream runs: keep a
+ * few launches ahead of watch[0], stop when every watch[1 + m] != 0); the states are read as usual.
+ * The number of launches of a stage must be even (the state alternates between the caller's array
+ * and a shadow in the scratch): end with one more launch if it is not -- a launch with nothing to
+ * do returns at once.  watch may be NULL. */
+int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
+                      const emf_image_t* points, const emf_track_params_t* params,
+                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
+                      uint32_t* watch, uint32_t seq, emf_stream_t stream);
+
 /* Level 1: replaces emf::cuda::TSDF::computePoseGradients (TSDF.cuh, TSDF.cu:603-660).
  * grads6: (W*H) x 6 f32, every row written (zeros where the reference leaves its setTo(0));
  * grads: N^3 x 3 gradient volume or NULL (forward differences blended on the fly, same values). */

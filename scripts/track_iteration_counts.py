@@ -1,0 +1,24 @@
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch
+from emfusion_amd import ops, pipeline
+from emfusion_amd.devmem import DeviceArray
+W, H = 640, 480
+prm = pipeline.make_params(W, H, 512, 0.01, 128)
+K = np.array(prm.K, np.float32)
+synth = pipeline.SyntheticStream(W, H, K, 4, seed=0xE3F5)
+fus = pipeline.Fusion(prm, None)
+ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(4)]
+fus.set_tracking(True, True)
+cam, obj = [], []
+for f in range(60):
+    depth, sid = synth.render(f); R, t = synth.camera_pose(f)
+    poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
+    rm = f % prm.mask_frames == 0
+    masks = {i: DeviceArray.from_numpy((sid == i).astype(np.uint8)) for i in ids} if rm else {}
+    d = DeviceArray.from_numpy(depth)
+    fus.process_frame(ops.image_view(d), R, t, poses, {i: ops.image_view(m) for i, m in masks.items()}, rm)
+    fus.synchronize()
+    if f:
+        cam.append(fus.track_result(0)["iterations"]); obj.append(max(fus.track_result(i)["iterations"] for i in ids))
+print("cam", cam); print("obj", obj)
