@@ -7,25 +7,27 @@
 // written, re-read, scaled and column-reduced, two device->host copies with stream syncs, a 6x6
 // solve on the host and -- on every trial step -- another lookup pass and a third sync.
 //
-// Here an iteration is five small launches and NO host round trip; all Levenberg-Marquardt state
-// lives in device memory (emf_track_state_t), so a frame's iterations are enqueued back to back
-// (or replayed from a hipGraph) and the host reads the final pose once:
-//   k_track_maxw    per pixel: the clamped integration-weight lookup; its image maximum (the
-//                   NORM_INF of cv::cuda::normalize) via wave max + one atomicMax per workgroup
-//   k_track_accum   per pixel: pose gradient (6), residual, Huber x normalised-weight x
-//                   association weight; the 21 + 6 unique sums of A = sum w g g^T, b = sum w r g
-//                   and the error sum r^2 w are reduced in registers (wave shuffles), through LDS,
-//                   to one row of partials per workgroup -- `As` is never materialised
-//   k_track_solve   one wave per model: adds the partials in a fixed order, convergence test,
-//                   mu initialisation, (A + mu I) x = b by LU with partial pivoting, step-size
-//                   test, trial pose exp(-x) * pose
-//   k_track_error   per pixel: residual at the trial pose, partial sums of r^2 w
-//   k_track_update  one wave per model: gain ratio, accept / reject, damping update
-// Kernels of a converged model, or of an iteration that may not re-evaluate the gradient
-// (TSDF.cpp `evaluateGradient`), return at once on a device-side flag.
-// Measured and dropped: running solve / update in the LAST workgroup of the per-pixel kernel before
-// them (ticket counter, __threadfence) to save two launches per iteration -- on this multi-XCD part a
-// device-scope release writes the XCD's L2 back, 1200 times per kernel: 51 -> 325 us per iteration.
+// Here an iteration is ONE launch and no host round trip; all Levenberg-Marquardt state lives in
+// device memory (emf_track_state_t), so a stage's iterations are enqueued back to back and the host
+// reads the final pose once:
+//   k_track_maxw   first launch of a stage only: the clamped integration-weight lookup per pixel and
+//                  its image maximum (the NORM_INF of cv::cuda::normalize)
+//   k_track_step   [prologue | per-pixel body] -- see the comment above the kernel.  Prologue, in every
+//                  workgroup: the previous launch's partial sums added in a fixed order, the gain
+//                  ratio and accept / reject of the pending trial step, damping, convergence tests,
+//                  (A + mu I) x = b, the next trial pose exp(-x) * pose.  Body: residual of the trial
+//                  pose under the current weights, the integration weights and their maximum there,
+//                  and the pose gradient (6), Huber x normalised weight x association weight and the
+//                  21 + 6 + 1 sums A = sum w g g^T, b = sum w r g, sum r^2 w the NEXT iteration needs
+//                  if the step is accepted -- reduced in registers (v_permlane swaps), through LDS, to
+//                  one row of partials per 1024 pixels; `As` is never materialised.
+// The four launches this replaced (sums | solve | trial error | verdict; round 1) cost 46 us per
+// iteration, of which 20 were the 168 ds_bpermute shuffles of the 28 wave sums; now 15-23 us.
+// Measured and dropped: finishing the scalar part in the LAST workgroup of the per-pixel kernel
+// (ticket counter, __threadfence) -- on this multi-XCD part a device-scope release writes the XCD's L2
+// back, 1200 times per kernel: 51 -> 325 us per iteration; fetching value, gradient and weight of a
+// pixel in one batch of 28 loads instead of three dependent ones (the 64 registers that let two
+// workgroups share a CU spill: -7 %).
 //
 // Parity: per-pixel quantities follow the reference's operations one by one (the pose gradient
 // is bit-identical to the oracle; tests/test_gpu_tracking.py).  Sums are formed in a different --
