@@ -239,3 +239,29 @@ def test_speculation_miss_takes_the_extra_launch_and_stays_exact(oracle, ops, de
     assert abs(st.mu - float(ot.mu)) <= 1e-3 * float(ot.mu)
     # and with weights whose maximum does not move (the common case) one call is enough
     assert DeviceTracker(ops, world, [0]).iterate(iters)[0].iterations == iters
+
+
+def test_large_image_many_blocks(oracle, ops, dev, monkeypatch):
+    """1280 x 960: 1200 blocks of 1024 pixels -- more than a launch has workgroups (each takes several
+    blocks) and more rows of partial sums than one batch of the prologue's loads (3 batches)."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", 1280)
+    monkeypatch.setattr(mod, "H", 960)
+    monkeypatch.setattr(mod, "K", intrinsics(1280, 960))
+    big = world.__wrapped__(oracle)
+    dt = DeviceTracker(ops, big, [0, 1])
+    sts = dt.iterate(3)
+    for k in (0, 1):
+        ot = _oracle_tracker(oracle, big, k)
+        for _ in range(3):
+            ot.iterate(big["points"], big["assoc"][k])
+        st, h = sts[k], ot.history[-1]
+        assert st.iterations == 3 and st.accepted == ot.accepted
+        A = np.array(st.A, np.float32).reshape(6, 6)
+        assert np.abs(A - h["A"]).max() <= 2e-5 * np.abs(h["A"]).max(), "Hessian of the third iteration"
+        assert abs(st.errNew - h["err_new"]) <= 2e-5 * h["err_new"]
+        assert np.allclose(np.array(st.R, np.float32).reshape(3, 3), ot.R, atol=2e-6)
+        assert np.allclose(np.array(st.t, np.float32), ot.t, atol=2e-6)
+        one = DeviceTracker(ops, big, [k]).iterate(3)[0]  # another grid (blocks per workgroup), same sums
+        assert _fields(one) == _fields(st)
