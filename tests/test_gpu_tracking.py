@@ -265,3 +265,28 @@ def test_large_image_many_blocks(oracle, ops, dev, monkeypatch):
         assert np.allclose(np.array(st.t, np.float32), ot.t, atol=2e-6)
         one = DeviceTracker(ops, big, [k]).iterate(3)[0]  # another grid (blocks per workgroup), same sums
         assert _fields(one) == _fields(st)
+
+
+def test_launch_by_launch_with_progress_words(ops, dev, world):
+    """emf_hip_trackStep: the same states as emf_hip_trackIterate, and the progress words say what the
+    states say (here in device memory and read back; EMFusion::trackModels points them at pinned host
+    memory and reads them while the stream runs)."""
+    ref = DeviceTracker(ops, world, [0, 1]).iterate(100)
+    dt = DeviceTracker(ops, world, [0, 1])
+    watch = dev_full((3,), 0, np.uint32)
+    launch = 0
+    while True:
+        for _ in range(8):
+            ops.track_step(dt.table, dt.states, dt.n, dt.points, dt.params, dt.scratch, dt.per_model, launch, 100,
+                           watch.ptr, launch + 1)
+            launch += 1
+        w = to_np(watch)
+        assert w[0] == launch
+        if w[1] and w[2]:
+            break
+        assert launch < 220
+    sts = ops.read_track_states(dt.states, 2)  # (an even number of launches: the state is in the caller's array)
+    for k in (0, 1):
+        assert _fields(sts[k]) == _fields(ref[k])
+        assert w[1 + k] == (1 if sts[k].converged else 2)
+    assert launch < 100  # both converge long before the iteration budget
