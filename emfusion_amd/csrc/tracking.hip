@@ -477,7 +477,9 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #ifdef EMF_TRACK_TRACE  // timing probe: 10 ns stamps of workgroup (EMF_TRACK_TRACE) of model 0, per launch
     long long* stamps = reinterpret_cast<long long*>(state_buf(f, 0, 1) + 1) + 8 * f.launch;
     const bool tracer = blockIdx.x == EMF_TRACK_TRACE && m == 0 && threadIdx.x == 0 && f.launch < 24;
-#define STAMP(i) do { if (tracer) stamps[i] = wall_clock64(); } while (0)
+#define STAMP(i) do { if (tracer) stamps[i] = wall_clock64(); \
+        if ((i == 0 || i == 6) && m == 0 && threadIdx.x == 0 && f.launch == 5) /* every workgroup of launch 5 */ \
+            (reinterpret_cast<long long*>(state_buf(f, 0, 1) + 1) + 8 * 24)[2 * blockIdx.x + (i ? 1 : 0)] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -780,7 +782,7 @@ size_t emf_hip_trackScratchBytes(int width, int height) {
     const size_t nblocks = ceil_div(px, kTrackBlock);
     size_t bytes = (4 * px + 2 * nblocks * kCols) * sizeof(float) + sizeof(emf_track_state_t);
 #ifdef EMF_TRACK_TRACE
-    bytes += 24 * 8 * sizeof(long long);
+    bytes += (24 * 8 + 2 * nblocks) * sizeof(long long);
 #endif
     return (bytes + 255) / 256 * 256;
 }

@@ -18,6 +18,15 @@ raw = T.to_np(tr.scratch)[:tr.per_model]
 px, nb = T.W * T.H, -(-T.W * T.H // 1024)
 off = (4 * px + 2 * nb * 30) * 4 + C.sizeof(_lib.EmfTrackState)
 st = raw[off:off + 24 * 64].view(np.int64).reshape(24, 8)
+wg = raw[off + 24 * 64:off + 24 * 64 + 16 * nb].view(np.int64).reshape(nb, 2)
+if wg[:, 0].any():
+    t0 = wg[wg[:, 0] > 0, 0].min()
+    s0, e0 = (wg[:, 0] - t0) / 100.0, (wg[:, 1] - t0) / 100.0
+    print("launch 5, all %d workgroups: start us min/med/max %.2f %.2f %.2f   end us min/med/max %.2f %.2f %.2f" % (
+        nb, s0.min(), np.median(s0), s0.max(), e0.min(), np.median(e0), e0.max()))
+    order = np.argsort(e0)
+    print("  last to end:", [(int(i), round(float(s0[i]), 2), round(float(e0[i]), 2)) for i in order[-6:]])
+    print("  first to end:", [(int(i), round(float(s0[i]), 2), round(float(e0[i]), 2)) for i in order[:4]])
 for i, r in enumerate(st):
     if r[0] == 0: continue
     print(i, " ".join("%6.2f" % ((x - r[0]) / 100.0) if x else "   -  " for x in r[1:7]))
