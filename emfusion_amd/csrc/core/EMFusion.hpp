@@ -94,8 +94,9 @@ public:
     /**
      * Track the camera against the background volume (reference EMFusion.cpp:673-685) or all
      * objects against the camera (EMFusion.cpp:689-723) with the current association weights.
-     * Device-resident Levenberg-Marquardt (emf_hip_trackIterate): params.maxTrackingIter
-     * iterations are enqueued without host round trips; the poses are read back once.
+     * Device-resident Levenberg-Marquardt (emf_hip_trackStep, one launch per iteration, up to
+     * params.maxTrackingIter): the host only stops enqueuing when the device reports every model
+     * done; the poses are read back once per stage.
      */
     void trackCamera();
     void trackObjects();
