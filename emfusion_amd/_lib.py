@@ -59,6 +59,7 @@ SIGNATURES = {
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
+    "emf_hip_estepBatchedFromDepth": [_FP, _FP, C.c_int, _IMG, _F9, _IMG, C.c_int, _IMG, _IMG, _STREAM],
     "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, C.c_int,
                                C.c_int, _FP, _FP, _FP, _STREAM],
     "emf_hip_signMapBytes": [_I3],

@@ -42,6 +42,10 @@ struct EstepArgs {
     Img<float> norm, objSum;
     int w, h;
     int normalize;
+    // the first E-step of a frame: points from depth on the way (k_compute_points' arithmetic), stored too
+    Img<const float> depth;
+    Img<float> pointsOut;
+    float fx, fy, cx, cy;
 };
 
 __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const EstepArgs a) {
@@ -51,8 +55,19 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
     const bool inside = x < a.w;
     V3 pc = v3(0.f, 0.f, 0.f);
     if (inside) {
-        const float* pp = a.points.row(y) + 3 * x;
-        pc = v3(pp[0], pp[1], pp[2]);
+        if (a.depth.data) {  // (uniform) reference EMFusion.cu:39-46
+            const float d = a.depth.row(y)[x];
+            pc = v3((static_cast<float>(x) - a.cx) * d / a.fx, (static_cast<float>(y) - a.cy) * d / a.fy, d);
+            if (threadIdx.y == 0) {
+                float* po = a.pointsOut.row(y) + 3 * x;
+                po[0] = pc.x;
+                po[1] = pc.y;
+                po[2] = pc.z;
+            }
+        } else {
+            const float* pp = a.points.row(y) + 3 * x;
+            pc = v3(pp[0], pp[1], pp[2]);
+        }
     }
     // threadIdx.y is wave-uniform (64 x-lanes = one wave): keep the model index scalar
     for (int m = __builtin_amdgcn_readfirstlane(threadIdx.y); m < a.nmodels; m += kEstepLanes) {
@@ -868,10 +883,11 @@ using namespace emf_hip;
 
 extern "C" {
 
-int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
-                         const emf_image_t* points, int normalize, const emf_image_t* norm,
-                         const emf_image_t* objSum, emf_stream_t stream) {
-    EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "estepBatched"));
+namespace {
+int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                 const emf_image_t* depth, const float* K, const emf_image_t* points, int normalize,
+                 const emf_image_t* norm, const emf_image_t* objSum, emf_stream_t stream, const char* fn) {
+    EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, fn));
     EMF_TRY(check_image(points, 12, "estepBatched: points"));
     EstepArgs a;
     a.models = models_dev;
@@ -883,6 +899,21 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
     a.normalize = normalize ? 1 : 0;
     a.norm = Img<float>{nullptr, 0};
     a.objSum = Img<float>{nullptr, 0};
+    a.depth = Img<const float>{nullptr, 0};
+    a.pointsOut = Img<float>{nullptr, 0};
+    a.fx = a.fy = 1.f;
+    a.cx = a.cy = 0.f;
+    if (depth) {
+        EMF_TRY(check_image(depth, 4, "estepBatchedFromDepth: depth"));
+        EMF_TRY(check_same_size(depth, points, "depth", "points"));
+        if (!K) return fail(EMF_E_NULL, "estepBatchedFromDepth: K is NULL");
+        a.depth = img<const float>(depth);
+        a.pointsOut = img<float>(points);
+        a.fx = K[0];
+        a.fy = K[4];
+        a.cx = K[2];
+        a.cy = K[5];
+    }
     if (norm) {
         EMF_TRY(check_image(norm, 4, "estepBatched: norm"));
         EMF_TRY(check_same_size(norm, points, "norm", "points"));
@@ -896,7 +927,24 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
     }
     hipLaunchKernelGGL(k_estep, dim3(ceil_div(a.w, kEstepPixels), a.h),
                        dim3(kEstepPixels, kEstepLanes), 0, as_stream(stream), a);
-    return launch_status("estepBatched");
+    return launch_status(fn);
+}
+}  // namespace
+
+int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                         const emf_image_t* points, int normalize, const emf_image_t* norm,
+                         const emf_image_t* objSum, emf_stream_t stream) {
+    return estep_launch(models_dev, poseCO_host, nmodels, nullptr, nullptr, points, normalize, norm, objSum,
+                        stream, "estepBatched");
+}
+
+int emf_hip_estepBatchedFromDepth(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                                  const emf_image_t* depth, const float K[9], const emf_image_t* points,
+                                  int normalize, const emf_image_t* norm, const emf_image_t* objSum,
+                                  emf_stream_t stream) {
+    if (!depth) return fail(EMF_E_NULL, "estepBatchedFromDepth: depth is NULL");
+    return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, normalize, norm, objSum, stream,
+                        "estepBatchedFromDepth");
 }
 
 size_t emf_hip_signMapBytes(const int32_t res[3]) {

@@ -83,6 +83,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
     if (const char* tw = std::getenv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
+    if (const char* fp = std::getenv("EMF_FUSE_POINTS")) fusePoints = fp[0] != '0';
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
@@ -431,7 +432,10 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
         preprocessDepth(depthDev, depthFiltered.view());
         depth = depthFiltered.view();
     }
-    {
+    // computePoints (EMFusion.cpp:73): on the batched path the first E-step of the frame forms the
+    // points from the depth on its way and stores them (one launch less); frame 0 has no E-step
+    pointsPending = batched && frameCount > 0 && fusePoints;
+    if (!pointsPending) {
         const emf_image_t pv = points.view();
         auto kt = ktimers.scope(KernelTimers::Points, pixels(), main);
         emfCheck(emf_hip_computePoints(&depth, &pv, params.intr.val, main.abi()),
@@ -1139,19 +1143,25 @@ void EMFusion::estepBatched() {
     const int n = static_cast<int>(co.size());
     const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
     const emf_model_t* table = currentTable();
-    if (!sharded) {
+    const bool fromDepth = pointsPending;  // the frame's first E-step also makes the points
+    pointsPending = false;
+    auto launch = [&](int normalize, const emf_image_t* norm, const emf_image_t* objSum) {
         auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
-        emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 1, &nv, nullptr, main.abi()),
-                 "estepBatched");
+        if (fromDepth)
+            emfCheck(emf_hip_estepBatchedFromDepth(table, co.data(), n, &depth, params.intr.val, &pv, normalize,
+                                                   norm, objSum, main.abi()),
+                     "estepBatchedFromDepth");
+        else
+            emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, normalize, norm, objSum, main.abi()),
+                     "estepBatched");
+    };
+    if (!sharded) {
+        launch(1, &nv, nullptr);
         return;
     }
     // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
     // xGMI, then every rank normalises its own maps
-    {
-        auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
-        emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, 0, nullptr, &sv, main.abi()),
-                 "estepBatched");
-    }
+    launch(0, nullptr, &sv);
     comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), main);
     std::vector<emf_image_t> maps;
     maps.push_back(bg_associationWeights.view());

@@ -276,6 +276,8 @@ private:
     void posesCO(std::vector<emf_pose_t>& out) const;
     void posesOC(std::vector<emf_pose_t>& out) const;
     void estepBatched();
+    bool fusePoints = true;       // the frame's first E-step makes the points (EMF_FUSE_POINTS=0: own launch)
+    bool pointsPending = false;   // ... and has not run yet
     void raycastBatched();
     void integrateBatched();
     void compositeAndVisibility(bool deviceGate);

@@ -291,6 +291,18 @@ def estep_batched(models_dev, poses_co, points, normalize=True, norm=None, obj_s
                                   _stream(stream)))
 
 
+def estep_batched_from_depth(models_dev, poses_co, depth, K, points, normalize=True, norm=None, obj_sum=None,
+                             stream=None):
+    """compute_points + estep_batched in one launch; `points` is written."""
+    check("emf_hip_estepBatchedFromDepth",
+          _L.emf_hip_estepBatchedFromDepth(_ptr(models_dev), _poses(poses_co), len(poses_co),
+                                           C.byref(image_view(depth)), _f(K, 9), C.byref(image_view(points)),
+                                           int(normalize),
+                                           C.byref(image_view(norm)) if norm is not None else None,
+                                           C.byref(image_view(obj_sum)) if obj_sum is not None else None,
+                                           _stream(stream)))
+
+
 def voxel_reciprocal(voxel_size) -> float:
     """1 / voxel_size if the device check finds it usable in place of x / voxel_size, else 0."""
     r = C.c_float(0.0)

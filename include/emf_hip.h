@@ -284,6 +284,14 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
                          const emf_image_t* points, int normalize, const emf_image_t* norm,
                          const emf_image_t* objSum, emf_stream_t stream);
 
+/* emf_hip_computePoints + emf_hip_estepBatched in one launch, for the first E-step of a frame
+ * (EMFusion.cpp:73, 79): each pixel's point is formed from `depth` with computePoints' arithmetic,
+ * used, and stored to `points` (f32x3 W x H, every pixel written) for the frame's later stages. */
+int emf_hip_estepBatchedFromDepth(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                                  const emf_image_t* depth, const float K[9], const emf_image_t* points,
+                                  int normalize, const emf_image_t* norm, const emf_image_t* objSum,
+                                  emf_stream_t stream);
+
 /* Raycast of all models in one launch (TSDF.cu:466-601 per model, ObjTSDF.cpp:203-216).
  * Unlike emf_hip_raycastTSDF the outputs need no pre-zeroing: every pixel of every model's
  * raylengths / vertices / normals / hitMask is written (zeros where there is no hit), which is

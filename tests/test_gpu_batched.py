@@ -232,6 +232,31 @@ def test_estep_batched_matches_per_model_calls(ops, oracle, scene, dev):
         assert_parity(to_np(m.d_assoc), wv, f"map {m.id} vs oracle", rtol=4e-6)
 
 
+@pytest.mark.parametrize("normalize", [True, False], ids=["normalised", "partial_sums"])
+def test_estep_from_depth_equals_points_then_estep(ops, oracle, scene, dev, normalize):
+    """The frame's first E-step forms the points from the depth itself: the same points image (bit
+    for bit the oracle's) and the same maps as compute_points followed by the E-step."""
+    cam, depth, _ = frame(4)
+    table = ops.upload_models([m.table_entry() for m in scene])
+    poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
+    d_depth = to_dev(depth)
+    d_pts = ops.compute_points(d_depth, K, dev_full((H, W, 3), 5.0))
+    d_a, d_b = dev_full((H, W), 7.0), dev_full((H, W), 7.0)
+    kw = dict(norm=d_a) if normalize else dict(obj_sum=d_a)
+    ops.estep_batched(table, poses, d_pts, normalize=normalize, **kw)
+    want = [to_np(m.d_assoc).copy() for m in scene]
+    for m in scene:
+        m.d_assoc.copy_from(np.full((H, W), 3.0, np.float32))
+    d_pts2 = dev_full((H, W, 3), 5.0)
+    kw = dict(norm=d_b) if normalize else dict(obj_sum=d_b)
+    ops.estep_batched_from_depth(table, poses, d_depth, K, d_pts2, normalize=normalize, **kw)
+    assert_parity(to_np(d_pts2), oracle.compute_points(depth, K), "points", exact=True)
+    assert_parity(to_np(d_pts2), to_np(d_pts), "points vs compute_points", exact=True)
+    assert_parity(to_np(d_b), to_np(d_a), "normaliser / partial sum", exact=True)
+    for m, w in zip(scene, want):
+        assert_parity(to_np(m.d_assoc), w, f"map {m.id}", exact=True)
+
+
 @pytest.mark.parametrize("use_flags,footprints", [(False, False), (True, False), (False, True)],
                          ids=["plain", "brick_flags", "object_footprints"])
 def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, use_flags, footprints):
