@@ -943,11 +943,15 @@ void EMFusion::trackModels(int first, int count) {
                                sizeof(emf_track_state_t) * EMF_MAX_BATCH, hipHostMallocDefault),
                  "hipHostMalloc");
         // progress words the step kernel writes while the stream runs (emf_hip_trackStep)
-        hipCheck(hipHostMalloc(reinterpret_cast<void**>(&trackWatch), sizeof(uint32_t) * (1 + EMF_MAX_BATCH),
-                               hipHostMallocCoherent | hipHostMallocMapped),
-                 "hipHostMalloc");
-        hipCheck(hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0),
-                 "hipHostGetDevicePointer");
+        if (trackWindow > 0 &&
+            (hipHostMalloc(reinterpret_cast<void**>(&trackWatch), sizeof(uint32_t) * (1 + EMF_MAX_BATCH),
+                           hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+             hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0) != hipSuccess)) {
+            (void)hipGetLastError();  // no device-visible host memory here: poll in chunks instead
+            if (trackWatch) (void)hipHostFree(trackWatch);
+            trackWatch = trackWatchDev = nullptr;
+            trackWindow = 0;
+        }
     }
     std::vector<emf_pose_t> co;
     posesCO(co);
