@@ -58,17 +58,18 @@ def world(oracle):
     return dict(vols=vols, cam=cam, guess=guess, points=points, assoc=assoc)
 
 
-def _models(ops, world, which):
+def _models(ops, world, which, grad_volumes=None):
     keep, entries = [], []
     for k in which:
         v = world["vols"][k]
         d = dict(tsdf=to_dev(v["tsdf"]), wts=to_dev(v["wts"]), assoc=to_dev(world["assoc"][k]),
+                 grads=None if grad_volumes is None else to_dev(grad_volumes[k]),
                  ray=dev_full((H, W), 0.0), vert=dev_full((H, W, 3), 0.0), nrm=dev_full((H, W, 3), 0.0),
                  hit=dev_full((H, W), 0, np.uint8))
         keep.append(d)
         entries.append(ops.make_model(d["tsdf"], d["wts"], d["assoc"], d["ray"], d["vert"], d["nrm"],
                                       d["hit"], float(np.float32(v["vox"])), float(np.float32(10 * v["vox"])),
-                                      64.0, 0.02, 0.8, 1.0, model_id=k))
+                                      64.0, 0.02, 0.8, 1.0, model_id=k, grads=d["grads"]))
     return ops.upload_models(entries), keep
 
 
@@ -78,10 +79,10 @@ def _start_pose(world, k):
 
 
 class DeviceTracker:
-    def __init__(self, ops, world, which):
+    def __init__(self, ops, world, which, grad_volumes=None):
         from emfusion_amd import _lib
         self.ops, self.n = ops, len(which)
-        self.table, self.keep = _models(ops, world, which)
+        self.table, self.keep = _models(ops, world, which, grad_volumes)
         self.states = dev_full((self.n * C.sizeof(_lib.EmfTrackState),), 0, np.uint8)
         self.per_model = ops.track_scratch_bytes(W, H)
         self.scratch = dev_full((self.n * self.per_model,), 0, np.uint8)
@@ -290,3 +291,13 @@ def test_launch_by_launch_with_progress_words(ops, dev, world):
         assert _fields(sts[k]) == _fields(ref[k])
         assert w[1 + k] == (1 if sts[k].converged else 2)
     assert launch < 100  # both converge long before the iteration budget
+
+
+def test_gradient_volume_gives_the_same_states(oracle, ops, dev, world):
+    """With the reference's materialised gradient volume (TSDF.cu:429-464) in the model table the LM
+    loop blends stored differences instead of taking them on the fly: the same values, the same states."""
+    grads = {k: oracle.compute_tsdf_grads(world["vols"][k]["tsdf"]) for k in (0, 1)}
+    a = DeviceTracker(ops, world, [0, 1]).iterate(15)
+    b = DeviceTracker(ops, world, [0, 1], grad_volumes=grads).iterate(15)
+    for k in (0, 1):
+        assert a[k].iterations == 15 and _fields(a[k]) == _fields(b[k]), k
