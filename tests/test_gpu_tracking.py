@@ -301,3 +301,21 @@ def test_gradient_volume_gives_the_same_states(oracle, ops, dev, world):
     b = DeviceTracker(ops, world, [0, 1], grad_volumes=grads).iterate(15)
     for k in (0, 1):
         assert a[k].iterations == 15 and _fields(a[k]) == _fields(b[k]), k
+
+
+def test_frame_without_valid_depth_converges_at_once(oracle, ops, dev, world):
+    """No valid point: every wave of the first pass is skipped as dead, A = b = 0, max |b| < eps1 --
+    converged with the pose untouched, as the oracle (TSDF.cpp:276-278)."""
+    empty = dict(world, points=np.zeros_like(world["points"]))
+    dt = DeviceTracker(ops, empty, [0, 1])
+    sts = dt.iterate(4)
+    for k in (0, 1):
+        ot = _oracle_tracker(oracle, empty, k)
+        ot.iterate(empty["points"], empty["assoc"][k])
+        assert ot.converged and ot.iterations == 0
+        st = sts[k]
+        assert st.converged == 1 and st.iterations == 0 and st.haveTrial == 0
+        R, t = _start_pose(world, k)
+        assert list(st.R) == [float(x) for x in np.asarray(R, np.float32).reshape(-1)]
+        assert list(st.t) == [float(x) for x in np.asarray(t, np.float32)]
+        assert list(st.b) == [0.0] * 6 and st.err == 0.0
