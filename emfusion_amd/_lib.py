@@ -64,6 +64,8 @@ SIGNATURES = {
                                C.c_int, _FP, _FP, _FP, _STREAM],
     "emf_hip_signMapBytes": [_I3],
     "emf_hip_rebuildSignMaps": [_FP, _I3, _FP, _STREAM],
+    "emf_hip_unseenTileBytes": [_I3],
+    "emf_hip_rebuildUnseenTiles": [_FP, _FP, _I3, _FP, _STREAM],
     "emf_hip_raycastFarBoundBytes": [C.c_int, C.c_int, C.c_int],
     "emf_hip_raycastFarBounds": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_uint32, _FP, _STREAM],
     "emf_hip_relevantTileBytes": [_I3],
@@ -121,7 +123,7 @@ class EmfModel(C.Structure):
                 ("fgProbs", C.c_void_p), ("fgVolMask", C.c_void_p), ("brickFlags", C.c_void_p),
                 ("assoc", C.c_void_p), ("raylengths", C.c_void_p), ("vertices", C.c_void_p),
                 ("normals", C.c_void_p), ("hitMask", C.c_void_p), ("signMaps", C.c_void_p),
-                ("relevantTiles", C.c_void_p), ("res", C.c_int32 * 3),
+                ("relevantTiles", C.c_void_p), ("unseenTiles", C.c_void_p), ("res", C.c_int32 * 3),
                 ("id", C.c_int32), ("voxelSize", C.c_float), ("truncdist", C.c_float),
                 ("maxWeight", C.c_float), ("assocC1", C.c_float), ("assocC2", C.c_float),
                 ("alpha", C.c_float), ("assocC3", C.c_float), ("reserved", C.c_int32),
@@ -184,6 +186,7 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.emf_hip_trackScratchBytes.restype = C.c_size_t
+    lib.emf_hip_unseenTileBytes.restype = C.c_size_t
     lib.emf_hip_pointStatsScratchBytes.restype = C.c_size_t
     lib.emf_hip_meshScratchBytes.restype = C.c_size_t
     lib.emf_hip_integrateCullScratchBytes.restype = C.c_size_t

@@ -572,6 +572,29 @@ __global__ __launch_bounds__(256) void k_sign_maps(const float* __restrict__ tsd
     }
 }
 
+// unseen-tile map (emf_model_t.unseenTiles) from the values: every weight 0 and every tsdf finite
+__global__ __launch_bounds__(256) void k_unseen_tiles(const float* __restrict__ tsdf, const float* __restrict__ weights,
+                                                      I3 n, uint8_t* __restrict__ map) {
+    const int ntx = (n.x + kTileX - 1) / kTileX, nty = (n.y + kTileY - 1) / kTileY;
+    const int t = blockIdx.x;
+    const int tx = t % ntx, ty = (t / ntx) % nty, tz = t / (ntx * nty);
+    const int xg = threadIdx.x & 7, yy = (threadIdx.x >> 3) & 7, zs = threadIdx.x >> 6;
+    bool seen = false;
+    const int y = ty * kTileY + yy;
+    for (int i = 0; i < 2; ++i) {
+        const int z = tz * kTileZ + zs + 4 * i;
+        for (int e = 0; e < 4; ++e) {
+            const int x = tx * kTileX + 4 * xg + e;
+            if (x < n.x && y < n.y && z < n.z) {
+                const size_t v = (static_cast<size_t>(z) * n.y + y) * n.x + x;
+                seen = seen || !(weights[v] == 0.f) || !(fabsf(tsdf[v]) <= 3.0e38f);
+            }
+        }
+    }
+    const int any = __syncthreads_or(seen);
+    if (threadIdx.x == 0) map[t] = any ? 0 : 1;
+}
+
 // ---- batched integration ---------------------------------------------------------------------------
 
 __device__ __forceinline__ size_t tile_count(const I3& n) {
@@ -622,9 +645,11 @@ __global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchA
         atomicAdd(a.stats, static_cast<unsigned long long>(g.n.x) * g.n.y * g.n.z);
     const int ntx = (g.n.x + kTileX - 1) / kTileX, nty = (g.n.y + kTileY - 1) / kTileY;
     const int tx = b % ntx, ty = (b / ntx) % nty, tz = b / (ntx * nty);
-    uint8_t* sp = md.signMaps ? md.signMaps + tile_index(g.n, tx * kTileX, ty * kTileY, tz * kTileZ) : nullptr;
+    const size_t tile = tile_index(g.n, tx * kTileX, ty * kTileY, tz * kTileZ);
+    uint8_t* sp = md.signMaps ? md.signMaps + tile : nullptr;
     integrate_tile(g, md.tsdf, md.weights, md.brickFlags, tx * kTileX, ty * kTileY, tz * kTileZ,
-                   lds, nullptr, nullptr, 0, nullptr, nullptr, false, sp, sp ? sp + tile_count(g.n) : nullptr);
+                   lds, nullptr, nullptr, 0, nullptr, nullptr, false, sp, sp ? sp + tile_count(g.n) : nullptr,
+                   md.unseenTiles ? md.unseenTiles + tile : nullptr);
 }
 
 // Models whose Nx is not a multiple of 4 (object volumes after ObjTSDF::resize, which only keeps the
@@ -807,10 +832,11 @@ __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a
             const int force = (dp[t] ? 1 : 0) | (dp[nt + t] ? 2 : 0);
             integrate_tile<true>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
                                  a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
-                                 a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr);
+                                 a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr,
+                                 md.unseenTiles ? md.unseenTiles + t : nullptr);
         } else {
             integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, nullptr, nullptr, 0, nullptr, nullptr,
-                           false, sp, sp ? sp + nt : nullptr);
+                           false, sp, sp ? sp + nt : nullptr, md.unseenTiles ? md.unseenTiles + t : nullptr);
         }
     }
 }
@@ -945,6 +971,22 @@ int emf_hip_estepBatchedFromDepth(const emf_model_t* models_dev, const emf_pose_
     if (!depth) return fail(EMF_E_NULL, "estepBatchedFromDepth: depth is NULL");
     return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, normalize, norm, objSum, stream,
                         "estepBatchedFromDepth");
+}
+
+size_t emf_hip_unseenTileBytes(const int32_t res[3]) { return emf_hip_signMapBytes(res) / 2; }
+
+int emf_hip_rebuildUnseenTiles(const float* tsdf, const float* weights, const int32_t res[3], uint8_t* unseenTiles,
+                               emf_stream_t stream) {
+    EMF_REQUIRE_PTR(tsdf);
+    EMF_REQUIRE_PTR(weights);
+    EMF_REQUIRE_PTR(unseenTiles);
+    EMF_REQUIRE_PTR(res);
+    EMF_TRY(check_res(res));
+    const size_t tiles = emf_hip_unseenTileBytes(res);
+    if (tiles > 0x7fffffffu) return fail(EMF_E_LIMIT, "rebuildUnseenTiles: volume too large");
+    hipLaunchKernelGGL(k_unseen_tiles, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, as_stream(stream), tsdf,
+                       weights, I3{res[0], res[1], res[2]}, unseenTiles);
+    return launch_status("rebuildUnseenTiles");
 }
 
 size_t emf_hip_signMapBytes(const int32_t res[3]) {

@@ -128,6 +128,7 @@ Vec3f ObjTSDF::resize(const Vec3f& p10, const Vec3f& p90, float volPad, Stream& 
     signMaps = DeviceBuffer();   // new resolution, shifted values: rebuilt by refreshSignMaps()
     signMapsValid = false;
     relevantTiles = DeviceBuffer();
+    unseenTiles = DeviceBuffer();
     computeFgProbs(stream);
     return newCenter;
 }

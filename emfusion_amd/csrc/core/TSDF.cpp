@@ -40,10 +40,14 @@ void TSDF::reset(const Affine3f& _pose) {
         signMapsValid = true;
         if (relevantTiles.empty()) relevantTiles = DeviceBuffer(emf_hip_relevantTileBytes(volumeRes.val));
         relevantTiles.setZero(s);  // count 0: nothing can be hit in an empty volume
+        // ... and every tile of it is unseen (allocation rounded up to whole words for the fill)
+        if (unseenTiles.empty()) unseenTiles = DeviceBuffer((emf_hip_unseenTileBytes(volumeRes.val) + 3) / 4 * 4);
+        unseenTiles.fill32(0x01010101u, s);
     } else {
         signMaps = DeviceBuffer();
         signMapsValid = false;
         relevantTiles = DeviceBuffer();
+        unseenTiles = DeviceBuffer();
     }
     if (doubleBuffered()) {  // equal copies, clean maps
         tsdfBack.setZero(s);
@@ -65,6 +69,11 @@ void TSDF::refreshSignMaps(Stream& stream) {
     const size_t rb = emf_hip_relevantTileBytes(volumeRes.val);
     if (relevantTiles.empty() || relevantTiles.bytes() != rb) relevantTiles = DeviceBuffer(rb);
     relevantTiles.setZero(stream);  // the owner rebuilds the list (emf_hip_updateRelevantTiles) before it is used
+    const size_t ub = (emf_hip_unseenTileBytes(volumeRes.val) + 3) / 4 * 4;
+    if (unseenTiles.empty() || unseenTiles.bytes() != ub) unseenTiles = DeviceBuffer(ub);
+    emfCheck(emf_hip_rebuildUnseenTiles(tsdfVol.as<float>(), tsdfWeights.as<float>(), volumeRes.val,
+                                        unseenTiles.as<uint8_t>(), stream.abi()),
+             "TSDF::refreshSignMaps");
 }
 
 void TSDF::enableDoubleBuffer() {
@@ -211,6 +220,9 @@ void TSDF::describe(emf_model_t& m) const {
     m.relevantTiles = m.signMaps && !relevantTiles.empty() && emf_hip_signMapBytes(volumeRes.val) / 2 >= 8192
                           ? relevantTiles.as<uint32_t>()
                           : nullptr;
+    // (kept valid together with the sign maps: the same launches maintain both)
+    static const bool useUnseen = !(std::getenv("EMF_UNSEEN_TILES") && std::getenv("EMF_UNSEEN_TILES")[0] == '0');
+    m.unseenTiles = useUnseen && m.signMaps && !unseenTiles.empty() ? unseenTiles.as<uint8_t>() : nullptr;
     m.pad_ = 0;
 }
 

@@ -147,6 +147,7 @@ protected:
     DeviceBuffer signMaps;      // per 32x8x8 tile: holds a positive tsdf / holds a negative tsdf
     bool signMapsValid = false;
     DeviceBuffer relevantTiles; // count + indices of the tiles in which a raycast hit can be completed
+    DeviceBuffer unseenTiles;   // per tile: every weight is 0 (emf_model_t.unseenTiles); valid with the sign maps
     int dirtyPrev = 0;  // index of the map the last out-of-place integration wrote
 };
 

@@ -168,6 +168,35 @@ __device__ __forceinline__ int apply_voxel(int kind, float samp, float aw, float
     return 0;
 }
 
+// apply_voxel for a voxel whose weight is known to be 0 and whose tsdf has NOT been loaded: the branch
+// either determines the new value whatever the old one was (a finite old value assumed -- the owner of
+// the unseen-tile map guarantees it), or keeps the old one.  Returns true = "keeps it: load it".
+//   kFuse:  (0 * old + aw * samp) / (0 + aw): 0 * old is a zero of either sign and vanishes in the sum
+//           unless aw * samp is itself -0 (a denormal weight), which is left to the loaded form;
+//           the new weight is min(0 + aw, maxWeight)
+__device__ __forceinline__ bool apply_unseen(int kind, float samp, float aw, float maxWeight, float& tv,
+                                             float& wv) {
+    wv = 0.f;
+    if (kind == kFuse) {
+        const float prod = aw * samp;
+        if (0.f + aw > 0 && __float_as_uint(prod) != 0x80000000u) {  // TSDF.cu:392-397
+            tv = (0.f + prod) / (0.f + aw);
+            wv = fminf(0.f + aw, maxWeight);
+            return false;
+        }
+        return true;
+    }
+    if (kind == kZeroIfUnseen) {
+        tv = 0.f;
+        return false;
+    }
+    if (kind == kNegIfUnseen) {
+        tv = -1.f;
+        return false;
+    }
+    return true;  // kSkip
+}
+
 // Conservative frustum test for an axis-aligned box of voxels [x0,x1] x [y0,y1] x [z0,z1]
 // (inclusive voxel indices): true only if EVERY voxel inside takes the kSkip branch, i.e.
 // projects strictly in front of the camera and outside the image.  Perspective projection maps
@@ -367,7 +396,8 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                                                float* __restrict__ weightsOut = nullptr,
                                                int force = 0, uint8_t* dirtyT = nullptr,
                                                uint8_t* dirtyW = nullptr, bool copyOnly = false,
-                                               uint8_t* signPos = nullptr, uint8_t* signNeg = nullptr) {
+                                               uint8_t* signPos = nullptr, uint8_t* signNeg = nullptr,
+                                               uint8_t* unseen = nullptr) {
     const V3 half = half_extent(a.n);
     // copyOnly (OUT, block-uniform): the model is not integrated this frame (visibility gate closed),
     // its second copy only has to catch up
@@ -393,6 +423,10 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
         tsdfOut = tsdf;
         weightsOut = weights;
     }
+    // Unseen tile (block-uniform; emf_model_t.unseenTiles): every weight is 0, so no voxel's new value
+    // depends on what the tile holds -- nothing is loaded up front, the new values are stored.
+    const bool fast = unseen && !bricks && *unseen != 0;
+    bool gotWeight = false;  // a voxel of this lane has been fused into
     int anyChanged = 0;
     bool sawPos = false, sawNeg = false;  // signs among the tsdf values this lane holds at the end
     const int tid = threadIdx.x;
@@ -445,9 +479,13 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 tl = make_float4(0.f, 0.f, 0.f, 0.f), wl = tl;
-            if ((bricks && live[i]) || touch[i] || (OUT && (force & 1) && live[i]))
-                tl = load4<OUT>(tsdf + base[i]);
-            if (touch[i] || (OUT && (force & 2) && live[i])) wl = load4<OUT>(weights + base[i]);
+            if (fast) {  // only a group that is merely copied needs its old values now
+                if (!touch[i] && OUT && (force & 1) && live[i]) tl = load4<OUT>(tsdf + base[i]);
+            } else {
+                if ((bricks && live[i]) || touch[i] || (OUT && (force & 1) && live[i]))
+                    tl = load4<OUT>(tsdf + base[i]);
+                if (touch[i] || (OUT && (force & 2) && live[i])) wl = load4<OUT>(weights + base[i]);
+            }
             tv[i][0] = tl.x; tv[i][1] = tl.y; tv[i][2] = tl.z; tv[i][3] = tl.w;
             wv[i][0] = wl.x; wv[i][1] = wl.y; wv[i][2] = wl.z; wv[i][3] = wl.w;
         }
@@ -455,7 +493,35 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int changed = 0;
-            if (touch[i]) {
+            if (touch[i] && fast) {
+                unsigned keep = 0;  // voxels of the group that keep their old value
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    VoxelShot s;
+                    s.px = pix[i][e] & 0xffffu;
+                    s.py = pix[i][e] >> 16;
+                    s.inImage = (inMask >> (4 * i + e)) & 1u;
+                    s.behind = (behindMask >> (4 * i + e)) & 1u;
+                    s.n2 = n2[i][e];
+                    const float ile = haveIl ? il[i][e] : inv_lambda_at(a.K, s.px, s.py);
+                    float samp = 0.f;
+                    bool band;
+                    const int kind = classify_shot(a, s, d[i][e], ile, samp, band);
+                    const float aw = band ? a.assoc.row(s.py)[s.px] : 1.f;
+                    if (apply_unseen(kind, samp, aw, a.maxWeight, tv[i][e], wv[i][e])) keep |= 1u << e;
+                }
+                if (keep) {  // pixels outside the image, association weight 0: rare, and only then a load
+                    const float4 tl = load4<OUT>(tsdf + base[i]);
+                    if (keep & 1u) tv[i][0] = tl.x;
+                    if (keep & 2u) tv[i][1] = tl.y;
+                    if (keep & 4u) tv[i][2] = tl.z;
+                    if (keep & 8u) tv[i][3] = tl.w;
+                }
+                // what the tile held is not known: it counts as changed
+                changed = 1 | ((wv[i][0] != 0.f || wv[i][1] != 0.f || wv[i][2] != 0.f || wv[i][3] != 0.f) ? 2 : 0);
+                gotWeight = gotWeight || (changed & 2) != 0;
+                anyChanged |= changed;
+            } else if (touch[i]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     VoxelShot s;
@@ -471,6 +537,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                     const float aw = band ? a.assoc.row(s.py)[s.px] : 1.f;
                     changed |= apply_voxel(kind, samp, aw, a.maxWeight, tv[i][e], wv[i][e]);
                 }
+                gotWeight = gotWeight || (changed & 2) != 0;  // (weights only ever grow)
                 anyChanged |= changed;
             }
             if (signPos && (touch[i] || (OUT && (force & 1) && live[i]))) {  // values that were loaded
@@ -496,6 +563,10 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
             if (n) *signNeg = 1;
         }
     }
+    // Unseen-tile map: cleared by whichever wave fuses into the tile (same value from all).  The flag is read
+    // per wave at the top; should a wave read it after another one has cleared it, it merely takes the
+    // loading path for its own voxels.
+    if (unseen && __ballot(gotWeight) != 0ull && (tid & 63) == 0) *unseen = 0;
     if (OUT && dirtyT) {  // one store per wave that changed something (same value from all)
         const bool t = __ballot((anyChanged & 1) != 0) != 0ull, w = __ballot((anyChanged & 2) != 0) != 0ull;
         if ((tid & 63) == 0) {

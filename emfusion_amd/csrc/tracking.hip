@@ -880,4 +880,4 @@ int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const em
 }  // extern "C"
 
 static_assert(sizeof(emf_track_state_t) == 484, "emf_track_state_t layout is mirrored in _lib.py");
-static_assert(sizeof(emf_model_t) == 160, "emf_model_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_model_t) == 168, "emf_model_t layout is mirrored in _lib.py");

@@ -240,7 +240,8 @@ def device_info():
 
 def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, voxel_size,
                truncdist, max_weight, sigma, alpha, uni_prior, model_id=0, grads=None,
-               fg_probs=None, fg_mask=None, brick_flags=None, rcp_voxel=0.0, sign_maps=None, relevant_tiles=None) -> "_lib.EmfModel":
+               fg_probs=None, fg_mask=None, brick_flags=None, rcp_voxel=0.0, sign_maps=None, relevant_tiles=None,
+               unseen_tiles=None) -> "_lib.EmfModel":
     """Fill an emf_model_t from device arrays (images must be unpadded)."""
     f32 = np.float32
     m = _lib.EmfModel()
@@ -251,6 +252,7 @@ def make_model(tsdf, weights, assoc, raylengths, vertices, normals, hit_mask, vo
     m.brickFlags = brick_flags.ptr if brick_flags is not None else None
     m.signMaps = sign_maps.ptr if sign_maps is not None else None
     m.relevantTiles = relevant_tiles.ptr if relevant_tiles is not None else None
+    m.unseenTiles = unseen_tiles.ptr if unseen_tiles is not None else None
     for name, im in (("assoc", assoc), ("raylengths", raylengths), ("vertices", vertices),
                      ("normals", normals), ("hitMask", hit_mask)):
         assert not im.padded
@@ -331,6 +333,17 @@ def rebuild_sign_maps(tsdf, sign_maps, stream=None):
     nz, ny, nx = tsdf.shape
     check("emf_hip_rebuildSignMaps",
           _L.emf_hip_rebuildSignMaps(_ptr(tsdf), (C.c_int32 * 3)(nx, ny, nz), _ptr(sign_maps), _stream(stream)))
+
+
+def unseen_tile_bytes(res) -> int:
+    return int(_L.emf_hip_unseenTileBytes((C.c_int32 * 3)(*[int(v) for v in res])))
+
+
+def rebuild_unseen_tiles(tsdf, weights, unseen_tiles, stream=None):
+    nz, ny, nx = tsdf.shape
+    check("emf_hip_rebuildUnseenTiles",
+          _L.emf_hip_rebuildUnseenTiles(_ptr(tsdf), _ptr(weights), (C.c_int32 * 3)(nx, ny, nz), _ptr(unseen_tiles),
+                                        _stream(stream)))
 
 
 def raycast_far_bounds(models_dev, poses_co, res_list, width, height, K, bounds=None, stream=None, scan_mask=0xffffffff):

@@ -253,6 +253,10 @@ typedef struct emf_model {
                              * tsdf", then per tile "holds a negative tsdf"; kept by the tile integration
                              * launches (sticky), read by emf_hip_raycastFarBounds */
     uint32_t* relevantTiles; /* emf_hip_relevantTileBytes(res) bytes or NULL (emf_hip_updateRelevantTiles) */
+    uint8_t* unseenTiles;   /* emf_hip_unseenTileBytes(res) bytes or NULL: per 32x8x8 tile "every weight is 0 (and
+                             * every tsdf finite)"; set by the owner (a cleared volume: all 1;
+                             * emf_hip_rebuildUnseenTiles), cleared by the tile integration launches, which
+                             * integrate such a tile without reading it */
     int32_t res[3];
     int32_t id;             /* 0 = background */
     float voxelSize, truncdist, maxWeight;
@@ -329,6 +333,15 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
  * kernels, emf_hip_updateTSDF). */
 size_t emf_hip_signMapBytes(const int32_t res[3]);
 int emf_hip_rebuildSignMaps(const float* tsdf, const int32_t res[3], uint8_t* signMaps, emf_stream_t stream);
+/* Unseen-tile map (emf_model_t.unseenTiles).  A voxel nobody has fused into (weight 0) is set to 0, to
+ * -1 or to its first sample by kernel_updateTSDF whatever it held (TSDF.cu:352-355, 369-372, 392-400), or
+ * left alone (pixel outside the image, association weight 0): for a tile of such voxels the tile
+ * integration launches compute the new values without loading the old ones (they load what a voxel
+ * keeps) and store them -- behind surfaces and outside the truncation band, where depth drop-outs flip
+ * unseen voxels between -1 and 0 from frame to frame, that is two thirds of the bytes the sweep moved. */
+size_t emf_hip_unseenTileBytes(const int32_t res[3]);
+int emf_hip_rebuildUnseenTiles(const float* tsdf, const float* weights, const int32_t res[3], uint8_t* unseenTiles,
+                               emf_stream_t stream);
 size_t emf_hip_raycastFarBoundBytes(int nmodels, int width, int height);
 /* scanMask: bit m set = model m has every tile of its sign maps examined (a neighbourhood scan per tile:
  * fine for an object volume, ~50 us for a 512^3 one); clear = its relevant-tile list is walked

@@ -120,7 +120,8 @@ class Model:
             float(self.vox), float(self.trunc), MAXW, SIGMA, ALPHA, PRIOR, model_id=self.id,
             fg_probs=self.d_probs if self.is_obj else None,
             fg_mask=self.d_vmask if self.is_obj else None, brick_flags=self.d_flags,
-            rcp_voxel=self.ops.voxel_reciprocal(self.vox), sign_maps=self.d_sign, relevant_tiles=self.d_rel)
+            rcp_voxel=self.ops.voxel_reciprocal(self.vox), sign_maps=self.d_sign, relevant_tiles=self.d_rel,
+            unseen_tiles=getattr(self, "d_unseen", None))
 
 
 @pytest.fixture(scope="module")
@@ -449,6 +450,69 @@ def test_sign_maps_kept_by_the_integration_cover_the_exact_ones(ops, oracle, dev
             for got, name in ((to_np(m.d_sign), "in place"), (to_np(f.d_sign), "out of place")):
                 assert ((got != 0) | (exact == 0)).all(), (i, m.id, name)  # got covers exact
                 assert got.sum() <= exact.sum() + 0.2 * exact.size       # ... without being everything
+
+
+def tile_all(a, pred):
+    """per 32 x 8 x 8 tile (index (tz * nty + ty) * ntx + tx): pred holds for every voxel"""
+    nz, ny, nx = a.shape
+    ntx, nty, ntz = -(-nx // 32), -(-ny // 8), -(-nz // 8)
+    out = np.zeros(ntx * nty * ntz, np.uint8)
+    for tz in range(ntz):
+        for ty in range(nty):
+            for tx in range(ntx):
+                out[(tz * nty + ty) * ntx + tx] = pred(a[tz * 8:tz * 8 + 8, ty * 8:ty * 8 + 8, tx * 32:tx * 32 + 32]).all()
+    return out
+
+
+def test_unseen_tiles_are_integrated_without_being_read_and_to_the_same_bits(ops, oracle, dev):
+    """With emf_model_t.unseenTiles a tile whose weights are all 0 is integrated from the depth alone (drop-outs
+    flip unseen voxels between -1 and 0 from frame to frame, pixels outside the image and association weight
+    0 keep what is there): volumes bit-identical to the launches without the map -- in place and out of
+    place, under a swinging camera -- and the map stays exactly "every weight of the tile is 0"."""
+    shapes = [((96, 64, 72), 0.035, Pose(t=[0, 0, 1.28]), False), ((32, 32, 32), 0.025, Pose(t=SPHERES[0][0]), True)]
+    mk = lambda: [Model(ops, oracle, r, v, p, o, i) for i, (r, v, p, o) in enumerate(shapes)]
+    ref, a, b, b2 = mk(), mk(), mk(), mk()
+    for m in ref + a + b + b2:
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+    for m in a + b:
+        m.d_unseen = dev_full((ops.unseen_tile_bytes(m.res),), 1, np.uint8)  # cleared volumes: every tile unseen
+    for x, y in zip(b, b2):
+        y.d_unseen = x.d_unseen  # the two copies of a volume share the map
+    maps = [[dev_full((ops.integrate_dirty_map_bytes(r),), 0, np.uint8) for _ in range(2)] for r, _, _, _ in shapes]
+    visible = dev_full((2,), 1, np.int32)
+    rng = np.random.default_rng(11)
+    front, back = b, b2
+    for i in range(6):
+        base, depth, _ = frame(i)
+        cam = Pose(base.R @ rot([0, 1, 0], [0, 25, -20, 0, 8, 30][i]), base.t)
+        assoc = rng.uniform(0.0, 1.0, (H, W)).astype(np.float32)
+        assoc[rng.uniform(size=(H, W)) < 0.2] = 0.0  # association weight 0: the voxel keeps its value
+        poses = [(rel_OC(cam, m.pose).R32, rel_OC(cam, m.pose).t32) for m in ref]
+        d_depth, res = to_dev(depth), [m.res for m in ref]
+        for group in (ref, a, front):
+            for m in group:
+                m.d_assoc.copy_from(assoc)
+        ops.integrate_batched_culled(ops.upload_models([m.table_entry() for m in ref]), poses, res, visible, d_depth, K)
+        ops.integrate_batched_culled(ops.upload_models([m.table_entry() for m in a]), poses, res, visible, d_depth, K)
+        outs = [(bk.d_tsdf, bk.d_wts, mp[i % 2], mp[1 - i % 2]) for bk, mp in zip(back, maps)]
+        ops.integrate_batched_culled_out(ops.upload_models([m.table_entry() for m in front]), poses, res, visible,
+                                         d_depth, K, outs)
+        dev.synchronize()
+        front, back = back, front
+        for r, m, f in zip(ref, a, front):
+            want_t, want_w = to_np(r.d_tsdf), to_np(r.d_wts)
+            assert (want_w > 0).any() and (want_t == -1).any()
+            for got, name in ((m, "in place"), (f, "out of place")):
+                assert_parity(to_np(got.d_tsdf), want_t, f"frame {i} model {r.id} tsdf {name}", exact=True)
+                assert_parity(to_np(got.d_wts), want_w, f"frame {i} model {r.id} weights {name}", exact=True)
+                exact = tile_all(want_w, lambda w: w == 0)
+                assert np.array_equal(to_np(got.d_unseen) != 0, exact != 0), (i, r.id, name)
+        assert 0 < (to_np(a[0].d_unseen) != 0).sum() < a[0].d_unseen.shape[0]
+    # the map from the values
+    m = a[0]
+    again = dev_full((ops.unseen_tile_bytes(m.res),), 7, np.uint8)
+    ops.rebuild_unseen_tiles(m.d_tsdf, m.d_wts, again)
+    assert np.array_equal(to_np(again), tile_all(to_np(m.d_wts), lambda w: w == 0))
 
 
 @pytest.mark.parametrize("table", [False, True], ids=["inline", "table"])
