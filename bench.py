@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--grads", choices=["onthefly", "materialize"], default="onthefly",
                     help="surface normals from on-the-fly TSDF differences (default) or from the "
                          "reference's materialised gradient volume (rebuilt every frame)")
+    ap.add_argument("--no-stats-replay", action="store_true",
+                    help="skip the untimed replay that counts march samples (roofline.achieved of the raycast is "
+                         "then null): for profiler passes that should see each launch once")
     ap.add_argument("--track", action="store_true",
                     help="timed frames track the camera and the objects (LM-ICP, SURVEY f-1) instead "
                          "of taking their poses as inputs; changes the metric name -- the headline "
@@ -210,7 +213,6 @@ def main():
         fus.kernel_timers_enable(launches_per_frame * args.steps + 64)
         if not args.all_kernel_events:
             fus.kernel_timers_select(["raycast", "integrate_bg", "track"] if fus.background_overlap() else ["raycast", "integrate", "track"])
-    fus.enable_raycast_stats(True)
     if args.track:
         fus.set_tracking(camera=True, objects=True)
     barrier()
@@ -230,9 +232,41 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stats = fus.raycast_stats()
     kern = None if args.no_kernel_events else fus.kernel_timers_collect()
     visible = fus.visible_objects()
+
+
+    def replay_with_counters():
+        """March samples and hits of exactly the timed launches, counted in an UNTIMED replay (the byte model of
+        the raycast needs them; the per-wave counters cost the raycast and the sweep beside it ~13 % when they
+        run inside the timed region, as they did until round 2).  The stream and every kernel are
+        deterministic: same frames from a cleared state, same launches."""
+        if args.no_stats_replay:
+            return None
+        if not args.no_kernel_events:
+            fus.kernel_timers_enable(0)  # no event pairs in the replay
+        if args.track:
+            fus.set_tracking(camera=False, objects=False)
+        fus.reset()
+        for k in range(nobj_total):
+            c, r, vs = synth.sphere(k, 0)
+            assert fus.add_object(c, vs) == ids[k]
+        for f in range(nframes):
+            if f == args.warmup:
+                fus.synchronize()
+                fus.enable_raycast_stats(True)
+                if args.track:
+                    fus.set_tracking(camera=True, objects=True)
+            step(f)
+        fus.synchronize()
+        return fus.raycast_stats()
+
+    # the copy-bandwidth probe comes first: its kernel also marks, in a kernel trace of this command, where
+    # the measured run ends and the replay begins (scripts/summarize_profile.py)
+    copy_gbs = copy_bandwidth(devmem, ops) if rank == 0 else None
+    barrier()
+    stats = replay_with_counters()
+    barrier()
 
     result = None
     if rank == 0:
@@ -275,7 +309,6 @@ def main():
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
         }
-        copy_gbs = copy_bandwidth(devmem, ops)
         # the committed PMC summary was taken on configs[1] without tracking: quote it only there
         profiled = (world, nobj_total, args.bg_res, args.obj_res, W, H, args.track) == \
                    (1, 4, 512, 128, 640, 480, False)
@@ -333,6 +366,8 @@ def algorithmic_bytes(kind, summ, stats, P):
     if kind == "grads":       # B_grad: 4 B read + 12 B written per voxel
         return 16.0 * u
     if kind == "raycast":     # B_ray: 16 gathers per march sample, gradient blend at hits, outputs
+        if stats is None:     # --no-stats-replay: the samples were not counted
+            return 0.0
         S, hits = stats[0], stats[1]
         return 64.0 * S + 96.0 * hits + 29.0 * u
     if kind == "assoc":       # B_em per model and pixel: 12 B point + 32 B tsdf gather + 4 B out
@@ -411,7 +446,7 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
         "achieved": dom["achieved_GBs"],
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
+        "frac": round((dom["achieved_GBs"] or 0.0) / HBM_PEAK_GBS, 4),
         # bytes/launch from the committed PMC pass of this workload; null for other workloads
         "traffic": measured_traffic(dom["kind"]) if profiled else None,
         "avg_launch_ms": dom["avg_ms"],
@@ -419,7 +454,7 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
         "dropped_launches": kern.get("_dropped", 0),
     }
     if copy_gbs:
-        roof["frac_of_copy"] = round(dom["achieved_GBs"] / copy_gbs, 4)
+        roof["frac_of_copy"] = round((dom["achieved_GBs"] or 0.0) / copy_gbs, 4)
     if roof["traffic"]:  # what the PMC pass saw moving at the HBM side, at this launch's duration
         roof["traffic_GBs"] = round(roof["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9, 1)
     if dom["kind"] == "raycast":
@@ -450,7 +485,7 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
                     "shares the chip with k_raycast (its duration is that of the contended run; alone it "
                     "takes ~0.23 ms, EMF_BG_OVERLAP=0)",
         }
-    if dom["kind"] == "raycast":
+    if dom["kind"] == "raycast" and stats is not None:
         roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)
     return roof, rows
 

@@ -7,7 +7,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 BENCH="python bench.py --steps 60 --warmup 30 --no-cpu-baseline"
-PMCBENCH="python bench.py --steps 20 --warmup 30 --no-cpu-baseline --no-kernel-events"
+PMCBENCH="python bench.py --steps 20 --warmup 30 --no-cpu-baseline --no-kernel-events --no-stats-replay"
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- $BENCH > $out/trace.log 2>&1; echo "trace rc=$?"
 # HBM-side read requests by size (4 TCC slots), then write requests: separate passes, no trace domains
 timeout 200 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace -d $out/pmc_rd -o p -- $PMCBENCH > $out/pmc_rd.log 2>&1; echo "pmc_rd rc=$?"

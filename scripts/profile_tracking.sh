@@ -5,7 +5,7 @@ tag=${1:-r02d}
 out=gpurun_out/prof_${tag}_track
 rm -rf $out; mkdir -p $out gpurun_out/summary
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps 60 --warmup 30 --no-cpu-baseline --track"
+CMD="python bench.py --steps 60 --warmup 30 --no-cpu-baseline --no-stats-replay --track"
 timeout 300 rocprofv3 --kernel-trace --stats -d $out -o t -- $CMD > $out/trace.log 2>&1; echo "trace rc=$?"
 python bench.py --steps 100 --warmup 30 --no-cpu-baseline --track 2>/dev/null | grep '"metric"' > $out/bench_untraced.json
 python - "$tag" "$out" "$CMD" <<'PY'

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/quick_trace
 rm -rf $out; mkdir -p $out
-timeout 200 rocprofv3 --kernel-trace --stats -d $out -o t -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline "$@" > $out/log.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $out -o t -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline --no-stats-replay "$@" > $out/log.txt 2>&1
 python - <<'PY'
 import glob, sqlite3
 f = glob.glob("gpurun_out/quick_trace/*.db") + glob.glob("gpurun_out/quick_trace/*/*.db")
