@@ -281,7 +281,12 @@ void EMFusion::rebuildModelTable() {
     listMask = 0;
     for (const auto& md : modelsHost) {
         const unsigned bit = 1u << (voxelHost.size() & 31);
-        if (md.signMaps && !md.relevantTiles) scanMask |= bit;
+        // A volume too small for a relevant-tile list (an object: < 8192 tiles) could have its sign maps scanned
+        // for far bounds; its rays are short anyway and the scan (23 us beside the E-steps, which it slows from
+        // 12 to 37 us) costs the frame more than the cut saves the raycast: 0.6095 vs 0.5956 ms.  EMF_FAR_SCAN=1
+        // scans them.
+        static const bool scanSmall = std::getenv("EMF_FAR_SCAN") && std::getenv("EMF_FAR_SCAN")[0] == '1';
+        if (md.signMaps && !md.relevantTiles && scanSmall) scanMask |= bit;
         if (md.signMaps && md.relevantTiles) listMask |= bit;
         voxelHost.push_back(md.voxelSize);
         resHost.insert(resHost.end(), md.res, md.res + 3);
