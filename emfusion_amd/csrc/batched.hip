@@ -9,6 +9,8 @@
 //                       zero-filled by the kernel itself (no memsets)
 //   k_integrate_batched all models' 32x8x8 voxel tiles in one grid, visibility gate read on device
 // All arithmetic comes from device_core.hpp, i.e. it is the same code the per-volume kernels run.
+#include <cstdlib>
+
 #include "march_wave.hpp"
 
 namespace emf_hip {
@@ -726,9 +728,11 @@ struct IntegrateCullArgs {
     IntegrateBatchArgs b;
     int boxStart[EMF_MAX_BATCH + 1];  // prefix sum of boxes per model (0 boxes for untiled models)
     unsigned* list;                    // entries: model << 24 | box index within the model
-    unsigned* count;                   // survivors appended so far (zeroed by the caller's memset)
+    unsigned* count;                   // survivors appended so far; count[1]: float bits of the frame's largest
+                                       // depth (both zeroed by the caller's memset, made by k_integrate_cull)
     IntegrateOutTable out;             // second copies (haveOut != 0), by value like the poses
     int haveOut;
+    int deepTiles;                     // let integrate_tile use count[1] (EMF_DEEP_TILES=0: not)
 };
 
 
@@ -753,6 +757,18 @@ __device__ __forceinline__ IntegrateGeom geom_of(const IntegrateBatchArgs& a, in
 
 __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    {   // the frame's largest depth, for the deep tiles of the listed launch (integrate_tile): non-negative
+        // floats order like their bits; NaN and values <= 0 never win
+        float mx = 0.f;
+        const int npix = a.b.w * a.b.h, stride = gridDim.x * 256;
+        for (int p = i; p < npix; p += stride) {
+            const float d = a.b.depth.row(p / a.b.w)[p % a.b.w];
+            mx = d > mx ? d : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(a.count + 1, __float_as_uint(mx));
+    }
     bool keep = false;
     unsigned entry = 0;
     if (i < a.boxStart[a.b.nmodels]) {
@@ -816,7 +832,8 @@ __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a
                                                       unsigned* lds) {
     const unsigned entry = a.list[e];
     const int m = static_cast<int>(entry >> 24), box = static_cast<int>(entry & 0xffffffu);
-    const IntegrateGeom g = geom_of(a.b, m);
+    IntegrateGeom g = geom_of(a.b, m);
+    g.maxDepthBits = a.deepTiles ? a.count + 1 : nullptr;  // written by k_integrate_cull, the launch before this one
     const emf_model_t& md = a.b.models[m];
     const int nbx = (g.n.x + kBoxX - 1) / kBoxX, nby = (g.n.y + kBoxY - 1) / kBoxY;
     const int bx = box % nbx, by = (box / nbx) % nby, bz = box / (nbx * nby);
@@ -1275,7 +1292,7 @@ int emf_hip_integratePrepareOut(const emf_volume_out_t* out_host, const int32_t*
     EMF_REQUIRE_PTR(res_host);
     EMF_REQUIRE_PTR(scratch_dev);
     if (nmodels < 1 || nmodels > EMF_MAX_BATCH) return fail(EMF_E_LIMIT, "integratePrepareOut: nmodels = %d", nmodels);
-    hipError_t e = hipMemsetAsync(scratch_dev, 0, sizeof(unsigned), as_stream(stream));
+    hipError_t e = hipMemsetAsync(scratch_dev, 0, 2 * sizeof(unsigned), as_stream(stream));
     for (int m = 0; e == hipSuccess && out_host && m < nmodels; ++m) {
         if (!out_host[m].dirtyNext) return fail(EMF_E_NULL, "integratePrepareOut: model %d has no dirtyNext map", m);
         EMF_TRY(check_res(res_host + 3 * m));
@@ -1331,8 +1348,10 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
     a.list = a.count + 4;
     a.out = IntegrateOutTable{};
     a.haveOut = out_host ? 1 : 0;
+    static const bool deepTiles = !(std::getenv("EMF_DEEP_TILES") && std::getenv("EMF_DEEP_TILES")[0] == '0');
+    a.deepTiles = deepTiles ? 1 : 0;
     const unsigned total = static_cast<unsigned>(a.boxStart[nmodels]);
-    const hipError_t e = prepared ? hipSuccess : hipMemsetAsync(a.count, 0, sizeof(unsigned), as_stream(stream));
+    const hipError_t e = prepared ? hipSuccess : hipMemsetAsync(a.count, 0, 2 * sizeof(unsigned), as_stream(stream));
     if (e != hipSuccess) {
         set_error("integrateBatchedCulled: memset: %s", hipGetErrorString(e));
         return static_cast<int>(e);

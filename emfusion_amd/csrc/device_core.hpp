@@ -85,6 +85,10 @@ struct IntegrateGeom {
     I3 n;
     float voxelSize, truncdist, maxWeight;
     bool pinhole;  // K = (fx 0 cx; 0 fy cy; 0 0 1): set by is_pinhole(K) on the host
+    // float bits of the largest depth of the frame (0 bits = no valid pixel), made by the launch that
+    // lists the boxes, or nullptr: lets a tile of unseen voxels that lies wholly behind everything the
+    // camera sees skip the signed distance (integrate_tile)
+    const unsigned* maxDepthBits = nullptr;
 };
 
 #ifndef EMF_INT_WPE
@@ -426,6 +430,25 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
     // Unseen tile (block-uniform; emf_model_t.unseenTiles): every weight is 0, so no voxel's new value
     // depends on what the tile holds -- nothing is loaded up front, the new values are stored.
     const bool fast = unseen && !bricks && *unseen != 0;
+    // Deep tile (block-uniform): an unseen tile every voxel of which lies behind the truncation band of
+    // the farthest surface of the frame.  A voxel with a valid pixel then has
+    //   sdf = d - |p_cam| / lambda(pix) <= dmax - z (1 - delta) < -truncdist,
+    // (|p_cam| = z lambda(exact pixel); rounding to the pixel centre moves lambda by at most
+    // 0.75 / min(fx, fy) =: delta; z >= the smallest z of the tile's corners, the camera z being linear
+    // in the voxel index), i.e. the reference sets it to -1 (TSDF.cu:398-400) -- or to 0 on a depth
+    // hole, or leaves it (pixel outside the image) -- without the distance ever mattering: no
+    // 1 / lambda fetch, no square root, no band test for eight in ten tiles of the sweep.
+    bool deep = false;
+    if (fast && a.maxDepthBits && a.pinhole) {
+        float zmin = __builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            zmin = fminf(zmin, voxel_in_camera(a, half, x0 + ((k & 1) ? kTileX - 1 : 0), y0 + ((k & 2) ? kTileY - 1 : 0),
+                                               z0 + ((k & 4) ? kTileZ - 1 : 0)).z);
+        const float dmax = __uint_as_float(*a.maxDepthBits);
+        const float delta = 0.75f / fminf(fabsf(a.K.r0.x), fabsf(a.K.r1.y));
+        deep = zmin * (1.f - delta) * (1.f - 1e-5f) - 1e-6f > dmax + a.truncdist * (1.f + 1e-5f);  // (false for NaN / inf)
+    }
     bool gotWeight = false;  // a voxel of this lane has been fused into
     int anyChanged = 0;
     bool sawPos = false, sawNeg = false;  // signs among the tsdf values this lane holds at the end
@@ -472,7 +495,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                 if (inMask & (1u << (4 * i + e))) {
                     const int px = pix[i][e] & 0xffffu, py = pix[i][e] >> 16;
                     d[i][e] = a.depth.row(py)[px];
-                    if (haveIl) il[i][e] = a.invLambda.row(py)[px];
+                    if (haveIl && !deep) il[i][e] = a.invLambda.row(py)[px];
                 }
             }
         float tv[2][4], wv[2][4];
@@ -503,11 +526,16 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                     s.inImage = (inMask >> (4 * i + e)) & 1u;
                     s.behind = (behindMask >> (4 * i + e)) & 1u;
                     s.n2 = n2[i][e];
-                    const float ile = haveIl ? il[i][e] : inv_lambda_at(a.K, s.px, s.py);
-                    float samp = 0.f;
-                    bool band;
-                    const int kind = classify_shot(a, s, d[i][e], ile, samp, band);
-                    const float aw = band ? a.assoc.row(s.py)[s.px] : 1.f;
+                    float samp = 0.f, aw = 1.f;
+                    int kind;
+                    if (deep) {  // classify_shot with "behind the band" known: TSDF.cu:351, 362, 367, 398
+                        kind = s.behind ? kZeroIfUnseen : (!s.inImage ? kSkip : (d[i][e] <= 0.f ? kZeroIfUnseen : kNegIfUnseen));
+                    } else {
+                        const float ile = haveIl ? il[i][e] : inv_lambda_at(a.K, s.px, s.py);
+                        bool band;
+                        kind = classify_shot(a, s, d[i][e], ile, samp, band);
+                        if (band) aw = a.assoc.row(s.py)[s.px];
+                    }
                     if (apply_unseen(kind, samp, aw, a.maxWeight, tv[i][e], wv[i][e])) keep |= 1u << e;
                 }
                 if (keep) {  // pixels outside the image, association weight 0: rare, and only then a load
