@@ -57,6 +57,8 @@ SIGNATURES = {
     "emf_hip_sumAssociation": [_IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_compositeRaycast": [C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG,
                                  _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, _STREAM],
+    "emf_hip_compositeVisibility": [C.c_int, _I3, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG,
+                                    _IMG, _IMG, _IMG, _IMG, _IMG, C.c_int, _FP, C.c_int, _FP, _FP, _STREAM],
     "emf_hip_occludedMask": [_IMG, _IMG, C.c_int, _IMG, _STREAM],
     "emf_hip_estepBatched": [_FP, _FP, C.c_int, _IMG, C.c_int, _IMG, _IMG, _STREAM],
     "emf_hip_estepBatchedFromDepth": [_FP, _FP, C.c_int, _IMG, _F9, _IMG, C.c_int, _IMG, _IMG, _STREAM],

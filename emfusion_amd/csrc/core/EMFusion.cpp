@@ -84,6 +84,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
     if (const char* tw = std::getenv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
     if (const char* fp = std::getenv("EMF_FUSE_POINTS")) fusePoints = fp[0] != '0';
+    if (const char* fv = std::getenv("EMF_FUSE_VISIBILITY")) fuseVisibility = fv[0] != '0';
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
@@ -1372,17 +1373,31 @@ void EMFusion::compositeAndVisibility(bool deviceGate) {
     const int nobj = static_cast<int>(ids.size());
     {
         auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nobj), main);
-        emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(),
-                                          onorm.data(), oseg.data(), &v_bgRay, &v_bgVert,
-                                          &v_bgNorm, &v_bgMask, &v_ray, &v_vert, &v_norm, &v_seg,
-                                          &v_diff, &v_noObj, params.boundary,
-                                          visCounts.as<int32_t>(), main.abi()),
-                 "compositeRaycast");
-        if (deviceGate)  // the counts also go to pinned host memory straight from the kernel
-            emfCheck(emf_hip_visibilityFlags(visCounts.as<int32_t>(), nobj + 1,
-                                             params.visibilityThresh, visibleDev.as<int32_t>(),
-                                             visibleHost, main.abi()),
-                     "visibilityFlags");
+        if (deviceGate && fuseVisibility) {
+            // the composite's own launch counts; the counts also go to pinned host memory straight from
+            // the flag kernel, which leaves visCounts cleared for the next frame
+            if (!visCountsClear) visCounts.setZero(main);  // (another path left its numbers there)
+            visCountsClear = true;
+            emfCheck(emf_hip_compositeVisibility(nobj, ids.data(), oray.data(), overt.data(), onorm.data(),
+                                                 oseg.data(), &v_bgRay, &v_bgVert, &v_bgNorm, &v_bgMask, &v_ray,
+                                                 &v_vert, &v_norm, &v_seg, &v_diff, &v_noObj, params.boundary,
+                                                 visCounts.as<int32_t>(), params.visibilityThresh,
+                                                 visibleDev.as<int32_t>(), visibleHost, main.abi()),
+                     "compositeVisibility");
+        } else {
+            visCountsClear = false;
+            emfCheck(emf_hip_compositeRaycast(nobj, ids.data(), oray.data(), overt.data(),
+                                              onorm.data(), oseg.data(), &v_bgRay, &v_bgVert,
+                                              &v_bgNorm, &v_bgMask, &v_ray, &v_vert, &v_norm, &v_seg,
+                                              &v_diff, &v_noObj, params.boundary,
+                                              visCounts.as<int32_t>(), main.abi()),
+                     "compositeRaycast");
+            if (deviceGate)  // the counts also go to pinned host memory straight from the kernel
+                emfCheck(emf_hip_visibilityFlags(visCounts.as<int32_t>(), nobj + 1,
+                                                 params.visibilityThresh, visibleDev.as<int32_t>(),
+                                                 visibleHost, main.abi()),
+                         "visibilityFlags");
+        }
     }
     stamp(kComposite);
     vis_objs.clear();
@@ -1431,6 +1446,7 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
                                      hitKeys.as<uint64_t>(), w, h, main.abi()),
                  "packHitKeys");
         comm->allReduceMinU64(hitKeys.as<uint64_t>(), params.frameSize.area(), main);
+        visCountsClear = false;
         emfCheck(emf_hip_compositeFromKeys(hitKeys.as<uint64_t>(), nall, allIds.data(), nlocal,
                                            listPos.data(), oray.data(), overt.data(),
                                            onorm.data(), &v_bgRay, &v_bgVert, &v_bgNorm,

@@ -278,6 +278,8 @@ private:
     void estepBatched();
     bool fusePoints = true;       // the frame's first E-step makes the points (EMF_FUSE_POINTS=0: own launch)
     bool pointsPending = false;   // ... and has not run yet
+    bool visCountsClear = true;   // visCounts holds zeros (cleared at construction, left so by the fused pair)
+    bool fuseVisibility = true;   // the composite's launch takes the visibility counts (EMF_FUSE_VISIBILITY=0: own launch)
     void raycastBatched();
     void integrateBatched();
     void compositeAndVisibility(bool deviceGate);

@@ -179,6 +179,11 @@ struct CompositeTable {
     int count;
 };
 
+// seg value -> object index (-1: no object has that id)
+struct SlotTable {
+    int16_t slot[256];
+};
+
 struct CompositeArgs {
     Img<const float> bgRay, bgVert, bgNorm;
     Img<const uint8_t> bgMask;
@@ -188,6 +193,11 @@ struct CompositeArgs {
     int first, last;  // chunk position
     int32_t* zero;    // first chunk: visCounts to clear for k_vis_counts, which runs after the last chunk
     int nzero;        // (<= 255: one workgroup's worth; saves the memset launch between the two)
+    // last chunk, fused form (emf_hip_compositeVisibility): the visibility counts of k_vis_counts are taken here,
+    // from the segmentation values this launch writes; `counts` must be zero when the launch starts
+    int32_t* counts;
+    int boundary;
+    SlotTable slots;
 };
 
 __global__ __launch_bounds__(256) void k_composite(const CompositeTable t, const CompositeArgs a) {
@@ -196,10 +206,12 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeTable t, const
         if (i < a.nzero) a.zero[i] = 0;
     }
     int x, y;
-    if (!pixel_of(a.w, a.h, x, y)) return;
+    const bool in = pixel_of(a.w, a.h, x, y);
+    if (!in && !a.counts) return;  // (the fused form has barriers below)
+    uint8_t s = 0;
+    if (in) {
     float r = 0.f;
     V3 vv = v3(0.f, 0.f, 0.f), nn = v3(0.f, 0.f, 0.f);
-    uint8_t s = 0;
     if (!a.first) {  // resume from the composite the previous chunk left
         r = a.ray.row(y)[x];
         const float* pv = a.vert.row(y) + 3 * x;
@@ -246,14 +258,36 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeTable t, const
     on[1] = nn.y;
     on[2] = nn.z;
     a.seg.row(y)[x] = s;
+    }
+    if (a.counts) {  // (uniform) k_vis_counts on the values just written
+        __shared__ int lh[256];
+        const int tid = threadIdx.y * kTileX + threadIdx.x;
+        lh[tid] = 0;
+        __syncthreads();
+        if (in && s && x >= a.boundary && x < a.w - a.boundary && y >= a.boundary && y < a.h - a.boundary)
+            atomicAdd(&lh[s], 1);
+        __syncthreads();
+        const int k = a.slots.slot[tid];
+        if (k >= 0 && lh[tid]) atomicAdd(&a.counts[k], lh[tid]);
+    }
+}
+
+// the gate of emf_hip_visibilityFlags, leaving the counts cleared for the next composite
+__global__ void k_vis_flags_clear(int32_t* __restrict__ counts, int nmodels, int thresh,
+                                  int32_t* __restrict__ visible, int32_t* __restrict__ mirror) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nmodels) return;
+    const int32_t c = s == 0 ? 0 : counts[s - 1];
+    visible[s] = s == 0 ? 1 : (c > thresh ? 1 : 0);
+    if (s > 0) {
+        if (mirror) mirror[s - 1] = c;  // host-visible copy: no copy kernel, no copy engine
+        counts[s - 1] = 0;
+    }
 }
 
 // visibility: per-object pixel counts inside the inset rectangle (EMFusion.cpp:778-791).
 // Each workgroup builds a 256-bin LDS histogram of the segmentation, then adds the non-empty bins
 // to the owning object's counter (slot = seg value -> object index, -1 if no object has that id).
-struct SlotTable {
-    int16_t slot[256];
-};
 
 __global__ __launch_bounds__(256) void k_vis_counts(Img<const uint8_t> seg, int w, int h,
                                                     int boundary, const SlotTable slots,
@@ -585,15 +619,16 @@ int emf_hip_sumAssociation(const emf_image_t* maps_host, int nmaps, const emf_im
     return launch_status("sumAssociation");
 }
 
-int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
-                             const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
-                             const emf_image_t* objSeg_host, const emf_image_t* bgRay,
-                             const emf_image_t* bgVert, const emf_image_t* bgNorm,
-                             const emf_image_t* bgMask, const emf_image_t* ray,
-                             const emf_image_t* vert, const emf_image_t* norm,
-                             const emf_image_t* seg, const emf_image_t* diff,
-                             const emf_image_t* noObj, int boundary, int32_t* visCounts,
-                             emf_stream_t stream) {
+namespace {
+int composite_impl(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                   const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                   const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                   const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                   const emf_image_t* bgMask, const emf_image_t* ray,
+                   const emf_image_t* vert, const emf_image_t* norm,
+                   const emf_image_t* seg, const emf_image_t* diff,
+                   const emf_image_t* noObj, int boundary, int32_t* visCounts, bool fused,
+                   emf_stream_t stream) {
     if (nobj < 0 || nobj > EMF_MAX_MODELS - 1)
         return fail(EMF_E_LIMIT, "compositeRaycast: nobj = %d, expected 0..%d", nobj,
                     EMF_MAX_MODELS - 1);
@@ -633,6 +668,12 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
     a.noObj = img<uint8_t>(noObj);
     a.w = w;
     a.h = h;
+    a.counts = nullptr;
+    a.boundary = boundary;
+    for (int v = 0; v < 256; ++v) a.slots.slot[v] = -1;
+    for (int k = 0; k < nobj; ++k)  // compare(seg, id): ids outside 1..255 never match
+        if (ids_host[k] >= 1 && ids_host[k] <= 255 && a.slots.slot[ids_host[k]] < 0)
+            a.slots.slot[ids_host[k]] = static_cast<int16_t>(k);
     const dim3 g = pixel_grid(w, h), b = pixel_block();
     int k0 = 0;
     do {
@@ -658,23 +699,51 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
         }
         a.first = k0 == 0;
         a.last = k0 + cnt >= nobj;
-        a.zero = a.first ? visCounts : nullptr;
+        a.zero = a.first && !fused ? visCounts : nullptr;
         a.nzero = nobj;
+        a.counts = fused && a.last && nobj > 0 ? visCounts : nullptr;
         hipLaunchKernelGGL(k_composite, g, b, 0, as_stream(stream), t, a);
         k0 += cnt;
     } while (k0 < nobj);
     EMF_TRY(launch_status("compositeRaycast"));
-    if (nobj > 0) {
-        SlotTable slots;
-        for (int v = 0; v < 256; ++v) slots.slot[v] = -1;
-        for (int k = 0; k < nobj; ++k)  // compare(seg, id): ids outside 1..255 never match
-            if (ids_host[k] >= 1 && ids_host[k] <= 255 && slots.slot[ids_host[k]] < 0)
-                slots.slot[ids_host[k]] = static_cast<int16_t>(k);
+    if (nobj > 0 && !fused) {
         hipLaunchKernelGGL(k_vis_counts, g, b, 0, as_stream(stream), img<const uint8_t>(seg), w, h,
-                           boundary, slots, visCounts);
+                           boundary, a.slots, visCounts);
         return launch_status("compositeRaycast: visibility");
     }
     return EMF_OK;
+}
+}  // namespace
+
+int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                             const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                             const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                             const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                             const emf_image_t* bgMask, const emf_image_t* ray,
+                             const emf_image_t* vert, const emf_image_t* norm,
+                             const emf_image_t* seg, const emf_image_t* diff,
+                             const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                             emf_stream_t stream) {
+    return composite_impl(nobj, ids_host, objRay_host, objVert_host, objNorm_host, objSeg_host, bgRay, bgVert,
+                          bgNorm, bgMask, ray, vert, norm, seg, diff, noObj, boundary, visCounts, false, stream);
+}
+
+int emf_hip_compositeVisibility(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                                const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                                const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                                const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                                const emf_image_t* bgMask, const emf_image_t* ray,
+                                const emf_image_t* vert, const emf_image_t* norm,
+                                const emf_image_t* seg, const emf_image_t* diff,
+                                const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                                int visibilityThresh, int32_t* visible_dev, int32_t* countsMirror,
+                                emf_stream_t stream) {
+    EMF_REQUIRE_PTR(visible_dev);
+    EMF_TRY(composite_impl(nobj, ids_host, objRay_host, objVert_host, objNorm_host, objSeg_host, bgRay, bgVert,
+                           bgNorm, bgMask, ray, vert, norm, seg, diff, noObj, boundary, visCounts, true, stream));
+    hipLaunchKernelGGL(k_vis_flags_clear, dim3(ceil_div(nobj + 1, 64)), dim3(64), 0, as_stream(stream), visCounts,
+                       nobj + 1, visibilityThresh, visible_dev, countsMirror);
+    return launch_status("compositeVisibility");
 }
 
 int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int id,

@@ -198,6 +198,25 @@ def sum_association(maps, out, stream=None):
     return out
 
 
+def composite_visibility(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert, bg_norm, bg_mask,
+                         ray, vert, norm, seg, diff, no_obj, boundary, vis_counts, thresh, visible, mirror=None,
+                         stream=None):
+    """emf_hip_compositeVisibility: vis_counts must hold zeros and holds zeros again afterwards; the numbers go
+    to `mirror` (int32 device array of len(ids)) and into `visible` (int32, len(ids) + 1)."""
+    n = len(ids)
+    ids_arr = (C.c_int32 * max(n, 1))(*[int(i) for i in ids])
+    check("emf_hip_compositeVisibility",
+          _L.emf_hip_compositeVisibility(n, ids_arr, _views(obj_ray), _views(obj_vert),
+                                         _views(obj_norm), _views(obj_seg),
+                                         C.byref(image_view(bg_ray)), C.byref(image_view(bg_vert)),
+                                         C.byref(image_view(bg_norm)), C.byref(image_view(bg_mask)),
+                                         C.byref(image_view(ray)), C.byref(image_view(vert)),
+                                         C.byref(image_view(norm)), C.byref(image_view(seg)),
+                                         C.byref(image_view(diff)), C.byref(image_view(no_obj)),
+                                         boundary, _ptr(vis_counts), int(thresh), _ptr(visible),
+                                         _ptr(mirror) if mirror is not None else None, _stream(stream)))
+
+
 def composite_raycast(ids, obj_ray, obj_vert, obj_norm, obj_seg, bg_ray, bg_vert, bg_norm, bg_mask,
                       ray, vert, norm, seg, diff, no_obj, boundary, vis_counts, stream=None):
     n = len(ids)

@@ -222,6 +222,21 @@ int emf_hip_compositeRaycast(int nobj, const int32_t* ids_host, const emf_image_
                              const emf_image_t* noObj, int boundary, int32_t* visCounts,
                              emf_stream_t stream);
 
+/* emf_hip_compositeRaycast + emf_hip_visibilityFlags in two launches instead of three: the launch that
+ * writes the composite also counts (its last chunk, on the segmentation values it writes), the flag launch
+ * clears the counts behind itself.  visCounts is scratch of the pair here: ZERO on entry, zero on return
+ * (the numbers go to countsMirror, if given, and into the flags). */
+int emf_hip_compositeVisibility(int nobj, const int32_t* ids_host, const emf_image_t* objRay_host,
+                                const emf_image_t* objVert_host, const emf_image_t* objNorm_host,
+                                const emf_image_t* objSeg_host, const emf_image_t* bgRay,
+                                const emf_image_t* bgVert, const emf_image_t* bgNorm,
+                                const emf_image_t* bgMask, const emf_image_t* ray,
+                                const emf_image_t* vert, const emf_image_t* norm,
+                                const emf_image_t* seg, const emf_image_t* diff,
+                                const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                                int visibilityThresh, int32_t* visible_dev, int32_t* countsMirror,
+                                emf_stream_t stream);
+
 /* Replaces the occlusion mask of EMFusion::integrateMasks (EMFusion.cpp:897-900):
  * occluded = saturate_u8(objSeg - (seg == id ? 255 : 0)).  All u8 W x H. */
 int emf_hip_occludedMask(const emf_image_t* objSeg, const emf_image_t* seg, int id,

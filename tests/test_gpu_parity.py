@@ -461,6 +461,26 @@ def test_composite_and_visibility(oracle, ops, dev, nobj):
     if nobj:
         assert to_np(vis)[:nobj].tolist() == want[5].tolist()
         assert want[5].sum() > 0
+    # the fused pair (the composite's launch counts, the flag launch clears): same images, same numbers
+    ray2, vert2, nrm2 = dev_full((H, W), 5.0), dev_full((H, W, 3), 5.0), dev_full((H, W, 3), 5.0)
+    seg2, no_obj2, d_diff2 = dev_full((H, W), 5, np.uint8), dev_full((H, W), 5, np.uint8), d(diff0)
+    vis2 = dev_full((max(nobj, 1),), 0, np.int32)
+    mirror = dev_full((max(nobj, 1),), -7, np.int32)
+    visible = dev_full((nobj + 1,), -7, np.int32)
+    thresh = int(np.median(want[5])) if nobj else 0
+    for _ in range(2):  # twice: the counts are cleared behind the first call
+        ops.composite_visibility(ids, [d(a) for a in obj_ray], [d(a) for a in obj_vert], [d(a) for a in obj_norm],
+                                 [d(a) for a in obj_seg], d(bg_ray), d(bg_vert), d(bg_norm), d(bg_mask), ray2, vert2,
+                                 nrm2, seg2, d_diff2, no_obj2, 10, vis2, thresh, visible, mirror)
+        dev.synchronize()
+        for g, w_, name in zip([ray2, vert2, nrm2, seg2, no_obj2], want[:5], names):
+            assert_parity(to_np(g), w_, name + " (fused)", exact=True)
+        assert to_np(visible)[0] == 1
+        if nobj:
+            assert to_np(mirror)[:nobj].tolist() == want[5].tolist()
+            assert to_np(visible)[1:].tolist() == [int(c > thresh) for c in want[5]]
+            assert not to_np(vis2)[:nobj].any()
+        d_diff2 = d(diff0)
 
 
 def test_occluded_mask(oracle, ops, dev):
