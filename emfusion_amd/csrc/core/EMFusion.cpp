@@ -85,6 +85,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     if (const char* tw = std::getenv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
     if (const char* fp = std::getenv("EMF_FUSE_POINTS")) fusePoints = fp[0] != '0';
     if (const char* fv = std::getenv("EMF_FUSE_VISIBILITY")) fuseVisibility = fv[0] != '0';
+    if (const char* ef = std::getenv("EMF_EARLY_FAR_BOUNDS")) earlyFarBounds = ef[0] != '0';
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
@@ -147,6 +148,7 @@ EMFusion::~EMFusion() {
     if (visibleHost) (void)hipHostFree(visibleHost);
     if (trackStatesHost) (void)hipHostFree(trackStatesHost);
     if (trackWatch) (void)hipHostFree(trackWatch);
+    if (rayDone) (void)hipEventDestroy(rayDone);
     if (lifecycleHost) (void)hipHostFree(lifecycleHost);
 }
 
@@ -955,6 +957,7 @@ void EMFusion::trackModels(int first, int count) {
              hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0) != hipSuccess)) {
             (void)hipGetLastError();  // no device-visible host memory here: poll in chunks instead
             if (trackWatch) (void)hipHostFree(trackWatch);
+    if (rayDone) (void)hipEventDestroy(rayDone);
             trackWatch = trackWatchDev = nullptr;
             trackWindow = 0;
         }
@@ -1206,6 +1209,11 @@ void EMFusion::raycastBatched() {
                                         flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
                                         band, far, useFootprints ? voxelHost.data() : nullptr, stats, main.abi()),
                  "raycastBatched");
+        if (far) {  // what the next frame's far bounds wait for before they overwrite the buffer
+            if (!rayDone) hipCheck(hipEventCreateWithFlags(&rayDone, hipEventDisableTiming), "hipEventCreate");
+            hipCheck(hipEventRecord(rayDone, main.get()), "hipEventRecord");
+            rayDoneValid = true;
+        }
         if (band) {
             comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), band, h, main);
             comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), band, h, main);
@@ -1222,7 +1230,14 @@ void EMFusion::raycastBatched() {
 void EMFusion::computeFarBounds(const std::vector<emf_pose_t>& co) {
     farBoundsReady = false;
     if (!batched || farBounds.empty() || TSDF::brickFlagMode() != 0) return;
-    lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
+    // Listed models only (no sign-map scan: nothing of this frame's object integration is read), the
+    // background's list rebuilt on `lists` itself: the bounds need nothing of `main` but the previous raycast
+    // to be through with the buffer -- they run beside the composite and the objects' integration instead of
+    // beside the E-steps.
+    if (earlyFarBounds && scanMask == 0 && rayDoneValid && overlapUsable() && !bgBackStale)
+        hipCheck(hipStreamWaitEvent(lists.get(), rayDone, 0), "hipStreamWaitEvent");
+    else
+        lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
     emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
                                       params.frameSize.width, params.frameSize.height, params.intr.val, scanMask,
                                       farBounds.as<float>(), lists.abi()),
