@@ -768,3 +768,55 @@ def test_argument_checks_of_the_newer_entry_points(ops, dev):
     assert e.value.code == -2
     v, n, t = ops.extract_mesh(vol, vol, 0.01)  # smallest useful volume: nothing observed, empty mesh
     assert len(v) == 0 and len(t) == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_unseen_and_deep_tiles_under_random_cameras(ops, oracle, dev, seed):
+    """Random intrinsics (short and unequal focal lengths: the margin of the deep-tile test depends on
+    them), random camera poses around and inside the volume, depth maps that are near, far, full of holes
+    or empty: the two-level launch with the unseen-tile map (and its deep-tile shortcut) leaves the bytes
+    of the one-level launch without any map, frame after frame."""
+    rng = np.random.default_rng(1000 + seed)
+    res, vox = (96, 64, 56), 0.03
+    w, h = 96, 72
+    fx, fy = rng.uniform(40, 160), rng.uniform(40, 160)
+    Kr = np.array([fx, 0, w / 2 - 0.5 + rng.uniform(-5, 5), 0, fy, h / 2 - 0.5 + rng.uniform(-5, 5), 0, 0, 1], np.float32)
+
+    def vol():
+        m = Model(ops, oracle, res, vox, Pose(t=[0, 0, 1.5]), False, 0)
+        m.d_probs = m.d_vmask = dev_full((1,), 0, np.uint8)
+        m.d_assoc = dev_full((h, w), 1.0)
+        return m
+    plain, fast = vol(), vol()
+    fast.d_unseen = dev_full((ops.unseen_tile_bytes(res),), 1, np.uint8)
+    visible = dev_full((1,), 1, np.int32)
+    for i in range(7):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            depth = rng.uniform(0.3, 1.2, (h, w)).astype(np.float32)
+        elif kind == 1:
+            depth = rng.uniform(1.0, 4.0, (h, w)).astype(np.float32)
+        elif kind == 2:
+            depth = np.full((h, w), rng.uniform(0.4, 2.0), np.float32)
+        elif kind == 3:
+            depth = (rng.uniform(0.5, 2.5, (h, w)) * (rng.uniform(size=(h, w)) < 0.5)).astype(np.float32)
+        else:
+            depth = np.zeros((h, w), np.float32)
+        if kind != 4:
+            depth[rng.uniform(size=(h, w)) < 0.03] = 0.0
+        ang = rng.uniform(-40, 40, 3)
+        cam = Pose(rot([1, 0, 0], ang[0]) @ rot([0, 1, 0], ang[1]) @ rot([0, 0, 1], ang[2]),
+                   rng.uniform(-0.6, 0.6, 3) + np.array([0, 0, rng.uniform(-0.5, 1.2)]))
+        assoc = rng.uniform(0.0, 1.0, (h, w)).astype(np.float32)
+        assoc[rng.uniform(size=(h, w)) < 0.1] = 0.0
+        for m in (plain, fast):
+            m.d_assoc.copy_from(assoc)
+        oc = rel_OC(cam, plain.pose)
+        d_depth = to_dev(depth)
+        ops.integrate_batched(ops.upload_models([plain.table_entry()]), [(oc.R32, oc.t32)], [res], visible, d_depth, Kr)
+        ops.integrate_batched_culled(ops.upload_models([fast.table_entry()]), [(oc.R32, oc.t32)], [res], visible,
+                                     d_depth, Kr)
+        dev.synchronize()
+        assert_parity(to_np(fast.d_tsdf), to_np(plain.d_tsdf), f"seed {seed} frame {i} (depth kind {kind}) tsdf", exact=True)
+        assert_parity(to_np(fast.d_wts), to_np(plain.d_wts), f"seed {seed} frame {i} weights", exact=True)
+        assert np.array_equal(to_np(fast.d_unseen) != 0, tile_all(to_np(plain.d_wts), lambda x: x == 0) != 0)
