@@ -282,3 +282,71 @@ def test_hip_reproduces_next_row_vectors(dev, kv, nv, tag):
         out = dev_full(nv["prep_in"].shape, -1.0)
         ops.preprocess_depth(to_dev(nv["prep_in"]), out, 7, 0.04, 4.5)
         assert np.allclose(out.numpy(), nv["prep_out"], rtol=1e-5, atol=1e-6)
+
+
+# ---- tracker (f-1): tests/golden/tracking_v1.npz (make_golden_tracking.py) ---------------------------------
+
+@pytest.fixture(scope="module")
+def tv():
+    return np.load(GOLD / "tracking_v1.npz")
+
+
+TRACK_ITER = (1, 3, 40)
+
+
+@pytest.mark.parametrize("k", [0, 1], ids=["background", "object"])
+def test_oracle_reproduces_tracking_vectors(oracle, tv, k):
+    from tests.oracle_tracking import OracleTracker
+    for n_it in TRACK_ITER:
+        tr = OracleTracker(oracle, tv[f"m{k}_tsdf"], tv[f"m{k}_wts"], float(tv[f"m{k}_vox"]))
+        tr.prepare(tv[f"m{k}_R0"], tv[f"m{k}_t0"])
+        for _ in range(n_it):
+            tr.iterate(tv["points"], tv[f"m{k}_assoc"])
+        p = f"m{k}_it{n_it}_"
+        assert [tr.iterations, tr.accepted, int(tr.converged)] == tv[p + "counts"].tolist(), n_it
+        # the oracle's sums run over OpenMP threads in double: reproducible to rounding, not to the bit
+        assert np.allclose(tr.R, tv[p + "R"], atol=2e-6) and np.allclose(tr.t, tv[p + "t"], atol=2e-6), n_it
+        assert abs(float(tr.mu) - float(tv[p + "mu"])) <= 1e-4 * float(tv[p + "mu"])
+        h = tr.history[-1]
+        assert np.abs(h["A"] - tv[p + "A"]).max() <= 1e-5 * np.abs(tv[p + "A"]).max()
+        assert abs(h["err"] - tv[p + "err"][0]) <= 1e-5 * tv[p + "err"][0]
+    assert tv[f"m{k}_it40_counts"][1] >= 5  # the vectors hold accepted and rejected steps
+    assert tv[f"m{k}_it40_counts"][0] > tv[f"m{k}_it40_counts"][1]
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_tracking_vectors(dev, tv):
+    """Both models in lock-step through emf_hip_trackIterate against the committed LM histories."""
+    import ctypes as C
+    from emfusion_amd import _lib, ops
+    from tests.parity_util import dev_full, to_dev
+    H, W = tv["points"].shape[:2]
+    keep, entries = [], []
+    for k in (0, 1):
+        vox = float(tv[f"m{k}_vox"])
+        d = dict(tsdf=to_dev(tv[f"m{k}_tsdf"]), wts=to_dev(tv[f"m{k}_wts"]), assoc=to_dev(tv[f"m{k}_assoc"]),
+                 ray=dev_full((H, W), 0.0), vert=dev_full((H, W, 3), 0.0), nrm=dev_full((H, W, 3), 0.0),
+                 hit=dev_full((H, W), 0, np.uint8))
+        keep.append(d)
+        entries.append(ops.make_model(d["tsdf"], d["wts"], d["assoc"], d["ray"], d["vert"], d["nrm"], d["hit"], vox,
+                                      float(np.float32(10 * vox)), 64.0, 0.02, 0.8, 1.0, model_id=k))
+    table = ops.upload_models(entries)
+    points = to_dev(tv["points"])
+    per = ops.track_scratch_bytes(W, H)
+    for n_it in TRACK_ITER:
+        states = dev_full((2 * C.sizeof(_lib.EmfTrackState),), 0, np.uint8)
+        scratch = dev_full((2 * per,), 0, np.uint8)
+        ops.track_prepare(states, [(tv[f"m{k}_R0"], tv[f"m{k}_t0"]) for k in (0, 1)])
+        ops.track_iterate(table, states, 2, points, _lib.EmfTrackParams.defaults(), scratch, per, n_it)
+        for k, st in enumerate(ops.read_track_states(states, 2)):
+            p = f"m{k}_it{n_it}_"
+            if n_it <= 3:
+                assert [st.iterations, st.accepted, int(st.converged)] == tv[p + "counts"].tolist(), (k, n_it)
+            else:  # where the step-size test fires is a matter of the last bits: a few steps earlier or later
+                assert int(st.converged) == tv[p + "counts"][2] and abs(st.iterations - tv[p + "counts"][0]) <= 6, (k, n_it)
+            tol = 1e-4 if n_it > 3 else 2e-6  # the north-star tolerance once rounding has had 40 steps to grow
+            assert np.abs(np.array(st.R, np.float32).reshape(3, 3) - tv[p + "R"]).max() < tol, (k, n_it)
+            assert np.abs(np.array(st.t, np.float32) - tv[p + "t"]).max() < tol, (k, n_it)
+            if n_it <= 3:
+                A = np.array(st.A, np.float32).reshape(6, 6)
+                assert np.abs(A - tv[p + "A"]).max() <= 2e-5 * np.abs(tv[p + "A"]).max(), (k, n_it)
