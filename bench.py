@@ -16,6 +16,10 @@ configs[3]: every rank holds a replica of the background and `--objects-per-gpu`
 of its own; ranks exchange one RCCL all-reduce per E-step (normaliser) and one per raycast
 (nearest-hit merge).  Weak scaling: per-GPU work is fixed, the scene grows with N.
 
+The timed region holds the product path plus one HIP-event pair per long kernel (raycast, background
+integration, tracking stage) and nothing else: the march-sample counters the byte model of `roofline` needs are
+collected afterwards, in an untimed replay of the same frames from a cleared state (--no-stats-replay skips it).
+
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
 torch is used for torch.distributed only (gloo rendezvous, barriers, max-reduce of the time); all
 device memory and streams belong to the product's own HIP runtime (emfusion_amd/devmem.py).
