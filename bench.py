@@ -495,13 +495,17 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
 
 
 def cpu_baseline(args, prm, K, synth, ids):
-    """The oracle (our CPU restatement, kind "port") on the host cores of this box, on a bounded
-    sample of the SAME workload: frame 0 untimed (first integration), then whole frames of the
-    schedule until about --cpu-seconds of CPU time are spent."""
+    """The oracle (our CPU restatement, kind "port") on the host cores of this box, as SURVEY 8(d) defines
+    the CPU baseline: built -O3 -march=native ON this host (same unfused arithmetic, same bits), OpenMP over
+    the threads this process may really use (affinity mask capped by the cgroup's CPU quota), on a bounded
+    sample of the SAME workload -- frame 0 untimed (first integration), frame 1 on ONE thread, then whole
+    frames of the schedule on all threads until about --cpu-seconds are spent.  `value` is the all-thread
+    figure; the 1-thread figure stands beside it."""
     from oracle import binding as oracle
     from tests.oracle_pipeline import Affine32, OraclePipeline
 
-    cores = oracle.set_threads(0)  # all host cores
+    native = oracle.use_native(True)
+    cores = oracle.host_threads()
     W, H = args.width, args.height
     orc = OraclePipeline(oracle, W, H, K, args.bg_res, args.bg_voxel, list(prm.volume_pose_t),
                          args.obj_res, visibility_thresh=prm.visibility_thresh,
@@ -519,18 +523,34 @@ def cpu_baseline(args, prm, K, synth, ids):
         orc.process_frame(depth, Affine32(R.reshape(3, 3), t), poses, masks, bool(masks))
         return time.perf_counter() - t0
 
+    oracle.set_threads(cores)
     run(0)
+    oracle.set_threads(1)
+    one = run(1)  # one whole frame of the schedule on one thread
+    oracle.set_threads(cores)
     spent, n = 0.0, 0
     while spent < args.cpu_seconds and n < 20:
-        spent += run(1 + n)
+        spent += run(2 + n)
         n += 1
+    oracle.use_native(False)
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {
         "value": round(n / spent, 4),
         "unit": "frames/s",
         "cores": cores,
         "kind": "port",
-        "sample": (f"frames 1..{n} of the same synthetic stream (frame 0 untimed), full schedule, "
-                   f"bg {args.bg_res}^3 + {len(ids)} obj {args.obj_res}^3, {W}x{H}; OpenMP over "
+        "one_thread": {"value": round(1.0 / one, 4), "unit": "frames/s", "cores": 1,
+                       "sample": f"frame 1 of the same stream, {one:.1f} s"},
+        "speedup_over_one_thread": round((n / spent) * one, 1),
+        "build": ("gcc -O3 -march=native -ffp-contract=off -fopenmp, built on this host" if native else
+                  "gcc -O2 -ffp-contract=off -fopenmp (portable build: the native build failed on this host)"),
+        "host": f"{cpu_model}; {os.cpu_count()} logical CPUs, {cores} usable (affinity mask and cgroup quota)",
+        "sample": (f"frames 2..{1 + n} of the same synthetic stream (frame 0 untimed, frame 1 on one thread), "
+                   f"full schedule, bg {args.bg_res}^3 + {len(ids)} obj {args.obj_res}^3, {W}x{H}; OpenMP over "
                    f"{cores} host threads, {spent:.1f} s"),
     }
 

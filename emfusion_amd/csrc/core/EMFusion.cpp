@@ -957,7 +957,6 @@ void EMFusion::trackModels(int first, int count) {
              hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0) != hipSuccess)) {
             (void)hipGetLastError();  // no device-visible host memory here: poll in chunks instead
             if (trackWatch) (void)hipHostFree(trackWatch);
-    if (rayDone) (void)hipEventDestroy(rayDone);
             trackWatch = trackWatchDev = nullptr;
             trackWindow = 0;
         }

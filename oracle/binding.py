@@ -23,20 +23,64 @@ _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
-def build() -> None:
-    subprocess.run(["make", "-s", "-C", str(HERE)], check=True)
+def build(target: str = "all") -> None:
+    subprocess.run(["make", "-s", "-C", str(HERE), target], check=True)
 
 
-def lib(fma: bool = False) -> C.CDLL:
+_default = False  # what lib(False) means: the portable -O2 build, or (use_native) the -O3 -march=native one
+
+
+def use_native(on: bool = True) -> bool:
+    """bench.py's cpu_baseline leg: build libemf_oracle_native.so (-O3 -march=native, still
+    -ffp-contract=off: same bits) ON THIS HOST and make it what every binding call uses.  Returns
+    whether the native build is in use (False: the compiler refused, the portable build stays)."""
+    global _default
+    _default = False
+    if on:
+        try:
+            subprocess.run(["make", "-s", "-B", "-C", str(HERE), "native"], check=True)  # always for THIS host
+            C.CDLL(str(HERE / "libemf_oracle_native.so"))
+            _default = "native"
+        except (subprocess.CalledProcessError, OSError):
+            _default = False
+    return _default == "native"
+
+
+def lib(fma=False) -> C.CDLL:
     """The oracle library; ``fma=True`` loads the build with a*b+c contraction enabled."""
-    name = "libemf_oracle_fma.so" if fma else "libemf_oracle.so"
+    variant = fma or _default
+    name = {False: "libemf_oracle.so", True: "libemf_oracle_fma.so",
+            "native": "libemf_oracle_native.so"}[variant]
     if name not in _libs:
         path = HERE / name
         if not path.exists():
+            if variant == "native":
+                raise RuntimeError("call use_native() first: the native oracle is built per host")
             build()
         _libs[name] = C.CDLL(str(path))
         _libs[name].orc_set_threads.restype = C.c_int
     return _libs[name]
+
+
+def host_threads() -> int:
+    """Threads this process may really use: its CPU affinity mask, capped by the cgroup's CPU quota
+    (cpu.max of cgroup v2, cfs quota of v1) -- omp_get_num_procs() sees only the former."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def _c(a, dtype=np.float32):

@@ -11,7 +11,7 @@ from collections import OrderedDict, defaultdict
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_integrate_listed_rest", "integrate_rest"),
+SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_stream_copy", "stream_copy"), ("k_integrate_listed_rest", "integrate_rest"),
                      ("k_integrate_listed<true>", "integrate_bg"), ("k_integrate_listed<(bool)1>", "integrate_bg"),
                      ("k_integrate_listed", "integrate"), ("k_integrate_cull", "integrate_cull"),
                      ("k_far_bounds_listed", "far_bounds_listed"), ("k_far_bounds", "far_bounds_scan"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
@@ -36,10 +36,11 @@ def db(path):
 
 
 out_md = [f"# rocprofv3 summary, round tag `{tag}`", "",
-          "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 60 --warmup 30 "
-          "--no-cpu-baseline` on one MI355X (gfx950), BASELINE.json configs[1] "
-          "(bg 512^3 + 4 obj 128^3, 640x480).  All 90 frames (30 warm-up + 60 timed) are in the "
-          "trace; frame 0 has no raycast/E-step.", ""]
+          "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %s --warmup %s "
+          "--no-cpu-baseline` (the driver's protocol) on one MI355X (gfx950), BASELINE.json configs[1] "
+          "(bg 512^3 + 4 obj 128^3, 640x480).  Warm-up and timed frames are in the "
+          "trace; frame 0 has no raycast/E-step." % (__import__("os").environ.get("EMF_PROFILE_STEPS", "20"),
+                                                     __import__("os").environ.get("EMF_PROFILE_WARMUP", "5")), ""]
 con = db("trace")
 stats = {}
 if con:
@@ -47,20 +48,29 @@ if con:
     # more with the march counters on.  The table is over the measured run only.
     cut = con.execute("select min(start) from kernels where name like '%k_stream_copy%'").fetchone()[0]
     where = f"where start < {cut}" if cut else ""
+    import os
+    STEPS_, WARMUP_ = int(os.environ.get("EMF_PROFILE_STEPS", "20")), int(os.environ.get("EMF_PROFILE_WARMUP", "5"))
     rows = con.execute(f"select name, count(*), avg(end-start), min(end-start), max(end-start), "
                        f"sum(end-start) from kernels {where} group by name order by 6 desc").fetchall()
     if cut:
         out_md += ["(launches before the copy-bandwidth probe: the warm-up and the timed frames; the replay with the "
-                   "march counters that follows it is left out)", ""]
+                   "march counters that follows it is left out.  `timed avg` = the launches of the timed frames only, "
+                   "what bench.py's HIP events average over)", ""]
     total = sum(r[5] for r in rows)
     out_md += ["## Kernel trace (all launches of the run)", "",
-               "| kernel | launches | avg us | min us | max us | total ms | share |",
-               "|---|---:|---:|---:|---:|---:|---:|"]
+               "| kernel | launches | avg us | min us | max us | total ms | share | timed launches | timed avg us |",
+               "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    frames = STEPS_ + WARMUP_
     for name, n, avg, mn, mx, tot in rows:
+        durs = [r[0] for r in con.execute(f"select end-start from kernels {where + ' and' if where else 'where'} name = ? "
+                                          "order by start", (name,)).fetchall()]
+        per_frame = 1 if n in (frames, frames - 1) else (round(n / (frames - 1)) if n >= frames - 1 and n % (frames - 1) == 0 else 0)
+        timed = durs[-STEPS_ * per_frame:] if per_frame else durs
+        tavg = sum(timed) / max(len(timed), 1)
         out_md.append(f"| `{short(name)}` | {n} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | "
-                      f"{tot / 1e6:.2f} | {100 * tot / total:.1f}% |")
+                      f"{tot / 1e6:.2f} | {100 * tot / total:.1f}% | {len(timed)} | {tavg / 1e3:.1f} |")
         stats[short(name)] = dict(kernel=name.split("(")[0], launches=n, avg_us=avg / 1e3,
-                                  total_ms=tot / 1e6)
+                                  total_ms=tot / 1e6, timed_launches=len(timed), timed_avg_us=tavg / 1e3)
     out_md.append("")
 
 traffic = defaultdict(dict)
@@ -101,6 +111,46 @@ if traffic:
                      hbm_bytes_per_launch=rd + wr, l2_hit_rate=hr, launches=nd)
     json.dump(dict(tag=tag, source="rocprofv3 --pmc TCC_EA0_* (scripts/profile_round.sh)",
                    kernels=tj, trace=stats), open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
+    out_md.append("")
+# ---- issue / L1 / L2 counters of the timed launches (what bench.py's roofline prices the kernels against) ----
+import os
+STEPS, WARMUP = int(os.environ.get("EMF_PROFILE_STEPS", "20")), int(os.environ.get("EMF_PROFILE_WARMUP", "5"))
+counters = defaultdict(dict)
+for pas in ("pmc_sq", "pmc_sq2", "pmc_tcp", "pmc_tcc", "pmc_rd", "pmc_wr"):
+    con = db(pas)
+    if not con:
+        continue
+    rows = con.execute("select kernel_name, counter_name, dispatch_id, sum(value), count(*) from counters_collection "
+                       "group by kernel_name, counter_name, dispatch_id order by dispatch_id").fetchall()
+    per = defaultdict(list)
+    for kn, cn, did, v, inst in rows:
+        per[(short(kn), cn)].append((v, inst))
+    for (k, cn), vals in per.items():
+        n = len(vals)
+        frames = STEPS + WARMUP
+        # launches per frame: the timed launches are the last STEPS * per_frame ones (frame 0 has no raycast / E-step)
+        per_frame = 1 if n in (frames, frames - 1) else (round(n / (frames - 1)) if n >= frames - 1 and n % (frames - 1) == 0 else 0)
+        timed = vals[-STEPS * per_frame:] if per_frame else vals
+        counters[k][cn] = dict(per_launch=sum(v for v, _ in timed) / len(timed), instances=timed[0][1],
+                               launches=len(timed), of=n)
+if counters:
+    # durations of the same launches from the kernel trace of the PMC passes are perturbed by the counters; the
+    # un-perturbed durations are those of the trace pass (`trace` in *_traffic.json) and of bench.py's HIP events
+    json.dump(dict(tag=tag, protocol=f"python bench.py --steps {STEPS} --warmup {WARMUP} (timed launches only)",
+                   source="rocprofv3 --pmc, one pass per counter group (scripts/profile_round.sh)",
+                   kernels=counters), open(f"{dst}/{tag}_counters.json", "w"), indent=1)
+    out_md += ["## Issue / L1 / L2 counters per timed launch", "",
+               "| kernel | VALU insts | VALU busy quad-cyc | SALU insts | VMEM rd insts | wave quad-cyc | L1 line accesses | "
+               "L1->L2 read req | L2 req | GRBM cycles |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    def g(k, c):
+        return counters[k].get(c, {}).get("per_launch", float("nan"))
+    for k in counters:
+        if k in ("memset", "memcpy"):
+            continue
+        inst = counters[k].get("GRBM_GUI_ACTIVE", {}).get("instances", 1) or 1
+        out_md.append(f"| `{k}` | {g(k, 'SQ_INSTS_VALU'):.3g} | {g(k, 'SQ_ACTIVE_INST_VALU'):.3g} | {g(k, 'SQ_INSTS_SALU'):.3g} | "
+                      f"{g(k, 'SQ_INSTS_VMEM_RD'):.3g} | {g(k, 'SQ_WAVE_CYCLES'):.3g} | {g(k, 'TCP_TOTAL_CACHE_ACCESSES_sum'):.3g} | "
+                      f"{g(k, 'TCP_TCC_READ_REQ_sum'):.3g} | {g(k, 'TCC_REQ_sum'):.3g} | {g(k, 'GRBM_GUI_ACTIVE') / inst:.3g} |")
     out_md.append("")
 try:
     line = open(f"{src}/bench_under_trace.json").read().strip()
