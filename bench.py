@@ -387,20 +387,77 @@ def algorithmic_bytes(kind, summ, stats, P):
     return 0.0
 
 
-def measured_traffic(kind):
-    """HBM-side bytes per launch of one kernel kind from the newest committed PMC summary
-    (profiles/*_traffic.json, produced by scripts/profile_round.sh + summarize_profile.py: sized
-    TCC_EA0 read/write request counters, collected in their own rocprofv3 --pmc passes).  The
-    counters cannot be read from inside this process, so this is the figure of the profiled run of
-    the same command and workload; None if no summary is committed."""
-    files = sorted((ROOT / "profiles").glob("*_traffic.json"))
+def committed_profile():
+    """The newest committed PMC summary of this workload under profiles/ (scripts/profile_round.sh +
+    summarize_profile.py): `*_traffic.json` (HBM-side bytes per launch from the sized TCC_EA0 request
+    counters) and `*_counters.json` (issue / L1 / L2 counters per launch), both over the timed launches of
+    the driver's protocol.  The counters cannot be read from inside this process: they are those of the
+    profiled run of the same command, and the line says which one (`counters_from`)."""
+    out = {"tag": None, "traffic": {}, "counters": {}, "protocol": None}
+    files = sorted((ROOT / "profiles").glob("*_counters.json"))
     if not files:
-        return None
+        return out
     try:
-        k = json.loads(files[-1].read_text())["kernels"].get(kind)
-        return None if k is None else round(k["hbm_bytes_per_launch"], 1)
-    except (OSError, ValueError, KeyError):
+        c = json.loads(files[-1].read_text())
+        out.update(tag=c.get("tag"), counters=c.get("kernels", {}), protocol=c.get("protocol"))
+        t = files[-1].with_name(files[-1].name.replace("_counters.json", "_traffic.json"))
+        if t.exists():
+            out["traffic"] = json.loads(t.read_text()).get("kernels", {})
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+# Peaks the resource fractions are priced against (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz max
+# clock; a wave64 VALU instruction occupies its SIMD for 2 cycles; L2 ~34.5 TB/s; HBM3E 8 TB/s spec).  The
+# vector L1 looks up one 64-byte tag per cycle and CU: bench's own copy kernel moves 1 KiB per wave
+# instruction in 16 TCP_TOTAL_CACHE_ACCESSES, and a 64-lane 8-byte gather costs 16 accesses (one per 4
+# lanes) however few lines it touches -- the march's bound while the chip is full (DESIGN.md 5.3).
+CLOCK_HZ = 2.4e9
+PEAKS = {
+    "valu": ("G wave-instr/s", 256 * 4 * CLOCK_HZ / 2.0 / 1e9),
+    "l1": ("G tag lookups/s", 256 * CLOCK_HZ / 1e9),
+    "l2": ("GB/s", 34500.0),
+    "hbm": ("GB/s", HBM_PEAK_GBS),
+}
+
+
+def resource_fractions(kind, avg_ms, prof):
+    """Achieved rate and fraction of peak of every resource the committed counters price, for one kernel
+    kind at the launch duration measured LIVE in this run (HIP events): {resource: {achieved, peak, unit,
+    frac}}.  frac <= 1 by construction of the peaks (a counter-backed utilisation, not a byte model)."""
+    c = prof["counters"].get(kind)
+    if not c or avg_ms <= 0:
         return None
+    t = avg_ms * 1e-3
+
+    def per(name):
+        return c.get(name, {}).get("per_launch")
+
+    # request sizes at the L2, calibrated in the same passes by the 1 GiB copy kernel (known bytes)
+    cal = prof["counters"].get("stream_copy", {})
+    rd_req = cal.get("TCC_READ_sum", {}).get("per_launch")
+    wr_req = cal.get("TCC_WRITE_sum", {}).get("per_launch")
+    rd_bytes = (2.0 ** 30) / rd_req if rd_req else 128.0
+    wr_bytes = (2.0 ** 30) / wr_req if wr_req else 64.0
+    rates = {}
+    if per("SQ_INSTS_VALU") is not None:
+        rates["valu"] = per("SQ_INSTS_VALU") / t / 1e9
+    if per("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
+        rates["l1"] = per("TCP_TOTAL_CACHE_ACCESSES_sum") / t / 1e9
+    if per("TCC_READ_sum") is not None and per("TCC_WRITE_sum") is not None:
+        rates["l2"] = (per("TCC_READ_sum") * rd_bytes + per("TCC_WRITE_sum") * wr_bytes) / t / 1e9
+    tr = prof["traffic"].get(kind)
+    if tr:
+        rates["hbm"] = tr["hbm_bytes_per_launch"] / t / 1e9
+    out = {}
+    for r, a in rates.items():
+        unit, peak = PEAKS[r]
+        out[r] = {"achieved": round(a, 2), "peak": round(peak, 1), "unit": unit, "frac": round(a / peak, 4)}
+    waves = per("SQ_WAVE_CYCLES")
+    if waves is not None:  # quad-cycles summed over the waves -> mean resident waves per SIMD
+        out["mean_waves_per_simd"] = round(waves * 4.0 / (t * CLOCK_HZ * 1024), 2)
+    return out
 
 
 def copy_bandwidth(devmem, ops, mib=1024, reps=10):
@@ -423,6 +480,13 @@ def copy_bandwidth(devmem, ops, mib=1024, reps=10):
 
 
 def roofline(kern, stats, P, copy_gbs=None, profiled=True):
+    """`roofline` of the JSON line: the dominant kernel against the resource that binds it.
+
+    bound / achieved / peak / frac come from hardware counters (resource_fractions): VALU issue, vector-L1
+    tag lookups (the gather path), L2 bytes, HBM bytes -- the largest fraction is the bound.  SURVEY 8(d)'s
+    algorithmic byte model stays in the line as `model_GBs` (an upper bound on gather bytes that the caches
+    beat, NOT a fraction of anything)."""
+    prof = committed_profile() if profiled else {"tag": None, "traffic": {}, "counters": {}, "protocol": None}
     rows = []
     for kind, summ in kern.items():
         if kind.startswith("_") or summ["launches"] == 0:
@@ -430,12 +494,16 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
         total_b = algorithmic_bytes(kind, summ, stats, P)
         n = summ["launches"]
         avg_ms = summ["total_ms"] / n
-        rows.append({
+        row = {
             "kernel": KERNEL_NAMES[kind], "kind": kind, "launches": n,
             "avg_ms": round(avg_ms, 5), "total_ms": round(summ["total_ms"], 3),
             "alg_bytes_per_launch": round(total_b / n, 1),
-            "achieved_GBs": round(total_b / n / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None,
-        })
+            "model_GBs": round(total_b / n / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None,
+        }
+        res = resource_fractions(kind, avg_ms, prof)
+        if res:
+            row["resources"] = res
+        rows.append(row)
     rows.sort(key=lambda r: -r["total_ms"])
     # The dominant kernel is the longest one on the frame's critical stream.  The background's integration
     # runs beside the raycast on a second, lowest-priority stream and the main stream only joins it after the
@@ -444,51 +512,50 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
     ray = next((r for r in rows if r["kind"] == "raycast"), None)
     dom = next(r for r in rows
                if not (r["kind"] == "integrate_bg" and ray is not None and r["avg_ms"] < 1.1 * ray["avg_ms"]))
-    roof = {
-        "kernel": dom["kernel"],
-        "bound": "hbm",
-        "achieved": dom["achieved_GBs"],
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round((dom["achieved_GBs"] or 0.0) / HBM_PEAK_GBS, 4),
-        # bytes/launch from the committed PMC pass of this workload; null for other workloads
-        "traffic": measured_traffic(dom["kind"]) if profiled else None,
-        "avg_launch_ms": dom["avg_ms"],
-        "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
-        "dropped_launches": kern.get("_dropped", 0),
-    }
+    res = {k: v for k, v in (dom.get("resources") or {}).items() if isinstance(v, dict)}
+    roof = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"], "dropped_launches": kern.get("_dropped", 0)}
+    if res:
+        bound = max(res, key=lambda k: res[k]["frac"])
+        roof.update(bound=bound, achieved=res[bound]["achieved"], peak=res[bound]["peak"], unit=res[bound]["unit"],
+                    frac=res[bound]["frac"], resources=dom["resources"])
+        tr = prof["traffic"].get(dom["kind"])
+        roof["traffic"] = round(tr["hbm_bytes_per_launch"], 1) if tr else None
+        roof["counters_from"] = (f"profiles/{prof['tag']}_counters.json + _traffic.json: rocprofv3 --pmc passes of "
+                                 f"{prof['protocol']}; durations are this run's HIP events")
+    else:  # no committed counters for this workload: nothing to price the kernel against
+        roof.update(bound=None, achieved=None, peak=None, unit=None, frac=None, traffic=None,
+                    counters_from="none committed for this workload (profiles/ holds configs[1] without tracking)")
+    roof["model_GBs"] = dom["model_GBs"]
+    roof["alg_bytes_per_launch"] = dom["alg_bytes_per_launch"]
+    roof["model_note"] = ("model_GBs = SURVEY 8(d)'s algorithmic bytes per launch over the launch duration; for the "
+                          "raycast that is 64 B per march sample + 96 B per hit + 29 B per pixel and model, an upper "
+                          "bound on gather bytes that L1 / L2 serve (hit rate 0.86), so it can exceed the HBM peak -- "
+                          "it is a rate of the byte model, not a roofline fraction")
     if copy_gbs:
-        roof["frac_of_copy"] = round((dom["achieved_GBs"] or 0.0) / copy_gbs, 4)
-    if roof["traffic"]:  # what the PMC pass saw moving at the HBM side, at this launch's duration
-        roof["traffic_GBs"] = round(roof["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9, 1)
-    if dom["kind"] == "raycast":
-        roof["note"] = ("achieved = SURVEY 8(d)'s gather-byte model (64 B per march sample + 96 B per hit + 29 B per "
-                        "pixel and model) over the launch duration: an upper bound on the bytes that, as 8(d) says, "
-                        "caches beat -- the 8 corners of consecutive samples and neighbouring rays are served by L1 / "
-                        "L2 (hit rate 0.85-0.90), so frac can pass 1 while the HBM side moves only `traffic`. The "
-                        "kernel is bound by the latency chain of its longest marches and the CU's gather path "
-                        "(DESIGN.md 5.3), not by HBM; the streaming kernel of the path is integrate_stream.")
-    # SURVEY 8(d) headline for the streaming part: algorithmic integrate bytes over integrate time
+        roof["hbm_copy_GBs"] = copy_gbs
+    # the kernel that runs BESIDE the dominant one shares its resources: the chip's utilisation while the
+    # raycast runs is the sum of both
     integ = next((r for r in rows if r["kind"] == "integrate_bg"), None)
-    overlapped = integ is not None  # the background's integration runs beside the raycast on a second stream
+    overlapped = integ is not None
     if integ is None:
         integ = next((r for r in rows if r["kind"] == "integrate"), None)
     if integ:
-        roof["integrate_stream"] = {
-            "kernel": integ["kernel"], "concurrent_with_raycast": overlapped,
-            "achieved": integ["achieved_GBs"], "unit": "GB/s",
-            "frac": round(integ["achieved_GBs"] / HBM_PEAK_GBS, 4),
-            "frac_of_copy": round(integ["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
-            "avg_launch_ms": integ["avg_ms"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"],
-            "traffic": measured_traffic(integ["kind"]) if profiled else None,
-            "traffic_GBs": (round(measured_traffic(integ["kind"]) / (integ["avg_ms"] * 1e-3) / 1e9, 1)
-                            if profiled and measured_traffic(integ["kind"]) else None),
-            "note": "alg_bytes = 16 B x every voxel of the integrated volumes (SURVEY 8d); boxes outside "
-                    "the view cone are culled before they are touched, so the model rate can exceed the "
-                    "HBM peak -- `traffic` is what really moves.  With concurrent_with_raycast the launch "
-                    "shares the chip with k_raycast (its duration is that of the contended run; alone it "
-                    "takes ~0.23 ms, EMF_BG_OVERLAP=0)",
-        }
+        ires = {k: v for k, v in (integ.get("resources") or {}).items() if isinstance(v, dict)}
+        entry = {"kernel": integ["kernel"], "concurrent_with_raycast": overlapped, "avg_launch_ms": integ["avg_ms"],
+                 "model_GBs": integ["model_GBs"], "alg_bytes_per_launch": integ["alg_bytes_per_launch"]}
+        if ires:
+            b = max(ires, key=lambda k: ires[k]["frac"])
+            tr = prof["traffic"].get(integ["kind"])
+            entry.update(bound=b, frac=ires[b]["frac"], resources=integ["resources"],
+                         traffic=round(tr["hbm_bytes_per_launch"], 1) if tr else None)
+        entry["note"] = ("model_GBs = 16 B x every voxel of the integrated volumes (SURVEY 8d) over the launch time: "
+                         "full-sweep equivalent -- boxes outside the view cone are culled before they are touched and "
+                         "unseen tiles are integrated without being read, so `traffic` is what really moves")
+        roof["integrate_stream"] = entry
+        if overlapped and res and ires and dom["kind"] == "raycast":
+            roof["chip_while_raycast_runs"] = {
+                k: round(res[k]["frac"] + ires[k]["frac"] * min(1.0, integ["avg_ms"] / dom["avg_ms"]), 4)
+                for k in res if k in ires}
     if dom["kind"] == "raycast" and stats is not None:
         roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)
     return roof, rows

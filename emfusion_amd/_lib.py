@@ -73,6 +73,10 @@ SIGNATURES = {
     "emf_hip_relevantTileBytes": [_I3],
     "emf_hip_updateRelevantTiles": [_FP, _I3, C.c_int, _STREAM],
     "emf_hip_voxelReciprocal": [C.c_float, C.POINTER(C.c_float)],
+    "emf_hip_voxelReciprocalCached": [C.c_float, C.POINTER(C.c_float)],
+    "emf_hip_voxelReciprocalBegin": [C.c_float, C.c_void_p, _STREAM],
+    "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
+    "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
     "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],
     "emf_hip_pointStatsScratchBytes": [],

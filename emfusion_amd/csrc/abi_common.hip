@@ -2,6 +2,9 @@
 // emf_hip_* entry point.
 #include "common.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace emf_hip {
 
 static thread_local char g_err[512] = {0};
@@ -81,6 +84,21 @@ __global__ __launch_bounds__(256) void k_check_reciprocal(float d, float rcp,
     if (bad) atomicAdd(mismatches, static_cast<unsigned long long>(bad));
 }
 
+__global__ void k_check_reciprocal_begin(unsigned long long* mismatches) {
+    if (threadIdx.x == 0) *mismatches = 0ull;
+}
+
+// One wave that stays resident until the host sets *release (device-visible host memory) or `ticks` of
+// the 100 MHz wall clock have passed: while it runs, its stream is "not ready" -- a probe for whether a
+// host call synchronised with the whole device (tests/test_gpu_dynamic_objects.py).
+__global__ void k_spin_probe(const volatile uint32_t* release, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+        if (__hip_atomic_load(const_cast<const uint32_t*>(release), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 // device-to-device stream copy, 16 bytes per lane and iteration (the bandwidth yardstick of bench.py)
 __global__ __launch_bounds__(256) void k_stream_copy(float4* __restrict__ dst,
                                                      const float4* __restrict__ src, size_t n16) {
@@ -107,28 +125,115 @@ int emf_hip_streamCopy(void* dst, const void* src, size_t bytes, emf_stream_t st
     return launch_status("streamCopy");
 }
 
+// ---- checked reciprocal: process-wide cache + asynchronous check ---------------------------------
+// The check is a property of the voxel size's bit pattern alone, so its verdict is kept for the life
+// of the process: a volume created with a size seen before costs a table look-up, no device work.
+namespace {
+struct RcpVerdict {
+    uint32_t sizeBits;
+    float rcp;  // 1 / voxelSize if all 2^32 inputs agreed, 0 otherwise
+};
+uint32_t rcp_bits(float f) {
+    uint32_t b;
+    memcpy(&b, &f, sizeof(b));
+    return b;
+}
+std::mutex g_rcpMutex;
+std::vector<RcpVerdict> g_rcpVerdicts;
+unsigned long long* g_rcpCounter = nullptr;  // device word of the blocking form, allocated once
+
+bool rcp_lookup(float voxelSize, float* rcp) {
+    const uint32_t bits = rcp_bits(voxelSize);
+    std::lock_guard<std::mutex> lock(g_rcpMutex);
+    for (const RcpVerdict& v : g_rcpVerdicts)
+        if (v.sizeBits == bits) {
+            *rcp = v.rcp;
+            return true;
+        }
+    return false;
+}
+void rcp_remember(float voxelSize, float rcp) {
+    const uint32_t bits = rcp_bits(voxelSize);
+    std::lock_guard<std::mutex> lock(g_rcpMutex);
+    for (const RcpVerdict& v : g_rcpVerdicts)
+        if (v.sizeBits == bits) return;
+    g_rcpVerdicts.push_back(RcpVerdict{bits, rcp});
+}
+int rcp_check_size(float voxelSize, const char* who) {
+    if (!(voxelSize >= 1e-6f && voxelSize <= 1e3f))  // quotients of the checked range stay finite
+        return emf_hip::fail(EMF_E_ARG, "%s: voxelSize %g outside [1e-6, 1e3]", who, voxelSize);
+    return EMF_OK;
+}
+}  // namespace
+
 int emf_hip_voxelReciprocal(float voxelSize, float* rcp) {
     using namespace emf_hip;
     if (!rcp) return fail(EMF_E_NULL, "voxelReciprocal: rcp is NULL");
     *rcp = 0.f;
-    if (!(voxelSize >= 1e-6f && voxelSize <= 1e3f))  // quotients of the checked range stay finite
-        return fail(EMF_E_ARG, "voxelReciprocal: voxelSize %g outside [1e-6, 1e3]", voxelSize);
-    unsigned long long* dev = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(dev, 0, sizeof(unsigned long long));
+    if (const int rc = rcp_check_size(voxelSize, "voxelReciprocal")) return rc;
+    if (rcp_lookup(voxelSize, rcp)) return EMF_OK;  // seen before: no device work
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_rcpMutex);
+        if (!g_rcpCounter) e = hipMalloc(reinterpret_cast<void**>(&g_rcpCounter), sizeof(unsigned long long));
+    }
+    // its own stream: the wait below is for this check alone, not for the device
+    hipStream_t st = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     unsigned long long bad = 1;
+    if (e == hipSuccess) e = hipMemsetAsync(g_rcpCounter, 0, sizeof(unsigned long long), st);
     if (e == hipSuccess) {
         const float r = 1.0f / voxelSize;
-        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, nullptr, voxelSize, r, dev);
-        e = hipMemcpy(&bad, dev, sizeof(bad), hipMemcpyDeviceToHost);  // synchronises
-        if (e == hipSuccess && bad == 0) *rcp = r;
+        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, r, g_rcpCounter);
+        e = hipMemcpyAsync(&bad, g_rcpCounter, sizeof(bad), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            *rcp = bad == 0 ? r : 0.f;
+            rcp_remember(voxelSize, *rcp);
+        }
     }
-    if (dev) (void)hipFree(dev);
+    if (st) (void)hipStreamDestroy(st);
     if (e != hipSuccess) {
         set_error("voxelReciprocal: %s", hipGetErrorString(e));
         return static_cast<int>(e);
     }
     return EMF_OK;
+}
+
+int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp) {
+    using namespace emf_hip;
+    if (!rcp) return fail(EMF_E_NULL, "voxelReciprocalCached: rcp is NULL");
+    *rcp = 0.f;
+    if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalCached")) return rc;
+    return rcp_lookup(voxelSize, rcp) ? EMF_OK : EMF_E_NOTREADY;
+}
+
+int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream) {
+    using namespace emf_hip;
+    if (!mismatches) return fail(EMF_E_NULL, "voxelReciprocalBegin: mismatches is NULL");
+    if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalBegin")) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_check_reciprocal_begin, dim3(1), dim3(64), 0, st, mismatches);
+    hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, 1.0f / voxelSize, mismatches);
+    return launch_status("voxelReciprocalBegin");
+}
+
+int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp) {
+    using namespace emf_hip;
+    if (!rcp) return fail(EMF_E_NULL, "voxelReciprocalEnd: rcp is NULL");
+    *rcp = 0.f;
+    if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalEnd")) return rc;
+    *rcp = mismatches == 0 ? 1.0f / voxelSize : 0.f;
+    rcp_remember(voxelSize, *rcp);
+    return EMF_OK;
+}
+
+int emf_hip_spinProbe(const volatile uint32_t* release, uint32_t maxMilliseconds, emf_stream_t stream) {
+    using namespace emf_hip;
+    if (!release) return fail(EMF_E_NULL, "spinProbe: release is NULL");
+    hipLaunchKernelGGL(k_spin_probe, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), release,
+                       static_cast<unsigned long long>(maxMilliseconds) * 100000ull);
+    return launch_status("spinProbe");
 }
 
 int emf_hip_abi_version(void) { return EMF_HIP_ABI_VERSION; }

@@ -138,6 +138,8 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     s.waitForCompletion();
     streamOf(0);
     rebuildModelTable();
+    // volumes created from here on (objects, inside frames) do not wait for a reciprocal check
+    TSDF::deferReciprocalChecks(true);
 }
 
 EMFusion::~EMFusion() {
@@ -210,7 +212,7 @@ int EMFusion::addObject(const Vec3f& center, float volSize) {
 int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
     if (static_cast<int>(allIds.size()) >= EMF_MAX_MODELS - 1)
         throw HipError("EMFusion::addObject: too many live objects", EMF_E_LIMIT);
-    synchronize();  // object creation is rare and changes the model table
+    quiesce();  // object creation changes the model table: nothing of this instance may be in flight
     refreshVisibleFromDevice();
     const int id = nextId++;
     allIds.push_back(id);
@@ -343,6 +345,26 @@ void EMFusion::rebuildModelTable() {
     }
 }
 
+// Verdicts of deferred reciprocal checks (TSDF::pollReciprocal) that have come in: from this frame on those
+// volumes are marched with the reciprocal instead of the division -- same results, so a launch that reads the
+// table while it is patched sees either form.  One small copy per adopted volume; no wait.
+void EMFusion::adoptReciprocals() {
+    auto adopt = [&](TSDF& vol, size_t slot) {
+        if (!vol.pollReciprocal() || !batched || slot >= modelsHost.size()) return;
+        modelsHost[slot].rcpVoxel = vol.reciprocal();
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !background.doubleBuffered()) break;
+            emf_model_t* row = modelTable.as<emf_model_t>() + t * EMF_MAX_BATCH + slot;
+            hipCheck(hipMemcpyAsync(&row->rcpVoxel, &modelsHost[slot].rcpVoxel, sizeof(float),
+                                    hipMemcpyHostToDevice, main.get()),
+                     "reciprocal patch");
+        }
+    };
+    adopt(background, 0);  // (a second instance in the process: its background was created with deferral on)
+    size_t slot = 1;
+    for (auto& obj : objects) adopt(obj, slot++);
+}
+
 void EMFusion::posesCO(std::vector<emf_pose_t>& out) const {
     out.clear();
     out.push_back(toPose(background.getPose().inv() * pose));  // reference TSDF.cpp:141,162
@@ -372,6 +394,18 @@ float EMFusion::stamp(int slot) {
 double EMFusion::pixels() const { return static_cast<double>(params.frameSize.area()); }
 
 void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+
+// Wait for everything THIS instance has enqueued -- its three frame streams, the per-volume streams and the
+// null stream its constructors clear on -- and for nothing else: unlike hipDeviceSynchronize() this does not
+// stall on (or get stalled by) other work on the device.  What the frame itself uses where the object set
+// changes (reference EMFusion.cpp:495-560, 827-863, 922-980 run inside processFrame).
+void EMFusion::quiesce() {
+    main.waitForCompletion();
+    aux.waitForCompletion();
+    lists.waitForCompletion();
+    for (auto& kv : streams) kv.second.waitForCompletion();
+    Stream::Null().waitForCompletion();
+}
 
 void EMFusion::enableRaycastStats(bool on) {
     statsOn = on;
@@ -432,6 +466,7 @@ void EMFusion::preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& d
 }
 
 void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
+    adoptReciprocals();
     depth = depthDev;
     stamp(kStart);
     if (sharded && depthRoot >= 0)  // 1.2 MB at VGA, once per frame
@@ -825,7 +860,7 @@ Vec3f EMFusion::updateObject(int id, const emf_image_t& mask) {
     if (sharded) throw HipError("EMFusion::updateObject: not available on the sharded path", EMF_E_ARG);
     for (auto& obj : objects)
         if (obj.getID() == id) {
-            synchronize();
+            quiesce();
             refreshVisibleFromDevice();  // rebuildModelTable below uploads the gate from the host set
             const Vec3f offset = updateObj(obj, mask);
             if (poseLog) {  // several calls between two frames add up
@@ -897,7 +932,7 @@ std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_i
         const int id = it->getID();
         if (spurious.count(id) || !vis_objs.count(id)) {
             deleted.push_back(id);
-            synchronize();  // nothing in flight may still use the volume
+            quiesce();  // nothing in flight may still use the volume
             deleteObj(id);
             if (poseLog && !(ignorePerson && isPerson(*it))) {
                 meshes[id] = it->getMesh();  // saveOutput: EMFusion.cpp:962-966
@@ -1275,7 +1310,7 @@ bool EMFusion::overlapUsable() const {
 void EMFusion::integrateBackgroundAsync() {
     if (!overlapUsable() || bgInFlight) return;
     if (bgBackStale) {  // an in-place integration (other path) in between: re-equalise the copies
-        synchronize();
+        quiesce();
         background.resyncBack();
         bgBackStale = false;
         bgPrepared = false;

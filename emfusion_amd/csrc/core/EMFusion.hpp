@@ -223,6 +223,8 @@ public:
 
     /** Block until everything enqueued so far has finished. */
     void synchronize();
+    /** Wait for the work of this instance only (its streams), not for the device. */
+    void quiesce();
 
     // ---- state access ----
     int frameIndex() const { return frameCount; }
@@ -273,6 +275,7 @@ private:
     void runSchedule(const emf_image_t& depthDev, const FrameInputs& in);
     // batched (model-table) path: one launch per stage, no host synchronisation inside a frame
     void rebuildModelTable();
+    void adoptReciprocals();
     void posesCO(std::vector<emf_pose_t>& out) const;
     void posesOC(std::vector<emf_pose_t>& out) const;
     void estepBatched();

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 namespace emf {
 
@@ -19,12 +20,105 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
       brickFlags(2 * static_cast<size_t>((_volumeRes[0] + 3) / 4) * ((_volumeRes[1] + 3) / 4) *
                  ((_volumeRes[2] + 3) / 4)) {  // raw flags + dilated flags
     if (gradMode == Gradients::Materialized) tsdfGrads = DeviceBuffer(voxels() * 3 * sizeof(float));
-    // once per volume: is 1 / voxelSize usable in place of the march's divisions?  (exhaustive
-    // device check, ~3 ms; EMF_VOXEL_RCP=0 keeps the divisions for A/B measurements)
-    const char* vr = std::getenv("EMF_VOXEL_RCP");
-    if (!(vr && vr[0] == '0') && emf_hip_voxelReciprocal(voxelSize, &rcpVoxel) != EMF_OK)
-        rcpVoxel = 0.f;  // voxel size outside the checked range: the march divides
+    obtainReciprocal();
     reset(_pose);
+}
+
+// ---- checked reciprocal of the voxel size ---------------------------------------------------------
+// Is 1 / voxelSize usable in place of the march's divisions?  An exhaustive device check per distinct
+// voxel size and process (emf_hip_voxelReciprocal*); EMF_VOXEL_RCP=0 keeps the divisions for A/B runs.
+namespace {
+bool g_deferReciprocal = false;
+std::mutex g_rcpSlotMutex;
+unsigned long long* g_rcpSlots = nullptr;  // device-visible host words, allocated once, never freed
+constexpr int kRcpSlots = 256;
+bool g_rcpSlotUsed[kRcpSlots] = {};
+hipStream_t g_rcpStream = nullptr;         // lowest priority: the check must not delay a frame
+
+int take_rcp_slot() {
+    std::lock_guard<std::mutex> lock(g_rcpSlotMutex);
+    if (!g_rcpSlots) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(unsigned long long) * kRcpSlots, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        g_rcpSlots = static_cast<unsigned long long*>(p);
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&g_rcpStream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            g_rcpStream = nullptr;
+            return -1;
+        }
+    }
+    if (!g_rcpStream) return -1;
+    for (int i = 0; i < kRcpSlots; ++i)
+        if (!g_rcpSlotUsed[i]) {
+            g_rcpSlotUsed[i] = true;
+            return i;
+        }
+    return -1;
+}
+void give_rcp_slot(int i) {
+    std::lock_guard<std::mutex> lock(g_rcpSlotMutex);
+    g_rcpSlotUsed[i] = false;
+}
+}  // namespace
+
+struct TSDF::PendingReciprocal {
+    int slot = -1;
+    hipEvent_t done = nullptr;
+};
+void TSDF::PendingDeleter::operator()(PendingReciprocal* p) const {
+    if (!p) return;
+    // the check may still be running and will write its slot: wait for THAT kernel (rare: a volume
+    // destroyed within milliseconds of its creation), then hand the slot back
+    if (p->done) {
+        (void)hipEventSynchronize(p->done);
+        (void)hipEventDestroy(p->done);
+    }
+    if (p->slot >= 0) give_rcp_slot(p->slot);
+    delete p;
+}
+
+void TSDF::deferReciprocalChecks(bool on) { g_deferReciprocal = on; }
+
+void TSDF::obtainReciprocal() {
+    rcpVoxel = 0.f;
+    const char* vr = std::getenv("EMF_VOXEL_RCP");
+    if (vr && vr[0] == '0') return;
+    const int known = emf_hip_voxelReciprocalCached(voxelSize, &rcpVoxel);
+    if (known == EMF_OK) return;            // this size has been checked in this process
+    if (known != EMF_E_NOTREADY) return;    // outside the checked range: the march divides
+    if (g_deferReciprocal) {
+        const int slot = take_rcp_slot();
+        if (slot >= 0) {
+            std::unique_ptr<PendingReciprocal, PendingDeleter> p(new PendingReciprocal);
+            p->slot = slot;
+            if (hipEventCreateWithFlags(&p->done, hipEventDisableTiming) == hipSuccess &&
+                emf_hip_voxelReciprocalBegin(voxelSize, g_rcpSlots + slot,
+                                             reinterpret_cast<emf_stream_t>(g_rcpStream)) == EMF_OK &&
+                hipEventRecord(p->done, g_rcpStream) == hipSuccess) {
+                pendingRcp = std::move(p);
+                return;  // rcpVoxel stays 0 until pollReciprocal() sees the verdict
+            }
+            (void)hipGetLastError();
+        }
+    }
+    if (emf_hip_voxelReciprocal(voxelSize, &rcpVoxel) != EMF_OK) rcpVoxel = 0.f;
+}
+
+bool TSDF::pollReciprocal() {
+    if (!pendingRcp) return false;
+    if (hipEventQuery(pendingRcp->done) != hipSuccess) {
+        (void)hipGetLastError();  // not ready
+        return false;
+    }
+    const unsigned long long bad = g_rcpSlots[pendingRcp->slot];
+    pendingRcp.reset();
+    if (emf_hip_voxelReciprocalEnd(voxelSize, bad, &rcpVoxel) != EMF_OK) rcpVoxel = 0.f;
+    return rcpVoxel != 0.f;
 }
 
 void TSDF::reset(const Affine3f& _pose) {

@@ -8,6 +8,7 @@
 // syncTrack) and meshing are outside this build's scope.
 #pragma once
 
+#include <memory>
 #include <vector>
 
 #include "data.hpp"
@@ -126,6 +127,19 @@ public:
     /** 0 / 1 / 2 from the environment variable EMF_BRICK_FLAGS, see TSDF.cpp. */
     static int brickFlagMode();
 
+    /**
+     * The checked reciprocal of the voxel size (emf_hip_voxelReciprocal) is a verdict over all 2^32
+     * inputs: ~2.3 ms of device time the first time a size is seen in the process.  With deferral on,
+     * a constructor that meets a new size does not wait for it: the check is enqueued on a stream of
+     * its own, the march divides (same results) and pollReciprocal() adopts the verdict once it is in.
+     * emf::EMFusion turns this on after its background exists, so objects created inside a frame
+     * (reference EMFusion.cpp:495-560) never stall it.
+     */
+    static void deferReciprocalChecks(bool on);
+    /** True if the verdict arrived with this call (the owner refreshes its model table). */
+    bool pollReciprocal();
+    float reciprocal() const { return rcpVoxel; }
+
 protected:
     Mesh extractMesh(const uint8_t* fgVolMask);
     TSDFParams params;
@@ -149,6 +163,14 @@ protected:
     DeviceBuffer relevantTiles; // count + indices of the tiles in which a raycast hit can be completed
     DeviceBuffer unseenTiles;   // per tile: every weight is 0 (emf_model_t.unseenTiles); valid with the sign maps
     int dirtyPrev = 0;  // index of the map the last out-of-place integration wrote
+
+private:
+    struct PendingReciprocal;
+    struct PendingDeleter {
+        void operator()(PendingReciprocal* p) const;
+    };
+    std::unique_ptr<PendingReciprocal, PendingDeleter> pendingRcp;  // a deferred check in flight
+    void obtainReciprocal();
 };
 
 }  // namespace emf

@@ -1,7 +1,11 @@
 // types.cpp -- RAII wrappers over HIP streams / device memory used by the host classes.
 #include "types.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace emf {
 
@@ -15,19 +19,132 @@ void emfCheck(int rc, const char* what) {
         throw HipError(std::string(what) + ": " + emf_hip_last_error_string(), rc);
 }
 
+// ---- live streams + device memory pool ------------------------------------------------------------
+// hipFree synchronises the whole device and hipMalloc of tens of MB takes a fraction of a millisecond;
+// objects are created, resized and deleted INSIDE frames (reference EMFusion.cpp:495-560, 827-863,
+// 922-980).  So a released DeviceBuffer is not freed: it goes to a pool together with one event per live
+// stream of this library, recorded at the stream's tail at the moment of the release -- everything that
+// could still touch the memory was enqueued before -- and is handed out again (same size) once all of
+// them have completed (hipEventQuery: no wait).  Nothing else in the process shares these buffers.
+namespace {
+struct Pooled {
+    void* p;
+    size_t bytes;
+    std::vector<hipEvent_t> fences;
+};
+std::mutex g_poolMutex;
+std::vector<hipStream_t> g_streams;  // streams created by emf::Stream
+std::vector<Pooled> g_pool;
+std::vector<hipEvent_t> g_spareEvents;
+size_t g_pooledBytes = 0;
+
+size_t pool_cap() {  // bytes the pool may hold before it really frees (EMF_POOL_MIB, default 16 GiB of 288)
+    static const size_t cap = [] {
+        const char* e = std::getenv("EMF_POOL_MIB");
+        return (e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : size_t(16384)) << 20;
+    }();
+    return cap;
+}
+bool fences_passed(Pooled& b) {
+    while (!b.fences.empty()) {
+        if (hipEventQuery(b.fences.back()) != hipSuccess) {
+            (void)hipGetLastError();  // hipErrorNotReady is not an error
+            return false;
+        }
+        g_spareEvents.push_back(b.fences.back());
+        b.fences.pop_back();
+    }
+    return true;
+}
+void* pool_acquire(size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].bytes == bytes && fences_passed(g_pool[i])) {
+            void* p = g_pool[i].p;
+            g_pooledBytes -= bytes;
+            g_pool[i] = std::move(g_pool.back());
+            g_pool.pop_back();
+            return p;
+        }
+    return nullptr;
+}
+void pool_release(void* p, size_t bytes) {
+    std::unique_lock<std::mutex> lock(g_poolMutex);
+    if (g_pooledBytes + bytes > pool_cap()) {  // over the cap: a real free (synchronises the device)
+        lock.unlock();
+        (void)hipFree(p);
+        return;
+    }
+    Pooled b{p, bytes, {}};
+    std::vector<hipStream_t> streams = g_streams;
+    streams.push_back(nullptr);  // the null stream: clears and uploads of constructors run there
+    for (hipStream_t st : streams) {
+        hipEvent_t ev = nullptr;
+        if (!g_spareEvents.empty()) {
+            ev = g_spareEvents.back();
+            g_spareEvents.pop_back();
+        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            ev = nullptr;
+        }
+        if (!ev || hipEventRecord(ev, st) != hipSuccess) {  // cannot fence it: free it the slow, safe way
+            (void)hipGetLastError();
+            if (ev) g_spareEvents.push_back(ev);
+            for (hipEvent_t e : b.fences) g_spareEvents.push_back(e);
+            lock.unlock();
+            (void)hipFree(p);
+            return;
+        }
+        b.fences.push_back(ev);
+    }
+    g_pooledBytes += bytes;
+    g_pool.push_back(std::move(b));
+}
+void register_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    g_streams.push_back(s);
+}
+void unregister_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    g_streams.erase(std::remove(g_streams.begin(), g_streams.end(), s), g_streams.end());
+}
+}  // namespace
+
+size_t DeviceBuffer::pooledBytes() {
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    return g_pooledBytes;
+}
+void DeviceBuffer::trimPool() {
+    std::vector<Pooled> all;
+    {
+        std::lock_guard<std::mutex> lock(g_poolMutex);
+        all.swap(g_pool);
+        g_pooledBytes = 0;
+    }
+    for (Pooled& b : all) {
+        (void)hipFree(b.p);  // synchronises the device: the fences have passed afterwards
+        std::lock_guard<std::mutex> lock(g_poolMutex);
+        for (hipEvent_t e : b.fences) g_spareEvents.push_back(e);
+    }
+}
+
 Stream::Stream() : owned_(true) {
     hipCheck(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking), "hipStreamCreate");
+    register_stream(s_);
 }
 Stream::Stream(int priority) : owned_(true) {
     int least = 0, greatest = 0;  // numerically lower = higher priority
     hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
     const int p = priority > 0 ? greatest : (priority < 0 ? least : (least + greatest) / 2);
     hipCheck(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, p), "hipStreamCreateWithPriority");
+    register_stream(s_);
 }
 Stream::Stream(hipStream_t s) : s_(s), owned_(false) {}
 Stream::~Stream() {
     if (ev_) (void)hipEventDestroy(ev_);
-    if (owned_ && s_) (void)hipStreamDestroy(s_);
+    if (owned_ && s_) {
+        unregister_stream(s_);
+        (void)hipStreamDestroy(s_);
+    }
 }
 Stream::Stream(Stream&& o) noexcept : s_(o.s_), owned_(o.owned_), ev_(o.ev_) {
     o.s_ = nullptr;
@@ -37,7 +154,10 @@ Stream::Stream(Stream&& o) noexcept : s_(o.s_), owned_(o.owned_), ev_(o.ev_) {
 Stream& Stream::operator=(Stream&& o) noexcept {
     if (this != &o) {
         if (ev_) (void)hipEventDestroy(ev_);
-        if (owned_ && s_) (void)hipStreamDestroy(s_);
+        if (owned_ && s_) {
+            unregister_stream(s_);
+            (void)hipStreamDestroy(s_);
+        }
         s_ = o.s_;
         owned_ = o.owned_;
         ev_ = o.ev_;
@@ -65,10 +185,12 @@ void Stream::waitFor(Stream& other) {
 }
 
 DeviceBuffer::DeviceBuffer(size_t bytes) : n_(bytes) {
-    if (bytes) hipCheck(hipMalloc(&p_, bytes), "hipMalloc");
+    if (!bytes) return;
+    p_ = pool_acquire(bytes);
+    if (!p_) hipCheck(hipMalloc(&p_, bytes), "hipMalloc");
 }
 DeviceBuffer::~DeviceBuffer() {
-    if (p_) (void)hipFree(p_);
+    if (p_) pool_release(p_, n_);
 }
 DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_) {
     o.p_ = nullptr;
@@ -76,7 +198,7 @@ DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_) {
 }
 DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
     if (this != &o) {
-        if (p_) (void)hipFree(p_);
+        if (p_) pool_release(p_, n_);
         p_ = o.p_;
         n_ = o.n_;
         o.p_ = nullptr;

@@ -160,7 +160,7 @@ private:
     hipEvent_t ev_ = nullptr;  // lazily created by record()
 };
 
-// Continuous device buffer (what cv::cuda::createContinuous gives): RAII over hipMalloc.
+// Continuous device buffer (what cv::cuda::createContinuous gives): RAII over hipMalloc + a pool.
 class DeviceBuffer {
 public:
     DeviceBuffer() = default;
@@ -177,6 +177,10 @@ public:
     }
     size_t bytes() const { return n_; }
     bool empty() const { return p_ == nullptr; }
+    // Released buffers wait in a process-wide pool (types.cpp, capped by EMF_POOL_MIB) instead of going
+    // through hipFree, which synchronises the device.  trimPool() really frees them (and does wait).
+    static size_t pooledBytes();
+    static void trimPool();
     void setZero(const Stream& s) const;
     void fill32(uint32_t pattern, const Stream& s) const;  // bytes() must be a multiple of 4
     void download(void* host, const Stream& s) const;       // synchronises `s`

@@ -45,6 +45,10 @@ for _name, _args in {
         "hipSetDevice": [C.c_int],
         "hipGetDeviceCount": [C.POINTER(C.c_int)],
         "hipStreamCreate": [C.POINTER(C.c_void_p)],
+        "hipStreamCreateWithFlags": [C.POINTER(C.c_void_p), C.c_uint],
+        "hipStreamQuery": [C.c_void_p],
+        "hipHostMalloc": [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint],
+        "hipHostFree": [C.c_void_p],
         "hipStreamDestroy": [C.c_void_p],
         "hipStreamSynchronize": [C.c_void_p],
         "hipEventCreate": [C.POINTER(C.c_void_p)],
@@ -79,16 +83,45 @@ def mem_info() -> Tuple[int, int]:
 
 
 class Stream:
-    def __init__(self):
+    def __init__(self, non_blocking: bool = False):
         self.handle = C.c_void_p()
-        _check(_hip.hipStreamCreate(C.byref(self.handle)), "hipStreamCreate")
+        if non_blocking:  # hipStreamNonBlocking: no implicit ordering with the null stream
+            _check(_hip.hipStreamCreateWithFlags(C.byref(self.handle), 1), "hipStreamCreateWithFlags")
+        else:
+            _check(_hip.hipStreamCreate(C.byref(self.handle)), "hipStreamCreate")
 
     def synchronize(self):
         _check(_hip.hipStreamSynchronize(self.handle), "hipStreamSynchronize")
 
+    def busy(self) -> bool:
+        """hipStreamQuery: True while work enqueued on the stream has not completed."""
+        rc = _hip.hipStreamQuery(self.handle)
+        if rc == 600:  # hipErrorNotReady
+            return True
+        _check(rc, "hipStreamQuery")
+        return False
+
     def __del__(self):
         if getattr(self, "handle", None):
             _hip.hipStreamDestroy(self.handle)
+
+
+class HostWord:
+    """One 32-bit word of pinned host memory the device can read (flags for probe kernels)."""
+
+    def __init__(self, value: int = 0):
+        self.ptr = C.c_void_p()
+        _check(_hip.hipHostMalloc(C.byref(self.ptr), 64, 0), "hipHostMalloc")
+        self._view = C.cast(self.ptr, C.POINTER(C.c_uint32))
+        self._view[0] = value
+
+    def set(self, value: int):
+        self._view[0] = value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _hip.hipHostFree(self.ptr)
+            self.ptr = None
 
 
 class Event:

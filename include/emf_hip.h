@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 5
+#define EMF_HIP_ABI_VERSION 6
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -47,7 +47,8 @@ enum {
     EMF_E_PITCH = -3,     /* pitch smaller than a row or not a multiple of the element alignment */
     EMF_E_ARG = -4,       /* scalar argument out of domain (voxelSize <= 0, channels not in 1..3 ...) */
     EMF_E_LIMIT = -5,     /* count exceeds a documented limit (EMF_MAX_*) */
-    EMF_E_NODEVICE = -6   /* no HIP device / library built without device code for this GPU */
+    EMF_E_NODEVICE = -6,  /* no HIP device / library built without device code for this GPU */
+    EMF_E_NOTREADY = -7   /* the answer is not known yet (emf_hip_voxelReciprocalCached: size never checked) */
 };
 
 /* GpuMat-like image view: `data` device pointer, `pitch` bytes per row (>= width * elemsize) */
@@ -144,9 +145,32 @@ int emf_hip_streamCopy(void* dst, const void* src, size_t bytes, emf_stream_t st
  * runs every one of the 2^32 float bit patterns x through  q = x * r; q = fma(fma(-q, d, x), r, q)
  * (r = 1 / d) and through the IEEE division on the device, and stores r in *rcp only if the two
  * agree bit for bit for all x with 1e-30 <= |x| <= 1e30 (0 otherwise; the march keeps its
- * arguments inside that range, see march_wave.hpp).  SYNCHRONOUS (about 3 ms): call it once per
- * volume, at creation. */
+ * arguments inside that range, see march_wave.hpp).  The verdict depends on the bit pattern of
+ * voxelSize alone and is remembered for the life of the process: the first call for a size runs
+ * the check on a stream of its own and waits for THAT (about 3 ms; no allocation, no device-wide
+ * synchronisation), later calls for the same size return at once without touching the device. */
 int emf_hip_voxelReciprocal(float voxelSize, float* rcp);
+
+/* The same check without any wait, for volumes created inside a frame (reference
+ * EMFusion.cpp:495-560, initNewObjVolume): the march divides (rcpVoxel = 0, same results) until the
+ * verdict is in.
+ *   ...Cached: *rcp and EMF_OK if this size has been checked before in this process, else
+ *              EMF_E_NOTREADY (nothing is enqueued);
+ *   ...Begin : enqueues the check on `stream`; it first stores 0 to *mismatches, then adds the
+ *              number of disagreeing inputs to it.  `mismatches` is the caller's (device memory, or
+ *              host memory the device can write); nothing is allocated, nothing waited for;
+ *   ...End   : the caller has seen the check complete (event, stream query) and read the count:
+ *              records the verdict for the process and returns the reciprocal (0 if any input
+ *              disagreed).  Pure host code. */
+int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp);
+int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream);
+int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp);
+
+/* Diagnostic: one wave that stays resident on `stream` until *release != 0 (host memory the device
+ * can read) or maxMilliseconds have passed.  While it runs the stream is "not ready", so a host call
+ * that synchronised with the whole device cannot have returned before it ended: the tests use it
+ * to show that a frame contains no device-wide synchronisation. */
+int emf_hip_spinProbe(const volatile uint32_t* release, uint32_t maxMilliseconds, emf_stream_t stream);
 
 /* Replaces emf::cuda::TSDF::getVolumeVals (TSDF.cuh:197-203, TSDF.cu:662-726).
  * vol: N^3 x channels f32 (channels 1..3, interleaved); points f32x3; vals f32 x channels.
