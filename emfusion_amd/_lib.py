@@ -77,6 +77,9 @@ SIGNATURES = {
     "emf_hip_voxelReciprocalBegin": [C.c_float, C.c_void_p, _STREAM],
     "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
     "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
+    "emf_hip_sweepFastPathPremises": [C.c_void_p, _STREAM],
+    "emf_hip_debugPixelRounding": [_FP, _FP, C.c_int, _FP, _FP, _STREAM],
+    "emf_hip_debugBandDecision": [_FP, _FP, _FP, C.c_int, C.c_float, _FP, _FP, _FP, _FP, _STREAM],
     "emf_hip_streamCopy": [_FP, _FP, C.c_size_t, _STREAM],
     "emf_hip_preprocessDepth": [_IMG, _IMG, C.c_int, C.c_float, C.c_float, _STREAM],
     "emf_hip_pointStatsScratchBytes": [],
@@ -176,6 +179,16 @@ def declared_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(emf_hip_\w+)\s*\(", text)))
 
 
+def load_variant(suffix: str) -> C.CDLL:
+    """A second build of the kernel library beside the product's, e.g. "_fma" = libemf_hip_fma.so
+    (`make -C csrc fma`: a*b+c contraction on).  For the tests that measure what contraction alone
+    changes; nothing in the product loads it."""
+    path = LIB_PATH.with_name(LIB_PATH.stem + suffix + LIB_PATH.suffix)
+    if not path.exists():
+        raise RuntimeError(f"{path} is missing: build it with `make -C {PKG_DIR / 'csrc'} fma`")
+    return _bind(C.CDLL(os.fspath(path)))
+
+
 def load() -> C.CDLL:
     """Load libemf_hip.so and bind every declared entry point."""
     global _lib
@@ -186,7 +199,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP library has not been built. Run "
             f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C {PKG_DIR / 'csrc'}`."
             " There is no CPU fallback.")
-    lib = C.CDLL(os.fspath(LIB_PATH))
+    _lib = _bind(C.CDLL(os.fspath(LIB_PATH)))
+    return _lib
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
@@ -202,7 +219,6 @@ def load() -> C.CDLL:
     lib.emf_hip_relevantTileBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
-    _lib = lib
     return lib
 
 

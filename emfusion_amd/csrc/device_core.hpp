@@ -273,6 +273,28 @@ __device__ __forceinline__ bool quotient_is_risky(float q) {
     return !(fabsf(q) < 1048576.f) || fabsf(f - 0.5f) <= fabsf(q) * 0x1p-21f;
 }
 
+// round(x / z) and round(y / z) of the projection (round-half-even, TSDF.cu:360-361).  FAST: the
+// reciprocal form wherever quotient_is_risky() lets it stand, the IEEE division otherwise -- the same
+// integers (premise: v_rcp_f32 within 1 ulp for every z whose reciprocal is a normal float, swept over all
+// 2^32 inputs by emf_hip_sweepFastPathPremises; adversarial quotients next to every tie:
+// tests/test_gpu_fast_paths.py through emf_hip_debugPixelRounding).
+template <bool FAST>
+__device__ __forceinline__ void round_pixel(float x, float y, float z, bool behind, int& px, int& py) {
+    if (FAST) {
+        const float rz = __builtin_amdgcn_rcpf(z);
+        float qx = x * rz, qy = y * rz;
+        if (!behind && (quotient_is_risky(qx) || quotient_is_risky(qy))) {
+            qx = x / z;
+            qy = y / z;
+        }
+        px = __float2int_rn(qx);
+        py = __float2int_rn(qy);
+    } else {
+        px = __float2int_rn(x / z);
+        py = __float2int_rn(y / z);
+    }
+}
+
 // Where a voxel lands in the image: everything of classify_voxel that needs no memory.
 struct VoxelShot {
     int px, py;    // rounded pixel (valid only if inImage)
@@ -287,22 +309,42 @@ __device__ __forceinline__ VoxelShot shoot_voxel(const IntegrateGeom& a, const V
     s.behind = pcam.z <= 0.f;
     const V3 proj = project(a, pcam);
     // for `behind` voxels the quotients are never used (the reference returns before dividing)
-#if EMF_INT_FAST
-    const float rz = __builtin_amdgcn_rcpf(proj.z);
-    float qx = proj.x * rz, qy = proj.y * rz;
-    if (!s.behind && (quotient_is_risky(qx) || quotient_is_risky(qy))) {
-        qx = proj.x / proj.z;
-        qy = proj.y / proj.z;
-    }
-    s.px = __float2int_rn(qx);  // round-half-even, TSDF.cu:360-361
-    s.py = __float2int_rn(qy);
-#else
-    s.px = __float2int_rn(proj.x / proj.z);  // round-half-even, TSDF.cu:360-361
-    s.py = __float2int_rn(proj.y / proj.z);
-#endif
+    round_pixel<EMF_INT_FAST != 0>(proj.x, proj.y, proj.z, s.behind, s.px, s.py);
     s.inImage = !s.behind && s.px >= 0 && s.px < a.w && s.py >= 0 && s.py < a.h;
     s.n2 = pcam.x * pcam.x + pcam.y * pcam.y + pcam.z * pcam.z;
     return s;
+}
+
+// The side of the truncation band a voxel with a valid depth lies on, and its clamped sample
+// (TSDF.cu:380-400): kFuse with the sample in [-1, 1] and `bandVoxel` = "sdf < truncdist: the pixel's
+// association weight applies", or kNegIfUnseen.
+// FAST: far from the surface only the SIDE of the band matters -- free space fuses the constant +1 with
+// weight 1, voxels behind the band are left alone.  With the 1-ulp v_sqrt_f32, sdf~ = d - il * sqrt~
+// differs from the reference's value by at most (|d| + |il n|) * 2^-21 (one ulp of the root, one rounding
+// of the product, one of the difference, each side); outside twice that margin around +-truncdist the
+// branch -- and the clamped sample -- are decided without the IEEE square root and without the division
+// by truncdist.  (Premise swept over all 2^32 inputs by emf_hip_sweepFastPathPremises; distances within
+// an ulp of +-truncdist: tests/test_gpu_fast_paths.py through emf_hip_debugBandDecision.)
+template <bool FAST>
+__device__ __forceinline__ int band_decision(float d, float il, float n2, float truncdist, float& tsdfSample,
+                                             bool& bandVoxel) {
+    bandVoxel = false;
+    if (FAST) {
+        const float t = il * __builtin_amdgcn_sqrtf(n2);
+        const float approx = d - t, margin = (fabsf(d) + fabsf(t)) * 0x1p-20f;
+        if (approx - margin > truncdist) {  // sdf > truncdist: |sdf / truncdist| >= 1 -> sample +1
+            tsdfSample = 1.f;
+            return kFuse;
+        }
+        if (approx + margin < -truncdist) return kNegIfUnseen;
+    }
+    const float sdf = d - il * sqrtf(n2);
+    if (sdf >= -truncdist) {
+        tsdfSample = copysignf(fminf(1.f, fabsf(sdf / truncdist)), sdf);
+        bandVoxel = sdf < truncdist;
+        return kFuse;
+    }
+    return kNegIfUnseen;
 }
 
 // The branch of kernel_updateTSDF a voxel takes, from its shot, the depth at its pixel and
@@ -315,30 +357,7 @@ __device__ __forceinline__ int classify_shot(const IntegrateGeom& a, const Voxel
     if (s.behind) return kZeroIfUnseen;
     if (!s.inImage) return kSkip;
     if (d <= 0.f) return kZeroIfUnseen;
-#if EMF_INT_FAST
-    // Far from the surface only the SIDE of the truncation band matters: free space fuses the
-    // constant +1 with weight 1, voxels behind the band are left alone.  With the 1-ulp v_sqrt_f32,
-    // sdf~ = d - il * sqrt~ differs from the reference's value by at most (|d| + |il n|) * 2^-21
-    // (one ulp of the root, one rounding of the product, one of the difference, each side); outside
-    // twice that margin around +-truncdist the branch -- and the clamped sample -- are decided
-    // without the IEEE square root and without the division by truncdist.
-    {
-        const float t = il * __builtin_amdgcn_sqrtf(s.n2);
-        const float approx = d - t, margin = (fabsf(d) + fabsf(t)) * 0x1p-20f;
-        if (approx - margin > a.truncdist) {  // sdf > truncdist: |sdf / truncdist| >= 1 -> sample +1
-            tsdfSample = 1.f;
-            return kFuse;
-        }
-        if (approx + margin < -a.truncdist) return kNegIfUnseen;
-    }
-#endif
-    const float sdf = d - il * sqrtf(s.n2);
-    if (sdf >= -a.truncdist) {
-        tsdfSample = copysignf(fminf(1.f, fabsf(sdf / a.truncdist)), sdf);
-        bandVoxel = sdf < a.truncdist;
-        return kFuse;
-    }
-    return kNegIfUnseen;
+    return band_decision<EMF_INT_FAST != 0>(d, il, s.n2, a.truncdist, tsdfSample, bandVoxel);
 }
 
 // 16-byte volume accesses of the out-of-place sweep: streamed once, never re-read by this kernel, and

@@ -111,7 +111,8 @@ class HostWord:
 
     def __init__(self, value: int = 0):
         self.ptr = C.c_void_p()
-        _check(_hip.hipHostMalloc(C.byref(self.ptr), 64, 0), "hipHostMalloc")
+        # hipHostMallocCoherent | hipHostMallocMapped: fine-grained, so a spinning kernel sees the host's store
+        _check(_hip.hipHostMalloc(C.byref(self.ptr), 64, 0x40000000 | 0x2), "hipHostMalloc")
         self._view = C.cast(self.ptr, C.POINTER(C.c_uint32))
         self._view[0] = value
 

@@ -166,6 +166,26 @@ int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream);
 int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp);
 
+/* Diagnostics behind the two arithmetic shortcuts of the tiled integration (device_core.hpp, on by
+ * default, EMF_INT_FAST): the pixel of a voxel as round(x * rcp(z)) unless that lies next to a rounding
+ * tie, and the side of the truncation band from the hardware square root unless the distance lies
+ * next to +-truncdist.  Both rest on "v_rcp_f32 / v_sqrt_f32 are accurate to 1 ulp".
+ *   ...sweepFastPathPremises: all 2^32 float bit patterns through both instructions against the
+ *      correctly rounded double results; out4 (device, 4 x u64, zeroed by the call): [0] inputs with
+ *      2^-126 <= |z| <= 2^126 whose reciprocal is off by more than 2^-23 relative, [1] inputs
+ *      n >= 2^-126 whose square root is, [2] / [3] the largest relative errors seen (float bits);
+ *   ...debugPixelRounding: fast[i] / exact[i] = the rounded quotient num[i] / den[i] by the shortcut
+ *      and by the IEEE division -- the very device functions the kernels call;
+ *   ...debugBandDecision: likewise for the branch (bits 0..3: 2 = behind the band, 3 = fuse; bit 4:
+ *      inside the band) and the clamped sample of a voxel with depth d, pixel factor invLambda and
+ *      squared distance n2. */
+int emf_hip_sweepFastPathPremises(unsigned long long* out4_dev, emf_stream_t stream);
+int emf_hip_debugPixelRounding(const float* num_dev, const float* den_dev, int n, int32_t* fast_dev,
+                               int32_t* exact_dev, emf_stream_t stream);
+int emf_hip_debugBandDecision(const float* d_dev, const float* invLambda_dev, const float* n2_dev, int n,
+                              float truncdist, int32_t* kindFast_dev, float* sampleFast_dev,
+                              int32_t* kindExact_dev, float* sampleExact_dev, emf_stream_t stream);
+
 /* Diagnostic: one wave that stays resident on `stream` until *release != 0 (host memory the device
  * can read) or maxMilliseconds have passed.  While it runs the stream is "not ready", so a host call
  * that synchronised with the whole device cannot have returned before it ended: the tests use it

@@ -35,8 +35,9 @@ def vol(n, ch=1, dt=np.float32):
     return np.zeros((n[2], n[1], n[0]) if ch == 1 else (n[2], n[1], n[0], ch), dt)
 
 
-def kernels():
-    """Stages whose arithmetic is +,-,*,/,sqrt only: results are machine independent."""
+def kernels(fma=False, save=True):
+    """Stages whose arithmetic is +,-,*,/,sqrt only: results are machine independent.
+    fma=True: the same sequence on the oracle built with a*b+c contraction on (make_golden_fma.py)."""
     g = {"K": K.astype(f32)}
     rng = np.random.default_rng(20240917)
     for tag, n, voxel in (("cube", (32, 32, 32), 0.08), ("ragged", (30, 22, 18), 0.085)):
@@ -48,7 +49,7 @@ def kernels():
             assoc = rng.uniform(0, 1, (H, W)).astype(f32)
             assoc[rng.uniform(size=(H, W)) < 0.05] = 0  # exercises w + a == 0 on unseen voxels
             oc = rel_OC(cam, pose)
-            orc.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, K, voxel, 10 * voxel, 3.0)
+            orc.update_tsdf(depth, assoc, tsdf, wts, oc.R32, oc.t32, K, voxel, 10 * voxel, 3.0, fma=fma)
             g[f"{tag}_depth{i}"], g[f"{tag}_assoc{i}"] = depth, assoc
             g[f"{tag}_Roc{i}"], g[f"{tag}_toc{i}"] = oc.R32, oc.t32
             if i != 1:  # frame 1 is covered through frame 2 (max weight 3: the cap is reached)
@@ -56,7 +57,7 @@ def kernels():
         g[f"{tag}_res"] = np.array(n, np.int32)
         g[f"{tag}_voxel"] = f32(voxel)
         g[f"{tag}_trunc"] = f32(10 * voxel)  # the float32 the kernels receive
-        g[f"{tag}_grads"] = orc.compute_tsdf_grads(tsdf)
+        g[f"{tag}_grads"] = orc.compute_tsdf_grads(tsdf, fma=fma)
         fg = np.zeros(tsdf.shape, np.uint8)  # foreground = the lower-x half, with a ragged edge
         fg[:, :, : n[0] // 2] = 255
         fg[rng.uniform(size=tsdf.shape) < 0.1] = 0
@@ -66,27 +67,28 @@ def kernels():
             co = rel_CO(cam, pose)
             for name, mask in ((("", None), ("_fg", fg)) if j == 0 else (("", None),)):
                 ray, vert, nrm, hit, steps = orc.raycast_tsdf(tsdf, None, wts, mask, W, H, co.R32, co.t32,
-                                                              K, voxel, 10 * voxel, count_steps=True)
+                                                              K, voxel, 10 * voxel, count_steps=True, fma=fma)
                 g[f"{tag}_ray{j}{name}"], g[f"{tag}_vert{j}{name}"] = ray, vert
                 g[f"{tag}_nrm{j}{name}"], g[f"{tag}_hit{j}{name}"] = nrm, hit
                 g[f"{tag}_steps{j}{name}"] = np.int64(steps.sum())
             g[f"{tag}_Rco{j}"], g[f"{tag}_tco{j}"] = co.R32, co.t32
         # trilinear lookups of 1 and 3 channels at the points of frame 2
-        pts = orc.compute_points(g[f"{tag}_depth2"], K)
+        pts = orc.compute_points(g[f"{tag}_depth2"], K, fma=fma)
         co = rel_CO(camera_path(2), pose)
         g[f"{tag}_points"] = pts
-        g[f"{tag}_vals1"] = orc.get_volume_vals(tsdf, pts, co.R32, co.t32, voxel)
-        g[f"{tag}_vals3"] = orc.get_volume_vals(g[f"{tag}_grads"], pts, co.R32, co.t32, voxel)
+        g[f"{tag}_vals1"] = orc.get_volume_vals(tsdf, pts, co.R32, co.t32, voxel, fma=fma)
+        g[f"{tag}_vals3"] = orc.get_volume_vals(g[f"{tag}_grads"], pts, co.R32, co.t32, voxel, fma=fma)
         # fg / bg counts and probabilities
         fgbg = vol(n, 2)
         m = (render_depth(W, H, K, camera_path(2), SPHERES, noise=0, dropout=0, seed=1)[1] == 1).astype(np.uint8)
         occ = (rng.uniform(size=(H, W)) < 0.1).astype(np.uint8) * 255
         oc = rel_OC(camera_path(2), pose)
-        orc.update_fgbg_probs(m, occ, tsdf, wts, fgbg, oc.R32, oc.t32, K, voxel)
+        orc.update_fgbg_probs(m, occ, tsdf, wts, fgbg, oc.R32, oc.t32, K, voxel, fma=fma)
         g[f"{tag}_mask"], g[f"{tag}_occluded"], g[f"{tag}_fgbg"] = m, occ, fgbg
-        probs, vmask = orc.compute_fg_probs(fgbg)
+        probs, vmask = orc.compute_fg_probs(fgbg, fma=fma)
         g[f"{tag}_probs"], g[f"{tag}_vmask"] = probs, vmask
-    np.savez_compressed(OUT / "kernels_v1.npz", **g)
+    if save:
+        np.savez_compressed(OUT / "kernels_v1.npz", **g)
     return g
 
 

@@ -55,9 +55,11 @@ def test_reciprocal_verdicts_are_cached_and_can_be_had_without_waiting(dev):
 
 
 def test_spawning_and_resizing_objects_never_synchronises_the_device(dev):
-    """30 frames: object 1 is spawned from a small patch of its mask (so its volume is too small), is
-    matched against the full mask from then on and outgrows / re-centres its volume; object 2 appears at
-    frame 8.  Every process_frame() returns while the probe wave is still spinning."""
+    """30 frames: object 1 is spawned from its mask; from frame 3 on its instance mask is reported too
+    generously (dilated onto the wall behind it), still matches, and the percentile box of the matched
+    points outgrows the volume: updateObj -> ObjTSDF::resize inside the frame; object 2 appears at frame
+    8.  Every process_frame() returns while the probe wave is still spinning."""
+    from scipy.ndimage import binary_dilation
     from emfusion_amd import _lib, devmem, pipeline
     from emfusion_amd.ops import image_view
     lib = _lib.load()
@@ -66,18 +68,16 @@ def test_spawning_and_resizing_objects_never_synchronises_the_device(dev):
     synth = pipeline.SyntheticStream(Wf, Hf, np.array(prm.K, np.float32), 2, seed=0xE3F5)
     fus = pipeline.Fusion(prm, None)
     probe, word = devmem.Stream(non_blocking=True), devmem.HostWord()
-    depth0, sid0 = synth.render(0)
-    ys, xs = np.nonzero(sid0 == 1)
-    cy, cx = int(ys.mean()), int(xs.mean())
-    patch = np.zeros((Hf, Wf), np.uint8)
-    patch[cy - 6:cy + 6, cx - 6:cx + 6] = 1
-    patch &= (sid0 == 1).astype(np.uint8)
+    disc = np.hypot(*np.mgrid[-9:10, -9:10]) <= 9.0
     keep, centres, created, res_history, stalled = [], {}, [], [], []
     for f in range(30):
         depth, sid = synth.render(f)
         R, t = synth.camera_pose(f)
         d = to_dev(depth)
-        inst = [to_dev(patch if f == 0 else (sid == 1).astype(np.uint8))]
+        m1 = sid == 1
+        if f >= 3:
+            m1 = binary_dilation(m1, disc) & (sid != 2)
+        inst = [to_dev(m1.astype(np.uint8))]
         if f >= 8:
             inst.append(to_dev((sid == 2).astype(np.uint8)))
         keep += [d, inst]
@@ -96,9 +96,9 @@ def test_spawning_and_resizing_objects_never_synchronises_the_device(dev):
             centres[i] = fus.pose(i)[1]  # a resize moves the volume's centre
         res_history.append({i: fus.volume("tsdf", i).shape[0] for i in fus.object_ids()})
     assert not stalled, f"process_frame() synchronised the device in frames {stalled}"
-    assert created == [1, 2], created
+    assert created[:2] == [1, 2] and len(created) <= 3, created
     sizes1 = [r[1] for r in res_history]
-    assert sizes1[0] == 32 and max(sizes1) > 32, sizes1   # spawned small, grown inside a frame
+    assert sizes1[0] == 32 and max(sizes1) > 32, sizes1   # grown inside a frame
     assert res_history[-1][2] >= 32 and sorted(fus.visible_objects()) == [1, 2]
     assert (fus.volume("weights", 1) > 0).sum() > 500 and (fus.volume("weights", 2) > 0).sum() > 500
     fus.close()
