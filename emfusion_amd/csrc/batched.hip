@@ -305,7 +305,9 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
         if (a.farBounds)
             cut = a.farBounds[(static_cast<size_t>(m) * (2 * a.tilesY) + 2 * tyy + (wave >> 1)) * (2 * a.tilesX) +
                               2 * txx + (wave & 1)];
-        const MarchCount c = march_wave(v, valid && cut > 0.f, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
+        // (a cell with cut == 0 still sets its rays up: one whose first sample lies in the volume's outer shell is
+        // exempt from the bound -- ray_setup -- and must be marched like in the reference)
+        const MarchCount c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
         if (valid && !c.hit) {  // zeros where there is no hit
             md.raylengths[pix] = 0.f;
             float* pv = md.vertices + 3 * pix;

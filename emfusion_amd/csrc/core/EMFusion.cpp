@@ -466,6 +466,10 @@ void EMFusion::preprocessDepth(const emf_image_t& depthRaw, const emf_image_t& d
 }
 
 void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
+    // A frame that threw between the fork of the background's integration and its join (object creation,
+    // mask integration ... run in between) leaves the fork open: that integration WAS the frame's own, so
+    // it is joined here -- copies flipped once, now -- instead of being mistaken for this frame's launch.
+    if (bgInFlight) joinBackground();
     adoptReciprocals();
     depth = depthDev;
     stamp(kStart);

@@ -62,9 +62,9 @@ def _unfilter(data: np.ndarray, h: int, stride: int, bpp: int, path) -> np.ndarr
     try:
         from . import pipeline
         lib = pipeline.load()
-    except (RuntimeError, OSError):
+    except (RuntimeError, OSError, AttributeError):  # no library, or a stale one without this entry
         lib = None
-    if lib is not None:
+    if lib is not None and hasattr(lib, "emf_io_png_unfilter"):
         rc = lib.emf_io_png_unfilter(data.ctypes.data, h, stride, bpp, out.ctypes.data)
         if rc != 0:
             raise ValueError(f"{path}: emf_io_png_unfilter failed ({rc})")
