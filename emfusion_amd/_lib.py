@@ -77,6 +77,7 @@ SIGNATURES = {
     "emf_hip_voxelReciprocalBegin": [C.c_float, C.c_void_p, _STREAM],
     "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
     "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
+    "emf_hip_spinDelay": [C.c_uint32, _STREAM],
     "emf_hip_sweepFastPathPremises": [C.c_void_p, _STREAM],
     "emf_hip_debugPixelRounding": [_FP, _FP, C.c_int, _FP, _FP, _STREAM],
     "emf_hip_debugBandDecision": [_FP, _FP, _FP, C.c_int, C.c_float, _FP, _FP, _FP, _FP, _STREAM],

@@ -99,6 +99,12 @@ __global__ void k_spin_probe(const volatile uint32_t* release, unsigned long lon
     }
 }
 
+// keeps its stream busy for `ticks` of the 100 MHz wall clock (Communicator.cpp: latency model)
+__global__ void k_spin_delay(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // device-to-device stream copy, 16 bytes per lane and iteration (the bandwidth yardstick of bench.py)
 __global__ __launch_bounds__(256) void k_stream_copy(float4* __restrict__ dst,
                                                      const float4* __restrict__ src, size_t n16) {
@@ -226,6 +232,14 @@ int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, f
     *rcp = mismatches == 0 ? 1.0f / voxelSize : 0.f;
     rcp_remember(voxelSize, *rcp);
     return EMF_OK;
+}
+
+int emf_hip_spinDelay(uint32_t microseconds, emf_stream_t stream) {
+    using namespace emf_hip;
+    if (microseconds > 1000000u) return fail(EMF_E_ARG, "spinDelay: %u us", microseconds);
+    hipLaunchKernelGGL(k_spin_delay, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<unsigned long long>(microseconds) * 100ull);
+    return launch_status("spinDelay");
 }
 
 int emf_hip_spinProbe(const volatile uint32_t* release, uint32_t maxMilliseconds, emf_stream_t stream) {

@@ -58,10 +58,58 @@ public:
         ncclCheck(ncclBroadcast(dev, dev, bytes, ncclUint8, root, comm_, s.get()),
                   "ncclBroadcast");
     }
+    void groupStart() override { ncclCheck(ncclGroupStart(), "ncclGroupStart"); }
+    void groupEnd() override { ncclCheck(ncclGroupEnd(), "ncclGroupEnd"); }
 
 private:
     ncclComm_t comm_ = nullptr;
     int rank_, world_;
+};
+
+// ---- latency model (see Communicator.hpp) ------------------------------------------------------------
+class DelayedCommunicator final : public Communicator {
+public:
+    DelayedCommunicator(std::shared_ptr<Communicator> inner, int us) : inner_(std::move(inner)), us_(us) {}
+    int rank() const override { return inner_->rank(); }
+    int size() const override { return inner_->size(); }
+    void allReduceSumF32(float* dev, size_t count, Stream& s) override {
+        delay(s);
+        inner_->allReduceSumF32(dev, count, s);
+    }
+    void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
+        delay(s);
+        inner_->allReduceMinU64(dev, count, s);
+    }
+    void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
+        delay(s);
+        inner_->broadcast(dev, bytes, root, s);
+    }
+    void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows, Stream& s) override {
+        delay(s);
+        inner_->gatherRowBands(dev, bytesPerRow, bandRows, totalRows, s);
+    }
+    void groupStart() override {
+        inGroup_ = true;
+        groupDelayed_ = false;
+        inner_->groupStart();
+    }
+    void groupEnd() override {
+        inner_->groupEnd();
+        inGroup_ = false;
+    }
+    uint64_t exchangesIssued() const override { return exchanges_; }
+
+private:
+    void delay(Stream& s) {
+        if (inGroup_ && groupDelayed_) return;  // one latency per group
+        groupDelayed_ = true;
+        ++exchanges_;
+        if (us_ > 0) emfCheck(emf_hip_spinDelay(static_cast<uint32_t>(us_), s.abi()), "spinDelay");
+    }
+    std::shared_ptr<Communicator> inner_;
+    int us_;
+    bool inGroup_ = false, groupDelayed_ = false;
+    uint64_t exchanges_ = 0;
 };
 
 // ---- in-process rehearsal group (see Communicator.hpp) -----------------------------------------------
@@ -209,6 +257,11 @@ private:
 };
 
 }  // namespace
+
+std::shared_ptr<Communicator> makeDelayedCommunicator(std::shared_ptr<Communicator> inner, int microseconds) {
+    if (!inner) throw HipError("makeDelayedCommunicator: no inner communicator", EMF_E_NULL);
+    return std::make_shared<DelayedCommunicator>(std::move(inner), microseconds);
+}
 
 std::shared_ptr<Communicator> makeHostStagedCommunicator(const HostStagedCallbacks& cb) {
     return std::make_shared<HostStagedCommunicator>(cb);

@@ -32,6 +32,15 @@ public:
      */
     virtual void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows,
                                 Stream& stream) = 0;
+    /**
+     * Collectives issued between groupStart() and groupEnd() (same stream) may be fused into ONE
+     * launch by the transport (ncclGroupStart / ncclGroupEnd): the nearest-hit merge and the two band
+     * gathers of a raycast travel as one exchange.  Backends without such a notion run them one by one.
+     */
+    virtual void groupStart() {}
+    virtual void groupEnd() {}
+    /** Collectives this communicator has issued (groups count once): what a frame costs in launches. */
+    virtual uint64_t exchangesIssued() const { return 0; }
 };
 
 /** Rank that owns an object volume: round-robin by (1-based) object id. */
@@ -74,5 +83,14 @@ struct HostStagedCallbacks {
     void* user = nullptr;
 };
 std::shared_ptr<Communicator> makeHostStagedCommunicator(const HostStagedCallbacks& cb);
+
+/**
+ * Latency model for single-GPU measurements of the exchange path: every exchange of `inner` (a group
+ * counts once) is preceded, on its stream, by a kernel that keeps the stream busy for `microseconds` --
+ * what a small-message collective over xGMI costs whatever its size (20-40 us).  Around a 1-rank RCCL
+ * communicator (EMF_FORCE_SHARDED=1) this shows how much of the per-frame exchange time the schedule
+ * hides: tests/test_gpu_rehearsal.py.
+ */
+std::shared_ptr<Communicator> makeDelayedCommunicator(std::shared_ptr<Communicator> inner, int microseconds);
 
 }  // namespace emf

@@ -104,6 +104,9 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
     const char* fs = std::getenv("EMF_FORCE_SHARDED");
     sharded = comm && (world > 1 || (fs && fs[0] == '1'));
+    // EMF_HIDE_EXCHANGE=0: the last E-step's all-reduce stays on the main stream, in front of the raycast
+    const char* hx = std::getenv("EMF_HIDE_EXCHANGE");
+    hideExchange = !(hx && hx[0] == '0');
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
@@ -401,6 +404,7 @@ void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchr
 // changes (reference EMFusion.cpp:495-560, 827-863, 922-980 run inside processFrame).
 void EMFusion::quiesce() {
     main.waitForCompletion();
+    xchg.waitForCompletion();
     aux.waitForCompletion();
     lists.waitForCompletion();
     for (auto& kv : streams) kv.second.waitForCompletion();
@@ -525,7 +529,9 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
             posesCO(co);
             computeFarBounds(co);
         }
+        lastEstepOfFrame = true;  // nothing before the integrations reads its maps: its exchange may trail
         computeAssociationWeights();
+        lastEstepOfFrame = false;
         stamp(kEstep);
         integrateBackgroundAsync();  // runs beside the raycast (see there)
         joinFarBounds();
@@ -561,6 +567,8 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     }
 
     integrateBackgroundAsync();  // frame 0 (no raycast): same path, nothing to overlap with
+    joinExchange(main);          // (sharded) from here on `main` reads the frame's final association weights
+    exchangePending = false;
     integrateDepth();
     stamp(kIntegrate);
 
@@ -1213,14 +1221,31 @@ void EMFusion::estepBatched() {
     // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
     // xGMI, then every rank normalises its own maps
     launch(0, nullptr, &sv);
-    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), main);
+    // The frame's LAST E-step feeds the integrations only (the raycast needs poses and volumes, not
+    // association weights): its all-reduce and normalisation go to the `xchg` stream and run beside the
+    // raycast; the background's sweep (aux) and the objects' integration (main) wait for them there
+    // (joinExchange).  The first two feed the tracking stages right behind them and stay on `main`.
+    Stream& st = (lastEstepOfFrame && hideExchange) ? xchg : main;
+    if (&st == &xchg) xchg.waitFor(main);
+    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), st);
     std::vector<emf_image_t> maps;
     maps.push_back(bg_associationWeights.view());
     for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
-    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
-    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
-                                          main.abi()),
-             "normalizeAssociation");
+    {
+        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), st);
+        emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
+                                              st.abi()),
+                 "normalizeAssociation");
+    }
+    if (&st == &xchg) {
+        xchg.record();
+        exchangePending = true;
+    }
+}
+
+// The consumer `s` of the last E-step's normalised maps waits for the trailing exchange (device side).
+void EMFusion::joinExchange(Stream& s) {
+    if (exchangePending) s.waitOn(xchg);
 }
 
 void EMFusion::raycastBatched() {
@@ -1252,10 +1277,7 @@ void EMFusion::raycastBatched() {
             hipCheck(hipEventRecord(rayDone, main.get()), "hipEventRecord");
             rayDoneValid = true;
         }
-        if (band) {
-            comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), band, h, main);
-            comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), band, h, main);
-        }
+        bandRowsPending = band;  // gathered together with the nearest-hit keys: one exchange (compositeAcrossRanks)
     }
     stamp(kRaycast);
     compositeAndVisibility(true);
@@ -1320,6 +1342,7 @@ void EMFusion::integrateBackgroundAsync() {
         bgPrepared = false;
     }
     aux.waitFor(main);
+    joinExchange(aux);  // (sharded) the background's association weights are normalised on `xchg`
     const emf_pose_t oc = toPose(pose.inv() * background.getPose());  // reference TSDF.cpp:112
     const double vox = static_cast<double>(resHost[0]) * resHost[1] * resHost[2];
     const emf_image_t il = invLambda.view();
@@ -1498,7 +1521,16 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
         emfCheck(emf_hip_packHitKeys(nlocal, listPos.data(), oray.data(), oseg.data(),
                                      hitKeys.as<uint64_t>(), w, h, main.abi()),
                  "packHitKeys");
+        // ONE exchange per raycast: nearest-hit keys of the objects + the ranks' bands of the background's
+        // raylengths and hit mask (ncclGroup: a single launch on the transport)
+        comm->groupStart();
         comm->allReduceMinU64(hitKeys.as<uint64_t>(), params.frameSize.area(), main);
+        if (bandRowsPending) {
+            comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), bandRowsPending, h, main);
+            comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), bandRowsPending, h, main);
+        }
+        comm->groupEnd();
+        bandRowsPending = 0;
         visCountsClear = false;
         emfCheck(emf_hip_compositeFromKeys(hitKeys.as<uint64_t>(), nall, allIds.data(), nlocal,
                                            listPos.data(), oray.data(), overt.data(),

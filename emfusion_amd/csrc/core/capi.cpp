@@ -666,6 +666,22 @@ int emf_comm_create_host_staged(const emf_comm_callbacks_t* cb, emf_comm_t** out
     });
 }
 
+int emf_comm_create_delayed(emf_comm_t* inner, int microseconds, emf_comm_t** out) {
+    REQ(inner);
+    REQ(out);
+    return guarded([&] {
+        auto c = std::make_unique<emf_comm>();
+        c->impl = makeDelayedCommunicator(inner->impl, microseconds);
+        *out = c.release();
+    });
+}
+
+int emf_comm_exchanges(emf_comm_t* c, uint64_t* out) {
+    REQ(c);
+    REQ(out);
+    return guarded([&] { *out = c->impl->exchangesIssued(); });
+}
+
 int emf_comm_create_local_group(int world, emf_comm_t** out) {
     REQ(out);
     return guarded([&] {

@@ -145,6 +145,8 @@ def load() -> C.CDLL:
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
         "emf_comm_destroy": [vp],
         "emf_comm_create_local_group": [C.c_int, C.POINTER(vp)],
+        "emf_comm_create_delayed": [vp, C.c_int, C.POINTER(vp)],
+        "emf_comm_exchanges": [vp, C.POINTER(C.c_uint64)],
         "emf_comm_create_host_staged": [vp, C.POINTER(vp)],
         "emf_synth_create": [C.c_int, C.c_int, fp, C.c_int, C.c_uint64, C.c_float, C.c_float,
                              C.POINTER(vp)],
@@ -261,6 +263,21 @@ class Communicator:
         _check("emf_comm_create_host_staged", load().emf_comm_create_host_staged(C.byref(cb), C.byref(c._h)))
         c.rank, c.world = rank, world
         return c
+
+    def delayed(self, microseconds: int) -> "Communicator":
+        """Latency model around this communicator: every exchange (a grouped one counts once) first keeps its
+        stream busy for `microseconds`.  Keep `self` alive as long as the result is used."""
+        c = Communicator.__new__(Communicator)
+        c._h = C.c_void_p()
+        _check("emf_comm_create_delayed", load().emf_comm_create_delayed(self._h, int(microseconds), C.byref(c._h)))
+        c.rank, c.world, c._inner = self.rank, self.world, self
+        return c
+
+    def exchanges(self) -> int:
+        """Exchanges issued so far through a delayed() communicator (0 for the others)."""
+        n = C.c_uint64(0)
+        _check("emf_comm_exchanges", load().emf_comm_exchanges(self._h, C.byref(n)))
+        return int(n.value)
 
     @staticmethod
     def unique_id() -> bytes:

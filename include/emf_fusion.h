@@ -218,6 +218,13 @@ void emf_comm_destroy(emf_comm_t* c);
  * refuses two ranks on a device).  N emf_fusion handles driven from N threads then run the code path
  * of an N-GPU job; collectives are staged through host memory.  out: array of `world` handles. */
 int emf_comm_create_local_group(int world, emf_comm_t** out);
+/* Latency model around another communicator (which must outlive the new handle's users but may be
+ * destroyed after it): every exchange -- a grouped one counts once -- first keeps its stream busy for
+ * `microseconds`.  With a 1-rank RCCL communicator and EMF_FORCE_SHARDED=1 it measures, on one GPU, how
+ * much per-collective latency the frame's schedule hides.  emf_comm_exchanges: exchanges issued so far
+ * through a delayed communicator (0 for the others). */
+int emf_comm_create_delayed(emf_comm_t* inner, int microseconds, emf_comm_t** out);
+int emf_comm_exchanges(emf_comm_t* c, uint64_t* out);
 /* Rehearsal backend, one process per rank: collectives are staged through host memory and handed to
  * the caller's functions (0 = success), e.g. torch.distributed over gloo -- lets the N-rank job run on
  * a box with fewer than N GPUs (bench.py --comm gloo). */

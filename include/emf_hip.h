@@ -191,6 +191,9 @@ int emf_hip_debugBandDecision(const float* d_dev, const float* invLambda_dev, co
  * that synchronised with the whole device cannot have returned before it ended: the tests use it
  * to show that a frame contains no device-wide synchronisation. */
 int emf_hip_spinProbe(const volatile uint32_t* release, uint32_t maxMilliseconds, emf_stream_t stream);
+/* Diagnostic: keeps `stream` busy for `microseconds` (one sleeping wave): the latency of a small
+ * collective in single-GPU measurements of the exchange path (emf::makeDelayedCommunicator). */
+int emf_hip_spinDelay(uint32_t microseconds, emf_stream_t stream);
 
 /* Replaces emf::cuda::TSDF::getVolumeVals (TSDF.cuh:197-203, TSDF.cu:662-726).
  * vol: N^3 x channels f32 (channels 1..3, interleaved); points f32x3; vals f32 x channels.
