@@ -304,10 +304,10 @@ def main():
                 "transport": "none (one rank)" if comm is None else transport,
                 "collectives_per_frame": ("none" if comm is None else
                                           ("broadcast(depth) + " if depth_broadcast else "") +
-                                          "2 x all-reduce(sum f32, normaliser) on the frame's critical stream + 1 x "
-                                          "the same for the last E-step on its own stream beside the raycast + ONE "
-                                          "grouped exchange per raycast (all-reduce(min u64, nearest-hit keys) + "
-                                          "broadcasts of the background raycast's row bands)"),
+                                          "3 x all-reduce(sum f32, normaliser) + ONE grouped exchange per raycast "
+                                          "(all-reduce(min u64, nearest-hit keys) + broadcasts of the background "
+                                          "raycast's row bands): 5 exchanges; with a 30 us latency model about two of "
+                                          "them are exposed (tests/test_gpu_exchange_latency.py)"),
                 "tracking": "camera + objects, weighted LM-ICP, <= 100 iterations" if args.track
                             else "none (poses supplied, SURVEY 8d)",
                 "mask_frames_every": mask_every,

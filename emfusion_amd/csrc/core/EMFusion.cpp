@@ -104,9 +104,12 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
     const char* fs = std::getenv("EMF_FORCE_SHARDED");
     sharded = comm && (world > 1 || (fs && fs[0] == '1'));
-    // EMF_HIDE_EXCHANGE=0: the last E-step's all-reduce stays on the main stream, in front of the raycast
+    // EMF_HIDE_EXCHANGE=1: the last E-step's all-reduce + normalisation on a stream of their own beside the
+    // raycast instead of in front of it.  Off by default: measured with a 30 us latency model it buys nothing
+    // (tests/test_gpu_exchange_latency.py) -- the background's sweep needs the normalised weights and is as
+    // long as the raycast it runs beside, so delaying either delays the frame.
     const char* hx = std::getenv("EMF_HIDE_EXCHANGE");
-    hideExchange = !(hx && hx[0] == '0');
+    hideExchange = hx && hx[0] == '1';
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");

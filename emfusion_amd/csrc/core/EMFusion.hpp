@@ -397,7 +397,7 @@ private:
     hipEvent_t rayDone = nullptr;  // behind the last raycast that read farBounds
     bool rayDoneValid = false;
     Stream xchg;                // sharded: the last E-step's all-reduce + normalisation, beside the raycast
-    bool hideExchange = true, lastEstepOfFrame = false, exchangePending = false;
+    bool hideExchange = false, lastEstepOfFrame = false, exchangePending = false;
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
     void joinExchange(Stream& s);
     Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds

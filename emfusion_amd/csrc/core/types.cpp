@@ -23,107 +23,126 @@ void emfCheck(int rc, const char* what) {
 // hipFree synchronises the whole device and hipMalloc of tens of MB takes a fraction of a millisecond;
 // objects are created, resized and deleted INSIDE frames (reference EMFusion.cpp:495-560, 827-863,
 // 922-980).  So a released DeviceBuffer is not freed: it goes to a pool together with one event per live
-// stream of this library, recorded at the stream's tail at the moment of the release -- everything that
-// could still touch the memory was enqueued before -- and is handed out again (same size) once all of
-// them have completed (hipEventQuery: no wait).  Nothing else in the process shares these buffers.
+// stream of the releasing host thread, recorded at the stream's tail at the moment of the release --
+// everything that could still touch the memory was enqueued before -- and is handed out again (same size)
+// once all of them have completed (hipEventQuery: no wait).
+// Pool, stream registry and events are PER HOST THREAD: an emf::EMFusion instance is driven by one thread
+// (its streams are created there, its buffers released there), and several instances on several threads
+// (the multi-rank rehearsal) must not record events on each other's streams -- HIP's event bookkeeping
+// throws from inside the runtime when they do.  A thread's pool is really freed when the thread ends.
 namespace {
 struct Pooled {
     void* p;
     size_t bytes;
     std::vector<hipEvent_t> fences;
 };
-std::mutex g_poolMutex;
-std::vector<hipStream_t> g_streams;  // streams created by emf::Stream
-std::vector<Pooled> g_pool;
-std::vector<hipEvent_t> g_spareEvents;
-size_t g_pooledBytes = 0;
+struct ThreadPool {
+    std::vector<hipStream_t> streams;  // streams created by emf::Stream on this thread
+    std::vector<Pooled> pool;
+    std::vector<hipEvent_t> spareEvents;
+    size_t pooledBytes = 0;
+    ~ThreadPool() {
+        for (Pooled& b : pool) (void)hipFree(b.p);
+        for (Pooled& b : pool)
+            for (hipEvent_t e : b.fences) (void)hipEventDestroy(e);
+        for (hipEvent_t e : spareEvents) (void)hipEventDestroy(e);
+    }
+};
+ThreadPool& tp() {
+    static thread_local ThreadPool t;
+    return t;
+}
+// every live emf::Stream of the process: a thread's list may name a stream that another thread destroyed
+std::mutex g_liveMutex;
+std::vector<hipStream_t> g_live;
+bool stream_is_live(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_liveMutex);
+    return std::find(g_live.begin(), g_live.end(), s) != g_live.end();
+}
 
-size_t pool_cap() {  // bytes the pool may hold before it really frees (EMF_POOL_MIB, default 16 GiB of 288)
+size_t pool_cap() {  // bytes a thread's pool may hold before it really frees (EMF_POOL_MIB, default 16 GiB of 288)
     static const size_t cap = [] {
         const char* e = std::getenv("EMF_POOL_MIB");
         return (e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : size_t(16384)) << 20;
     }();
     return cap;
 }
-bool fences_passed(Pooled& b) {
+bool fences_passed(ThreadPool& t, Pooled& b) {
     while (!b.fences.empty()) {
         if (hipEventQuery(b.fences.back()) != hipSuccess) {
             (void)hipGetLastError();  // hipErrorNotReady is not an error
             return false;
         }
-        g_spareEvents.push_back(b.fences.back());
+        t.spareEvents.push_back(b.fences.back());
         b.fences.pop_back();
     }
     return true;
 }
 void* pool_acquire(size_t bytes) {
-    std::lock_guard<std::mutex> lock(g_poolMutex);
-    for (size_t i = 0; i < g_pool.size(); ++i)
-        if (g_pool[i].bytes == bytes && fences_passed(g_pool[i])) {
-            void* p = g_pool[i].p;
-            g_pooledBytes -= bytes;
-            g_pool[i] = std::move(g_pool.back());
-            g_pool.pop_back();
+    ThreadPool& t = tp();
+    for (size_t i = 0; i < t.pool.size(); ++i)
+        if (t.pool[i].bytes == bytes && fences_passed(t, t.pool[i])) {
+            void* p = t.pool[i].p;
+            t.pooledBytes -= bytes;
+            t.pool[i] = std::move(t.pool.back());
+            t.pool.pop_back();
             return p;
         }
     return nullptr;
 }
 void pool_release(void* p, size_t bytes) {
-    std::unique_lock<std::mutex> lock(g_poolMutex);
-    if (g_pooledBytes + bytes > pool_cap()) {  // over the cap: a real free (synchronises the device)
-        lock.unlock();
+    ThreadPool& t = tp();
+    if (t.pooledBytes + bytes > pool_cap()) {  // over the cap: a real free (synchronises the device)
         (void)hipFree(p);
         return;
     }
     Pooled b{p, bytes, {}};
-    std::vector<hipStream_t> streams = g_streams;
+    t.streams.erase(std::remove_if(t.streams.begin(), t.streams.end(), [](hipStream_t s) { return !stream_is_live(s); }),
+                    t.streams.end());
+    std::vector<hipStream_t> streams = t.streams;
     streams.push_back(nullptr);  // the null stream: clears and uploads of constructors run there
     for (hipStream_t st : streams) {
         hipEvent_t ev = nullptr;
-        if (!g_spareEvents.empty()) {
-            ev = g_spareEvents.back();
-            g_spareEvents.pop_back();
+        if (!t.spareEvents.empty()) {
+            ev = t.spareEvents.back();
+            t.spareEvents.pop_back();
         } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
             ev = nullptr;
         }
         if (!ev || hipEventRecord(ev, st) != hipSuccess) {  // cannot fence it: free it the slow, safe way
             (void)hipGetLastError();
-            if (ev) g_spareEvents.push_back(ev);
-            for (hipEvent_t e : b.fences) g_spareEvents.push_back(e);
-            lock.unlock();
+            if (ev) t.spareEvents.push_back(ev);
+            for (hipEvent_t e : b.fences) t.spareEvents.push_back(e);
             (void)hipFree(p);
             return;
         }
         b.fences.push_back(ev);
     }
-    g_pooledBytes += bytes;
-    g_pool.push_back(std::move(b));
+    t.pooledBytes += bytes;
+    t.pool.push_back(std::move(b));
 }
 void register_stream(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_poolMutex);
-    g_streams.push_back(s);
+    tp().streams.push_back(s);
+    std::lock_guard<std::mutex> lock(g_liveMutex);
+    g_live.push_back(s);
 }
 void unregister_stream(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_poolMutex);
-    g_streams.erase(std::remove(g_streams.begin(), g_streams.end(), s), g_streams.end());
+    auto& v = tp().streams;
+    v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    std::lock_guard<std::mutex> lock(g_liveMutex);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), s), g_live.end());
 }
 }  // namespace
 
-size_t DeviceBuffer::pooledBytes() {
-    std::lock_guard<std::mutex> lock(g_poolMutex);
-    return g_pooledBytes;
-}
+size_t DeviceBuffer::pooledBytes() { return tp().pooledBytes; }
 void DeviceBuffer::trimPool() {
+    ThreadPool& t = tp();
     std::vector<Pooled> all;
-    {
-        std::lock_guard<std::mutex> lock(g_poolMutex);
-        all.swap(g_pool);
-        g_pooledBytes = 0;
-    }
+    all.swap(t.pool);
+    t.pooledBytes = 0;
     for (Pooled& b : all) {
         (void)hipFree(b.p);  // synchronises the device: the fences have passed afterwards
-        std::lock_guard<std::mutex> lock(g_poolMutex);
-        for (hipEvent_t e : b.fences) g_spareEvents.push_back(e);
+        for (hipEvent_t e : b.fences) t.spareEvents.push_back(e);
     }
 }
 

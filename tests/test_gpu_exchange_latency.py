@@ -5,22 +5,33 @@ through a real 1-rank RCCL communicator (EMF_FORCE_SHARDED=1) wrapped in the lat
 
 Per frame the schedule issues FIVE exchanges: the depth broadcast, one all-reduce(sum) of the object
 normaliser partials per E-step (three), and ONE grouped exchange per raycast (all-reduce(min) of the
-nearest-hit keys + the background raycast's row bands).  The last E-step's all-reduce feeds the
-integrations only and runs on its own stream beside the raycast: four of the five are exposed."""
+nearest-hit keys + the background raycast's row bands).  Measured with 30 us each: the frame grows by about
+two of them (0.58 -> 0.64 ms) -- the grouped exchange behind the raycast is covered by the background's
+sweep on the second stream, which is as long as the raycast + composite chain.  Moving the last E-step's
+all-reduce to a stream of its own beside the raycast (EMF_HIDE_EXCHANGE=1) buys nothing: the background's
+sweep needs the normalised weights and is the other half of the critical path; so it is off by default."""
+import json
 import os
+import subprocess
+import sys
 import time
+from pathlib import Path
 
 import numpy as np
 import pytest
 
-from tests.parity_util import to_dev
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from tests.parity_util import to_dev  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 W, H = 640, 480
 LATENCY_US = 30
 
 
-def _run(delay_us, hide, frames=50, warm=10):
+def _run(delay_us, hide, frames=90, warm=10):
     from emfusion_amd import pipeline
     from emfusion_amd.ops import image_view
     os.environ["EMF_FORCE_SHARDED"] = "1"
@@ -54,8 +65,10 @@ def _run(delay_us, hide, frames=50, warm=10):
         fus.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / (frames - warm)
         per_frame = (comm.exchanges() - x0) / (frames - warm)
-        out = dict(ms=ms, exchanges=per_frame, ray=fus.image("raylengths"), seg=fus.image("segmentation"),
-                   assoc=fus.image("bg_assoc"), tsdf_digest=hash(fus.volume("tsdf", 1).tobytes()))
+        import xxhash
+        out = dict(ms=ms, exchanges=per_frame,
+                   digest=[xxhash.xxh3_128(a.tobytes()).hexdigest() for a in
+                           (fus.image("raylengths"), fus.image("segmentation"), fus.image("bg_assoc"), fus.volume("tsdf", 1))])
         fus.close()
         comm.close()
         base.close()
@@ -66,20 +79,29 @@ def _run(delay_us, hide, frames=50, warm=10):
         os.environ.pop("EMF_HIDE_EXCHANGE", None)
 
 
-def test_five_exchanges_per_frame_four_of_them_exposed(dev):
-    free = _run(0, True)
-    slow = _run(LATENCY_US, True)
-    slow_unhidden = _run(LATENCY_US, False)
+def test_five_exchanges_per_frame_and_what_they_cost(dev):
+    # a process of its own: which hardware queue a stream lands on depends on how many streams the process
+    # has created before, and two of the frame's streams on one queue serialise the frame
+    run = subprocess.run([sys.executable, str(Path(__file__).resolve())], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    res = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("LATENCY_RESULT ")][-1][15:])
+    free, slow, slow_unhidden = res["free"], res["hidden"], res["unhidden"]
     for r in (free, slow, slow_unhidden):
         assert r["exchanges"] == 5.0, r["exchanges"]
     # the latency model and the placement of the last exchange change no result
-    for k in ("ray", "seg", "assoc"):
-        assert free[k].tobytes() == slow[k].tobytes() == slow_unhidden[k].tobytes(), k
-    assert free["tsdf_digest"] == slow["tsdf_digest"] == slow_unhidden["tsdf_digest"]
+    assert free["digest"] == slow["digest"] == slow_unhidden["digest"]
     added, added_unhidden = slow["ms"] - free["ms"], slow_unhidden["ms"] - free["ms"]
-    print(f"frame {free['ms']:.3f} ms; +{added * 1e3:.0f} us with {LATENCY_US} us per exchange "
-          f"({100 * added / free['ms']:.0f} %), +{added_unhidden * 1e3:.0f} us with the last all-reduce in "
-          "front of the raycast")
-    # four exposed exchanges (+ a launch each); the fifth hides behind the raycast
-    assert added < 4.6 * LATENCY_US * 1e-3, (free["ms"], slow["ms"])
-    assert added_unhidden > added + 0.4 * LATENCY_US * 1e-3, (added, added_unhidden)
+    print(f"frame {free['ms']:.3f} ms; +{added_unhidden * 1e3:.0f} us with {LATENCY_US} us per exchange "
+          f"({100 * added_unhidden / free['ms']:.0f} %), +{added * 1e3:.0f} us with the last all-reduce on a "
+          "stream of its own beside the raycast")
+    # not all five are exposed (the raycast's grouped exchange is covered by the sweep on the second stream)
+    assert added_unhidden < 3.7 * LATENCY_US * 1e-3, (free["ms"], slow_unhidden["ms"])
+    assert added < 4.2 * LATENCY_US * 1e-3, (free["ms"], slow["ms"])
+
+
+if __name__ == "__main__":
+    from emfusion_amd import devmem
+    devmem.set_device(0)
+    out = dict(free=_run(0, False), hidden=_run(LATENCY_US, True), unhidden=_run(LATENCY_US, False))
+    print("LATENCY_RESULT " + json.dumps(out), flush=True)
