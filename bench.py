@@ -75,10 +75,12 @@ def parse_args():
     ap.add_argument("--no-depth-broadcast", action="store_true",
                     help="multi-GPU: every rank already holds the frame; skip the per-frame "
                          "ncclBroadcast of the depth image from rank 0")
-    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
+    ap.add_argument("--comm", choices=["rccl", "gloo", "peer"], default="rccl",
                     help="rccl: the product's transport (one GPU per rank).  gloo: rehearsal -- the "
                          "collectives are staged through host memory and carried by torch.distributed, "
-                         "so N ranks can share fewer than N GPUs; not a measurement")
+                         "so N ranks can share fewer than N GPUs; not a measurement.  peer: the direct peer-write "
+                         "exchanges (hipIpc-mapped receive buffers, three small launches per exchange, no library "
+                         "collective; handles travel over gloo) -- works with ranks sharing a GPU too")
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the cross-rank exchange path (RCCL all-reduces) even with one "
                          "rank, to exercise the multi-GPU code on a single GPU")
@@ -140,6 +142,10 @@ def main():
         if args.comm == "gloo" and dist is not None:
             comm = pipeline.Communicator.host_staged(dist)
             transport = "gloo (rehearsal, --comm gloo)"
+        elif args.comm == "peer" and dist is not None:
+            comm = pipeline.Communicator.peer(dist, W * H * 8)
+            transport = "peer-write (direct stores into hipIpc-mapped peer buffers, --comm peer)" + \
+                ("" if devmem.device_count() >= world else "; ranks share a GPU: rehearsal")
         else:
             err = None
             try:
@@ -289,7 +295,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: collectives over gloo, ranks may share a GPU -- not a "
-                                   "measurement)" if comm is not None and transport != "rccl" else ""),
+                                   "measurement)" if comm is not None and (transport.startswith("gloo") or
+                                                                             "rehearsal" in transport) else ""),
             "config": {
                 "workload": (f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj_total} obj "
                              f"{args.obj_res}^3, {W}x{H}, full EM association + weighted fusion"

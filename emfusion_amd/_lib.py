@@ -78,6 +78,12 @@ SIGNATURES = {
     "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
     "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
     "emf_hip_spinDelay": [C.c_uint32, _STREAM],
+    "emf_hip_peerBufferBytes": [C.c_int, C.c_size_t],
+    "emf_hip_peerScatter": [C.c_void_p, _FP, C.c_size_t, C.c_size_t, C.c_uint32, _STREAM],
+    "emf_hip_peerSignalWait": [C.c_void_p, C.c_uint32, C.c_uint32, _STREAM],
+    "emf_hip_peerReduceSumF32": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
+    "emf_hip_peerReduceMinU64": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
+    "emf_hip_peerCopyFromSlot": [C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, _FP, C.c_size_t, _STREAM],
     "emf_hip_sweepFastPathPremises": [C.c_void_p, _STREAM],
     "emf_hip_debugPixelRounding": [_FP, _FP, C.c_int, _FP, _FP, _STREAM],
     "emf_hip_debugBandDecision": [_FP, _FP, _FP, C.c_int, C.c_float, _FP, _FP, _FP, _FP, _STREAM],
@@ -218,6 +224,7 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.emf_hip_signMapBytes.restype = C.c_size_t
     lib.emf_hip_raycastFarBoundBytes.restype = C.c_size_t
     lib.emf_hip_relevantTileBytes.restype = C.c_size_t
+    lib.emf_hip_peerBufferBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     return lib

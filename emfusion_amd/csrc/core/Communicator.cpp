@@ -66,6 +66,123 @@ private:
     int rank_, world_;
 };
 
+// ---- direct peer-write exchanges (see Communicator.hpp, csrc/peer_exchange.hip) -----------------------
+// What one rank owns: its receive buffer, its flag words (device memory the peers write into) and an error
+// word in host memory the waiting kernel can reach.
+struct PeerMemory {
+    void* rx = nullptr;
+    uint32_t* flags = nullptr;
+    uint32_t* error = nullptr;  // pinned host word
+    size_t rxBytes = 0;
+    PeerMemory(int world, size_t slotBytes) : rxBytes(emf_hip_peerBufferBytes(world, slotBytes)) {
+        // fine-grained: stores of another device must become visible without a cache flush of this one
+        if (hipExtMallocWithFlags(&rx, rxBytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            hipCheck(hipMalloc(&rx, rxBytes), "hipMalloc(peer receive buffer)");
+        }
+        void* f = nullptr;
+        if (hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            hipCheck(hipMalloc(&f, 4096), "hipMalloc(peer flags)");
+        }
+        flags = static_cast<uint32_t*>(f);
+        hipCheck(hipMemset(flags, 0, 4096), "hipMemset(peer flags)");
+        hipCheck(hipHostMalloc(reinterpret_cast<void**>(&error), 64, hipHostMallocCoherent | hipHostMallocMapped),
+                 "hipHostMalloc(peer error word)");
+        *error = 0;
+        hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    ~PeerMemory() {
+        if (rx) (void)hipFree(rx);
+        if (flags) (void)hipFree(flags);
+        if (error) (void)hipHostFree(error);
+    }
+    PeerMemory(const PeerMemory&) = delete;
+    PeerMemory& operator=(const PeerMemory&) = delete;
+};
+
+class PeerCommunicator final : public Communicator {
+public:
+    // `own` is this rank's memory; `keep` holds whatever else must outlive the communicator (the group's
+    // memories in the in-process form).  slots / flags of all ranks are already addressable from here.
+    PeerCommunicator(int rank, int world, size_t slotBytes, std::shared_ptr<PeerMemory> own,
+                     std::vector<std::shared_ptr<PeerMemory>> keep, const std::vector<void*>& slots,
+                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped)
+        : rank_(rank), world_(world), own_(std::move(own)), keep_(std::move(keep)), ipcMapped_(std::move(ipcMapped)) {
+        g_.rank = rank;
+        g_.world = world;
+        g_.slotBytes = slotBytes;
+        g_.error = own_->error;
+        for (int p = 0; p < world; ++p) {
+            g_.slots[p] = slots[p];
+            g_.flags[p] = flags[p];
+        }
+    }
+    ~PeerCommunicator() override {
+        (void)hipDeviceSynchronize();
+        for (void* p : ipcMapped_) (void)hipIpcCloseMemHandle(p);
+    }
+    int rank() const override { return rank_; }
+    int size() const override { return world_; }
+
+    void allReduceSumF32(float* dev, size_t count, Stream& s) override {
+        const uint32_t seq = begin(count * sizeof(float));
+        emfCheck(emf_hip_peerScatter(&g_, dev, count * sizeof(float), 0, seq, s.abi()), "peerScatter");
+        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
+        emfCheck(emf_hip_peerReduceSumF32(&g_, seq, count, dev, s.abi()), "peerReduceSumF32");
+    }
+    void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
+        const uint32_t seq = begin(count * sizeof(uint64_t));
+        emfCheck(emf_hip_peerScatter(&g_, dev, count * sizeof(uint64_t), 0, seq, s.abi()), "peerScatter");
+        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
+        emfCheck(emf_hip_peerReduceMinU64(&g_, seq, count, dev, s.abi()), "peerReduceMinU64");
+    }
+    void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
+        const uint32_t seq = begin(bytes);
+        if (rank_ == root) emfCheck(emf_hip_peerScatter(&g_, dev, bytes, 0, seq, s.abi()), "peerScatter");
+        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
+        if (rank_ != root) emfCheck(emf_hip_peerCopyFromSlot(&g_, seq, root, 0, dev, bytes, s.abi()), "peerCopyFromSlot");
+    }
+    void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows, Stream& s) override {
+        const uint32_t seq = begin(bytesPerRow * static_cast<size_t>(totalRows));
+        auto band = [&](int r, size_t& off, size_t& bytes) {
+            const int r0 = r * bandRows, n = std::min(bandRows, totalRows - r0);
+            off = static_cast<size_t>(std::max(r0, 0)) * bytesPerRow;
+            bytes = n > 0 ? static_cast<size_t>(n) * bytesPerRow : 0;
+        };
+        size_t off, bytes;
+        band(rank_, off, bytes);
+        if (bytes)
+            emfCheck(emf_hip_peerScatter(&g_, static_cast<char*>(dev) + off, bytes, off, seq, s.abi()), "peerScatter");
+        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
+        for (int r = 0; r < world_; ++r) {
+            band(r, off, bytes);
+            if (r != rank_ && bytes)
+                emfCheck(emf_hip_peerCopyFromSlot(&g_, seq, r, off, static_cast<char*>(dev) + off, bytes, s.abi()),
+                         "peerCopyFromSlot");
+        }
+    }
+    uint64_t exchangesIssued() const override { return seq_; }
+
+private:
+    static constexpr uint32_t kTimeoutMs = 5000;
+    uint32_t begin(size_t bytes) {
+        if (*own_->error)
+            throw HipError("peer exchange " + std::to_string(*own_->error) + ": a peer's flag did not arrive within " +
+                           std::to_string(kTimeoutMs) + " ms (ranks disagree about the sequence of exchanges?)", EMF_E_ARG);
+        if (bytes > g_.slotBytes)
+            throw HipError("peer exchange: message of " + std::to_string(bytes) + " bytes exceeds the slot size " +
+                           std::to_string(g_.slotBytes), EMF_E_LIMIT);
+        return ++seq_;
+    }
+    int rank_, world_;
+    std::shared_ptr<PeerMemory> own_;
+    std::vector<std::shared_ptr<PeerMemory>> keep_;
+    std::vector<void*> ipcMapped_;
+    emf_peer_t g_{};
+    uint32_t seq_ = 0;
+};
+
 // ---- latency model (see Communicator.hpp) ------------------------------------------------------------
 class DelayedCommunicator final : public Communicator {
 public:
@@ -257,6 +374,59 @@ private:
 };
 
 }  // namespace
+
+std::vector<std::shared_ptr<Communicator>> makePeerCommunicatorsLocal(int worldSize, size_t slotBytes) {
+    if (worldSize < 1 || worldSize > EMF_MAX_PEERS) throw HipError("makePeerCommunicatorsLocal: world size", EMF_E_LIMIT);
+    slotBytes = (slotBytes + 15) / 16 * 16;
+    std::vector<std::shared_ptr<PeerMemory>> mem;
+    std::vector<void*> slots;
+    std::vector<uint32_t*> flags;
+    for (int r = 0; r < worldSize; ++r) {
+        mem.push_back(std::make_shared<PeerMemory>(worldSize, slotBytes));
+        slots.push_back(mem.back()->rx);
+        flags.push_back(mem.back()->flags);
+    }
+    std::vector<std::shared_ptr<Communicator>> out;
+    for (int r = 0; r < worldSize; ++r)
+        out.push_back(std::make_shared<PeerCommunicator>(r, worldSize, slotBytes, mem[r], mem, slots, flags,
+                                                         std::vector<void*>()));
+    return out;
+}
+
+std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, size_t slotBytes) {
+    if (boot.world < 1 || boot.world > EMF_MAX_PEERS || boot.rank < 0 || boot.rank >= boot.world || !boot.allGather)
+        throw HipError("makePeerCommunicator: bad bootstrap", EMF_E_ARG);
+    slotBytes = (slotBytes + 15) / 16 * 16;
+    auto own = std::make_shared<PeerMemory>(boot.world, slotBytes);
+    struct Handles {
+        hipIpcMemHandle_t rx, flags;
+    };
+    static_assert(sizeof(Handles) == 128, "two 64-byte hipIpcMemHandle_t");
+    Handles mine;
+    hipCheck(hipIpcGetMemHandle(&mine.rx, own->rx), "hipIpcGetMemHandle(receive buffer)");
+    hipCheck(hipIpcGetMemHandle(&mine.flags, own->flags), "hipIpcGetMemHandle(flags)");
+    std::vector<Handles> all(boot.world);
+    if (boot.allGather(boot.user, &mine, sizeof(mine), all.data()) != 0)
+        throw HipError("makePeerCommunicator: the bootstrap all-gather failed", EMF_E_ARG);
+    std::vector<void*> slots(boot.world), mapped;
+    std::vector<uint32_t*> flags(boot.world);
+    for (int p = 0; p < boot.world; ++p) {
+        if (p == boot.rank) {
+            slots[p] = own->rx;
+            flags[p] = own->flags;
+            continue;
+        }
+        void *a = nullptr, *b = nullptr;
+        hipCheck(hipIpcOpenMemHandle(&a, all[p].rx, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(receive buffer)");
+        hipCheck(hipIpcOpenMemHandle(&b, all[p].flags, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(flags)");
+        slots[p] = a;
+        flags[p] = static_cast<uint32_t*>(b);
+        mapped.push_back(a);
+        mapped.push_back(b);
+    }
+    return std::make_shared<PeerCommunicator>(boot.rank, boot.world, slotBytes, own,
+                                              std::vector<std::shared_ptr<PeerMemory>>(), slots, flags, mapped);
+}
 
 std::shared_ptr<Communicator> makeDelayedCommunicator(std::shared_ptr<Communicator> inner, int microseconds) {
     if (!inner) throw HipError("makeDelayedCommunicator: no inner communicator", EMF_E_NULL);

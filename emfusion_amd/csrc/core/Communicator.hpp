@@ -85,6 +85,29 @@ struct HostStagedCallbacks {
 std::shared_ptr<Communicator> makeHostStagedCommunicator(const HostStagedCallbacks& cb);
 
 /**
+ * Direct peer-write exchanges (SURVEY.md section 8e "Collective implementation"; kernels and protocol in
+ * csrc/peer_exchange.hip): every rank stores its contribution into a slot of every peer's receive buffer,
+ * raises a flag there, waits for the peers' flags and reduces the slots locally in rank order -- three small
+ * launches per exchange on the caller's stream, no library collective, the same bits on every rank.
+ * `slotBytes` bounds one message (the largest of the path: W*H*8 for the hit keys; multiple of 16).
+ * Messages must be multiples of 16 bytes (every image of the path at the usual sizes is).
+ *   makePeerCommunicatorsLocal : `worldSize` ranks of ONE process sharing a GPU (threads), plain pointers;
+ *   makePeerCommunicator       : one process per rank; the receive buffers are mapped into every peer with
+ *                                hipIpcGetMemHandle / hipIpcOpenMemHandle, the 128 handle bytes per rank
+ *                                travel through the caller's all-gather (e.g. torch.distributed over gloo).
+ * UNTESTED ON xGMI: no multi-GPU box exists in the build environment.  Exercised with 1 rank, with 2-4 ranks
+ * on threads and with 2-3 processes over hipIpc, all on one GPU (tests/test_gpu_peer_exchange.py).
+ */
+std::vector<std::shared_ptr<Communicator>> makePeerCommunicatorsLocal(int worldSize, size_t slotBytes);
+struct PeerBootstrap {
+    int rank = 0, world = 1;
+    /** all[r * bytes .. (r + 1) * bytes) := rank r's `mine`; 0 on success. */
+    int (*allGather)(void* user, const void* mine, size_t bytes, void* all) = nullptr;
+    void* user = nullptr;
+};
+std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, size_t slotBytes);
+
+/**
  * Latency model for single-GPU measurements of the exchange path: every exchange of `inner` (a group
  * counts once) is preceded, on its stream, by a kernel that keeps the stream busy for `microseconds` --
  * what a small-message collective over xGMI costs whatever its size (20-40 us).  Around a 1-rank RCCL

@@ -666,6 +666,64 @@ int emf_comm_create_host_staged(const emf_comm_callbacks_t* cb, emf_comm_t** out
     });
 }
 
+int emf_comm_create_peer_local_group(int world, size_t slot_bytes, emf_comm_t** out) {
+    REQ(out);
+    return guarded([&] {
+        auto group = makePeerCommunicatorsLocal(world, slot_bytes);
+        for (int r = 0; r < world; ++r) {
+            auto c = std::make_unique<emf_comm>();
+            c->impl = group[r];
+            out[r] = c.release();
+        }
+    });
+}
+
+int emf_comm_create_peer(int rank, int world, size_t slot_bytes, emf_allgather_fn all_gather, void* user,
+                         emf_comm_t** out) {
+    REQ(all_gather);
+    REQ(out);
+    return guarded([&] {
+        PeerBootstrap b;
+        b.rank = rank;
+        b.world = world;
+        b.allGather = all_gather;
+        b.user = user;
+        auto c = std::make_unique<emf_comm>();
+        c->impl = makePeerCommunicator(b, slot_bytes);
+        *out = c.release();
+    });
+}
+
+int emf_comm_all_reduce_sum_f32(emf_comm_t* c, float* dev, size_t count, void* stream) {
+    REQ(c);
+    return guarded([&] {
+        Stream s(static_cast<hipStream_t>(stream));
+        c->impl->allReduceSumF32(dev, count, s);
+    });
+}
+int emf_comm_all_reduce_min_u64(emf_comm_t* c, uint64_t* dev, size_t count, void* stream) {
+    REQ(c);
+    return guarded([&] {
+        Stream s(static_cast<hipStream_t>(stream));
+        c->impl->allReduceMinU64(dev, count, s);
+    });
+}
+int emf_comm_broadcast(emf_comm_t* c, void* dev, size_t bytes, int root, void* stream) {
+    REQ(c);
+    return guarded([&] {
+        Stream s(static_cast<hipStream_t>(stream));
+        c->impl->broadcast(dev, bytes, root, s);
+    });
+}
+int emf_comm_gather_row_bands(emf_comm_t* c, void* dev, size_t bytes_per_row, int band_rows, int total_rows,
+                              void* stream) {
+    REQ(c);
+    return guarded([&] {
+        Stream s(static_cast<hipStream_t>(stream));
+        c->impl->gatherRowBands(dev, bytes_per_row, band_rows, total_rows, s);
+    });
+}
+
 int emf_comm_create_delayed(emf_comm_t* inner, int microseconds, emf_comm_t** out) {
     REQ(inner);
     REQ(out);

@@ -146,6 +146,12 @@ def load() -> C.CDLL:
         "emf_comm_destroy": [vp],
         "emf_comm_create_local_group": [C.c_int, C.POINTER(vp)],
         "emf_comm_create_delayed": [vp, C.c_int, C.POINTER(vp)],
+        "emf_comm_all_reduce_sum_f32": [vp, vp, C.c_size_t, vp],
+        "emf_comm_all_reduce_min_u64": [vp, vp, C.c_size_t, vp],
+        "emf_comm_broadcast": [vp, vp, C.c_size_t, C.c_int, vp],
+        "emf_comm_gather_row_bands": [vp, vp, C.c_size_t, C.c_int, C.c_int, vp],
+        "emf_comm_create_peer_local_group": [C.c_int, C.c_size_t, C.POINTER(vp)],
+        "emf_comm_create_peer": [C.c_int, C.c_int, C.c_size_t, vp, vp, C.POINTER(vp)],
         "emf_comm_exchanges": [vp, C.POINTER(C.c_uint64)],
         "emf_comm_create_host_staged": [vp, C.POINTER(vp)],
         "emf_synth_create": [C.c_int, C.c_int, fp, C.c_int, C.c_uint64, C.c_float, C.c_float,
@@ -206,11 +212,16 @@ class Communicator:
         self.rank, self.world = rank, world
 
     @classmethod
-    def local_group(cls, world: int):
+    def local_group(cls, world: int, transport: str = "host", max_bytes: int = 0):
         """`world` communicators of THIS process for `world` Fusion objects on `world` threads sharing one
-        GPU (rehearsal of the multi-GPU code path; collectives are staged through host memory)."""
+        GPU (rehearsal of the multi-GPU code path).  transport "host": collectives staged through host
+        memory; "peer": the direct peer-write exchanges (max_bytes = the largest message, W * H * 8)."""
         handles = (C.c_void_p * world)()
-        _check("emf_comm_create_local_group", load().emf_comm_create_local_group(world, handles))
+        if transport == "peer":
+            _check("emf_comm_create_peer_local_group",
+                   load().emf_comm_create_peer_local_group(world, int(max_bytes), handles))
+        else:
+            _check("emf_comm_create_local_group", load().emf_comm_create_local_group(world, handles))
         out = []
         for r in range(world):
             c = cls.__new__(cls)
@@ -263,6 +274,51 @@ class Communicator:
         _check("emf_comm_create_host_staged", load().emf_comm_create_host_staged(C.byref(cb), C.byref(c._h)))
         c.rank, c.world = rank, world
         return c
+
+    @classmethod
+    def peer(cls, dist, max_bytes: int):
+        """One process per rank, direct peer-write exchanges: the ranks' receive buffers are mapped into each
+        other with hipIpc*, the handles travel through the given torch.distributed module (gloo)."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def gather(user, mine, nbytes, allp):
+            try:
+                t = torch.from_numpy(np.ctypeslib.as_array(C.cast(mine, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy())
+                outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t)
+                dst = np.ctypeslib.as_array(C.cast(allp, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                for r, o in enumerate(outs):
+                    dst[r * nbytes:(r + 1) * nbytes] = o.numpy()
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the C++ exception
+                print("peer bootstrap all-gather failed:", repr(e), flush=True)
+                return 1
+        f_ag = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        c = cls.__new__(cls)
+        c._keep = (f_ag(gather),)
+        c._h = C.c_void_p()
+        _check("emf_comm_create_peer", load().emf_comm_create_peer(rank, world, int(max_bytes),
+                                                                   C.cast(c._keep[0], C.c_void_p), None, C.byref(c._h)))
+        c.rank, c.world = rank, world
+        return c
+
+    # the four exchanges on their own (device arrays of emfusion_amd.devmem, stream = devmem.Stream or None)
+    def all_reduce_sum_f32(self, arr, stream=None):
+        _check("emf_comm_all_reduce_sum_f32", load().emf_comm_all_reduce_sum_f32(
+            self._h, C.c_void_p(arr.ptr), arr.nbytes // 4, stream.handle if stream else None))
+
+    def all_reduce_min_u64(self, arr, stream=None):
+        _check("emf_comm_all_reduce_min_u64", load().emf_comm_all_reduce_min_u64(
+            self._h, C.c_void_p(arr.ptr), arr.nbytes // 8, stream.handle if stream else None))
+
+    def broadcast(self, arr, root, stream=None):
+        _check("emf_comm_broadcast", load().emf_comm_broadcast(
+            self._h, C.c_void_p(arr.ptr), arr.nbytes, int(root), stream.handle if stream else None))
+
+    def gather_row_bands(self, arr, band_rows, stream=None):
+        _check("emf_comm_gather_row_bands", load().emf_comm_gather_row_bands(
+            self._h, C.c_void_p(arr.ptr), arr.pitch, int(band_rows), arr.shape[0], stream.handle if stream else None))
 
     def delayed(self, microseconds: int) -> "Communicator":
         """Latency model around this communicator: every exchange (a grouped one counts once) first keeps its

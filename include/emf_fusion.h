@@ -218,6 +218,24 @@ void emf_comm_destroy(emf_comm_t* c);
  * refuses two ranks on a device).  N emf_fusion handles driven from N threads then run the code path
  * of an N-GPU job; collectives are staged through host memory.  out: array of `world` handles. */
 int emf_comm_create_local_group(int world, emf_comm_t** out);
+/* Direct peer-write exchanges (include/emf_hip.h "direct peer-write exchanges"): no library collective,
+ * three small launches per exchange.  slot_bytes bounds one message (W * H * 8 for the hit keys).
+ *   ..._peer_local_group: `world` (<= 8) ranks of one process sharing a GPU, for N handles on N threads;
+ *   ..._peer            : one process per rank; the receive buffers are mapped into every peer through
+ *                         hipIpc*, the 128 handle bytes per rank travel through `all_gather` (0 = success;
+ *                         all[r * bytes ...] := rank r's block), e.g. torch.distributed over gloo.
+ * Untested on xGMI (no multi-GPU box in the build environment); exercised on one GPU. */
+typedef int (*emf_allgather_fn)(void* user, const void* mine, size_t bytes, void* all);
+int emf_comm_create_peer_local_group(int world, size_t slot_bytes, emf_comm_t** out);
+int emf_comm_create_peer(int rank, int world, size_t slot_bytes, emf_allgather_fn all_gather, void* user,
+                         emf_comm_t** out);
+/* The four exchanges of a communicator, callable on their own (tests of a transport without a frame around
+ * it).  dev pointers on the current device, `stream` a hipStream_t or NULL. */
+int emf_comm_all_reduce_sum_f32(emf_comm_t* c, float* dev, size_t count, void* stream);
+int emf_comm_all_reduce_min_u64(emf_comm_t* c, uint64_t* dev, size_t count, void* stream);
+int emf_comm_broadcast(emf_comm_t* c, void* dev, size_t bytes, int root, void* stream);
+int emf_comm_gather_row_bands(emf_comm_t* c, void* dev, size_t bytes_per_row, int band_rows, int total_rows,
+                              void* stream);
 /* Latency model around another communicator (which must outlive the new handle's users but may be
  * destroyed after it): every exchange -- a grouped one counts once -- first keeps its stream busy for
  * `microseconds`.  With a 1-rank RCCL communicator and EMF_FORCE_SHARDED=1 it measures, on one GPU, how

@@ -61,6 +61,7 @@ typedef struct emf_image {
 
 #define EMF_MAX_MODELS 256 /* background + objects handled by one call (seg ids are u8) */
 #define EMF_MAX_BATCH 32   /* models per batched (model-table) launch */
+#define EMF_MAX_PEERS 8    /* ranks of a direct peer-write exchange group (one MI355X node) */
 
 /* Brick uniformity flags: one byte per 4x4x4 brick of a TSDF volume, B = ceil(Nx/4) * ceil(Ny/4) *
  * ceil(Nz/4) bricks, x fastest.  0 = mixed; 1 / 2 / 4 = every voxel of the brick is exactly
@@ -165,6 +166,35 @@ int emf_hip_voxelReciprocal(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream);
 int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp);
+
+/* ---- direct peer-write exchanges ("Collective implementation"; new design, the
+ * reference is single-GPU) ---------------------------------------------------------------------------
+ * The exchanges of the sharded path move 1-5 MB: latency decides.  Instead of a library collective
+ * each rank stores its contribution straight into a slot of every peer's receive buffer (all xGMI
+ * links at once), raises a flag on every peer, waits for the peers' flags and reduces the slots locally
+ * in rank order.  emf_peer_t is what ONE rank knows about the group; the host maps the peers' buffers
+ * once (same process: the pointers themselves; one process per GPU: hipIpcOpenMemHandle) --
+ * emf::makePeerCommunicator.  Buffers: emf_hip_peerBufferBytes(world, slotBytes) bytes (two parities x
+ * world slots) and `world` u32 flags per rank, zeroed before the first exchange; slotBytes % 16 == 0.
+ * An exchange with sequence number seq (1, 2, 3 ... identical on all ranks) is
+ *     peerScatter (ranks that contribute) -> peerSignalWait (every rank) -> peerReduce* / peerCopyFromSlot
+ * enqueued on the caller's stream; nothing allocates or synchronises.  A wait that exceeds timeoutMs
+ * stores seq to *error (device-visible word of the caller's) and falls through. */
+typedef struct emf_peer {
+    int32_t rank, world;
+    void* slots[EMF_MAX_PEERS];      /* receive buffer of peer p as addressable from THIS device */
+    uint32_t* flags[EMF_MAX_PEERS];  /* flag words of peer p (world of them) */
+    size_t slotBytes;                /* capacity of one sender's slot */
+    uint32_t* error;                 /* this rank's error word */
+} emf_peer_t;
+size_t emf_hip_peerBufferBytes(int world, size_t slotBytes);
+int emf_hip_peerScatter(const emf_peer_t* group, const void* src, size_t bytes, size_t dstOffset, uint32_t seq,
+                        emf_stream_t stream);
+int emf_hip_peerSignalWait(const emf_peer_t* group, uint32_t seq, uint32_t timeoutMs, emf_stream_t stream);
+int emf_hip_peerReduceSumF32(const emf_peer_t* group, uint32_t seq, size_t count, float* out, emf_stream_t stream);
+int emf_hip_peerReduceMinU64(const emf_peer_t* group, uint32_t seq, size_t count, uint64_t* out, emf_stream_t stream);
+int emf_hip_peerCopyFromSlot(const emf_peer_t* group, uint32_t seq, int sender, size_t srcOffset, void* dst,
+                             size_t bytes, emf_stream_t stream);
 
 /* Diagnostics behind the two arithmetic shortcuts of the tiled integration (device_core.hpp, on by
  * default, EMF_INT_FAST): the pixel of a voxel as round(x * rcp(z)) unless that lies next to a rounding

@@ -1,0 +1,154 @@
+"""The direct peer-write exchanges (include/emf_hip.h "direct peer-write exchanges", csrc/peer_exchange.hip,
+emf::makePeerCommunicator*): SURVEY 8e's "one-shot direct peer-write all-reduce" behind the Communicator
+interface.  No multi-GPU box exists here, so the transport runs with every rank on ONE GPU:
+
+  * the four exchanges on their own, 1-4 ranks on threads of one process, against numpy (the sum in RANK
+    ORDER, bit for bit; 25 rounds back to back so that the two slot parities and the flag sequence wrap);
+  * the sharded pipeline on 2 and 4 threads through it == the same job through the host-staged rehearsal
+    communicator, bit for bit (both sum in rank order);
+  * bench.py under torch.distributed.run with one PROCESS per rank (--comm peer): the receive buffers are
+    mapped across processes with hipIpc*, which is the form an 8-GPU node uses.
+
+Each scenario runs in a process of its own with GPU_MAX_HW_QUEUES raised: a rank's waiting kernel spins until
+its peers' kernels have run, and with HIP's default four hardware queues two ranks' streams can share a queue --
+on one GPU that is a circular wait (it ends in the exchange's own 5 s time-out and an error, not a hang); on a
+node every rank has a GPU of its own."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+pytestmark = pytest.mark.gpu
+ENV = dict(GPU_MAX_HW_QUEUES="24", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+def _exchanges_scenario(world):
+    from emfusion_amd import devmem, pipeline
+    from emfusion_amd.devmem import DeviceArray
+    devmem.set_device(0)
+    H, W, ROUNDS = 120, 160, 25
+    comms = pipeline.Communicator.local_group(world, transport="peer", max_bytes=W * H * 8)
+    rng = np.random.default_rng(world)
+    data = [[dict(f=rng.standard_normal((H, W)).astype(np.float32) * 10.0 ** rng.integers(-3, 4),
+                  k=rng.integers(0, 2 ** 63, (H, W), dtype=np.uint64),
+                  b=rng.integers(0, 255, (H, W), dtype=np.uint8),
+                  img=rng.standard_normal((H, W)).astype(np.float32)) for _ in range(world)] for _ in range(ROUNDS)]
+    band = ((H + 15) // 16 + world - 1) // world * 16
+    got, errors = [[None] * world for _ in range(ROUNDS)], []
+
+    def rank_main(r):
+        try:
+            st = devmem.Stream(non_blocking=True)
+            for k in range(ROUNDS):
+                d = {n: DeviceArray.from_numpy(a) for n, a in data[k][r].items()}
+                comms[r].all_reduce_sum_f32(d["f"], st)
+                comms[r].all_reduce_min_u64(d["k"], st)
+                comms[r].broadcast(d["b"], k % world, st)
+                comms[r].gather_row_bands(d["img"], band, st)
+                st.synchronize()
+                got[k][r] = {n: a.numpy() for n, a in d.items()}
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank hangs"
+    assert not errors, errors
+    for k in range(ROUNDS):
+        want_f = data[k][0]["f"].copy()
+        for r in range(1, world):
+            want_f = want_f + data[k][r]["f"]  # rank order, float32
+        want_k = np.minimum.reduce([data[k][r]["k"] for r in range(world)])
+        want_img = data[k][0]["img"].copy()
+        for r in range(world):
+            r0 = r * band
+            want_img[r0:r0 + band] = data[k][r]["img"][r0:r0 + band]
+        for r in range(world):
+            assert got[k][r]["f"].tobytes() == want_f.tobytes(), ("sum", k, r)
+            assert np.array_equal(got[k][r]["k"], want_k), ("min", k, r)
+            assert np.array_equal(got[k][r]["b"], data[k][k % world]["b"]), ("broadcast", k, r)
+            assert np.array_equal(got[k][r]["img"], want_img), ("bands", k, r)
+    for c in comms:
+        assert c.exchanges() == 4 * ROUNDS
+        c.close()
+    print("SCENARIO_OK exchanges", world)
+
+
+def _pipeline_scenario(world):
+    import tests.test_gpu_rehearsal as reh
+    from emfusion_amd import devmem, pipeline
+    devmem.set_device(0)
+    host = reh.run_job(world, 4, True)
+    orig = pipeline.Communicator.local_group
+    pipeline.Communicator.local_group = classmethod(
+        lambda cls, w, transport="host", max_bytes=0: orig.__func__(cls, w, "peer", reh.W * reh.H * 8))
+    try:
+        peer = reh.run_job(world, 4, True)
+    finally:
+        pipeline.Communicator.local_group = orig
+    for r in range(world):
+        assert peer[r]["mine"] == host[r]["mine"] and peer[r]["vis"] == host[r]["vis"]
+        for k in ("seg", "ray", "bg_ray", "bg_assoc", "bg_tsdf", "bg_w"):
+            assert peer[r][k].tobytes() == host[r][k].tobytes(), (r, k)
+        for i in peer[r]["mine"]:
+            for a, b in zip(peer[r]["obj"][i], host[r]["obj"][i]):
+                assert a.tobytes() == b.tobytes(), (r, i)
+    assert (host[0]["seg"] > 0).sum() > 200
+    print("SCENARIO_OK pipeline", world)
+
+
+def _in_own_process(what, world):
+    run = subprocess.run([sys.executable, str(Path(__file__).resolve()), what, str(world)], cwd=ROOT,
+                         env=dict(os.environ, **ENV), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and f"SCENARIO_OK {what} {world}" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_the_four_exchanges_against_numpy(dev, world):
+    _in_own_process("exchanges", world)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_pipeline_through_peer_writes_equals_the_host_staged_one(dev, world):
+    _in_own_process("pipeline", world)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_with_one_process_per_rank_over_hipipc(dev, world):
+    args = ["--gpus", str(world), "--steps", "6", "--warmup", "3", "--bg-res", "128", "--bg-voxel", "0.04", "--obj-res", "32",
+            "--objects-per-gpu", "2", "--width", "320", "--height", "240", "--no-cpu-baseline"]
+    out = {}
+    for comm in ("peer", "gloo"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py")] + args + ["--comm", comm]
+        p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **ENV), capture_output=True,
+                           text=True, timeout=420)
+        assert p.returncode == 0, p.stdout[-2500:] + p.stderr[-2500:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(lines) == 1, p.stdout[-2000:]
+        out[comm] = json.loads(lines[0])
+    d = out["peer"]
+    assert d["n_gpus"] == world and d["value"] > 0 and "peer-write" in d["config"]["transport"]
+    assert d["config"]["visible_objects_last_frame"] == out["gloo"]["config"]["visible_objects_last_frame"] > 0
+
+
+if __name__ == "__main__":
+    {"exchanges": _exchanges_scenario, "pipeline": _pipeline_scenario}[sys.argv[1]](int(sys.argv[2]))
