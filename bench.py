@@ -142,6 +142,9 @@ def main():
         if args.comm == "gloo" and dist is not None:
             comm = pipeline.Communicator.host_staged(dist)
             transport = "gloo (rehearsal, --comm gloo)"
+        elif args.comm == "peer" and dist is None:  # --force-sharded with one rank: what the exchanges themselves cost
+            comm = pipeline.Communicator.local_group(1, transport="peer", max_bytes=W * H * 8)[0]
+            transport = "peer-write (one rank, --force-sharded)"
         elif args.comm == "peer" and dist is not None:
             comm = pipeline.Communicator.peer(dist, W * H * 8)
             transport = "peer-write (direct stores into hipIpc-mapped peer buffers, --comm peer)" + \

@@ -219,6 +219,15 @@ class DeviceArray:
                    "hipMemcpy D2H")
         return out
 
+    def numpy_nosync(self) -> np.ndarray:
+        """Copy to the host WITHOUT waiting for the device: the caller has synchronised the stream that
+        produced the data (threads sharing a GPU must not wait for each other's streams)."""
+        assert not self.padded
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            _check(_hip.hipMemcpy(out.ctypes.data, C.c_void_p(self.ptr), self.nbytes, _D2H), "hipMemcpy D2H")
+        return out
+
     def zero_(self):
         _check(_hip.hipMemset(C.c_void_p(self.ptr), 0, self.nbytes), "hipMemset")
         return self

@@ -39,24 +39,27 @@ def _exchanges_scenario(world):
     H, W, ROUNDS = 120, 160, 25
     comms = pipeline.Communicator.local_group(world, transport="peer", max_bytes=W * H * 8)
     rng = np.random.default_rng(world)
-    data = [[dict(f=rng.standard_normal((H, W)).astype(np.float32) * 10.0 ** rng.integers(-3, 4),
+    data = [[dict(f=(rng.standard_normal((H, W)) * 10.0 ** int(rng.integers(-3, 4))).astype(np.float32),
                   k=rng.integers(0, 2 ** 63, (H, W), dtype=np.uint64),
                   b=rng.integers(0, 255, (H, W), dtype=np.uint8),
                   img=rng.standard_normal((H, W)).astype(np.float32)) for _ in range(world)] for _ in range(ROUNDS)]
     band = ((H + 15) // 16 + world - 1) // world * 16
     got, errors = [[None] * world for _ in range(ROUNDS)], []
 
-    def rank_main(r):
+    keep = []  # device arrays are freed after the threads have joined: hipFree waits for the whole device,
+
+    def rank_main(r):  # i.e. for a peer's waiting kernel, whose signal this very thread still owes
         try:
             st = devmem.Stream(non_blocking=True)
             for k in range(ROUNDS):
                 d = {n: DeviceArray.from_numpy(a) for n, a in data[k][r].items()}
+                keep.append(d)
                 comms[r].all_reduce_sum_f32(d["f"], st)
                 comms[r].all_reduce_min_u64(d["k"], st)
                 comms[r].broadcast(d["b"], k % world, st)
                 comms[r].gather_row_bands(d["img"], band, st)
-                st.synchronize()
-                got[k][r] = {n: a.numpy() for n, a in d.items()}
+                st.synchronize()  # this rank's stream only
+                got[k][r] = {n: a.numpy_nosync() for n, a in d.items()}
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
@@ -120,8 +123,10 @@ def test_the_four_exchanges_against_numpy(dev, world):
     _in_own_process("exchanges", world)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2])
 def test_sharded_pipeline_through_peer_writes_equals_the_host_staged_one(dev, world):
+    # (two ranks: every rank's frame uses ~8 streams, and more ranks than that on threads of ONE process exhaust the
+    # process's hardware queues -- see the header; three ranks run as processes below)
     _in_own_process("pipeline", world)
 
 
