@@ -108,6 +108,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // raycast instead of in front of it.  Off by default: measured with a 30 us latency model it buys nothing
     // (tests/test_gpu_exchange_latency.py) -- the background's sweep needs the normalised weights and is as
     // long as the raycast it runs beside, so delaying either delays the frame.
+    if (const char* bd = std::getenv("EMF_BG_DELAY_US")) bgDelayUs = std::atoi(bd);
     const char* hx = std::getenv("EMF_HIDE_EXCHANGE");
     hideExchange = hx && hx[0] == '1';
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
@@ -1346,6 +1347,10 @@ void EMFusion::integrateBackgroundAsync() {
     }
     aux.waitFor(main);
     joinExchange(aux);  // (sharded) the background's association weights are normalised on `xchg`
+    // EMF_BG_DELAY_US (experiment): hold the sweep back while the raycast's waves are all resident (its first
+    // ~170 us are bound by the CUs' gather path, which the sweep's pixel gathers share) and let it fill the
+    // raycast's tail instead
+    if (bgDelayUs > 0 && frameCount > 0) emfCheck(emf_hip_spinDelay(static_cast<uint32_t>(bgDelayUs), aux.abi()), "spinDelay");
     const emf_pose_t oc = toPose(pose.inv() * background.getPose());  // reference TSDF.cpp:112
     const double vox = static_cast<double>(resHost[0]) * resHost[1] * resHost[2];
     const emf_image_t il = invLambda.view();

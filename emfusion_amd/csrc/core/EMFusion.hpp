@@ -398,6 +398,7 @@ private:
     bool rayDoneValid = false;
     Stream xchg;                // sharded: the last E-step's all-reduce + normalisation, beside the raycast
     bool hideExchange = false, lastEstepOfFrame = false, exchangePending = false;
+    int bgDelayUs = 0;          // EMF_BG_DELAY_US: experiment, see integrateBackgroundAsync
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
     void joinExchange(Stream& s);
     Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
