@@ -8,6 +8,14 @@
 //   L1  bricks BX x BY x BZ (x fastest inside a brick, bricks in (z, y, x) order): 8 dword loads at
 //       base + {0, dx} + {0, dy} + {0, dz}, the deltas switching to the brick stride on a brick face
 //   L2  same bricks: 4 pair loads + 4 exec-masked dword loads for the lanes whose x pair straddles a brick
+//   L3  linear volume + a per-wave LDS WINDOW of 8 x 8 x 8 voxels around the wave's rays: filled with 2 coalesced
+//       16-byte loads per lane whenever half of the marching lanes have left it, placed from ONE representative lane
+//       (3 v_readlane; lateral -3 .. +4, ahead along the dominant axis); corners come from LDS (4 ds_read2_b32),
+//       lanes outside the window gather from memory as in L0
+//   L4  the same window on a FIXED SCHEDULE along the rays' dominant axis (window k covers cells a0 + 6k .. + 7 there,
+//       laterally it is centred on the tile's central ray), so that window k + 1 is known in advance and its 2 x 16
+//       bytes per lane are requested right after window k has been filled and consumed at the next switch: the
+//       memory round trip of a fill is off the march's critical path (probe: z-dominant rays only)
 // Scenes (512^3, camera inside the front of the volume, VGA pinhole): tsdf == 0.5 (half-voxel steps, every
 // second sample re-uses its cell: the old probe's regime), tsdf == 0.9 (ONE voxel per step: what 83-87 % of
 // the product's samples are), and a yawed camera (rays at ~25 degrees to the z axis).
@@ -84,6 +92,40 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeVol v, int w, int h, float 
     const float* const row10 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + v.sz);
     const float* const row11 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + v.sz + v.sy);
     constexpr unsigned BX = 1u << LBX, BY = 1u << LBY, BZ = 1u << LBZ;
+    // L3: this wave's window (8 x 8 x 8 floats, x fastest) and its origin, wave-uniform
+    extern __shared__ __attribute__((aligned(16))) float winAll[];  // 2 KB per wave of the block
+    float* const win = winAll + wave * 512;
+    int ox = -100000, oy = -100000, oz = -100000;
+    int winCooldown = 0;
+    // L4: the central ray in voxel units (wave-uniform), the schedule's start, the prefetched window
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    f4u pf0 = {0.f, 0.f, 0.f, 0.f}, pf1 = pf0;
+    int kcur = -1000000, kpf = -1000000, a0 = 0;
+    float repPx = 0.f, repPy = 0.f, repPz = 0.f, repDx = 0.f, repDy = 0.f, repDz = 1.f;
+    if (LAYOUT == 4) {
+        const V3 p0 = v3(v.cam.x / vs, v.cam.y / vs, v.cam.z / vs) + half;
+        repPx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0.x), 27));
+        repPy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0.y), 27));
+        repPz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0.z), 27));
+        repDx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.x / vs), 27));
+        repDy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.y / vs), 27));
+        repDz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.z / vs), 27));
+        a0 = static_cast<int>(floorf(repPz)) - 1;
+    }
+    auto window_origin = [&](int k, int& wx, int& wy, int& wz) {  // wave-uniform
+        wz = a0 + 6 * k;
+        const float s = (static_cast<float>(wz) + 3.5f - repPz) / repDz;
+        wx = static_cast<int>(floorf(repPx + repDx * s)) - 3;
+        wy = static_cast<int>(floorf(repPy + repDy * s)) - 3;
+        const int hi = v.n - 8;
+        wx = min(max(wx, 0), hi); wy = min(max(wy, 0), hi); wz = min(max(wz, 0), hi);
+    };
+    auto window_loads = [&](int wx, int wy, int wz, f4u& r0, f4u& r1) {  // lane l: chunks l and l + 64 of 128
+        const int row0 = lane >> 1, q = lane & 1;
+        const unsigned g0 = mad24(static_cast<unsigned>(wz + (row0 >> 3)), v.sz, mad24(static_cast<unsigned>(wy + (row0 & 7)), v.sy, static_cast<unsigned>(wx + 4 * q) << 2));
+        r0 = *(const __attribute__((address_space(1))) f4u*)((gchar_p)v.tsdf + g0);
+        r1 = *(const __attribute__((address_space(1))) f4u*)((gchar_p)v.tsdf + g0 + 4u * v.sz);  // rows 32..63: four planes on
+    };
     float t = vs, step = vs, tsdf = 1.f, tmax = tmaxAll, acc = 0.f;
     unsigned samples = 0, linesInstr = 0, linesStep = 0;
     const unsigned long long w0 = wall_clock64(), c0 = clock64();
@@ -98,7 +140,82 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeVol v, int w, int h, float 
             ++samples;
             const float fxx = __builtin_amdgcn_fractf(p.x), fyy = __builtin_amdgcn_fractf(p.y), fzz = __builtin_amdgcn_fractf(p.z);
             float c[8];
-            if (LAYOUT == 0) {
+            if (LAYOUT == 4) {
+                bool inWin = max(max(static_cast<unsigned>(lx - ox), static_cast<unsigned>(ly - oy)), static_cast<unsigned>(lz - oz)) < 7u;
+                const unsigned long long missing = __ballot(!inWin);
+                if (__popcll(missing) > 32) {  // (the probe's 64 lanes all march to the end: no zombies needed here)
+                    const int first = __ffsll(static_cast<long long>(missing)) - 1;
+                    const int zl = __builtin_amdgcn_readlane(lz, first);
+                    const int knew = (zl - a0) / 6;
+                    window_origin(knew, ox, oy, oz);
+                    if (knew != kpf) window_loads(ox, oy, oz, pf0, pf1);  // not what was requested ahead: fetch it now
+                    const int row0 = lane >> 1, q = lane & 1;
+                    *reinterpret_cast<f4u*>(win + row0 * 8 + 4 * q) = pf0;
+                    *reinterpret_cast<f4u*>(win + (row0 + 32) * 8 + 4 * q) = pf1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    kcur = knew;
+                    int nx, ny, nz;  // request the next window now; nobody waits for it before the next switch
+                    window_origin(knew + 1, nx, ny, nz);
+                    window_loads(nx, ny, nz, pf0, pf1);
+                    kpf = knew + 1;
+                    inWin = max(max(static_cast<unsigned>(lx - ox), static_cast<unsigned>(ly - oy)), static_cast<unsigned>(lz - oz)) < 7u;
+                }
+                if (inWin) {
+                    const float* b = win + (((lz - oz) * 8 + (ly - oy)) * 8 + (lx - ox));
+                    c[0] = b[0]; c[1] = b[1]; c[2] = b[8]; c[3] = b[9]; c[4] = b[64]; c[5] = b[65]; c[6] = b[72]; c[7] = b[73];
+                } else {
+                    const unsigned off = mad24(static_cast<unsigned>(lz), v.sz, mad24(static_cast<unsigned>(ly), v.sy, static_cast<unsigned>(lx) << 2));
+                    const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off), e = gload2(row11, off);
+                    c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y; c[6] = e.x; c[7] = e.y;
+                }
+                if (COUNT) { linesInstr += inWin ? 0u : 4u; linesStep += __popcll(__ballot(inWin)); }
+            } else if (LAYOUT == 3) {
+                // ---- refill policy: wave-uniform, only lanes that march take part ----
+                const unsigned rx0 = static_cast<unsigned>(lx - ox), ry0 = static_cast<unsigned>(ly - oy), rz0 = static_cast<unsigned>(lz - oz);
+                bool inWin = max(max(rx0, ry0), rz0) < 7u;
+                const unsigned long long marching = __ballot(1), missing = __ballot(!inWin);
+                if (winCooldown > 0) --winCooldown;
+                if (2 * __popcll(missing) > __popcll(marching) && winCooldown == 0) {
+                    // representative: the marching lane nearest the tile's centre (lane 27), else the first one
+                    const int rep = (marching >> 27) & 1ull ? 27 : __ffsll(static_cast<long long>(marching)) - 1;
+                    const int cx_ = __builtin_amdgcn_readlane(lx, rep), cy_ = __builtin_amdgcn_readlane(ly, rep), cz_ = __builtin_amdgcn_readlane(lz, rep);
+                    const float dx_ = __builtin_amdgcn_readlane(__float_as_int(dir.x), rep) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.x), rep)) : 0.f;
+                    const float dy_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.y), rep));
+                    const float dz_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dir.z), rep));
+                    const float ax_ = fabsf(dx_), ay_ = fabsf(dy_), az_ = fabsf(dz_);
+                    int nox = cx_ - 3, noy = cy_ - 3, noz = cz_ - 3;
+                    if (ax_ >= ay_ && ax_ >= az_) nox = dx_ > 0.f ? cx_ - 1 : cx_ - 5;
+                    else if (ay_ >= az_) noy = dy_ > 0.f ? cy_ - 1 : cy_ - 5;
+                    else noz = dz_ > 0.f ? cz_ - 1 : cz_ - 5;
+                    const int hi = v.n - 8;
+                    ox = min(max(nox, 0), hi); oy = min(max(noy, 0), hi); oz = min(max(noz, 0), hi);
+                    // fill: 128 chunks of 4 floats over the marching lanes
+                    const int nw = __popcll(marching);
+                    const int me = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(marching >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(marching), 0u));
+                    for (int ch = me; ch < 128; ch += nw) {
+                        const int row = ch >> 1, q = ch & 1, wy = row & 7, wz = row >> 3;
+                        const unsigned goff = mad24(static_cast<unsigned>(oz + wz), v.sz, mad24(static_cast<unsigned>(oy + wy), v.sy, static_cast<unsigned>(ox + 4 * q) << 2));
+                            const f4u val = *(const __attribute__((address_space(1))) f4u*)((gchar_p)v.tsdf + goff);
+                        float* d = win + row * 8 + 4 * q;
+                        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned rx1 = static_cast<unsigned>(lx - ox), ry1 = static_cast<unsigned>(ly - oy), rz1 = static_cast<unsigned>(lz - oz);
+                    inWin = max(max(rx1, ry1), rz1) < 7u;
+                    if (2 * __popcll(__ballot(inWin)) < nw) winCooldown = 16;  // the tube does not fit: leave it for a while
+                }
+                if (inWin) {
+                    const float* b = win + (((lz - oz) * 8 + (ly - oy)) * 8 + (lx - ox));
+                    c[0] = b[0]; c[1] = b[1]; c[2] = b[8]; c[3] = b[9]; c[4] = b[64]; c[5] = b[65]; c[6] = b[72]; c[7] = b[73];
+                } else {
+                    const unsigned off = mad24(static_cast<unsigned>(lz), v.sz, mad24(static_cast<unsigned>(ly), v.sy, static_cast<unsigned>(lx) << 2));
+                    const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off), e = gload2(row11, off);
+                    c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y; c[6] = e.x; c[7] = e.y;
+                }
+                if (COUNT) { linesInstr += inWin ? 0u : 4u; linesStep += __popcll(__ballot(inWin)); }
+            } else if (LAYOUT == 0) {
                 const unsigned off = mad24(static_cast<unsigned>(lz), v.sz, mad24(static_cast<unsigned>(ly), v.sy, static_cast<unsigned>(lx) << 2));
                 const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off), e = gload2(row11, off);
                 c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = d.x; c[5] = d.y; c[6] = e.x; c[7] = e.y;
@@ -209,10 +326,10 @@ template <int LAYOUT, int LBX, int LBY, int LBZ>
 static void launch(bool count, int blocks, int threads, const ProbeVol& v, int W, int H, const float K[4], int tile0, int tilesX,
                    float tmax, Rec* rec) {
     if (count)
-        hipLaunchKernelGGL((k_probe<LAYOUT, LBX, LBY, LBZ, true>), dim3(blocks), dim3(threads), 0, 0, v, W, H, K[0], K[1], K[2], K[3],
+        hipLaunchKernelGGL((k_probe<LAYOUT, LBX, LBY, LBZ, true>), dim3(blocks), dim3(threads), (threads / 64) * 2048, 0, v, W, H, K[0], K[1], K[2], K[3],
                            tile0, tilesX, tmax, rec);
     else
-        hipLaunchKernelGGL((k_probe<LAYOUT, LBX, LBY, LBZ, false>), dim3(blocks), dim3(threads), 0, 0, v, W, H, K[0], K[1], K[2], K[3],
+        hipLaunchKernelGGL((k_probe<LAYOUT, LBX, LBY, LBZ, false>), dim3(blocks), dim3(threads), (threads / 64) * 2048, 0, v, W, H, K[0], K[1], K[2], K[3],
                            tile0, tilesX, tmax, rec);
 }
 
@@ -233,7 +350,9 @@ int main(int argc, char** argv) {
                               {"L2 bricks 4x4x4, 4 pairs + x fix ", 2, 2, 2, 2},
                               {"L1 bricks 8x2x4, 8 dword loads   ", 1, 3, 1, 2},
                               {"L2 bricks 8x2x4, 4 pairs + x fix ", 2, 3, 1, 2},
-                              {"L2 bricks 8x4x4, 4 pairs + x fix ", 2, 3, 2, 2}};
+                              {"L2 bricks 8x4x4, 4 pairs + x fix ", 2, 3, 2, 2},
+                              {"L3 linear + 8^3 LDS window       ", 3, 0, 0, 0},
+                              {"L4 window on a schedule, prefetch", 4, 0, 0, 0}};
     struct Scene { const char* name; float a, b; float yawDeg; };
     const Scene scenes[] = {{"half-voxel steps (tsdf 0.5)", 0.5f, 0.5f, 0.f},
                             {"ONE voxel per step (0.9)   ", 0.9f, 0.9f, 0.f},
@@ -246,7 +365,7 @@ int main(int argc, char** argv) {
                           {"whole image (4800 w)", 1200, 256, 0}};
     for (const Scene& sc : scenes)
         for (const Layout& L : layouts) {
-            hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, tsdf, N, L.layout, L.lbx, L.lby, L.lbz, sc.a, sc.b);
+            hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, tsdf, N, L.layout >= 3 ? 0 : L.layout, L.lbx, L.lby, L.lbz, sc.a, sc.b);
             CK(hipDeviceSynchronize());
             ProbeVol v{};
             v.tsdf = tsdf;
@@ -266,7 +385,7 @@ int main(int argc, char** argv) {
                     if (mode == 0) { CK(hipMemset(flush, 0, flushBytes)); CK(hipDeviceSynchronize()); }
                     const bool count = mode == 2;
 #define GO(LY, A, B, C) if (L.layout == LY && L.lbx == A && L.lby == B && L.lbz == C) launch<LY, A, B, C>(count, cs.blocks, cs.threads, v, W, H, K, cs.tile0, tilesX, tmax, rec)
-                    GO(0, 0, 0, 0); GO(1, 2, 2, 2); GO(2, 2, 2, 2); GO(1, 3, 1, 2); GO(2, 3, 1, 2); GO(2, 3, 2, 2);
+                    GO(0, 0, 0, 0); GO(3, 0, 0, 0); GO(4, 0, 0, 0); GO(1, 2, 2, 2); GO(2, 2, 2, 2); GO(1, 3, 1, 2); GO(2, 3, 1, 2); GO(2, 3, 2, 2);
 #undef GO
                     CK(hipDeviceSynchronize());
                     const int nw = cs.blocks * cs.threads / 64;
