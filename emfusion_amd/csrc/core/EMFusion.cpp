@@ -104,13 +104,6 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
     const char* fs = std::getenv("EMF_FORCE_SHARDED");
     sharded = comm && (world > 1 || (fs && fs[0] == '1'));
-    // EMF_HIDE_EXCHANGE=1: the last E-step's all-reduce + normalisation on a stream of their own beside the
-    // raycast instead of in front of it.  Off by default: measured with a 30 us latency model it buys nothing
-    // (tests/test_gpu_exchange_latency.py) -- the background's sweep needs the normalised weights and is as
-    // long as the raycast it runs beside, so delaying either delays the frame.
-    if (const char* bd = std::getenv("EMF_BG_DELAY_US")) bgDelayUs = std::atoi(bd);
-    const char* hx = std::getenv("EMF_HIDE_EXCHANGE");
-    hideExchange = hx && hx[0] == '1';
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
@@ -408,7 +401,6 @@ void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchr
 // changes (reference EMFusion.cpp:495-560, 827-863, 922-980 run inside processFrame).
 void EMFusion::quiesce() {
     main.waitForCompletion();
-    xchg.waitForCompletion();
     aux.waitForCompletion();
     lists.waitForCompletion();
     for (auto& kv : streams) kv.second.waitForCompletion();
@@ -533,9 +525,7 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
             posesCO(co);
             computeFarBounds(co);
         }
-        lastEstepOfFrame = true;  // nothing before the integrations reads its maps: its exchange may trail
         computeAssociationWeights();
-        lastEstepOfFrame = false;
         stamp(kEstep);
         integrateBackgroundAsync();  // runs beside the raycast (see there)
         joinFarBounds();
@@ -571,8 +561,6 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
     }
 
     integrateBackgroundAsync();  // frame 0 (no raycast): same path, nothing to overlap with
-    joinExchange(main);          // (sharded) from here on `main` reads the frame's final association weights
-    exchangePending = false;
     integrateDepth();
     stamp(kIntegrate);
 
@@ -1225,12 +1213,10 @@ void EMFusion::estepBatched() {
     // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
     // xGMI, then every rank normalises its own maps
     launch(0, nullptr, &sv);
-    // The frame's LAST E-step feeds the integrations only (the raycast needs poses and volumes, not
-    // association weights): its all-reduce and normalisation go to the `xchg` stream and run beside the
-    // raycast; the background's sweep (aux) and the objects' integration (main) wait for them there
-    // (joinExchange).  The first two feed the tracking stages right behind them and stay on `main`.
-    Stream& st = (lastEstepOfFrame && hideExchange) ? xchg : main;
-    if (&st == &xchg) xchg.waitFor(main);
+    // (Measured and dropped, round 3: the frame's LAST all-reduce + normalisation on a stream of their own beside
+    // the raycast -- they feed the integrations only.  With a 30 us latency model the frame got no shorter: the
+    // background's sweep needs the normalised weights and is as long as the raycast it runs beside.)
+    Stream& st = main;
     comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), st);
     std::vector<emf_image_t> maps;
     maps.push_back(bg_associationWeights.view());
@@ -1241,15 +1227,6 @@ void EMFusion::estepBatched() {
                                               st.abi()),
                  "normalizeAssociation");
     }
-    if (&st == &xchg) {
-        xchg.record();
-        exchangePending = true;
-    }
-}
-
-// The consumer `s` of the last E-step's normalised maps waits for the trailing exchange (device side).
-void EMFusion::joinExchange(Stream& s) {
-    if (exchangePending) s.waitOn(xchg);
 }
 
 void EMFusion::raycastBatched() {
@@ -1346,11 +1323,6 @@ void EMFusion::integrateBackgroundAsync() {
         bgPrepared = false;
     }
     aux.waitFor(main);
-    joinExchange(aux);  // (sharded) the background's association weights are normalised on `xchg`
-    // EMF_BG_DELAY_US (experiment): hold the sweep back while the raycast's waves are all resident (its first
-    // ~170 us are bound by the CUs' gather path, which the sweep's pixel gathers share) and let it fill the
-    // raycast's tail instead
-    if (bgDelayUs > 0 && frameCount > 0) emfCheck(emf_hip_spinDelay(static_cast<uint32_t>(bgDelayUs), aux.abi()), "spinDelay");
     const emf_pose_t oc = toPose(pose.inv() * background.getPose());  // reference TSDF.cpp:112
     const double vox = static_cast<double>(resHost[0]) * resHost[1] * resHost[2];
     const emf_image_t il = invLambda.view();

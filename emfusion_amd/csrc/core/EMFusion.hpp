@@ -396,11 +396,7 @@ private:
     bool earlyFarBounds = true;    // far bounds wait for the previous raycast only (EMF_EARLY_FAR_BOUNDS=0: for `main`)
     hipEvent_t rayDone = nullptr;  // behind the last raycast that read farBounds
     bool rayDoneValid = false;
-    Stream xchg;                // sharded: the last E-step's all-reduce + normalisation, beside the raycast
-    bool hideExchange = false, lastEstepOfFrame = false, exchangePending = false;
-    int bgDelayUs = 0;          // EMF_BG_DELAY_US: experiment, see integrateBackgroundAsync
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
-    void joinExchange(Stream& s);
     Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
     bool bgListPending = false; // the background was forked; its list rebuild is not enqueued yet
     bool bgPrepared = false;    // bgCullScratch's counter and the next dirtyNext map are already cleared
