@@ -31,21 +31,23 @@ void emfCheck(int rc, const char* what) {
 // (the multi-rank rehearsal) must not record events on each other's streams -- HIP's event bookkeeping
 // throws from inside the runtime when they do.  A thread's pool is really freed when the thread ends.
 namespace {
+struct Fence {
+    hipEvent_t event;
+    hipStream_t stream;  // where it was recorded: an event must not outlive its stream (see retire_fences_of)
+};
 struct Pooled {
     void* p;
     size_t bytes;
-    std::vector<hipEvent_t> fences;
+    std::vector<Fence> fences;
 };
 struct ThreadPool {
     std::vector<hipStream_t> streams;  // streams created by emf::Stream on this thread
     std::vector<Pooled> pool;
-    std::vector<hipEvent_t> spareEvents;
     size_t pooledBytes = 0;
     ~ThreadPool() {
         for (Pooled& b : pool) (void)hipFree(b.p);
         for (Pooled& b : pool)
-            for (hipEvent_t e : b.fences) (void)hipEventDestroy(e);
-        for (hipEvent_t e : spareEvents) (void)hipEventDestroy(e);
+            for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
     }
 };
 ThreadPool& tp() {
@@ -69,11 +71,11 @@ size_t pool_cap() {  // bytes a thread's pool may hold before it really frees (E
 }
 bool fences_passed(ThreadPool& t, Pooled& b) {
     while (!b.fences.empty()) {
-        if (hipEventQuery(b.fences.back()) != hipSuccess) {
+        if (hipEventQuery(b.fences.back().event) != hipSuccess) {
             (void)hipGetLastError();  // hipErrorNotReady is not an error
             return false;
         }
-        t.spareEvents.push_back(b.fences.back());
+        (void)hipEventDestroy(b.fences.back().event);  // (not re-used: an event remembers its last stream)
         b.fences.pop_back();
     }
     return true;
@@ -103,20 +105,15 @@ void pool_release(void* p, size_t bytes) {
     streams.push_back(nullptr);  // the null stream: clears and uploads of constructors run there
     for (hipStream_t st : streams) {
         hipEvent_t ev = nullptr;
-        if (!t.spareEvents.empty()) {
-            ev = t.spareEvents.back();
-            t.spareEvents.pop_back();
-        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            ev = nullptr;
-        }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
         if (!ev || hipEventRecord(ev, st) != hipSuccess) {  // cannot fence it: free it the slow, safe way
             (void)hipGetLastError();
-            if (ev) t.spareEvents.push_back(ev);
-            for (hipEvent_t e : b.fences) t.spareEvents.push_back(e);
+            if (ev) (void)hipEventDestroy(ev);
+            for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
             (void)hipFree(p);
             return;
         }
-        b.fences.push_back(ev);
+        b.fences.push_back(Fence{ev, st});
     }
     t.pooledBytes += bytes;
     t.pool.push_back(std::move(b));
@@ -126,7 +123,26 @@ void register_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_liveMutex);
     g_live.push_back(s);
 }
+// A stream is about to be destroyed: HIP's event bookkeeping keeps a reference to the stream an event was last
+// recorded on, and querying such an event after the stream is gone throws from inside the runtime
+// ("std::get: wrong index for variant").  So the stream is drained here, which completes every fence recorded
+// on it, and those fences are destroyed -- not re-used -- before the stream goes.
+void retire_fences_of(hipStream_t s) {
+    ThreadPool& t = tp();
+    bool any = false;
+    for (const Pooled& b : t.pool)
+        for (const Fence& f : b.fences) any = any || f.stream == s;
+    if (!any) return;
+    (void)hipStreamSynchronize(s);
+    for (Pooled& b : t.pool) {
+        for (Fence& f : b.fences)
+            if (f.stream == s) (void)hipEventDestroy(f.event);
+        b.fences.erase(std::remove_if(b.fences.begin(), b.fences.end(), [s](const Fence& f) { return f.stream == s; }),
+                       b.fences.end());
+    }
+}
 void unregister_stream(hipStream_t s) {
+    retire_fences_of(s);
     auto& v = tp().streams;
     v.erase(std::remove(v.begin(), v.end(), s), v.end());
     std::lock_guard<std::mutex> lock(g_liveMutex);
@@ -142,7 +158,7 @@ void DeviceBuffer::trimPool() {
     t.pooledBytes = 0;
     for (Pooled& b : all) {
         (void)hipFree(b.p);  // synchronises the device: the fences have passed afterwards
-        for (hipEvent_t e : b.fences) t.spareEvents.push_back(e);
+        for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
     }
 }
 
