@@ -1,7 +1,7 @@
 """Per-kernel timeline of one bench frame from the rocprofv3 database scripts/quick_trace.sh leaves in
 gpurun_out/quick_trace/: start (us after the frame's raycast), duration, queue, idle gap in front of it."""
-import glob, re, sqlite3
-f = glob.glob("gpurun_out/quick_trace/*.db") + glob.glob("gpurun_out/quick_trace/*/*.db")
+import glob, re, sqlite3, sys
+f = sys.argv[1:] or glob.glob("gpurun_out/quick_trace/*.db") + glob.glob("gpurun_out/quick_trace/*/*.db")
 con = sqlite3.connect(f[0])
 rows = con.execute("select name, start, end, queue_id from kernels order by start").fetchall()
 ray = [i for i, r in enumerate(rows) if "k_raycast_batched" in r[0]]
