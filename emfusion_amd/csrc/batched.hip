@@ -1350,7 +1350,8 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
     a.list = a.count + 4;
     a.out = IntegrateOutTable{};
     a.haveOut = out_host ? 1 : 0;
-    static const bool deepTiles = !(std::getenv("EMF_DEEP_TILES") && std::getenv("EMF_DEEP_TILES")[0] == '0');
+    const char* dt = std::getenv("EMF_DEEP_TILES");  // (per call: A/B switch, same results)
+    const bool deepTiles = !(dt && dt[0] == '0');
     a.deepTiles = deepTiles ? 1 : 0;
     const unsigned total = static_cast<unsigned>(a.boxStart[nmodels]);
     const hipError_t e = prepared ? hipSuccess : hipMemsetAsync(a.count, 0, 2 * sizeof(unsigned), as_stream(stream));

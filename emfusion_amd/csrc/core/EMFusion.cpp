@@ -290,7 +290,8 @@ void EMFusion::rebuildModelTable() {
         // for far bounds; its rays are short anyway and the scan (23 us beside the E-steps, which it slows from
         // 12 to 37 us) costs the frame more than the cut saves the raycast: 0.6095 vs 0.5956 ms.  EMF_FAR_SCAN=1
         // scans them.
-        static const bool scanSmall = std::getenv("EMF_FAR_SCAN") && std::getenv("EMF_FAR_SCAN")[0] == '1';
+        const char* fsc = std::getenv("EMF_FAR_SCAN");
+        const bool scanSmall = fsc && fsc[0] == '1';
         if (md.signMaps && !md.relevantTiles && scanSmall) scanMask |= bit;
         if (md.signMaps && md.relevantTiles) listMask |= bit;
         voxelHost.push_back(md.voxelSize);

@@ -273,12 +273,9 @@ void TSDF::computeAssociation(const emf_image_t& points, const Affine3f& cam_pos
              "TSDF::computeAssociation");
 }
 
-int TSDF::brickFlagMode() {
-    static const int mode = [] {
-        const char* e = std::getenv("EMF_BRICK_FLAGS");
-        return e ? (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)) : 0;
-    }();
-    return mode;
+int TSDF::brickFlagMode() {  // (read on every call: an instance picks the switch up when it is constructed)
+    const char* e = std::getenv("EMF_BRICK_FLAGS");
+    return e ? (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)) : 0;
 }
 
 void TSDF::describe(emf_model_t& m) const {
@@ -315,7 +312,8 @@ void TSDF::describe(emf_model_t& m) const {
                           ? relevantTiles.as<uint32_t>()
                           : nullptr;
     // (kept valid together with the sign maps: the same launches maintain both)
-    static const bool useUnseen = !(std::getenv("EMF_UNSEEN_TILES") && std::getenv("EMF_UNSEEN_TILES")[0] == '0');
+    const char* ut = std::getenv("EMF_UNSEEN_TILES");
+    const bool useUnseen = !(ut && ut[0] == '0');
     m.unseenTiles = useUnseen && m.signMaps && !unseenTiles.empty() ? unseenTiles.as<uint8_t>() : nullptr;
     m.pad_ = 0;
 }
