@@ -16,8 +16,8 @@ configs[3]: every rank holds a replica of the background and `--objects-per-gpu`
 of its own; ranks exchange one RCCL all-reduce per E-step (normaliser) and one per raycast
 (nearest-hit merge).  Weak scaling: per-GPU work is fixed, the scene grows with N.
 
-The timed region holds the product path plus one HIP-event pair per long kernel (raycast, background
-integration, tracking stage) and nothing else: the march-sample counters the byte model of `roofline` needs are
+The timed region holds the product path plus a HIP-event pair around every 4th launch of the long kernels
+(raycast, background integration, tracking stage; --event-stride) and nothing else: the march-sample counters the byte model of `roofline` needs are
 collected afterwards, in an untimed replay of the same frames from a cleared state (--no-stats-replay skips it).
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
@@ -70,6 +70,9 @@ def parse_args():
                     help="bracket EVERY launch with a HIP event pair (full per-kernel table; the event "
                          "records around the ~5 us kernels cost ~5 %% of the frame).  Default: only the "
                          "large kernels (raycast, integrate, tracking) are bracketed")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket every N-th launch of the long kernels with a HIP-event pair (default 4; 1 = every "
+                         "launch).  The records sit on the streams they time: all of them cost 2.6 %% of the frame rate")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernel launches with HIP events in the timed region")
     ap.add_argument("--no-depth-broadcast", action="store_true",
@@ -226,6 +229,7 @@ def main():
         fus.kernel_timers_enable(launches_per_frame * args.steps + 64)
         if not args.all_kernel_events:
             fus.kernel_timers_select(["raycast", "integrate_bg", "track"] if fus.background_overlap() else ["raycast", "integrate", "track"])
+            fus.kernel_timers_stride(max(1, args.event_stride))
     if args.track:
         fus.set_tracking(camera=True, objects=True)
     barrier()
@@ -329,7 +333,7 @@ def main():
         profiled = (world, nobj_total, args.bg_res, args.obj_res, W, H, args.track) == \
                    (1, 4, 512, 128, 640, 480, False)
         if kern is not None:
-            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs, profiled)
+            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs, profiled, args.steps)
         else:
             result["roofline"] = None
         result["hbm_copy_GBs"] = copy_gbs  # attainable D2D stream bandwidth of THIS box (read + write)
@@ -373,10 +377,12 @@ KERNEL_NAMES = {
 }
 
 
-def algorithmic_bytes(kind, summ, stats, P):
-    """Algorithmic bytes summed over all launches of one kernel kind -- SURVEY.md section 8(d),
-    restated in DESIGN.md "Byte model".  `units` = voxels (sweeps) or pixels (image kernels)."""
+def algorithmic_bytes(kind, summ, stats, P, steps=None):
+    """Algorithmic bytes summed over the BRACKETED launches of one kernel kind -- SURVEY.md section 8(d),
+    restated in DESIGN.md "Byte model".  `units` = voxels (sweeps) or pixels (image kernels) of those launches;
+    the march samples are counted over all `steps` timed frames (untimed replay) and scaled to them."""
     u, n = summ["units"], max(summ["launches"], 1)
+    share = n / float(steps) if steps else 1.0  # bracketed launches / timed launches (--event-stride)
     if kind in ("integrate", "integrate_bg"):   # B_int: read tsdf + weight, write tsdf + weight per voxel
         return 16.0 * u
     if kind == "grads":       # B_grad: 4 B read + 12 B written per voxel
@@ -384,7 +390,7 @@ def algorithmic_bytes(kind, summ, stats, P):
     if kind == "raycast":     # B_ray: 16 gathers per march sample, gradient blend at hits, outputs
         if stats is None:     # --no-stats-replay: the samples were not counted
             return 0.0
-        S, hits = stats[0], stats[1]
+        S, hits = stats[0] * share, stats[1] * share
         return 64.0 * S + 96.0 * hits + 29.0 * u
     if kind == "assoc":       # B_em per model and pixel: 12 B point + 32 B tsdf gather + 4 B out
         return 48.0 * u       # (objects add a 32 B fg gather; counted at the background's rate)
@@ -491,7 +497,7 @@ def copy_bandwidth(devmem, ops, mib=1024, reps=10):
     return round(2.0 * n * 4 / (ms * 1e-3) / 1e9, 1)
 
 
-def roofline(kern, stats, P, copy_gbs=None, profiled=True):
+def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None):
     """`roofline` of the JSON line: the dominant kernel against the resource that binds it.
 
     bound / achieved / peak / frac come from hardware counters (resource_fractions): VALU issue, vector-L1
@@ -503,7 +509,7 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
     for kind, summ in kern.items():
         if kind.startswith("_") or summ["launches"] == 0:
             continue
-        total_b = algorithmic_bytes(kind, summ, stats, P)
+        total_b = algorithmic_bytes(kind, summ, stats, P, steps if kind == "raycast" else None)
         n = summ["launches"]
         avg_ms = summ["total_ms"] / n
         row = {
@@ -525,7 +531,9 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
     dom = next(r for r in rows
                if not (r["kind"] == "integrate_bg" and ray is not None and r["avg_ms"] < 1.1 * ray["avg_ms"]))
     res = {k: v for k, v in (dom.get("resources") or {}).items() if isinstance(v, dict)}
-    roof = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"], "dropped_launches": kern.get("_dropped", 0)}
+    roof = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
+            "timed_launches": f"{dom['launches']} of {steps} bracketed by HIP events (--event-stride)" if steps else dom["launches"],
+            "dropped_launches": kern.get("_dropped", 0)}
     if res:
         bound = max(res, key=lambda k: res[k]["frac"])
         roof.update(bound=bound, achieved=res[bound]["achieved"], peak=res[bound]["peak"], unit=res[bound]["unit"],
@@ -569,7 +577,7 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True):
                 k: round(res[k]["frac"] + ires[k]["frac"] * min(1.0, integ["avg_ms"] / dom["avg_ms"]), 4)
                 for k in res if k in ires}
     if dom["kind"] == "raycast" and stats is not None:
-        roof["march_samples_per_launch"] = round(stats[0] / max(dom["launches"], 1), 1)
+        roof["march_samples_per_launch"] = round(stats[0] / max(steps or dom["launches"], 1), 1)
     return roof, rows
 
 

@@ -507,6 +507,11 @@ int emf_fusion_kernel_timers_select(emf_fusion_t* h, uint32_t kind_mask) {
     return guarded([&] { h->impl->kernelTimers().select(kind_mask); });
 }
 
+int emf_fusion_kernel_timers_stride(emf_fusion_t* h, uint32_t every) {
+    REQ(h);
+    return guarded([&] { h->impl->kernelTimers().setStride(every); });
+}
+
 int emf_fusion_kernel_timers_collect(emf_fusion_t* h, emf_kernel_summary_t out[EMF_K_NUM_KINDS],
                                      uint64_t* dropped) {
     REQ(h);

@@ -133,6 +133,7 @@ def load() -> C.CDLL:
         "emf_fusion_kernel_timers_enable": [vp, C.c_uint64],
         "emf_fusion_kernel_timers_clear": [vp],
         "emf_fusion_kernel_timers_select": [vp, C.c_uint32],
+        "emf_fusion_kernel_timers_stride": [vp, C.c_uint32],
         "emf_fusion_kernel_timers_collect": [vp, C.POINTER(KernelSummary), C.POINTER(C.c_uint64)],
         "emf_fusion_get_image": [vp, C.c_int, C.c_int, img],
         "emf_fusion_get_volume": [vp, C.c_int, C.c_int, C.POINTER(vp), ip],
@@ -595,6 +596,10 @@ class Fusion:
         for k in kinds:
             mask |= 1 << KERNEL_KINDS.index(k)
         _check("emf_fusion_kernel_timers_select", load().emf_fusion_kernel_timers_select(self._h, mask))
+
+    def kernel_timers_stride(self, every: int):
+        """Bracket only every `every`-th launch of a kind with an event pair (1 = all)."""
+        _check("emf_fusion_kernel_timers_stride", load().emf_fusion_kernel_timers_stride(self._h, int(every)))
 
     def kernel_timers_clear(self):
         _check("emf_fusion_kernel_timers_clear", load().emf_fusion_kernel_timers_clear(self._h))

@@ -192,6 +192,8 @@ int emf_fusion_kernel_timers_enable(emf_fusion_t* h, uint64_t max_launches);
 int emf_fusion_kernel_timers_clear(emf_fusion_t* h);
 /* restrict the event pairs to the kinds whose bit (1 << emf_kernel_kind) is set; default all */
 int emf_fusion_kernel_timers_select(emf_fusion_t* h, uint32_t kind_mask);
+/* Bracket only every `every`-th launch of a kind (1 = all): the event records themselves cost the frame. */
+int emf_fusion_kernel_timers_stride(emf_fusion_t* h, uint32_t every);
 int emf_fusion_kernel_timers_collect(emf_fusion_t* h, emf_kernel_summary_t out[EMF_K_NUM_KINDS],
                                      uint64_t* dropped);
 
