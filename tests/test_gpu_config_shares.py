@@ -133,7 +133,7 @@ def test_config3_share_schedule_against_the_frame_level_oracle(oracle, dev):
     from emfusion_amd.ops import image_view
     cfg = SHARES["config3_share"]
     W, H = cfg["w"], cfg["h"]
-    oracle.set_threads(os.cpu_count() or 8)
+    oracle.set_threads(oracle.host_threads())
     prm = pipeline.make_params(W, H, cfg["bg"], cfg["vox"], cfg["obj"])
     Kp = np.array(prm.K, np.float32)
     synth = pipeline.SyntheticStream(W, H, Kp, cfg["nobj"], seed=0xE3F5)
@@ -198,7 +198,7 @@ def test_config4_share_kernels_against_the_oracle(oracle, ops, dev):
     W, H, n, vox, m = cfg["w"], cfg["h"], cfg["bg"], cfg["vox"], cfg["obj"]
     if _host_gib_available() < 64:
         pytest.skip("needs ~40 GiB of host memory for the 1024^3 volumes")
-    oracle.set_threads(os.cpu_count() or 8)
+    oracle.set_threads(oracle.host_threads())
     prm = pipeline.make_params(W, H, n, vox, m)
     Kp = np.array(prm.K, np.float32).reshape(3, 3)
     synth = pipeline.SyntheticStream(W, H, Kp.reshape(-1), cfg["nobj"], seed=0xE3F5)

@@ -168,7 +168,7 @@ def test_full_size_against_the_oracle(oracle, ops, dev, n, vox):
     from emfusion_amd import pipeline
     if n == 1024 and _host_gib_available() < 64:
         pytest.skip("needs ~40 GiB of host memory for the 1024^3 volumes")
-    oracle.set_threads(os.cpu_count() or 8)
+    oracle.set_threads(oracle.host_threads())
     prm = pipeline.make_params(W, H, n, vox, 128)
     Kp = np.array(prm.K, np.float32).reshape(3, 3)
     synth = pipeline.SyntheticStream(W, H, Kp.reshape(-1), 2, seed=0xE3F5)
