@@ -146,10 +146,10 @@ def main():
             comm = pipeline.Communicator.host_staged(dist)
             transport = "gloo (rehearsal, --comm gloo)"
         elif args.comm == "peer" and dist is None:  # --force-sharded with one rank: what the exchanges themselves cost
-            comm = pipeline.Communicator.local_group(1, transport="peer", max_bytes=W * H * 8)[0]
+            comm = pipeline.Communicator.local_group(1, transport="peer", max_bytes=W * H * 16)[0]
             transport = "peer-write (one rank, --force-sharded)"
         elif args.comm == "peer" and dist is not None:
-            comm = pipeline.Communicator.peer(dist, W * H * 8)
+            comm = pipeline.Communicator.peer(dist, W * H * 16)
             transport = "peer-write (direct stores into hipIpc-mapped peer buffers, --comm peer)" + \
                 ("" if devmem.device_count() >= world else "; ranks share a GPU: rehearsal")
         else:

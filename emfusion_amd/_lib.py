@@ -84,6 +84,19 @@ SIGNATURES = {
     "emf_hip_peerReduceSumF32": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
     "emf_hip_peerReduceMinU64": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
     "emf_hip_peerCopyFromSlot": [C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, _FP, C.c_size_t, _STREAM],
+    "emf_hip_peerWaitReduceSumF32": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
+    "emf_hip_peerWaitReduceMinU64": [C.c_void_p, C.c_uint32, C.c_size_t, _FP, _STREAM],
+    "emf_hip_peerWaitCopyFromSlots": [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      _STREAM],
+    "emf_hip_estepBatchedPeer": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, _STREAM],
+    "emf_hip_peerNormalizeAssociation": [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _STREAM],
+    "emf_hip_peerRaycastSlotBytes": [C.c_int, C.c_int],
+    "emf_hip_packHitKeysPeer": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                C.c_void_p, C.c_uint32, _STREAM],
+    "emf_hip_compositeFromKeysPeer": [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+                                     + [C.c_void_p] * 13 + [C.c_int, C.c_void_p, _STREAM],
+    "emf_hip_visibilityFlagsMirror": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _STREAM],
     "emf_hip_sweepFastPathPremises": [C.c_void_p, _STREAM],
     "emf_hip_debugPixelRounding": [_FP, _FP, C.c_int, _FP, _FP, _STREAM],
     "emf_hip_debugBandDecision": [_FP, _FP, _FP, C.c_int, C.c_float, _FP, _FP, _FP, _FP, _STREAM],
@@ -225,6 +238,7 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.emf_hip_raycastFarBoundBytes.restype = C.c_size_t
     lib.emf_hip_relevantTileBytes.restype = C.c_size_t
     lib.emf_hip_peerBufferBytes.restype = C.c_size_t
+    lib.emf_hip_peerRaycastSlotBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     return lib

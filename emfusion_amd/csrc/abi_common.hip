@@ -146,7 +146,11 @@ uint32_t rcp_bits(float f) {
 }
 std::mutex g_rcpMutex;
 std::vector<RcpVerdict> g_rcpVerdicts;
-unsigned long long* g_rcpCounter = nullptr;  // device word of the blocking form, allocated once
+// The blocking form runs ONE check at a time (g_rcpCheckMutex is held from the memset to the read-back):
+// concurrent first-time callers -- one host thread per rank in the rehearsal -- would otherwise clear or read
+// each other's mismatch count, and a wrong verdict would be cached for the life of the process.
+std::mutex g_rcpCheckMutex;
+std::vector<std::pair<int, unsigned long long*>> g_rcpCounters;  // one device word per device, allocated once
 
 bool rcp_lookup(float voxelSize, float* rcp) {
     const uint32_t bits = rcp_bits(voxelSize);
@@ -178,20 +182,26 @@ int emf_hip_voxelReciprocal(float voxelSize, float* rcp) {
     *rcp = 0.f;
     if (const int rc = rcp_check_size(voxelSize, "voxelReciprocal")) return rc;
     if (rcp_lookup(voxelSize, rcp)) return EMF_OK;  // seen before: no device work
-    hipError_t e = hipSuccess;
-    {
-        std::lock_guard<std::mutex> lock(g_rcpMutex);
-        if (!g_rcpCounter) e = hipMalloc(reinterpret_cast<void**>(&g_rcpCounter), sizeof(unsigned long long));
+    std::lock_guard<std::mutex> check(g_rcpCheckMutex);
+    if (rcp_lookup(voxelSize, rcp)) return EMF_OK;  // another caller finished the same check meanwhile
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    unsigned long long* counter = nullptr;
+    for (const auto& c : g_rcpCounters)
+        if (c.first == dev) counter = c.second;
+    if (e == hipSuccess && !counter) {
+        e = hipMalloc(reinterpret_cast<void**>(&counter), sizeof(unsigned long long));
+        if (e == hipSuccess) g_rcpCounters.emplace_back(dev, counter);
     }
     // its own stream: the wait below is for this check alone, not for the device
     hipStream_t st = nullptr;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     unsigned long long bad = 1;
-    if (e == hipSuccess) e = hipMemsetAsync(g_rcpCounter, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), st);
     if (e == hipSuccess) {
         const float r = 1.0f / voxelSize;
-        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, r, g_rcpCounter);
-        e = hipMemcpyAsync(&bad, g_rcpCounter, sizeof(bad), hipMemcpyDeviceToHost, st);
+        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, r, counter);
+        e = hipMemcpyAsync(&bad, counter, sizeof(bad), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e == hipSuccess) {
             *rcp = bad == 0 ? r : 0.f;

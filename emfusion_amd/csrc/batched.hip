@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "march_wave.hpp"
+#include "peer_core.hpp"
 
 namespace emf_hip {
 namespace {
@@ -48,6 +49,11 @@ struct EstepArgs {
     Img<const float> depth;
     Img<float> pointsOut;
     float fx, fy, cx, cy;
+    // sharded path over the direct peer-write transport (emf_hip_estepBatchedPeer): the per-pixel sum of the object
+    // maps is this rank's contribution to the E-step's exchange and goes straight into its slot on every peer
+    char* peerSlots[EMF_MAX_PEERS];
+    int peerWorld;    // 0: objSum is an ordinary image
+    size_t peerOff;   // byte offset of this rank's slot (parity included) in a peer's receive buffer
 };
 
 __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const EstepArgs a) {
@@ -107,7 +113,13 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
                 s = wl[1][tx];
                 for (int m = 2; m < a.nmodels; ++m) s = s + wl[m][tx];
             }
-            a.objSum.row(y)[x] = s;
+            if (a.peerWorld) {  // (uniform) write-through: the value must be in the peer's memory, not in my L2
+                for (int p = 0; p < a.peerWorld; ++p)
+                    __builtin_nontemporal_store(s, reinterpret_cast<float*>(a.peerSlots[p] + a.peerOff) + pix);
+                __threadfence_system();
+            } else {
+                a.objSum.row(y)[x] = s;
+            }
         }
     }
 }
@@ -931,7 +943,8 @@ extern "C" {
 namespace {
 int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
                  const emf_image_t* depth, const float* K, const emf_image_t* points, int normalize,
-                 const emf_image_t* norm, const emf_image_t* objSum, emf_stream_t stream, const char* fn) {
+                 const emf_image_t* norm, const emf_image_t* objSum, emf_stream_t stream, const char* fn,
+                 const emf_peer_t* group = nullptr, uint32_t seq = 0) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, fn));
     EMF_TRY(check_image(points, 12, "estepBatched: points"));
     EstepArgs a;
@@ -964,7 +977,18 @@ int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, i
         EMF_TRY(check_same_size(norm, points, "norm", "points"));
         a.norm = img<float>(norm);
     }
-    if (!normalize) {
+    a.peerWorld = 0;
+    a.peerOff = 0;
+    for (int p = 0; p < EMF_MAX_PEERS; ++p) a.peerSlots[p] = nullptr;
+    if (group) {
+        PeerArgs pa;
+        EMF_TRY(peer_args(group, pa, fn));
+        if (static_cast<size_t>(a.w) * a.h * sizeof(float) > pa.slotBytes)
+            return fail(EMF_E_ARG, "%s: %d x %d floats exceed the %zu-byte slot", fn, a.w, a.h, pa.slotBytes);
+        a.peerWorld = pa.world;
+        a.peerOff = (static_cast<size_t>(seq & 1u) * pa.world + pa.rank) * pa.slotBytes;
+        for (int p = 0; p < pa.world; ++p) a.peerSlots[p] = pa.slots[p];
+    } else if (!normalize) {
         if (!objSum) return fail(EMF_E_NULL, "estepBatched: objSum is required when normalize == 0");
         EMF_TRY(check_image(objSum, 4, "estepBatched: objSum"));
         EMF_TRY(check_same_size(objSum, points, "objSum", "points"));
@@ -990,6 +1014,14 @@ int emf_hip_estepBatchedFromDepth(const emf_model_t* models_dev, const emf_pose_
     if (!depth) return fail(EMF_E_NULL, "estepBatchedFromDepth: depth is NULL");
     return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, normalize, norm, objSum, stream,
                         "estepBatchedFromDepth");
+}
+
+int emf_hip_estepBatchedPeer(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                             const emf_image_t* depth, const float K[9], const emf_image_t* points,
+                             const emf_peer_t* group, uint32_t seq, emf_stream_t stream) {
+    if (!group) return fail(EMF_E_NULL, "estepBatchedPeer: group is NULL");
+    return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, 0, nullptr, nullptr, stream,
+                        "estepBatchedPeer", group, seq);
 }
 
 size_t emf_hip_unseenTileBytes(const int32_t res[3]) { return emf_hip_signMapBytes(res) / 2; }

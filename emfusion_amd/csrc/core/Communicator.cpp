@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -75,15 +76,22 @@ struct PeerMemory {
     uint32_t* error = nullptr;  // pinned host word
     size_t rxBytes = 0;
     PeerMemory(int world, size_t slotBytes) : rxBytes(emf_hip_peerBufferBytes(world, slotBytes)) {
-        // fine-grained: stores of another device must become visible without a cache flush of this one
-        if (hipExtMallocWithFlags(&rx, rxBytes, hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            hipCheck(hipMalloc(&rx, rxBytes), "hipMalloc(peer receive buffer)");
-        }
+        // fine-grained: stores of another device must become visible without a cache flush of this one, and
+        // coarse-grained memory gives no such promise -- so no silent fall-back for more than one rank
         void* f = nullptr;
-        if (hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            hipCheck(hipMalloc(&f, 4096), "hipMalloc(peer flags)");
+        if (world > 1) {
+            hipCheck(hipExtMallocWithFlags(&rx, rxBytes, hipDeviceMallocFinegrained),
+                     "hipExtMallocWithFlags(fine-grained peer receive buffer)");
+            hipCheck(hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(fine-grained peer flags)");
+        } else {
+            if (hipExtMallocWithFlags(&rx, rxBytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                hipCheck(hipMalloc(&rx, rxBytes), "hipMalloc(peer receive buffer)");
+            }
+            if (hipExtMallocWithFlags(&f, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                hipCheck(hipMalloc(&f, 4096), "hipMalloc(peer flags)");
+            }
         }
         flags = static_cast<uint32_t*>(f);
         hipCheck(hipMemset(flags, 0, 4096), "hipMemset(peer flags)");
@@ -107,12 +115,16 @@ public:
     // memories in the in-process form).  slots / flags of all ranks are already addressable from here.
     PeerCommunicator(int rank, int world, size_t slotBytes, std::shared_ptr<PeerMemory> own,
                      std::vector<std::shared_ptr<PeerMemory>> keep, const std::vector<void*>& slots,
-                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped)
+                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped, bool sharedDevice)
         : rank_(rank), world_(world), own_(std::move(own)), keep_(std::move(keep)), ipcMapped_(std::move(ipcMapped)) {
+        g_.sharedDevice = sharedDevice ? 1u : 0u;
         g_.rank = rank;
         g_.world = world;
         g_.slotBytes = slotBytes;
         g_.error = own_->error;
+        // EMF_PEER_TIMEOUT_MS: longer bound for rehearsals in which many ranks take turns on one GPU
+        if (const char* t = std::getenv("EMF_PEER_TIMEOUT_MS")) timeoutMs_ = static_cast<uint32_t>(std::max(1, std::atoi(t)));
+        g_.timeoutMs = timeoutMs_;
         for (int p = 0; p < world; ++p) {
             g_.slots[p] = slots[p];
             g_.flags[p] = flags[p];
@@ -125,54 +137,80 @@ public:
     int rank() const override { return rank_; }
     int size() const override { return world_; }
 
+    // Two launches per exchange (round 3: three): the contribution is scattered into the peers' slots, and the
+    // consuming kernel's first workgroup signals while all of its workgroups wait before they reduce / copy.
+    // What the sharded frame exchanges goes through peerGroup() / beginPeerExchange() instead, fused into the
+    // path's own kernels (core/EMFusion.cpp).
     void allReduceSumF32(float* dev, size_t count, Stream& s) override {
         const uint32_t seq = begin(count * sizeof(float));
         emfCheck(emf_hip_peerScatter(&g_, dev, count * sizeof(float), 0, seq, s.abi()), "peerScatter");
-        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
-        emfCheck(emf_hip_peerReduceSumF32(&g_, seq, count, dev, s.abi()), "peerReduceSumF32");
+        emfCheck(emf_hip_peerWaitReduceSumF32(&g_, seq, count, dev, s.abi()), "peerWaitReduceSumF32");
     }
     void allReduceMinU64(uint64_t* dev, size_t count, Stream& s) override {
         const uint32_t seq = begin(count * sizeof(uint64_t));
         emfCheck(emf_hip_peerScatter(&g_, dev, count * sizeof(uint64_t), 0, seq, s.abi()), "peerScatter");
-        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
-        emfCheck(emf_hip_peerReduceMinU64(&g_, seq, count, dev, s.abi()), "peerReduceMinU64");
+        emfCheck(emf_hip_peerWaitReduceMinU64(&g_, seq, count, dev, s.abi()), "peerWaitReduceMinU64");
     }
     void broadcast(void* dev, size_t bytes, int root, Stream& s) override {
+        if (root < 0 || root >= world_) throw HipError("peer broadcast: root " + std::to_string(root), EMF_E_ARG);
         const uint32_t seq = begin(bytes);
         if (rank_ == root) emfCheck(emf_hip_peerScatter(&g_, dev, bytes, 0, seq, s.abi()), "peerScatter");
-        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
-        if (rank_ != root) emfCheck(emf_hip_peerCopyFromSlot(&g_, seq, root, 0, dev, bytes, s.abi()), "peerCopyFromSlot");
+        const int32_t sender = root;
+        const size_t off = 0;
+        void* dst = dev;
+        emfCheck(emf_hip_peerWaitCopyFromSlots(&g_, seq, rank_ == root ? 0 : 1, &sender, &off, &dst, &bytes, s.abi()),
+                 "peerWaitCopyFromSlots");
     }
     void gatherRowBands(void* dev, size_t bytesPerRow, int bandRows, int totalRows, Stream& s) override {
-        const uint32_t seq = begin(bytesPerRow * static_cast<size_t>(totalRows));
+        if (bandRows < 1 || totalRows < 0 || (bytesPerRow * static_cast<size_t>(bandRows)) % 16)
+            throw HipError("peer gatherRowBands: bands of " + std::to_string(bandRows) + " rows x " +
+                           std::to_string(bytesPerRow) + " bytes are not whole 16-byte units", EMF_E_ARG);
         auto band = [&](int r, size_t& off, size_t& bytes) {
             const int r0 = r * bandRows, n = std::min(bandRows, totalRows - r0);
             off = static_cast<size_t>(std::max(r0, 0)) * bytesPerRow;
             bytes = n > 0 ? static_cast<size_t>(n) * bytesPerRow : 0;
         };
+        const uint32_t seq = begin(bytesPerRow * static_cast<size_t>(totalRows));
         size_t off, bytes;
         band(rank_, off, bytes);
         if (bytes)
             emfCheck(emf_hip_peerScatter(&g_, static_cast<char*>(dev) + off, bytes, off, seq, s.abi()), "peerScatter");
-        emfCheck(emf_hip_peerSignalWait(&g_, seq, kTimeoutMs, s.abi()), "peerSignalWait");
+        std::vector<int32_t> senders;
+        std::vector<size_t> offs, sizes;
+        std::vector<void*> dsts;
         for (int r = 0; r < world_; ++r) {
             band(r, off, bytes);
-            if (r != rank_ && bytes)
-                emfCheck(emf_hip_peerCopyFromSlot(&g_, seq, r, off, static_cast<char*>(dev) + off, bytes, s.abi()),
-                         "peerCopyFromSlot");
+            if (r == rank_ || !bytes) continue;
+            senders.push_back(r);
+            offs.push_back(off);
+            sizes.push_back(bytes);
+            dsts.push_back(static_cast<char*>(dev) + off);
         }
+        emfCheck(emf_hip_peerWaitCopyFromSlots(&g_, seq, static_cast<int>(senders.size()), senders.data(), offs.data(),
+                                               dsts.data(), sizes.data(), s.abi()),
+                 "peerWaitCopyFromSlots");
     }
     uint64_t exchangesIssued() const override { return seq_; }
-
-private:
-    static constexpr uint32_t kTimeoutMs = 5000;
-    uint32_t begin(size_t bytes) {
+    const emf_peer_t* peerGroup() const override { return &g_; }
+    uint32_t beginPeerExchange(Stream&) override { return begin(0); }
+    void check() override {
         if (*own_->error)
             throw HipError("peer exchange " + std::to_string(*own_->error) + ": a peer's flag did not arrive within " +
-                           std::to_string(kTimeoutMs) + " ms (ranks disagree about the sequence of exchanges?)", EMF_E_ARG);
+                           std::to_string(timeoutMs_) + " ms (ranks disagree about the sequence of exchanges?); the "
+                           "exchange's consumer left its outputs untouched", EMF_E_PEER_TIMEOUT);
+    }
+
+private:
+    uint32_t timeoutMs_ = 5000;
+    // every argument is validated BEFORE the sequence number moves: a rank that throws here has not taken part in
+    // the exchange and its peers' counters stay in step with its own
+    uint32_t begin(size_t bytes) {
+        check();
         if (bytes > g_.slotBytes)
             throw HipError("peer exchange: message of " + std::to_string(bytes) + " bytes exceeds the slot size " +
                            std::to_string(g_.slotBytes), EMF_E_LIMIT);
+        if (bytes % 16)
+            throw HipError("peer exchange: message of " + std::to_string(bytes) + " bytes is not a multiple of 16", EMF_E_ARG);
         return ++seq_;
     }
     int rank_, world_;
@@ -215,6 +253,12 @@ public:
         inGroup_ = false;
     }
     uint64_t exchangesIssued() const override { return exchanges_; }
+    const emf_peer_t* peerGroup() const override { return inner_->peerGroup(); }
+    uint32_t beginPeerExchange(Stream& s) override {
+        delay(s);
+        return inner_->beginPeerExchange(s);
+    }
+    void check() override { inner_->check(); }
 
 private:
     void delay(Stream& s) {
@@ -389,7 +433,7 @@ std::vector<std::shared_ptr<Communicator>> makePeerCommunicatorsLocal(int worldS
     std::vector<std::shared_ptr<Communicator>> out;
     for (int r = 0; r < worldSize; ++r)
         out.push_back(std::make_shared<PeerCommunicator>(r, worldSize, slotBytes, mem[r], mem, slots, flags,
-                                                         std::vector<void*>()));
+                                                         std::vector<void*>(), worldSize > 1));
     return out;
 }
 
@@ -400,9 +444,16 @@ std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, si
     auto own = std::make_shared<PeerMemory>(boot.world, slotBytes);
     struct Handles {
         hipIpcMemHandle_t rx, flags;
+        char bus[32];  // PCI bus id of the rank's device: ranks that share a GPU (rehearsals) are told apart by it
     };
-    static_assert(sizeof(Handles) == 128, "two 64-byte hipIpcMemHandle_t");
+    static_assert(sizeof(Handles) == 160, "two 64-byte hipIpcMemHandle_t + the bus id");
     Handles mine;
+    std::memset(&mine, 0, sizeof(mine));
+    {
+        int dev = 0;
+        hipCheck(hipGetDevice(&dev), "hipGetDevice");
+        hipCheck(hipDeviceGetPCIBusId(mine.bus, static_cast<int>(sizeof(mine.bus)) - 1, dev), "hipDeviceGetPCIBusId");
+    }
     hipCheck(hipIpcGetMemHandle(&mine.rx, own->rx), "hipIpcGetMemHandle(receive buffer)");
     hipCheck(hipIpcGetMemHandle(&mine.flags, own->flags), "hipIpcGetMemHandle(flags)");
     std::vector<Handles> all(boot.world);
@@ -410,6 +461,9 @@ std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, si
         throw HipError("makePeerCommunicator: the bootstrap all-gather failed", EMF_E_ARG);
     std::vector<void*> slots(boot.world), mapped;
     std::vector<uint32_t*> flags(boot.world);
+    bool shared = false;
+    for (int p = 0; p < boot.world; ++p)
+        for (int q = p + 1; q < boot.world; ++q) shared = shared || std::strncmp(all[p].bus, all[q].bus, sizeof(mine.bus)) == 0;
     for (int p = 0; p < boot.world; ++p) {
         if (p == boot.rank) {
             slots[p] = own->rx;
@@ -425,7 +479,7 @@ std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, si
         mapped.push_back(b);
     }
     return std::make_shared<PeerCommunicator>(boot.rank, boot.world, slotBytes, own,
-                                              std::vector<std::shared_ptr<PeerMemory>>(), slots, flags, mapped);
+                                              std::vector<std::shared_ptr<PeerMemory>>(), slots, flags, mapped, shared);
 }
 
 std::shared_ptr<Communicator> makeDelayedCommunicator(std::shared_ptr<Communicator> inner, int microseconds) {

@@ -41,6 +41,22 @@ public:
     virtual void groupEnd() {}
     /** Collectives this communicator has issued (groups count once): what a frame costs in launches. */
     virtual uint64_t exchangesIssued() const { return 0; }
+    /**
+     * Direct peer-write transports only (else nullptr): the group as the kernels see it.  With it the sharded path
+     * FUSES its exchanges into the kernels around them (emf_hip_estepBatchedPeer -> emf_hip_peerNormalizeAssociation,
+     * emf_hip_packHitKeysPeer -> emf_hip_compositeFromKeysPeer): the producer stores into the peers' slots, the
+     * consumer signals, waits and reduces -- one extra launch per exchange instead of four.
+     * beginPeerExchange() hands out the sequence number of the next exchange, which the caller then enqueues on
+     * `stream` with those entries (every rank must issue the same sequence of exchanges, fused or not).
+     */
+    virtual const emf_peer_t* peerGroup() const { return nullptr; }
+    virtual uint32_t beginPeerExchange(Stream& stream) {
+        (void)stream;
+        throw HipError("Communicator::beginPeerExchange: not a direct peer-write transport", EMF_E_ARG);
+    }
+    /** Throws (EMF_E_PEER_TIMEOUT) if an exchange enqueued earlier has timed out on the device; call after a
+     *  synchronisation.  Transports that report failures at the call itself do nothing. */
+    virtual void check() {}
 };
 
 /** Rank that owns an object volume: round-robin by (1-based) object id. */

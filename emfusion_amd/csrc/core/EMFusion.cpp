@@ -16,6 +16,7 @@
 #include "Output.hpp"
 
 #include <algorithm>
+#include <exception>
 #include <chrono>
 #include <cmath>
 #include <cmath>
@@ -95,15 +96,20 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_RAY_FOOTPRINTS=0: every object gets a marching workgroup for every tile of the image
     const char* rf = std::getenv("EMF_RAY_FOOTPRINTS");
     useFootprints = !(rf && rf[0] == '0');
-    // the background's sweep yields to the raycast when both have workgroups to place (its long chains
-    // should start as early as they can): lowest queue priority for the second stream (+1 % frames/s)
-    aux = Stream(-1);
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
     // 1-rank communicator too, so the whole exchange path can be exercised on a single GPU.
     const char* fs = std::getenv("EMF_FORCE_SHARDED");
     sharded = comm && (world > 1 || (fs && fs[0] == '1'));
+    // Over a direct peer-write transport the sharded path's exchanges are fused into the kernels around them
+    // (Communicator::peerGroup); EMF_PEER_FUSED=0 keeps the transport's own two-launch collectives (A/B; same bits)
+    if (sharded) {
+        const char* pf = std::getenv("EMF_PEER_FUSED");
+        const emf_peer_t* pg = comm->peerGroup();
+        peerFused = pg && !(pf && pf[0] == '0') &&
+                    pg->slotBytes >= emf_hip_peerRaycastSlotBytes(params.frameSize.width, params.frameSize.height);
+    }
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visCountsHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
@@ -136,7 +142,6 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
         emfCheck(emf_hip_computeInvLambda(params.intr.val, &il, s.abi()), "computeInvLambda");
     }
     s.waitForCompletion();
-    streamOf(0);
     rebuildModelTable();
     // volumes created from here on (objects, inside frames) do not wait for a reciprocal check
     TSDF::deferReciprocalChecks(true);
@@ -225,7 +230,6 @@ int EMFusion::addObject(const Vec3f& center, float volSize, const Vec3i& res) {
         objects.emplace_back(id, res, vox, params.objRelTruncDist * volSize / static_cast<float>(res[0]), obj_pose,
                              params.tsdfParams, params.frameSize, gradMode);
         createObj(id);
-        streamOf(id);
     }
     vis_objs.insert(id);  // a new object integrates its first frame (Q18)
     rebuildModelTable();
@@ -379,6 +383,11 @@ void EMFusion::posesOC(std::vector<emf_pose_t>& out) const {
 }
 
 void EMFusion::forkVolumeStreams() {
+    // one stream per volume, as in the reference (EMFusion.h:471) -- created when the per-volume path first runs,
+    // not with the volume: an instance on the batched path owns three streams, and every further stream of a
+    // process makes it likelier that two of them share a hardware queue
+    streamOf(0);
+    for (auto& obj : objects) streamOf(obj.getID());
     main.record();
     for (auto& kv : streams) kv.second.waitOn(main);
 }
@@ -394,7 +403,10 @@ float EMFusion::stamp(int slot) {
 
 double EMFusion::pixels() const { return static_cast<double>(params.frameSize.area()); }
 
-void EMFusion::synchronize() { hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+void EMFusion::synchronize() {
+    hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (comm) comm->check();  // an exchange that timed out on the device surfaces here (EMF_E_PEER_TIMEOUT)
+}
 
 // Wait for everything THIS instance has enqueued -- its three frame streams, the per-volume streams and the
 // null stream its constructors clear on -- and for nothing else: unlike hipDeviceSynchronize() this does not
@@ -1211,6 +1223,26 @@ void EMFusion::estepBatched() {
         launch(1, &nv, nullptr);
         return;
     }
+    std::vector<emf_image_t> maps;
+    maps.push_back(bg_associationWeights.view());
+    for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
+    if (peerFused && maps.size() <= 16) {
+        // direct peer writes: the E-step's kernel stores its partial sum straight into the peers' slots, and ONE
+        // more launch waits for the peers, sums the slots in rank order and normalises -- two launches per E-step
+        // where the unsharded frame has one (round 3: five)
+        const uint32_t seq = comm->beginPeerExchange(main);
+        {
+            auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
+            emfCheck(emf_hip_estepBatchedPeer(table, co.data(), n, fromDepth ? &depth : nullptr, params.intr.val, &pv,
+                                              comm->peerGroup(), seq, main.abi()),
+                     "estepBatchedPeer");
+        }
+        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+        emfCheck(emf_hip_peerNormalizeAssociation(comm->peerGroup(), seq, maps.data(), static_cast<int>(maps.size()), &sv,
+                                                  &nv, main.abi()),
+                 "peerNormalizeAssociation");
+        return;
+    }
     // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
     // xGMI, then every rank normalises its own maps
     launch(0, nullptr, &sv);
@@ -1219,9 +1251,6 @@ void EMFusion::estepBatched() {
     // background's sweep needs the normalised weights and is as long as the raycast it runs beside.)
     Stream& st = main;
     comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), st);
-    std::vector<emf_image_t> maps;
-    maps.push_back(bg_associationWeights.view());
-    for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
     {
         auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), st);
         emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
@@ -1497,20 +1526,58 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
                       v_ray = raylengths.view(), v_vert = vertices.view(),
                       v_norm = normals.view(), v_seg = modelSegmentation.view(),
                       v_diff = diffRaylengths.view(), v_noObj = noObjMask.view();
-    {
+    std::vector<int32_t> countIndex(1, 0);
+    countIndex.insert(countIndex.end(), listPos.begin(), listPos.end());
+    if (peerFused) {
+        // direct peer writes: k_pack_keys_peer stores the keys and this rank's band of the background raycast
+        // straight into the peers' slots; ONE more launch waits, takes the minimum key, fetches the foreign bands,
+        // composites and counts visibility; a one-workgroup launch turns the counts into the gate (as unsharded)
+        auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nlocal), main);
+        const uint32_t seq = comm->beginPeerExchange(main);
+        const int band = bandRowsPending;
+        const int row0 = std::min(rank * band, h);
+        emfCheck(emf_hip_packHitKeysPeer(nlocal, listPos.data(), oray.data(), oseg.data(), &v_bgRay, &v_bgMask, row0,
+                                         band ? std::min(band, h - row0) : 0, comm->peerGroup(), seq, main.abi()),
+                 "packHitKeysPeer");
+        if (!visCountsClear) visCounts.setZero(main);
+        emfCheck(emf_hip_compositeFromKeysPeer(comm->peerGroup(), seq, band, nall, allIds.data(), nlocal, listPos.data(),
+                                               oray.data(), overt.data(), onorm.data(), &v_bgRay, &v_bgVert, &v_bgNorm,
+                                               &v_bgMask, &v_ray, &v_vert, &v_norm, &v_seg, &v_diff, &v_noObj,
+                                               params.boundary, visCounts.as<int32_t>(), main.abi()),
+                 "compositeFromKeysPeer");
+        bandRowsPending = 0;
+        emfCheck(emf_hip_visibilityFlagsMirror(visCounts.as<int32_t>(), nall, nlocal + 1, countIndex.data(),
+                                               params.visibilityThresh, visibleDev.as<int32_t>(),
+                                               deviceGate ? visibleHost : visCountsHost, main.abi()),
+                 "visibilityFlagsMirror");
+        visCountsClear = true;
+    } else {
         auto kt = ktimers.scope(KernelTimers::Composite, pixels() * (1.0 + nlocal), main);
         emfCheck(emf_hip_packHitKeys(nlocal, listPos.data(), oray.data(), oseg.data(),
                                      hitKeys.as<uint64_t>(), w, h, main.abi()),
                  "packHitKeys");
         // ONE exchange per raycast: nearest-hit keys of the objects + the ranks' bands of the background's
         // raylengths and hit mask (ncclGroup: a single launch on the transport)
-        comm->groupStart();
-        comm->allReduceMinU64(hitKeys.as<uint64_t>(), params.frameSize.area(), main);
-        if (bandRowsPending) {
-            comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), bandRowsPending, h, main);
-            comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), bandRowsPending, h, main);
+        struct Group {  // closes the group also when a collective inside throws
+            Communicator& c;
+            const int unwinding = std::uncaught_exceptions();
+            explicit Group(Communicator& comm_) : c(comm_) { c.groupStart(); }
+            ~Group() noexcept(false) {
+                if (std::uncaught_exceptions() == unwinding) {
+                    c.groupEnd();
+                } else {
+                    try { c.groupEnd(); } catch (...) {}
+                }
+            }
+        };
+        {
+            Group group(*comm);
+            comm->allReduceMinU64(hitKeys.as<uint64_t>(), params.frameSize.area(), main);
+            if (bandRowsPending) {
+                comm->gatherRowBands(bg_raylengths.ptr(), static_cast<size_t>(w) * sizeof(float), bandRowsPending, h, main);
+                comm->gatherRowBands(bg_mask.ptr(), static_cast<size_t>(w), bandRowsPending, h, main);
+            }
         }
-        comm->groupEnd();
         bandRowsPending = 0;
         visCountsClear = false;
         emfCheck(emf_hip_compositeFromKeys(hitKeys.as<uint64_t>(), nall, allIds.data(), nlocal,
@@ -1521,8 +1588,6 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
                                            main.abi()),
                  "compositeFromKeys");
         if (deviceGate) {
-            std::vector<int32_t> countIndex(1, 0);
-            countIndex.insert(countIndex.end(), listPos.begin(), listPos.end());
             emfCheck(emf_hip_visibilityFlagsIndexed(visCounts.as<int32_t>(), nlocal + 1,
                                                     countIndex.data(), params.visibilityThresh,
                                                     visibleDev.as<int32_t>(), main.abi()),
@@ -1533,10 +1598,12 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
     vis_objs.clear();
     visPending = false;
     if (nall == 0) return;
-    int32_t* dst = deviceGate ? visibleHost : visCountsHost;
-    hipCheck(hipMemcpyAsync(dst, visCounts.data(), sizeof(int32_t) * nall, hipMemcpyDeviceToHost,
-                            main.get()),
-             "visCounts D2H");
+    if (!peerFused) {  // (the fused path's flag kernel has mirrored the counts already)
+        int32_t* dst = deviceGate ? visibleHost : visCountsHost;
+        hipCheck(hipMemcpyAsync(dst, visCounts.data(), sizeof(int32_t) * nall, hipMemcpyDeviceToHost,
+                                main.get()),
+                 "visCounts D2H");
+    }
     if (deviceGate) {
         hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
         visIds = allIds;

@@ -308,7 +308,7 @@ private:
     std::vector<int> allIds;             // every object id of the job, creation order
     std::map<int, ObjImages> objImages;  // per owned object
     std::map<int, Stream> streams;       // key 0 = background, else object id
-    Stream main;
+    Stream main{streamPriority("EMF_PRIO_MAIN", 0)};
     Affine3f pose;                       // current camera pose
     std::set<int> vis_objs;
     int frameCount = 0;
@@ -386,7 +386,9 @@ private:
     bool bgOverlap = true;
     bool bgInFlight = false;        // the out-of-place integration of this frame has been enqueued
     bool bgBackStale = false;       // the background was integrated in place: the copies differ
-    Stream aux;
+    // the background's sweep yields to the raycast when both have workgroups to place (its long chains should
+    // start as early as they can): lowest queue priority for the second stream (+1 % frames/s)
+    Stream aux{streamPriority("EMF_PRIO_AUX", -1)};
     // Raycast far bounds (emf_hip_raycastFarBounds): per model and 8x8-pixel cell, where a march may
     // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
     bool useFootprints = true;  // objects are marched only where their volume box projects to
@@ -396,8 +398,9 @@ private:
     bool earlyFarBounds = true;    // far bounds wait for the previous raycast only (EMF_EARLY_FAR_BOUNDS=0: for `main`)
     hipEvent_t rayDone = nullptr;  // behind the last raycast that read farBounds
     bool rayDoneValid = false;
+    bool peerFused = false;     // sharded over a direct peer-write transport: exchanges fused into the path's kernels
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
-    Stream lists;               // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
+    Stream lists{streamPriority("EMF_PRIO_LISTS", 0)};  // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
     bool bgListPending = false; // the background was forked; its list rebuild is not enqueued yet
     bool bgPrepared = false;    // bgCullScratch's counter and the next dirtyNext map are already cleared
     void rebuildBackgroundList();

@@ -123,6 +123,13 @@ int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion
 
 void emf_fusion_destroy(emf_fusion_t* h) { delete h; }
 
+int emf_fusion_trim_pool(uint64_t* bytes_freed) {
+    return guarded([&] {
+        if (bytes_freed) *bytes_freed = emf::DeviceBuffer::pooledBytes();
+        emf::DeviceBuffer::trimPool();
+    });
+}
+
 int emf_fusion_reset(emf_fusion_t* h) {
     REQ(h);
     return guarded([&] { h->impl->reset(); });

@@ -23,53 +23,118 @@ void emfCheck(int rc, const char* what) {
 // hipFree synchronises the whole device and hipMalloc of tens of MB takes a fraction of a millisecond;
 // objects are created, resized and deleted INSIDE frames (reference EMFusion.cpp:495-560, 827-863,
 // 922-980).  So a released DeviceBuffer is not freed: it goes to a pool together with one event per live
-// stream of the releasing host thread, recorded at the stream's tail at the moment of the release --
-// everything that could still touch the memory was enqueued before -- and is handed out again (same size)
-// once all of them have completed (hipEventQuery: no wait).
-// Pool, stream registry and events are PER HOST THREAD: an emf::EMFusion instance is driven by one thread
-// (its streams are created there, its buffers released there), and several instances on several threads
-// (the multi-rank rehearsal) must not record events on each other's streams -- HIP's event bookkeeping
-// throws from inside the runtime when they do.  A thread's pool is really freed when the thread ends.
+// stream of its HOME thread -- the host thread that allocated it, which is the thread that drives its
+// emf::EMFusion instance and created every emf::Stream that can touch it -- recorded at the streams' tails
+// no earlier than the release, and is handed out again (same size, same home) once all of them have
+// completed (hipEventQuery: no wait).
+// Registry and pool are process-wide under one mutex; what stays per thread is WHO fences WHAT:
+//   * events are only ever recorded by the thread that created the stream (several instances on several
+//     threads -- the multi-rank rehearsal -- must not record on each other's streams);
+//   * a buffer released on a FOREIGN thread (a handle closed or finalised elsewhere) is parked unfenced and
+//     fenced by its home thread at that thread's next pool operation -- later than the release, so still
+//     behind everything that was enqueued on the buffer; if the home thread has ended it is hipFree'd;
+//   * a stream destroyed on a foreign thread is drained first and its fences are retired wherever they
+//     are (an event must not outlive the stream it was recorded on: hipEventQuery then throws from inside
+//     the runtime), and the owner's parked buffers are fenced by that drain as well.
+// A thread's buffers are really freed when the thread ends, by trimPool(), or when hipMalloc fails.
 namespace {
 struct Fence {
     hipEvent_t event;
-    hipStream_t stream;  // where it was recorded: an event must not outlive its stream (see retire_fences_of)
+    hipStream_t stream;  // where it was recorded
 };
 struct Pooled {
     void* p;
     size_t bytes;
+    uint64_t home;
+    bool parked;  // released on a foreign thread: not fenced yet
     std::vector<Fence> fences;
 };
-struct ThreadPool {
-    std::vector<hipStream_t> streams;  // streams created by emf::Stream on this thread
+struct LiveStream {
+    hipStream_t s;
+    uint64_t owner;
+};
+struct Registry {
+    std::mutex m;
+    std::vector<LiveStream> streams;  // every live emf::Stream of the process
     std::vector<Pooled> pool;
+    std::vector<uint64_t> threads;    // live threads that have used the pool
     size_t pooledBytes = 0;
-    ~ThreadPool() {
-        for (Pooled& b : pool) (void)hipFree(b.p);
-        for (Pooled& b : pool)
-            for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
+    uint64_t nextId = 1;
+};
+Registry& reg() {
+    static Registry* r = new Registry;  // never destroyed: thread_local destructors may run after statics
+    return *r;
+}
+void free_entries_locked(Registry& r, std::vector<Pooled>& out, uint64_t home, bool all) {
+    for (size_t i = 0; i < r.pool.size();) {
+        if (all || r.pool[i].home == home) {
+            r.pooledBytes -= r.pool[i].bytes;
+            out.push_back(std::move(r.pool[i]));
+            r.pool[i] = std::move(r.pool.back());
+            r.pool.pop_back();
+        } else {
+            ++i;
+        }
+    }
+}
+void really_free(std::vector<Pooled>& v) {
+    for (Pooled& b : v) (void)hipFree(b.p);  // synchronises the device: every fence has passed afterwards
+    for (Pooled& b : v)
+        for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
+    v.clear();
+}
+struct ThreadTag {
+    uint64_t id;
+    ThreadTag() {
+        Registry& r = reg();
+        std::lock_guard<std::mutex> lock(r.m);
+        id = r.nextId++;
+        r.threads.push_back(id);
+    }
+    ~ThreadTag() {
+        Registry& r = reg();
+        std::vector<Pooled> mine;
+        {
+            std::lock_guard<std::mutex> lock(r.m);
+            r.threads.erase(std::remove(r.threads.begin(), r.threads.end(), id), r.threads.end());
+            free_entries_locked(r, mine, id, false);
+        }
+        really_free(mine);
     }
 };
-ThreadPool& tp() {
-    static thread_local ThreadPool t;
-    return t;
-}
-// every live emf::Stream of the process: a thread's list may name a stream that another thread destroyed
-std::mutex g_liveMutex;
-std::vector<hipStream_t> g_live;
-bool stream_is_live(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_liveMutex);
-    return std::find(g_live.begin(), g_live.end(), s) != g_live.end();
+uint64_t this_thread() {
+    static thread_local ThreadTag t;
+    return t.id;
 }
 
-size_t pool_cap() {  // bytes a thread's pool may hold before it really frees (EMF_POOL_MIB, default 16 GiB of 288)
+size_t pool_cap() {  // bytes the pool may hold before a release really frees (EMF_POOL_MIB, default 16 GiB of 288)
     static const size_t cap = [] {
         const char* e = std::getenv("EMF_POOL_MIB");
         return (e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : size_t(16384)) << 20;
     }();
     return cap;
 }
-bool fences_passed(ThreadPool& t, Pooled& b) {
+// fence `b` on every live stream of thread `me` and on the null stream (clears and uploads of constructors run
+// there); called by `me` only, registry locked.  false: could not fence it.
+bool fence_locked(Registry& r, Pooled& b, uint64_t me) {
+    std::vector<hipStream_t> streams;
+    for (const LiveStream& ls : r.streams)
+        if (ls.owner == me) streams.push_back(ls.s);
+    streams.push_back(nullptr);
+    for (hipStream_t st : streams) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        if (!ev || hipEventRecord(ev, st) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev) (void)hipEventDestroy(ev);
+            return false;
+        }
+        b.fences.push_back(Fence{ev, st});
+    }
+    b.parked = false;
+    return true;
+}
+bool fences_passed(Pooled& b) {
     while (!b.fences.empty()) {
         if (hipEventQuery(b.fences.back().event) != hipSuccess) {
             (void)hipGetLastError();  // hipErrorNotReady is not an error
@@ -80,86 +145,113 @@ bool fences_passed(ThreadPool& t, Pooled& b) {
     }
     return true;
 }
-void* pool_acquire(size_t bytes) {
-    ThreadPool& t = tp();
-    for (size_t i = 0; i < t.pool.size(); ++i)
-        if (t.pool[i].bytes == bytes && fences_passed(t, t.pool[i])) {
-            void* p = t.pool[i].p;
-            t.pooledBytes -= bytes;
-            t.pool[i] = std::move(t.pool.back());
-            t.pool.pop_back();
-            return p;
+// buffers of `me` that a foreign thread released: fence them now (registry locked, called by `me`)
+void adopt_parked_locked(Registry& r, uint64_t me, std::vector<Pooled>& unfenceable) {
+    for (size_t i = 0; i < r.pool.size();) {
+        Pooled& b = r.pool[i];
+        if (b.home == me && b.parked && !fence_locked(r, b, me)) {
+            r.pooledBytes -= b.bytes;
+            unfenceable.push_back(std::move(b));
+            r.pool[i] = std::move(r.pool.back());
+            r.pool.pop_back();
+        } else {
+            ++i;
         }
-    return nullptr;
+    }
 }
-void pool_release(void* p, size_t bytes) {
-    ThreadPool& t = tp();
-    if (t.pooledBytes + bytes > pool_cap()) {  // over the cap: a real free (synchronises the device)
-        (void)hipFree(p);
-        return;
+void* pool_acquire(size_t bytes) {
+    Registry& r = reg();
+    const uint64_t me = this_thread();
+    std::vector<Pooled> slow;
+    void* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        adopt_parked_locked(r, me, slow);
+        for (size_t i = 0; i < r.pool.size(); ++i)
+            if (r.pool[i].home == me && r.pool[i].bytes == bytes && fences_passed(r.pool[i])) {
+                p = r.pool[i].p;
+                r.pooledBytes -= bytes;
+                r.pool[i] = std::move(r.pool.back());
+                r.pool.pop_back();
+                break;
+            }
     }
-    Pooled b{p, bytes, {}};
-    t.streams.erase(std::remove_if(t.streams.begin(), t.streams.end(), [](hipStream_t s) { return !stream_is_live(s); }),
-                    t.streams.end());
-    std::vector<hipStream_t> streams = t.streams;
-    streams.push_back(nullptr);  // the null stream: clears and uploads of constructors run there
-    for (hipStream_t st : streams) {
-        hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
-        if (!ev || hipEventRecord(ev, st) != hipSuccess) {  // cannot fence it: free it the slow, safe way
-            (void)hipGetLastError();
-            if (ev) (void)hipEventDestroy(ev);
-            for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
-            (void)hipFree(p);
-            return;
+    really_free(slow);
+    return p;
+}
+void pool_release(void* p, size_t bytes, uint64_t home) {
+    Registry& r = reg();
+    const uint64_t me = this_thread();
+    std::vector<Pooled> slow;
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        Pooled b{p, bytes, home, me != home, {}};
+        const bool homeAlive = std::find(r.threads.begin(), r.threads.end(), home) != r.threads.end();
+        if (r.pooledBytes + bytes > pool_cap() || !homeAlive) {
+            slow.push_back(std::move(b));  // over the cap, or nobody left to fence it: a real free
+        } else {
+            if (me == home) {
+                adopt_parked_locked(r, me, slow);
+                if (!fence_locked(r, b, me)) {
+                    slow.push_back(std::move(b));
+                    b.p = nullptr;
+                }
+            }
+            if (b.p) {
+                r.pooledBytes += bytes;
+                r.pool.push_back(std::move(b));
+            }
         }
-        b.fences.push_back(Fence{ev, st});
     }
-    t.pooledBytes += bytes;
-    t.pool.push_back(std::move(b));
+    really_free(slow);
 }
 void register_stream(hipStream_t s) {
-    tp().streams.push_back(s);
-    std::lock_guard<std::mutex> lock(g_liveMutex);
-    g_live.push_back(s);
+    Registry& r = reg();
+    const uint64_t me = this_thread();
+    std::lock_guard<std::mutex> lock(r.m);
+    r.streams.push_back(LiveStream{s, me});
 }
-// A stream is about to be destroyed: HIP's event bookkeeping keeps a reference to the stream an event was last
-// recorded on, and querying such an event after the stream is gone throws from inside the runtime
-// ("std::get: wrong index for variant").  So the stream is drained here, which completes every fence recorded
-// on it, and those fences are destroyed -- not re-used -- before the stream goes.
-void retire_fences_of(hipStream_t s) {
-    ThreadPool& t = tp();
-    bool any = false;
-    for (const Pooled& b : t.pool)
-        for (const Fence& f : b.fences) any = any || f.stream == s;
-    if (!any) return;
-    (void)hipStreamSynchronize(s);
-    for (Pooled& b : t.pool) {
-        for (Fence& f : b.fences)
-            if (f.stream == s) (void)hipEventDestroy(f.event);
-        b.fences.erase(std::remove_if(b.fences.begin(), b.fences.end(), [s](const Fence& f) { return f.stream == s; }),
-                       b.fences.end());
-    }
-}
+// A stream is about to be destroyed (by any thread).  It is drained if a fence was recorded on it or if its
+// owner has parked buffers (work on them may sit on this stream and nothing else would order a later fence
+// behind it); that completes every fence recorded on it, and those are destroyed before the stream goes.
 void unregister_stream(hipStream_t s) {
-    retire_fences_of(s);
-    auto& v = tp().streams;
-    v.erase(std::remove(v.begin(), v.end(), s), v.end());
-    std::lock_guard<std::mutex> lock(g_liveMutex);
-    g_live.erase(std::remove(g_live.begin(), g_live.end(), s), g_live.end());
+    Registry& r = reg();
+    std::lock_guard<std::mutex> lock(r.m);
+    uint64_t owner = 0;
+    for (const LiveStream& ls : r.streams)
+        if (ls.s == s) owner = ls.owner;
+    bool drain = false;
+    for (const Pooled& b : r.pool) {
+        drain = drain || (b.parked && b.home == owner);
+        for (const Fence& f : b.fences) drain = drain || f.stream == s;
+    }
+    if (drain) {
+        (void)hipStreamSynchronize(s);
+        for (Pooled& b : r.pool) {
+            for (Fence& f : b.fences)
+                if (f.stream == s) (void)hipEventDestroy(f.event);
+            b.fences.erase(std::remove_if(b.fences.begin(), b.fences.end(), [s](const Fence& f) { return f.stream == s; }),
+                           b.fences.end());
+        }
+    }
+    r.streams.erase(std::remove_if(r.streams.begin(), r.streams.end(), [s](const LiveStream& ls) { return ls.s == s; }),
+                    r.streams.end());
 }
 }  // namespace
 
-size_t DeviceBuffer::pooledBytes() { return tp().pooledBytes; }
+size_t DeviceBuffer::pooledBytes() {
+    Registry& r = reg();
+    std::lock_guard<std::mutex> lock(r.m);
+    return r.pooledBytes;
+}
 void DeviceBuffer::trimPool() {
-    ThreadPool& t = tp();
+    Registry& r = reg();
     std::vector<Pooled> all;
-    all.swap(t.pool);
-    t.pooledBytes = 0;
-    for (Pooled& b : all) {
-        (void)hipFree(b.p);  // synchronises the device: the fences have passed afterwards
-        for (const Fence& f : b.fences) (void)hipEventDestroy(f.event);
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        free_entries_locked(r, all, 0, true);
     }
+    really_free(all);
 }
 
 Stream::Stream() : owned_(true) {
@@ -219,23 +311,31 @@ void Stream::waitFor(Stream& other) {
     waitOn(other);
 }
 
-DeviceBuffer::DeviceBuffer(size_t bytes) : n_(bytes) {
+DeviceBuffer::DeviceBuffer(size_t bytes) : n_(bytes), home_(this_thread()) {
     if (!bytes) return;
     p_ = pool_acquire(bytes);
-    if (!p_) hipCheck(hipMalloc(&p_, bytes), "hipMalloc");
+    if (p_) return;
+    hipError_t e = hipMalloc(&p_, bytes);
+    if (e == hipErrorOutOfMemory) {  // give the pool back (waits for the device) and try once more
+        (void)hipGetLastError();
+        trimPool();
+        e = hipMalloc(&p_, bytes);
+    }
+    hipCheck(e, "hipMalloc");
 }
 DeviceBuffer::~DeviceBuffer() {
-    if (p_) pool_release(p_, n_);
+    if (p_) pool_release(p_, n_, home_);
 }
-DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_) {
+DeviceBuffer::DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_), home_(o.home_) {
     o.p_ = nullptr;
     o.n_ = 0;
 }
 DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
     if (this != &o) {
-        if (p_) pool_release(p_, n_);
+        if (p_) pool_release(p_, n_, home_);
         p_ = o.p_;
         n_ = o.n_;
+        home_ = o.home_;
         o.p_ = nullptr;
         o.n_ = 0;
     }

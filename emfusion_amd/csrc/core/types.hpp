@@ -10,6 +10,7 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -160,6 +161,16 @@ private:
     hipEvent_t ev_ = nullptr;  // lazily created by record()
 };
 
+/** Queue priority of one of the frame's streams: `dflt` unless the environment variable `env` says "high" / "+1",
+ *  "normal" / "0" or "low" / "-1" (A/B measurements of the stream-to-queue mapping). */
+inline int streamPriority(const char* env, int dflt) {
+    const char* v = std::getenv(env);
+    if (!v || !v[0]) return dflt;
+    if (v[0] == 'h' || v[0] == '+' || v[0] == '1') return 1;
+    if (v[0] == 'l' || v[0] == '-') return -1;
+    return 0;
+}
+
 // Continuous device buffer (what cv::cuda::createContinuous gives): RAII over hipMalloc + a pool.
 class DeviceBuffer {
 public:
@@ -178,7 +189,8 @@ public:
     size_t bytes() const { return n_; }
     bool empty() const { return p_ == nullptr; }
     // Released buffers wait in a process-wide pool (types.cpp, capped by EMF_POOL_MIB) instead of going
-    // through hipFree, which synchronises the device.  trimPool() really frees them (and does wait).
+    // through hipFree, which synchronises the device.  trimPool() really frees them (and does wait);
+    // emf_fusion_trim_pool() is its C entry, and a failing hipMalloc trims and retries once.
     static size_t pooledBytes();
     static void trimPool();
     void setZero(const Stream& s) const;
@@ -189,6 +201,7 @@ public:
 private:
     void* p_ = nullptr;
     size_t n_ = 0;
+    uint64_t home_ = 0;  // the host thread that allocated it (types.cpp: only that thread fences and re-uses it)
 };
 
 // Continuous W x H image with C interleaved channels of T (the GpuMat of the reference).

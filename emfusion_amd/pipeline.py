@@ -92,6 +92,7 @@ def load() -> C.CDLL:
         "emf_fusion_create": [C.POINTER(FusionParams), vp, C.POINTER(vp)],
         "emf_fusion_destroy": [vp],
         "emf_fusion_reset": [vp],
+        "emf_fusion_trim_pool": [C.POINTER(C.c_uint64)],
         "emf_fusion_add_object": [vp, fp, C.c_float, ip],
         "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
                                      C.c_int],
@@ -216,7 +217,7 @@ class Communicator:
     def local_group(cls, world: int, transport: str = "host", max_bytes: int = 0):
         """`world` communicators of THIS process for `world` Fusion objects on `world` threads sharing one
         GPU (rehearsal of the multi-GPU code path).  transport "host": collectives staged through host
-        memory; "peer": the direct peer-write exchanges (max_bytes = the largest message, W * H * 8)."""
+        memory; "peer": the direct peer-write exchanges (max_bytes = the slot size: W * H * 16 holds the raycast's fused exchange -- keys, background band, mask; with less the frame falls back to unfused exchanges)."""
         handles = (C.c_void_p * world)()
         if transport == "peer":
             _check("emf_comm_create_peer_local_group",
@@ -664,6 +665,13 @@ class Fusion:
 
     def owns_object(self, obj_id: int) -> bool:
         return bool(load().emf_fusion_owns_object(self._h, obj_id))
+
+
+def trim_pool() -> int:
+    """Really free the device buffers the host classes keep pooled (waits for the device); bytes freed."""
+    n = C.c_uint64(0)
+    _check("emf_fusion_trim_pool", load().emf_fusion_trim_pool(C.byref(n)))
+    return int(n.value)
 
 
 def write_volume(filename, volume: np.ndarray, voxel_size: float):

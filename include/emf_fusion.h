@@ -73,6 +73,10 @@ void emf_fusion_default_params(emf_fusion_params_t* p);
 int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion_t** out);
 void emf_fusion_destroy(emf_fusion_t* h);
 int emf_fusion_reset(emf_fusion_t* h);
+/* Device buffers released by destroyed / resized volumes wait in a process-wide pool instead of going through
+ * hipFree (which synchronises the device; EMF_POOL_MIB caps the pool, default 16 GiB).  This really frees them
+ * -- it waits for the device -- and reports how many bytes were held (bytes_freed may be NULL). */
+int emf_fusion_trim_pool(uint64_t* bytes_freed);
 
 /* Create an object volume (edge vol_size metres, obj_res voxels) centred at `center` in world
  * coordinates; every rank issues the same calls.  *id_out = object id (1-based). */

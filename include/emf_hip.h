@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 6
+#define EMF_HIP_ABI_VERSION 7
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -48,7 +48,9 @@ enum {
     EMF_E_ARG = -4,       /* scalar argument out of domain (voxelSize <= 0, channels not in 1..3 ...) */
     EMF_E_LIMIT = -5,     /* count exceeds a documented limit (EMF_MAX_*) */
     EMF_E_NODEVICE = -6,  /* no HIP device / library built without device code for this GPU */
-    EMF_E_NOTREADY = -7   /* the answer is not known yet (emf_hip_voxelReciprocalCached: size never checked) */
+    EMF_E_NOTREADY = -7,  /* the answer is not known yet (emf_hip_voxelReciprocalCached: size never checked) */
+    EMF_E_PEER_TIMEOUT = -8 /* a peer's flag did not arrive within the bound of a direct peer-write exchange (reported by
+                             the host classes; the kernels raise the group's error word and skip the exchange's consumer) */
 };
 
 /* GpuMat-like image view: `data` device pointer, `pitch` bytes per row (>= width * elemsize) */
@@ -177,15 +179,28 @@ int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, f
  * emf::makePeerCommunicator.  Buffers: emf_hip_peerBufferBytes(world, slotBytes) bytes (two parities x
  * world slots) and `world` u32 flags per rank, zeroed before the first exchange; slotBytes % 16 == 0.
  * An exchange with sequence number seq (1, 2, 3 ... identical on all ranks) is
- *     peerScatter (ranks that contribute) -> peerSignalWait (every rank) -> peerReduce* / peerCopyFromSlot
- * enqueued on the caller's stream; nothing allocates or synchronises.  A wait that exceeds timeoutMs
- * stores seq to *error (device-visible word of the caller's) and falls through. */
+ *     scatter (ranks that contribute) -> signal + wait (every rank) -> reduce / copy out of the slots
+ * enqueued on the caller's stream; nothing allocates or synchronises.  A wait that exceeds the group's bound
+ * stores seq to *error (host-visible word of the caller's) and the exchange's consumer kernel leaves its outputs
+ * untouched; the host classes turn a non-zero error word into EMF_E_PEER_TIMEOUT at their next synchronisation.
+ * Three forms, same slots and flags:
+ *   three launches    peerScatter -> peerSignalWait -> peerReduce* / peerCopyFromSlot            (round 3)
+ *   two launches      peerScatter -> peerWaitReduce* / peerWaitCopyFromSlots: the consumer's first workgroup
+ *                     signals, every workgroup waits, then reduces / copies                     (round 4)
+ *   fused             the path's own kernels scatter and consume: emf_hip_estepBatchedPeer ->
+ *                     peerNormalizeAssociation (E-step), emf_hip_packHitKeysPeer ->
+ *                     emf_hip_compositeFromKeysPeer (raycast): one extra launch per exchange     (round 4) */
 typedef struct emf_peer {
     int32_t rank, world;
     void* slots[EMF_MAX_PEERS];      /* receive buffer of peer p as addressable from THIS device */
-    uint32_t* flags[EMF_MAX_PEERS];  /* flag words of peer p (world of them) */
+    uint32_t* flags[EMF_MAX_PEERS];  /* flag page of peer p: 4096 bytes; words 0..world-1 are the flags */
     size_t slotBytes;                /* capacity of one sender's slot */
     uint32_t* error;                 /* this rank's error word */
+    uint32_t timeoutMs;              /* bound of a wait in milliseconds (0: 5000) */
+    uint32_t sharedDevice;           /* != 0: ranks of the group share a GPU (single-box rehearsals).  The consumers
+                                        then do not wait themselves -- a grid of spinning workgroups per rank could fill
+                                        the device and keep a lagging rank's producer from starting -- and every
+                                        peerWait* / *Peer consumer entry enqueues the one-wave peerSignalWait in front */
 } emf_peer_t;
 size_t emf_hip_peerBufferBytes(int world, size_t slotBytes);
 int emf_hip_peerScatter(const emf_peer_t* group, const void* src, size_t bytes, size_t dstOffset, uint32_t seq,
@@ -195,7 +210,14 @@ int emf_hip_peerReduceSumF32(const emf_peer_t* group, uint32_t seq, size_t count
 int emf_hip_peerReduceMinU64(const emf_peer_t* group, uint32_t seq, size_t count, uint64_t* out, emf_stream_t stream);
 int emf_hip_peerCopyFromSlot(const emf_peer_t* group, uint32_t seq, int sender, size_t srcOffset, void* dst,
                              size_t bytes, emf_stream_t stream);
-
+/* signal + wait + reduce in one launch (out := sum / min over the world slots in rank order) */
+int emf_hip_peerWaitReduceSumF32(const emf_peer_t* group, uint32_t seq, size_t count, float* out, emf_stream_t stream);
+int emf_hip_peerWaitReduceMinU64(const emf_peer_t* group, uint32_t seq, size_t count, uint64_t* out, emf_stream_t stream);
+/* signal + wait + nparts copies dst[k][0, bytes[k]) := slot[senders[k]] + srcOffsets[k] in one launch (a broadcast:
+ * one part on the receivers, none on the root; a band gather: one part per peer and image); nparts <= 16 */
+int emf_hip_peerWaitCopyFromSlots(const emf_peer_t* group, uint32_t seq, int nparts, const int32_t* senders_host,
+                                  const size_t* srcOffsets_host, void* const* dsts_host, const size_t* bytes_host,
+                                  emf_stream_t stream);
 /* Diagnostics behind the two arithmetic shortcuts of the tiled integration (device_core.hpp, on by
  * default, EMF_INT_FAST): the pixel of a voxel as round(x * rcp(z)) unless that lies next to a rounding
  * tie, and the side of the truncation band from the hardware square root unless the distance lies
@@ -787,6 +809,44 @@ int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_d
 int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const emf_image_t* points,
                                  const float R_CO[9], const float t_CO[3], const int32_t res[3],
                                  float voxelSize, float* grads6, emf_stream_t stream);
+
+/* ---- direct peer-write exchanges fused into the path's kernels (types: see the peer section above) ---- */
+/* The E-step's exchange fused into the path (reference EMFusion.cpp:653-665; SURVEY 8e exchange 1):
+ *   estepBatchedPeer          = emf_hip_estepBatched / ...FromDepth (depth != NULL) with normalize = 0 whose per-pixel
+ *                               sum of the OBJECT maps goes straight into slot[me] (offset 0, W*H floats) of every peer;
+ *   peerNormalizeAssociation  waits, sums the slots in rank order (-> objSum, optional), norm := maps[0] + that sum,
+ *                               maps[k] := maps[k] / norm (x / 0 := 0): the values of peerWaitReduceSumF32 followed
+ *                               by emf_hip_normalizeAssociation(maps, nmaps, 1, objSum, norm).  nmaps <= 16. */
+int emf_hip_estepBatchedPeer(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
+                             const emf_image_t* depth, const float K[9], const emf_image_t* points,
+                             const emf_peer_t* group, uint32_t seq, emf_stream_t stream);
+int emf_hip_peerNormalizeAssociation(const emf_peer_t* group, uint32_t seq, const emf_image_t* maps_host, int nmaps,
+                                     const emf_image_t* objSum, const emf_image_t* norm, emf_stream_t stream);
+/* The raycast's exchange fused into the path (reference EMFusion.cpp:760-794; SURVEY 8e exchange 2 + the row bands
+ * of the replicated background's raycast).  Slot layout per sender: [W*H u64 hit keys][W*H f32 background
+ * raylengths][W*H u8 background hit mask] -- emf_hip_peerRaycastSlotBytes(W, H).
+ *   packHitKeysPeer          = emf_hip_packHitKeys whose keys go into slot[me] of every peer, together with rows
+ *                              [bandRow0, bandRow0 + bandRows) of bgRay / bgMask (bandRows = 0: no bands);
+ *   compositeFromKeysPeer    waits, takes the minimum key over the slots, fetches the foreign bands of bgRay / bgMask
+ *                              from their owners' slots (rows of owner r: [r * bandRowsPerRank, ...); also stored into
+ *                              the local images), then composites exactly as emf_hip_compositeFromKeys and counts
+ *                              visibility into visCounts (which must be zero at the launch's start);
+ *   visibilityFlagsMirror    the integrate gate from those counts (as visibilityFlagsIndexed), the nall counts mirrored
+ *                              to host-visible memory, visCounts left cleared for the next frame. */
+size_t emf_hip_peerRaycastSlotBytes(int width, int height);
+int emf_hip_packHitKeysPeer(int nlocal, const int32_t* listPos_host, const emf_image_t* objRay_host,
+                            const emf_image_t* objSeg_host, const emf_image_t* bgRay, const emf_image_t* bgMask,
+                            int bandRow0, int bandRows, const emf_peer_t* group, uint32_t seq, emf_stream_t stream);
+int emf_hip_compositeFromKeysPeer(const emf_peer_t* group, uint32_t seq, int bandRowsPerRank, int nall,
+                                  const int32_t* ids_host, int nlocal, const int32_t* listPos_host,
+                                  const emf_image_t* objRay_host, const emf_image_t* objVert_host,
+                                  const emf_image_t* objNorm_host, const emf_image_t* bgRay, const emf_image_t* bgVert,
+                                  const emf_image_t* bgNorm, const emf_image_t* bgMask, const emf_image_t* ray,
+                                  const emf_image_t* vert, const emf_image_t* norm, const emf_image_t* seg,
+                                  const emf_image_t* diff, const emf_image_t* noObj, int boundary, int32_t* visCounts,
+                                  emf_stream_t stream);
+int emf_hip_visibilityFlagsMirror(int32_t* visCounts, int nall, int nmodels, const int32_t* countIndex_host,
+                                  int visibilityThresh, int32_t* visible_dev, int32_t* countsMirror, emf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ def test_volumes_at_the_check_points(against_oracle, f):
     for name in ["bg tsdf", "bg weights"] + [f"obj {i} {w}" for i in range(1, L.NOBJ + 1)
                                               for w in ("tsdf", "weights", "fgprobs", "fgmask")]:
         exact, outside, worst = c[name]
-        assert outside <= 1e-3, f"frame {f}: {name}: {outside:.3e} outside 1e-4 (worst {worst}, bit-identical {exact:.5f})"
+        assert outside <= 1e-5, f"frame {f}: {name}: {outside:.3e} outside 1e-4 (worst {worst}, bit-identical {exact:.5f})"
     assert c["bg tsdf"][0] > 0.99 and c["bg weights"][0] > 0.99, (f, c["bg tsdf"], c["bg weights"])
     assert c["_bg_capped"] == c["_bg_capped_hip"] or abs(c["_bg_capped"] - c["_bg_capped_hip"]) < 1e-4 * c["_bg_capped"]
 
@@ -89,7 +89,7 @@ def test_images_at_the_check_points(against_oracle, f):
         exact, outside, worst = c[name]
         assert outside <= budget, f"frame {f}: {name}: {outside:.3e} outside tolerance (budget {budget}, worst {worst})"
     assert c["_assoc_sums_to_one"]
-    assert c["_bg_hits"] > 250000 and c["_hits"] > 30000
+    assert c["_bg_hits"] > 150000 and c["_hits"] > 30000
 
 
 def test_alternative_paths_produce_the_same_bytes_over_the_whole_stream(against_oracle, dev, frames):

@@ -37,7 +37,7 @@ def _exchanges_scenario(world):
     from emfusion_amd.devmem import DeviceArray
     devmem.set_device(0)
     H, W, ROUNDS = 120, 160, 25
-    comms = pipeline.Communicator.local_group(world, transport="peer", max_bytes=W * H * 8)
+    comms = pipeline.Communicator.local_group(world, transport="peer", max_bytes=W * H * 16)
     rng = np.random.default_rng(world)
     data = [[dict(f=(rng.standard_normal((H, W)) * 10.0 ** int(rng.integers(-3, 4))).astype(np.float32),
                   k=rng.integers(0, 2 ** 63, (H, W), dtype=np.uint64),
@@ -96,7 +96,7 @@ def _pipeline_scenario(world):
     host = reh.run_job(world, 4, True)
     orig = pipeline.Communicator.local_group
     pipeline.Communicator.local_group = classmethod(
-        lambda cls, w, transport="host", max_bytes=0: orig.__func__(cls, w, "peer", reh.W * reh.H * 8))
+        lambda cls, w, transport="host", max_bytes=0: orig.__func__(cls, w, "peer", reh.W * reh.H * 16))
     try:
         peer = reh.run_job(world, 4, True)
     finally:

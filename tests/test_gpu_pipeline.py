@@ -16,13 +16,16 @@ NOBJ, NFRAMES, MASK_EVERY = 2, 6, 3
 
 
 @pytest.fixture(scope="module", params=["batched", "batched_in_place", "per_volume", "sharded_1rank",
-                                         "sharded_1rank_per_volume"])
+                                         "sharded_1rank_per_volume", "sharded_1rank_peer", "sharded_1rank_peer_unfused"])
 def run(request, oracle, dev):
     """Execution paths of emf::EMFusion: batched model-table launches (default), the
     reference-shaped one-stream-per-volume path (EMF_PER_VOLUME=1), and the object-sharded
     multi-GPU path driven through a real RCCL communicator of ONE rank (EMF_FORCE_SHARDED=1):
     E-step partial sum -> ncclAllReduce(sum) -> normalise, hit keys -> ncclAllReduce(min) ->
-    composite from keys, indexed device-side visibility gate, per-frame depth broadcast."""
+    composite from keys, indexed device-side visibility gate, per-frame depth broadcast; "peer": the same path
+    over the direct peer-write transport with its exchanges fused into the path's kernels (E-step scattering its
+    partial sum, wait + reduce + normalise; key packing scattering keys and the background band, wait + min +
+    composite + visibility), "peer_unfused": that transport's own two-launch collectives (EMF_PEER_FUSED=0)."""
     import os
 
     from emfusion_amd import pipeline
@@ -35,7 +38,11 @@ def run(request, oracle, dev):
     comm = None
     if request.param.startswith("sharded"):
         os.environ["EMF_FORCE_SHARDED"] = "1"
-        comm = pipeline.Communicator(pipeline.Communicator.unique_id(), 0, 1)
+        if "peer" in request.param:
+            os.environ["EMF_PEER_FUSED"] = "0" if request.param.endswith("unfused") else "1"
+            comm = pipeline.Communicator.local_group(1, transport="peer", max_bytes=W * H * 16)[0]
+        else:
+            comm = pipeline.Communicator(pipeline.Communicator.unique_id(), 0, 1)
 
     # visibility threshold / boundary scaled to the small image (reference: 1600 px, 20 px @ VGA)
     prm = pipeline.make_params(W, H, BG_RES, BG_VOX, OBJ_RES, visibility_thresh=100, boundary=5,
@@ -73,6 +80,7 @@ def run(request, oracle, dev):
     os.environ.pop("EMF_PER_VOLUME", None)
     os.environ.pop("EMF_BG_OVERLAP", None)
     os.environ.pop("EMF_FORCE_SHARDED", None)
+    os.environ.pop("EMF_PEER_FUSED", None)
     yield fus, orc, ids, history
     fus.close()
     if comm is not None:
