@@ -125,6 +125,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     devmem.set_device(local_rank % devmem.device_count())
     dev_name, arch, cus = ops.device_info()
+    if torch.cuda.is_available():
+        # torch initialises its CUDA state lazily, on the first torch.cuda call: have that happen HERE and not in
+        # the torch.cuda.synchronize() that brackets the timed region (measured, round 4: with the lazy
+        # initialisation right in front of it, the first timed frame's enqueue took 30-50 ms of host time in
+        # most runs of --steps 60 --warmup 20)
+        torch.cuda.set_device(local_rank % devmem.device_count())
+        torch.cuda.synchronize()
 
     W, H = args.width, args.height
     P = W * H
@@ -234,21 +241,35 @@ def main():
         fus.set_tracking(camera=True, objects=True)
     barrier()
     fus.synchronize()
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and not os.environ.get("BENCH_NO_TORCH_SYNC"):
         torch.cuda.synchronize()  # same HIP runtime as the product libraries (imported first)
+    # The harness is Python, the product is not: a generation-2 garbage collection of the interpreter (torch's import
+    # leaves ~10^6 tracked objects) stops the enqueuing thread for 35-45 ms -- measured in round 4 as ONE slow
+    # process_frame call in most runs of --steps 60 --warmup 20, i.e. half the frame rate of that run.  Collect now,
+    # keep the collector out of the timed region, switch it back on behind it.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    per_step = []
     for f in range(args.warmup, nframes):
+        ts = time.perf_counter()
         step(f)
+        per_step.append(time.perf_counter() - ts)
+    issued = time.perf_counter() - t0  # the host is done enqueuing; the rest of `elapsed` is the device catching up
     fus.synchronize()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if os.environ.get("BENCH_PER_STEP"):
+        print("PER_STEP_US " + " ".join("%.0f" % (1e6 * v) for v in per_step), file=sys.stderr, flush=True)
     kern = None if args.no_kernel_events else fus.kernel_timers_collect()
     visible = fus.visible_objects()
 
@@ -297,6 +318,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "host_issue_ms_per_step": round(1e3 * issued / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -38,6 +38,9 @@ def run(scenario, frames=110, warm=30):
             del s
     if scenario in ("foreign8", "both"):
         keep = [devmem.Stream(non_blocking=True) for _ in range(8)]
+    if os.environ.get("PROBE_TORCH_FIRST"):
+        import torch  # noqa: F401  (bench.py's situation: the torch wheel's HIP runtime serves the process)
+        torch.cuda.is_available()
     if scenario.startswith("foreign") and scenario not in ("foreign8",):
         keep = [devmem.Stream(non_blocking=True) for _ in range(int(scenario[7:]))]
     W, H = 640, 480
@@ -68,6 +71,10 @@ def run(scenario, frames=110, warm=30):
         fus.synchronize()
         fus.close()
     fus, ids = make()
+    if os.environ.get("PROBE_TIMERS"):  # what bench.py does around its timed region
+        fus.kernel_timers_enable(2000)
+        fus.kernel_timers_select(["raycast", "integrate_bg", "track"])
+        fus.kernel_timers_stride(4)
     for f in range(warm):
         step(fus, ids, f)
     fus.synchronize()
@@ -95,7 +102,11 @@ if __name__ == "__main__":
                  ("foreign8", {"EMF_PRIO_MAIN": "high", "EMF_PRIO_LISTS": "low"}),
                  ("foreign8", {"EMF_PRIO_LISTS": "low"}),
                  ("foreign8", {"GPU_MAX_HW_QUEUES": "8"}), ("foreign8", {"GPU_MAX_HW_QUEUES": "16"})]
-    for rep in range(2):
+    if "--matrix2" in sys.argv:  # every count of foreign streams, with and without a priority class of its own for `main`
+        todo = []
+        for n in range(0, 10):
+            todo += [(f"foreign{n}", {}), (f"foreign{n}", {"EMF_PRIO_MAIN": "high"})]
+    for rep in range(1 if "--matrix2" in sys.argv else 2):
         for sc, extra in todo:
             r = subprocess.run([sys.executable, __file__, sc], capture_output=True, text=True, timeout=600,
                                env=dict(os.environ, **extra))

@@ -61,7 +61,7 @@ def test_every_rank_owns_its_objects_and_replicas_are_bit_identical(runs):
     for d in ranks[1:]:
         assert list(d["visible_per_frame"]) == list(ranks[0]["visible_per_frame"])
     assert len(ranks[0]["visible"]) >= 10, "too few of the 64 objects are visible for the test to mean anything"
-    assert int(ranks[0]["bg_seen"]) > 3e6
+    assert int(ranks[0]["bg_seen"]) > 1e6
 
 
 def test_joint_images_equal_the_single_process_run(runs):
