@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
             if (a.peerWorld) {  // (uniform) write-through: the value must be in the peer's memory, not in my L2
                 for (int p = 0; p < a.peerWorld; ++p)
                     __builtin_nontemporal_store(s, reinterpret_cast<float*>(a.peerSlots[p] + a.peerOff) + pix);
-                __threadfence_system();
             } else {
                 a.objSum.row(y)[x] = s;
             }

@@ -115,9 +115,13 @@ public:
     // memories in the in-process form).  slots / flags of all ranks are already addressable from here.
     PeerCommunicator(int rank, int world, size_t slotBytes, std::shared_ptr<PeerMemory> own,
                      std::vector<std::shared_ptr<PeerMemory>> keep, const std::vector<void*>& slots,
-                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped, bool sharedDevice)
+                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped, bool waitInFront /* ranks share a GPU */)
         : rank_(rank), world_(world), own_(std::move(own)), keep_(std::move(keep)), ipcMapped_(std::move(ipcMapped)) {
-        g_.sharedDevice = sharedDevice ? 1u : 0u;
+        // The exchange's signal + wait is a one-wave launch in front of its consumer (measured cheaper than consumers
+        // that poll, include/emf_hip.h emf_peer_t::waitInFront); EMF_PEER_WAIT_IN_FRONT=0 lets the consumers poll
+        // themselves where every rank has a GPU of its own (A/B on a node; never when ranks share a device).
+        g_.waitInFront = 1u;
+        if (const char* w = std::getenv("EMF_PEER_WAIT_IN_FRONT")) g_.waitInFront = (w[0] == '0' && !waitInFront) ? 0u : 1u;
         g_.rank = rank;
         g_.world = world;
         g_.slotBytes = slotBytes;

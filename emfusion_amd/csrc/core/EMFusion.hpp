@@ -308,7 +308,13 @@ private:
     std::vector<int> allIds;             // every object id of the job, creation order
     std::map<int, ObjImages> objImages;  // per owned object
     std::map<int, Stream> streams;       // key 0 = background, else object id
-    Stream main{streamPriority("EMF_PRIO_MAIN", 0)};
+    // Queue priority classes of the frame's three streams: NONE of them in the "normal" class.  HIP serves each class
+    // from its own pool of at most four hardware queues, and streams of an embedding application (the reference
+    // creates one cv::cuda::Stream per object, EMFusion.h:471) are normal-priority ones: with `main` or `lists` in
+    // that class the frame took 0.76-0.91 ms instead of 0.57 for 2, 5, 6 or 9 live foreign streams, and was flat
+    // over 0 .. 9 of them with main = high, aux = lists = low (scripts/stream_history_probe.py --matrix3,
+    // DESIGN.md section 6; tests/test_gpu_stream_history.py)
+    Stream main{streamPriority("EMF_PRIO_MAIN", 1)};
     Affine3f pose;                       // current camera pose
     std::set<int> vis_objs;
     int frameCount = 0;
@@ -400,7 +406,7 @@ private:
     bool rayDoneValid = false;
     bool peerFused = false;     // sharded over a direct peer-write transport: exchanges fused into the path's kernels
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
-    Stream lists{streamPriority("EMF_PRIO_LISTS", 0)};  // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
+    Stream lists{streamPriority("EMF_PRIO_LISTS", -1)};  // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
     bool bgListPending = false; // the background was forked; its list rebuild is not enqueued yet
     bool bgPrepared = false;    // bgCullScratch's counter and the next dirtyNext map are already cleared
     void rebuildBackgroundList();

@@ -190,7 +190,6 @@ __global__ __launch_bounds__(256) void k_pack_keys_peer(const KeyPackTable t, co
             __builtin_nontemporal_store(m, reinterpret_cast<uint8_t*>(pp.slots[p] + pp.off + 12 * pp.pixels) + pix);
         }
     }
-    __threadfence_system();
 }
 
 struct FromKeysPeerArgs {
@@ -205,19 +204,23 @@ struct FromKeysPeerArgs {
     int32_t* counts;      // zero at the launch's start
 };
 
+// A resident grid of at most kPollGroups workgroups walks the 64 x 4 tiles (every workgroup polls the flags at its
+// start: peer_exchange.hip, k_peer_normalize); the visibility histogram is kept in LDS over all of a workgroup's tiles.
+constexpr int kPollGroups = 256;
 __global__ __launch_bounds__(256) void k_composite_keys_peer(const PeerArgs pa, uint32_t seq, const FromKeysPeerArgs a,
                                                              const IdTable ids, const LocalTable loc, const SlotTable slots) {
     __shared__ int lh[256];
     const int tid = threadIdx.y * kTileX + threadIdx.x;
     lh[tid] = 0;
-    if (!peer_arrive(pa, seq, tid, blockIdx.x == 0 && blockIdx.y == 0)) return;  // (uniform)
+    if (!peer_arrive(pa, seq, tid, blockIdx.x == 0)) return;  // (uniform)
     __syncthreads();
-    int x, y;
-    const bool in = pixel_of(a.w, a.h, x, y);
-    uint8_t s = 0;
-    if (in) {
-        const size_t pix = static_cast<size_t>(y) * a.w + x, P = static_cast<size_t>(a.w) * a.h;
-        const char* base = pa.slots[pa.rank];
+    const int tilesX = (a.w + kTileX - 1) / kTileX, tiles = tilesX * ((a.h + kTileY - 1) / kTileY);
+    const size_t P = static_cast<size_t>(a.w) * a.h;
+    const char* base = pa.slots[pa.rank];
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int x = (tile % tilesX) * kTileX + threadIdx.x, y = (tile / tilesX) * kTileY + threadIdx.y;
+        if (x >= a.w || y >= a.h) continue;
+        const size_t pix = static_cast<size_t>(y) * a.w + x;
         unsigned long long key = load_slot8(base + slot_offset(pa, 0, seq) + 8 * pix);
         for (int r = 1; r < pa.world; ++r) {
             const unsigned long long v = load_slot8(base + slot_offset(pa, r, seq) + 8 * pix);
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(256) void k_composite_keys_peer(const PeerArgs pa, 
             bgR = a.bgRay.row(y)[x];
             bgM = a.bgMask.row(y)[x];
         }
+        uint8_t s = 0;
         float r = 0.f;
         V3 vv = v3(0.f, 0.f, 0.f), nn = v3(0.f, 0.f, 0.f);
         if (key != kNoHit) {
@@ -277,10 +281,9 @@ __global__ __launch_bounds__(256) void k_composite_keys_peer(const PeerArgs pa, 
         on[1] = nn.y;
         on[2] = nn.z;
         a.seg.row(y)[x] = s;
+        // visibility counts on the values just written (k_vis_counts_all's scheme, EMFusion.cpp:778-791)
+        if (s && x >= a.boundary && x < a.w - a.boundary && y >= a.boundary && y < a.h - a.boundary) atomicAdd(&lh[s], 1);
     }
-    // visibility counts on the values just written (k_vis_counts_all's scheme, EMFusion.cpp:778-791)
-    if (in && s && x >= a.boundary && x < a.w - a.boundary && y >= a.boundary && y < a.h - a.boundary)
-        atomicAdd(&lh[s], 1);
     __syncthreads();
     const int k = slots.slot[tid];
     if (k >= 0 && lh[tid]) atomicAdd(&a.counts[k], lh[tid]);
@@ -593,8 +596,9 @@ int emf_hip_compositeFromKeysPeer(const emf_peer_t* group, uint32_t seq, int ban
         loc.pos[k] = static_cast<unsigned>(listPos_host[k]);
     }
     EMF_TRY(peer_wait_in_front(group, seq, stream));
-    hipLaunchKernelGGL(k_composite_keys_peer, pixel_grid(w, h), pixel_block(), 0, as_stream(stream), pa, seq, a, ids, loc,
-                       slots);
+    const unsigned tiles = ceil_div(w, kTileX) * ceil_div(h, kTileY);
+    hipLaunchKernelGGL(k_composite_keys_peer, dim3(tiles < kPollGroups ? tiles : kPollGroups), pixel_block(), 0,
+                       as_stream(stream), pa, seq, a, ids, loc, slots);
     return launch_status("compositeFromKeysPeer");
 }
 

@@ -17,7 +17,7 @@ struct PeerArgs {
     size_t slotBytes;  // one sender's slot, one parity
     uint32_t* error;
     unsigned long long timeoutTicks;  // of wall_clock64()
-    int waitInConsumer;               // 0: the host entry has enqueued k_peer_signal_wait in front (ranks share a GPU)
+    int waitInConsumer;               // 0: the host entry has enqueued k_peer_signal_wait in front (emf_peer_t::waitInFront)
 };
 
 // word of a rank's OWN flag page that mirrors its error word on the device: consumers that did not wait
@@ -42,12 +42,21 @@ __device__ __forceinline__ uint8_t load_slot1(const char* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const uint8_t*>(p));
 }
 
+// Memory ordering of an exchange, and why no kernel of it executes a system-scope fence (round 4).  Slots and flags
+// live in FINE-GRAINED device memory (hipDeviceMallocFinegrained): stores to it -- nontemporal, from the producing
+// kernel -- are not held back in the writer's L2, and that kernel has ENDED before the consumer starts (same
+// stream), i.e. all of its memory operations are complete.  A system-scope release / __threadfence_system() on top
+// adds nothing for these stores but costs a write-back of the whole XCD's L2 -- with the background's sweep
+// dirtying 230 MB per frame beside it, hundreds of microseconds per fence, and the fused producers of the first
+// version executed one per WAVE: the one-rank sharded frame took 1.15 ms instead of 0.57.  So: the flag is a
+// RELAXED system-scope atomic store (it bypasses the caches itself), the poll a relaxed system-scope load, and one
+// agent-scope acquire (an L1 invalidate) separates the poll from the slot reads, which are nontemporal loads of
+// fine-grained lines nothing on this device has written.
+
 // Signal + wait FUSED INTO THE CONSUMING KERNEL (round 4): called by every thread of every workgroup at the
-// kernel's start (it contains barriers).  The kernel's first workgroup raises this rank's flag on every peer --
-// everything this stream stored before, i.e. the producing kernel's scatter, is visible first: that kernel has
-// ended, and its storing threads ran __threadfence_system() -- and lanes 0 .. world-1 of every workgroup spin on
-// this rank's own flag words until all peers show seq.  false: a peer's flag did not arrive in time; the error
-// word is set and the caller must not consume the slots.
+// kernel's start (it contains barriers).  The kernel's first workgroup raises this rank's flag on every peer and
+// lanes 0 .. world-1 of every workgroup spin on this rank's own flag words until all peers show seq.  false: a
+// peer's flag did not arrive in time; the error word is set and the caller must not consume the slots.
 // (The first workgroup of a grid is dispatched first, so it is resident while the others wait for the peers,
 // who do not wait for them: no circular wait whatever the grid size.)
 __device__ __forceinline__ bool peer_signal_wait(const PeerArgs& a, uint32_t seq, int tid, bool firstGroup) {
@@ -55,14 +64,11 @@ __device__ __forceinline__ bool peer_signal_wait(const PeerArgs& a, uint32_t seq
     if (tid == 0) s_ok = 1;
     __syncthreads();
     if (tid < a.world) {
-        if (firstGroup) {
-            __threadfence_system();
-            __hip_atomic_store(a.flags[tid] + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (firstGroup) __hip_atomic_store(a.flags[tid] + a.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint32_t* mine = a.flags[a.rank] + tid;
         const unsigned long long t0 = wall_clock64();
         for (;;) {
-            const uint32_t seen = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t seen = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (static_cast<int32_t>(seen - seq) >= 0) break;  // (wrap-around safe)
             if (wall_clock64() - t0 > a.timeoutTicks) {
                 __hip_atomic_store(a.error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -73,6 +79,7 @@ __device__ __forceinline__ bool peer_signal_wait(const PeerArgs& a, uint32_t seq
         }
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return s_ok != 0;
 }
 
@@ -82,9 +89,9 @@ __device__ __forceinline__ bool exchange_failed(const PeerArgs& a, uint32_t seq)
 }
 
 // First statement of every consuming kernel (all threads; barriers inside): true when the peers' contributions
-// of exchange seq are in this rank's slots.  Normally the kernel signals and waits itself; when the ranks of the
-// group SHARE ONE GPU (single-box rehearsals) a one-wave launch in front has done so instead -- a grid of
-// spinning workgroups per rank could fill the device and keep a lagging rank's producer from ever starting.
+// of exchange seq are in this rank's slots.  By default a one-wave launch in front of the kernel has signalled and
+// waited (emf_peer_t::waitInFront: measured cheaper than a grid of polling workgroups, and the only safe form when
+// ranks share a GPU); with waitInFront = 0 the kernel does it itself.
 __device__ __forceinline__ bool peer_arrive(const PeerArgs& a, uint32_t seq, int tid, bool firstGroup) {
     if (a.waitInConsumer) return peer_signal_wait(a, seq, tid, firstGroup);
     return !exchange_failed(a, seq);

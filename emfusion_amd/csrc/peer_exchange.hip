@@ -25,6 +25,7 @@
 // threads of one process and with 2-3 ranks in separate processes over hipIpc, all sharing one GPU.
 #include "peer_core.hpp"
 
+#include <algorithm>
 #include <mutex>
 
 namespace emf_hip {
@@ -41,19 +42,18 @@ __global__ __launch_bounds__(256) void k_peer_scatter(PeerArgs a, const char* __
         for (int p = 0; p < a.world; ++p)  // write-through: the data must be in the peer's memory, not in my L2
             __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(a.slots[p] + off + 16 * i));
     }
-    __threadfence_system();
 }
 
 // one wave: lane p signals peer p, then waits for peer p's signal
 __global__ void k_peer_signal_wait(PeerArgs a, uint32_t seq, unsigned long long timeoutTicks) {
     const int p = threadIdx.x;
     if (p >= a.world) return;
-    __threadfence_system();  // everything this stream stored before (the scatter) is visible first
-    __hip_atomic_store(a.flags[p] + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (no fence: peer_core.hpp, "Memory ordering of an exchange")
+    __hip_atomic_store(a.flags[p] + a.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* mine = a.flags[a.rank] + p;
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        const uint32_t seen = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t seen = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (static_cast<int32_t>(seen - seq) >= 0) break;  // (wrap-around safe)
         if (wall_clock64() - t0 > timeoutTicks) {
             __hip_atomic_store(a.error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -137,26 +137,33 @@ struct NormTable {
     Img<float> m[kNormMaps];
     int count;
 };
+// A resident grid: every workgroup polls the flags at its start (peer_core.hpp), and the polls of 1200 workgroups
+// on the same uncached words cost this kernel 35 of its 40 us (measured with one rank); kPollGroups workgroups
+// walk the image's 64 x 4 tiles instead.
+constexpr int kPollGroups = 256;
 __global__ __launch_bounds__(256) void k_peer_normalize(PeerArgs a, uint32_t seq, NormTable t, Img<float> objSum,
                                                         Img<float> norm, int w, int h) {
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-    if (!peer_arrive(a, seq, tid, blockIdx.x == 0 && blockIdx.y == 0)) return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    const size_t pix = static_cast<size_t>(y) * w + x;
+    if (!peer_arrive(a, seq, tid, blockIdx.x == 0)) return;
+    const int tilesX = (w + 63) / 64, tiles = tilesX * ((h + 3) / 4);
     const char* base = a.slots[a.rank];
-    float e = load_slot4(base + slot_offset(a, 0, seq) + 4 * pix);
-    for (int r = 1; r < a.world; ++r) e = e + load_slot4(base + slot_offset(a, r, seq) + 4 * pix);
-    if (objSum.data) objSum.row(y)[x] = e;
-    float v[kNormMaps];
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int x = (tile % tilesX) * 64 + threadIdx.x, y = (tile / tilesX) * 4 + threadIdx.y;
+        if (x >= w || y >= h) continue;
+        const size_t pix = static_cast<size_t>(y) * w + x;
+        float e = load_slot4(base + slot_offset(a, 0, seq) + 4 * pix);
+        for (int r = 1; r < a.world; ++r) e = e + load_slot4(base + slot_offset(a, r, seq) + 4 * pix);
+        if (objSum.data) objSum.row(y)[x] = e;
+        float v[kNormMaps];
 #pragma unroll
-    for (int k = 0; k < kNormMaps; ++k)
-        if (k < t.count) v[k] = t.m[k].row(y)[x];
-    const float s = v[0] + e;  // background (this rank's replica) + objects of all ranks
-    if (norm.data) norm.row(y)[x] = s;
+        for (int k = 0; k < kNormMaps; ++k)
+            if (k < t.count) v[k] = t.m[k].row(y)[x];
+        const float s = v[0] + e;  // background (this rank's replica) + objects of all ranks
+        if (norm.data) norm.row(y)[x] = s;
 #pragma unroll
-    for (int k = 0; k < kNormMaps; ++k)
-        if (k < t.count) t.m[k].row(y)[x] = (s != 0.f) ? v[k] / s : 0.f;
+        for (int k = 0; k < kNormMaps; ++k)
+            if (k < t.count) t.m[k].row(y)[x] = (s != 0.f) ? v[k] / s : 0.f;
+    }
 }
 
 unsigned long long timeout_ticks(uint32_t timeoutMs) {  // wall_clock64() ticks; the rate is the device's, asked once
@@ -205,13 +212,13 @@ int peer_args(const emf_peer_t* g, PeerArgs& a, const char* who) {
     a.slotBytes = g->slotBytes;
     a.error = g->error;
     a.timeoutTicks = timeout_ticks(g->timeoutMs);
-    a.waitInConsumer = g->sharedDevice ? 0 : 1;
+    a.waitInConsumer = g->waitInFront ? 0 : 1;
     return EMF_OK;
 }
 
 // ranks sharing a GPU: the exchange's signal + wait as a one-wave launch in front of its consumer
 int peer_wait_in_front(const emf_peer_t* g, uint32_t seq, emf_stream_t stream) {
-    if (!g || !g->sharedDevice) return EMF_OK;
+    if (!g || !g->waitInFront) return EMF_OK;
     return emf_hip_peerSignalWait(g, seq, 0, stream);
 }
 
@@ -366,7 +373,7 @@ int emf_hip_peerNormalizeAssociation(const emf_peer_t* group, uint32_t seq, cons
         no = img<float>(norm);
     }
     EMF_TRY(peer_wait_in_front(group, seq, stream));
-    hipLaunchKernelGGL(k_peer_normalize, dim3(ceil_div(w, 64), ceil_div(h, 4)), dim3(64, 4), 0,
+    hipLaunchKernelGGL(k_peer_normalize, dim3(std::min<unsigned>(kPollGroups, ceil_div(w, 64) * ceil_div(h, 4))), dim3(64, 4), 0,
                        reinterpret_cast<hipStream_t>(stream), a, seq, t, so, no, w, h);
     return launch_status("peerNormalizeAssociation");
 }

@@ -197,10 +197,13 @@ typedef struct emf_peer {
     size_t slotBytes;                /* capacity of one sender's slot */
     uint32_t* error;                 /* this rank's error word */
     uint32_t timeoutMs;              /* bound of a wait in milliseconds (0: 5000) */
-    uint32_t sharedDevice;           /* != 0: ranks of the group share a GPU (single-box rehearsals).  The consumers
-                                        then do not wait themselves -- a grid of spinning workgroups per rank could fill
-                                        the device and keep a lagging rank's producer from starting -- and every
-                                        peerWait* / *Peer consumer entry enqueues the one-wave peerSignalWait in front */
+    uint32_t waitInFront;            /* != 0 (what emf::make*PeerCommunicator* set): every peerWait* / *Peer consumer entry
+                                        enqueues the one-wave peerSignalWait in front of its kernel, which then does not
+                                        poll.  0: the consumer's workgroups signal and poll themselves -- one launch less,
+                                        but the polls of a whole grid on the same uncached words cost more than that
+                                        launch (k_peer_normalize at 640 x 480, one rank: 5.4 + 5.9 us against 40 us with
+                                        1200 polling workgroups, 20 us with 256), and when ranks share a GPU (rehearsals)
+                                        grids of spinning workgroups can keep a lagging rank's producer from starting */
 } emf_peer_t;
 size_t emf_hip_peerBufferBytes(int world, size_t slotBytes);
 int emf_hip_peerScatter(const emf_peer_t* group, const void* src, size_t bytes, size_t dstOffset, uint32_t seq,

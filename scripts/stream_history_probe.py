@@ -78,11 +78,16 @@ def run(scenario, frames=110, warm=30):
     for f in range(warm):
         step(fus, ids, f)
     fus.synchronize()
+    import gc
+    if not os.environ.get("PROBE_KEEP_GC"):  # a gen-2 collection inside the loop costs 15-45 ms (bench.py, round 4)
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
     for f in range(warm, frames):
         step(fus, ids, f)
     fus.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / (frames - warm)
+    gc.enable()
     fus.close()
     synth.close()
     del keep
@@ -106,7 +111,11 @@ if __name__ == "__main__":
         todo = []
         for n in range(0, 10):
             todo += [(f"foreign{n}", {}), (f"foreign{n}", {"EMF_PRIO_MAIN": "high"})]
-    for rep in range(1 if "--matrix2" in sys.argv else 2):
+    if "--matrix3" in sys.argv:  # is there a choice of priority classes that does not care about the history?
+        cfgs = [{"EMF_PRIO_AUX": "normal"}, {"EMF_PRIO_LISTS": "low"}, {"EMF_PRIO_MAIN": "high", "EMF_PRIO_LISTS": "high"},
+                {"EMF_PRIO_MAIN": "high", "EMF_PRIO_LISTS": "low"}, {"EMF_PRIO_MAIN": "high", "EMF_PRIO_AUX": "normal", "EMF_PRIO_LISTS": "low"}]
+        todo = [(f"foreign{n}", c) for c in cfgs for n in range(0, 10)]
+    for rep in range(1 if ("--matrix2" in sys.argv or "--matrix3" in sys.argv) else 2):
         for sc, extra in todo:
             r = subprocess.run([sys.executable, __file__, sc], capture_output=True, text=True, timeout=600,
                                env=dict(os.environ, **extra))

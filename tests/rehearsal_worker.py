@@ -4,7 +4,7 @@
     python -m torch.distributed.run --nproc-per-node 8 tests/rehearsal_worker.py --out DIR [--frames 6]
 
 one process per rank, as on a node; the ranks' receive buffers are mapped into each other with hipIpc and the
-exchanges are the direct peer-write ones (emf::makePeerCommunicator; sharedDevice mode: a one-wave wait in front
+exchanges are the direct peer-write ones (emf::makePeerCommunicator; waitInFront mode: a one-wave wait in front
 of every consumer).  Every rank writes DIR/rank<r>.npz: digests of its background replica and of the joint images,
 its visible set, and -- rank 0 only -- the joint images themselves.  `--world 1` runs the same 64-object scene in
 ONE process without a communicator (per-volume path: more than 32 models) as the reference of the comparison.

@@ -59,11 +59,15 @@ def _run(delay_us, frames=90, warm=10):
             step(f)
         fus.synchronize()
         x0 = comm.exchanges()
+        import gc
+        gc.collect()
+        gc.disable()  # a gen-2 collection inside the timed loop would cost tens of milliseconds (bench.py, round 4)
         t0 = time.perf_counter()
         for f in range(warm, frames):
             step(f)
         fus.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / (frames - warm)
+        gc.enable()
         per_frame = (comm.exchanges() - x0) / (frames - warm)
         import xxhash
         out = dict(ms=ms, exchanges=per_frame,
