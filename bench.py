@@ -64,6 +64,9 @@ def parse_args():
                          "of taking their poses as inputs; changes the metric name -- the headline "
                          "metric of BASELINE.json is measured WITHOUT this flag")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target", action="store_true",
+                    help="skip the second measurement (north_star's target configuration, bg 512^3 + 8 x 128^3) that the "
+                         "default N = 1 run appends as `target_config`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time for the oracle baseline sample")
     ap.add_argument("--all-kernel-events", action="store_true",
@@ -302,6 +305,7 @@ def main():
     # the copy-bandwidth probe comes first: its kernel also marks, in a kernel trace of this command, where
     # the measured run ends and the replay begins (scripts/summarize_profile.py)
     copy_gbs = copy_bandwidth(devmem, ops) if rank == 0 else None
+    l1p = l1_probe(devmem, ops) if rank == 0 else None
     barrier()
     stats = replay_with_counters()
     barrier()
@@ -351,11 +355,11 @@ def main():
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
         }
-        # the committed PMC summary was taken on configs[1] without tracking: quote it only there
-        profiled = (world, nobj_total, args.bg_res, args.obj_res, W, H, args.track) == \
-                   (1, 4, 512, 128, 640, 480, False)
+        # priced by the newest committed PMC summary of THIS workload (profiles/*_counters.json carry a workload key)
+        key = workload_key(W, H, args.bg_res, args.obj_res, nobj_total, args.track) if world == 1 else None
+        result["config"]["workload_key"] = key
         if kern is not None:
-            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs, profiled, args.steps)
+            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs, key or False, args.steps, l1p)
         else:
             result["roofline"] = None
         result["hbm_copy_GBs"] = copy_gbs  # attainable D2D stream bandwidth of THIS box (read + write)
@@ -366,10 +370,14 @@ def main():
                                   "the background, so frames/s of the joint scene is flat by design (ideal "
                                   "= the N=1 value); volume_frames_per_s is the aggregate work rate, which "
                                   "grows with N")
+    fus.close()
+    is_headline = (world, nobj_total, args.bg_res, args.obj_res, W, H, args.track, comm) == (1, 4, 512, 128, 640, 480, False, None)
+    if rank == 0 and is_headline and not args.no_target:
+        # north_star's own target (>= 30 frames/s with 8 object volumes), same protocol, same process, behind the headline
+        result["target_config"] = measure_target(args, pipeline, ops, DeviceArray, fus_params=prm)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
 
-    fus.close()
     synth.close()
     if comm is not None:
         comm.close()
@@ -382,6 +390,50 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
+    """north_star: ">= 30 frames/sec integrate+raycast+EM-update at 640x480 with 1 background (512^3) + 8 object (128^3)
+    volumes on 1 MI355X".  The headline's protocol (W warm-up frames, K timed ones between synchronisations, inputs
+    resident in HBM, the interpreter's collector kept out) on that scene, in a second emf::EMFusion of this process."""
+    import gc
+    W, H = args.width, args.height
+    prm = fus_params
+    K = np.array(prm.K, np.float32)
+    synth = pipeline.SyntheticStream(W, H, K, nobj, seed=0xE3F5)
+    fus = pipeline.Fusion(prm, None)
+    ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(nobj)]
+    frames, keep = [], []
+    for f in range(args.warmup + args.steps):
+        depth, sid = synth.render(f)
+        R, t = synth.camera_pose(f)
+        poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
+        rm = f % prm.mask_frames == 0
+        masks = {i: DeviceArray.from_numpy((sid == i).astype(np.uint8)) for i in ids} if rm else {}
+        d = DeviceArray.from_numpy(depth)
+        keep.append((d, masks))
+        frames.append((ops.image_view(d), R, t, poses, {i: ops.image_view(m) for i, m in masks.items()}, rm))
+    for f in range(args.warmup):
+        fus.process_frame(*frames[f])
+    fus.synchronize()
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        fus.process_frame(*frames[f])
+    fus.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    visible = len(fus.visible_objects())
+    fus.close()
+    synth.close()
+    return {"workload": f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj} obj {args.obj_res}^3, {W}x{H}, full EM "
+                        "association + weighted fusion (north_star's single-GPU target; also one GPU's share of "
+                        "BASELINE.json configs[3])",
+            "workload_key": workload_key(W, H, args.bg_res, args.obj_res, nobj),
+            "value": round(args.steps / elapsed, 3), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "steps": args.steps, "warmup": args.warmup, "target": 30.0, "visible_objects_last_frame": visible,
+            "note": "no HIP-event pairs in this second run (the headline's run has them around every 4th long launch)"}
 
 
 # kernel kind -> (HIP kernel symbol for the rocprof cross-check, per-unit algorithmic bytes note)
@@ -427,24 +479,33 @@ def algorithmic_bytes(kind, summ, stats, P, steps=None):
     return 0.0
 
 
-def committed_profile():
-    """The newest committed PMC summary of this workload under profiles/ (scripts/profile_round.sh +
+def workload_key(W, H, bg_res, obj_res, nobj, track=False):
+    """What a committed profile must have been taken on to price this run's kernels (profiles/*_counters.json)."""
+    return f"{W}x{H}_bg{bg_res}_obj{nobj}x{obj_res}" + ("_track" if track else "")
+
+
+HEADLINE_KEY = workload_key(640, 480, 512, 128, 4)
+
+
+def committed_profile(key=HEADLINE_KEY):
+    """The newest committed PMC summary of the workload `key` under profiles/ (scripts/profile_round.sh +
     summarize_profile.py): `*_traffic.json` (HBM-side bytes per launch from the sized TCC_EA0 request
     counters) and `*_counters.json` (issue / L1 / L2 counters per launch), both over the timed launches of
     the driver's protocol.  The counters cannot be read from inside this process: they are those of the
     profiled run of the same command, and the line says which one (`counters_from`)."""
-    out = {"tag": None, "traffic": {}, "counters": {}, "protocol": None}
-    files = sorted((ROOT / "profiles").glob("*_counters.json"))
-    if not files:
-        return out
-    try:
-        c = json.loads(files[-1].read_text())
-        out.update(tag=c.get("tag"), counters=c.get("kernels", {}), protocol=c.get("protocol"))
-        t = files[-1].with_name(files[-1].name.replace("_counters.json", "_traffic.json"))
-        if t.exists():
-            out["traffic"] = json.loads(t.read_text()).get("kernels", {})
-    except (OSError, ValueError):
-        pass
+    out = {"tag": None, "traffic": {}, "counters": {}, "protocol": None, "file": None}
+    for f in sorted((ROOT / "profiles").glob("*_counters.json"), reverse=True):
+        try:
+            c = json.loads(f.read_text())
+            if c.get("workload_key", HEADLINE_KEY) != key:  # (profiles older than round 4 carry no key: configs[1])
+                continue
+            out.update(tag=c.get("tag"), counters=c.get("kernels", {}), protocol=c.get("protocol"), file=f.name)
+            t = f.with_name(f.name.replace("_counters.json", "_traffic.json"))
+            if t.exists():
+                out["traffic"] = json.loads(t.read_text()).get("kernels", {})
+            return out
+        except (OSError, ValueError):
+            continue
     return out
 
 
@@ -519,14 +580,74 @@ def copy_bandwidth(devmem, ops, mib=1024, reps=10):
     return round(2.0 * n * 4 / (ms * 1e-3) / 1e9, 1)
 
 
-def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None):
+L1_PROBE = dict(footprint=16384, iterations=2048, workgroups=2048)  # 8192 waves x 2048 gathers = 16.8 M wave-instr
+
+
+def l1_probe(devmem, ops, reps=5):
+    """Gather instructions per second of emf_hip_l1GatherProbe on an L1-resident footprint at full occupancy, for 64 / 4 /
+    1 distinct lines per 64-lane 8-byte load: {lines: {"ms": launch time, "G_instr_s": rate}} (HIP events, this run)."""
+    from emfusion_amd.devmem import DeviceArray, Event
+    buf = DeviceArray.zeros((L1_PROBE["footprint"] // 4,), np.float32)
+    sink = DeviceArray.zeros((2,), np.float32)
+    out = {}
+    for lines in (64, 4, 1):
+        def run():
+            ops.l1_gather_probe(buf, L1_PROBE["footprint"], lines, L1_PROBE["iterations"], L1_PROBE["workgroups"], sink)
+        run()
+        e0, e1 = Event(), Event()
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_ms(e1) / reps
+        n = L1_PROBE["workgroups"] * 4 * L1_PROBE["iterations"]
+        out[lines] = {"ms": round(ms, 4), "G_instr_s": round(n / (ms * 1e-3) / 1e9, 2)}
+    return out
+
+
+def l1_measured_peak(probe, prof):
+    """Tag look-ups per second the probe reaches: TCP_TOTAL_CACHE_ACCESSES per launch of the same probe kernel in the
+    committed PMC profile over its launch time in THIS run; the largest of the three access patterns.  None without
+    committed counters of the probe (profiles older than round 4)."""
+    best = None
+    for lines, r in probe.items():
+        c = prof["counters"].get(f"l1_probe_{lines}", {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", {}).get("per_launch")
+        if c and r["ms"] > 0:
+            rate = c / (r["ms"] * 1e-3) / 1e9
+            best = rate if best is None or rate > best else best
+    return round(best, 1) if best else None
+
+
+def l1_probe_report(probe, prof):
+    rep = {"kernel": "k_l1_probe<lines>: 8-byte gathers, 16 KiB footprint, 8192 resident waves", "assumed_peak": 614.4,
+           "unit": "G tag lookups/s", "patterns": {}}
+    for lines, r in probe.items():
+        c = prof["counters"].get(f"l1_probe_{lines}", {}).get("TCP_TOTAL_CACHE_ACCESSES_sum", {}).get("per_launch")
+        n = L1_PROBE["workgroups"] * 4 * L1_PROBE["iterations"]
+        rep["patterns"][f"{lines}_lines_per_instr"] = {
+            "launch_ms": r["ms"], "G_gather_instr_s": r["G_instr_s"],
+            "lookups_per_instr": round(c / n, 2) if c else None,
+            "G_tag_lookups_s": round(c / (r["ms"] * 1e-3) / 1e9, 1) if c else None}
+    rep["value"] = l1_measured_peak(probe, prof)
+    rep["counters_from"] = prof.get("file")
+    return rep
+
+
+def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None, l1_probe=None):
     """`roofline` of the JSON line: the dominant kernel against the resource that binds it.
 
     bound / achieved / peak / frac come from hardware counters (resource_fractions): VALU issue, vector-L1
     tag lookups (the gather path), L2 bytes, HBM bytes -- the largest fraction is the bound.  SURVEY 8(d)'s
     algorithmic byte model stays in the line as `model_GBs` (an upper bound on gather bytes that the caches
     beat, NOT a fraction of anything)."""
-    prof = committed_profile() if profiled else {"tag": None, "traffic": {}, "counters": {}, "protocol": None}
+    key = HEADLINE_KEY if profiled is True else (None if profiled is False else profiled)
+    none = {"tag": None, "traffic": {}, "counters": {}, "protocol": None, "file": None}
+    prof = committed_profile(key) if key else none
+    if l1_probe:  # quote the L1 against what the probe kernel reaches on this box, not against one look-up per clock
+        peak = l1_measured_peak(l1_probe, prof if prof["counters"] else committed_profile())
+        if peak:
+            PEAKS["l1"] = ("G tag lookups/s", peak)
     rows = []
     for kind, summ in kern.items():
         if kind.startswith("_") or summ["launches"] == 0:
@@ -566,7 +687,8 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None):
                                  f"{prof['protocol']}; durations are this run's HIP events")
     else:  # no committed counters for this workload: nothing to price the kernel against
         roof.update(bound=None, achieved=None, peak=None, unit=None, frac=None, traffic=None,
-                    counters_from="none committed for this workload (profiles/ holds configs[1] without tracking)")
+                    counters_from=f"none committed for this workload ({key}; profiles/ holds "
+                                  f"{sorted(set(json.loads(f.read_text()).get('workload_key', HEADLINE_KEY) for f in (ROOT / 'profiles').glob('*_counters.json')))})")
     roof["model_GBs"] = dom["model_GBs"]
     roof["alg_bytes_per_launch"] = dom["alg_bytes_per_launch"]
     roof["model_note"] = ("model_GBs = SURVEY 8(d)'s algorithmic bytes per launch over the launch duration; for the "
@@ -575,6 +697,8 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None):
                           "it is a rate of the byte model, not a roofline fraction")
     if copy_gbs:
         roof["hbm_copy_GBs"] = copy_gbs
+    if l1_probe:
+        roof["l1_tag_peak_measured"] = l1_probe_report(l1_probe, prof if prof["counters"] else committed_profile())
     # the kernel that runs BESIDE the dominant one shares its resources: the chip's utilisation while the
     # raycast runs is the sum of both
     integ = next((r for r in rows if r["kind"] == "integrate_bg"), None)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
     "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
     "emf_hip_spinDelay": [C.c_uint32, _STREAM],
+    "emf_hip_l1GatherProbe": [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, _STREAM],
     "emf_hip_peerBufferBytes": [C.c_int, C.c_size_t],
     "emf_hip_peerScatter": [C.c_void_p, _FP, C.c_size_t, C.c_size_t, C.c_uint32, _STREAM],
     "emf_hip_peerSignalWait": [C.c_void_p, C.c_uint32, C.c_uint32, _STREAM],

@@ -105,6 +105,24 @@ __global__ void k_spin_delay(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// Calibration of the vector L1's gather rate (bench.py: the peak `roofline.frac` is quoted against when the L1 binds
+// a kernel).  Every wave issues `iters` independent 8-byte loads -- the march's gathers are 8-byte pair loads -- from
+// a footprint that stays resident in every CU's 32 KiB L1, at full occupancy; LINES = distinct 128-byte lines the 64
+// lanes of one instruction touch: 64 (a line per lane), 4 (64 consecutive words) or 1 (16 words, four lanes each).
+template <int LINES>
+__global__ __launch_bounds__(256) void k_l1_probe(const unsigned long long* __restrict__ buf, unsigned words, int iters,
+                                                  unsigned long long* __restrict__ sink) {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned mask = words - 1u;  // words: a power of two
+    unsigned idx = LINES == 64 ? lane * 16u : (LINES == 4 ? lane : (lane & 15u));
+    idx += wave * 16u;
+    const unsigned step = LINES == 4 ? 64u : 16u;
+    unsigned long long acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < iters; ++i) acc ^= buf[(idx + static_cast<unsigned>(i) * step) & mask];
+    if (acc == 0x0123456789abcdefull) *sink = acc;  // (never: keeps the loads alive)
+}
+
 // device-to-device stream copy, 16 bytes per lane and iteration (the bandwidth yardstick of bench.py)
 __global__ __launch_bounds__(256) void k_stream_copy(float4* __restrict__ dst,
                                                      const float4* __restrict__ src, size_t n16) {
@@ -242,6 +260,25 @@ int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, f
     *rcp = mismatches == 0 ? 1.0f / voxelSize : 0.f;
     rcp_remember(voxelSize, *rcp);
     return EMF_OK;
+}
+
+int emf_hip_l1GatherProbe(const void* buf, size_t footprintBytes, int linesPerInstruction, int iterations, int workgroups,
+                          void* sink, emf_stream_t stream) {
+    using namespace emf_hip;
+    if (!buf || !sink) return fail(EMF_E_NULL, "l1GatherProbe: NULL buffer");
+    if (footprintBytes < 8192 || (footprintBytes & (footprintBytes - 1)) || footprintBytes > (size_t(1) << 30))
+        return fail(EMF_E_ARG, "l1GatherProbe: footprint %zu (a power of two, 8 KiB .. 1 GiB)", footprintBytes);
+    if (iterations < 1 || workgroups < 1 || workgroups > 65535 * 16) return fail(EMF_E_ARG, "l1GatherProbe: iterations / workgroups");
+    const unsigned words = static_cast<unsigned>(footprintBytes / 8);
+    auto* b = static_cast<const unsigned long long*>(buf);
+    auto* sk = static_cast<unsigned long long*>(sink);
+    const dim3 g(static_cast<unsigned>(workgroups)), blk(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (linesPerInstruction == 64) hipLaunchKernelGGL(k_l1_probe<64>, g, blk, 0, st, b, words, iterations, sk);
+    else if (linesPerInstruction == 4) hipLaunchKernelGGL(k_l1_probe<4>, g, blk, 0, st, b, words, iterations, sk);
+    else if (linesPerInstruction == 1) hipLaunchKernelGGL(k_l1_probe<1>, g, blk, 0, st, b, words, iterations, sk);
+    else return fail(EMF_E_ARG, "l1GatherProbe: linesPerInstruction %d (64, 4 or 1)", linesPerInstruction);
+    return launch_status("l1GatherProbe");
 }
 
 int emf_hip_spinDelay(uint32_t microseconds, emf_stream_t stream) {

@@ -45,10 +45,17 @@ __global__ __launch_bounds__(256) void k_peer_scatter(PeerArgs a, const char* __
 }
 
 // one wave: lane p signals peer p, then waits for peer p's signal
-__global__ void k_peer_signal_wait(PeerArgs a, uint32_t seq, unsigned long long timeoutTicks) {
+__global__ void k_peer_signal_wait(PeerArgs a, uint32_t seq, unsigned long long timeoutTicks, int fences) {
     const int p = threadIdx.x;
     if (p >= a.world) return;
-    // (no fence: peer_core.hpp, "Memory ordering of an exchange")
+    // emf_peer_t::systemFences (wave-uniform): the belt to the braces of peer_core.hpp's "Memory ordering of an exchange"
+    // -- a system-scope release in front of the flags and an acquire behind the wait.  One wave per exchange, and still
+    // 6.6 us each while the background's sweep keeps the L2 dirty (0.654 -> 0.688 ms per one-rank sharded frame): off
+    // unless a node shows stale slots (EMF_PEER_FENCES=1).
+    if (fences) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_store(a.flags[p] + a.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t* mine = a.flags[a.rank] + p;
     const unsigned long long t0 = wall_clock64();
@@ -62,6 +69,7 @@ __global__ void k_peer_signal_wait(PeerArgs a, uint32_t seq, unsigned long long 
         }
         __builtin_amdgcn_s_sleep(2);
     }
+    if (fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 __global__ __launch_bounds__(256) void k_peer_reduce_sum_f32(PeerArgs a, uint32_t seq, size_t count, float* __restrict__ out,
@@ -248,7 +256,7 @@ int emf_hip_peerSignalWait(const emf_peer_t* group, uint32_t seq, uint32_t timeo
     PeerArgs a;
     if (const int rc = peer_args(group, a, "peerSignalWait")) return rc;
     hipLaunchKernelGGL(k_peer_signal_wait, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), a, seq,
-                       timeoutMs ? timeout_ticks(timeoutMs) : a.timeoutTicks);
+                       timeoutMs ? timeout_ticks(timeoutMs) : a.timeoutTicks, group->systemFences ? 1 : 0);
     return launch_status("peerSignalWait");
 }
 

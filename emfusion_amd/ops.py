@@ -247,6 +247,12 @@ def stream_copy(dst, src, stream=None):
     check("emf_hip_streamCopy", _L.emf_hip_streamCopy(_ptr(dst), _ptr(src), dst.nbytes, _stream(stream)))
 
 
+def l1_gather_probe(buf, footprint_bytes, lines, iterations, workgroups, sink, stream=None):
+    """emf_hip_l1GatherProbe: the vector L1's gather rate on a resident footprint (bench.py's calibration)."""
+    check("emf_hip_l1GatherProbe", _L.emf_hip_l1GatherProbe(_ptr(buf), int(footprint_bytes), int(lines), int(iterations),
+                                                            int(workgroups), _ptr(sink), _stream(stream)))
+
+
 def device_info():
     name = C.create_string_buffer(256)
     arch = C.create_string_buffer(256)

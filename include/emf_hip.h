@@ -169,6 +169,13 @@ int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream);
 int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp);
 
+/* Measurement aid (bench.py): `iterations` independent 8-byte gather loads per lane from a footprint that stays in every
+ * CU's vector L1, `workgroups` x 256 lanes; linesPerInstruction = distinct 128-byte lines one 64-lane instruction touches
+ * (64, 4 or 1).  Calibrates the L1 rate the raycast's `roofline.frac` is quoted against.  buf: footprintBytes (power of
+ * two) of readable device memory, sink: 8 writable bytes (never written in practice). */
+int emf_hip_l1GatherProbe(const void* buf, size_t footprintBytes, int linesPerInstruction, int iterations, int workgroups,
+                          void* sink, emf_stream_t stream);
+
 /* ---- direct peer-write exchanges ("Collective implementation"; new design, the
  * reference is single-GPU) ---------------------------------------------------------------------------
  * The exchanges of the sharded path move 1-5 MB: latency decides.  Instead of a library collective
@@ -204,6 +211,9 @@ typedef struct emf_peer {
                                         launch (k_peer_normalize at 640 x 480, one rank: 5.4 + 5.9 us against 40 us with
                                         1200 polling workgroups, 20 us with 256), and when ranks share a GPU (rehearsals)
                                         grids of spinning workgroups can keep a lagging rank's producer from starting */
+    uint32_t systemFences;           /* != 0: the wait launch brackets its flags with a system-scope release / acquire
+                                        (6.6 us per exchange beside the background's sweep, measured; off by default:
+                                        slots and flags are fine-grained memory, peer_core.hpp "Memory ordering") */
 } emf_peer_t;
 size_t emf_hip_peerBufferBytes(int world, size_t slotBytes);
 int emf_hip_peerScatter(const emf_peer_t* group, const void* src, size_t bytes, size_t dstOffset, uint32_t seq,

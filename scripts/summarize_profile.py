@@ -8,10 +8,13 @@ import sqlite3
 import sys
 from collections import OrderedDict, defaultdict
 
+import os as _os
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+EXTRA_ARGS = _os.environ.get("EMF_PROFILE_ARGS", "").strip()
 src = f"gpurun_out/prof_{tag}"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_stream_copy", "stream_copy"), ("k_integrate_listed_rest", "integrate_rest"),
+SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_stream_copy", "stream_copy"), ("k_l1_probe<64>", "l1_probe_64"),
+                     ("k_l1_probe<4>", "l1_probe_4"), ("k_l1_probe<1>", "l1_probe_1"), ("k_integrate_listed_rest", "integrate_rest"),
                      ("k_integrate_listed<true>", "integrate_bg"), ("k_integrate_listed<(bool)1>", "integrate_bg"),
                      ("k_integrate_listed", "integrate"), ("k_integrate_cull", "integrate_cull"),
                      ("k_far_bounds_listed", "far_bounds_listed"), ("k_far_bounds", "far_bounds_scan"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
@@ -37,10 +40,12 @@ def db(path):
 
 out_md = [f"# rocprofv3 summary, round tag `{tag}`", "",
           "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %s --warmup %s "
-          "--no-cpu-baseline` (the driver's protocol) on one MI355X (gfx950), BASELINE.json configs[1] "
-          "(bg 512^3 + 4 obj 128^3, 640x480).  Warm-up and timed frames are in the "
+          "--no-cpu-baseline%s` (the driver's protocol) on one MI355X (gfx950), %s.  Warm-up and timed frames are in the "
           "trace; frame 0 has no raycast/E-step." % (__import__("os").environ.get("EMF_PROFILE_STEPS", "20"),
-                                                     __import__("os").environ.get("EMF_PROFILE_WARMUP", "5")), ""]
+                                                     __import__("os").environ.get("EMF_PROFILE_WARMUP", "5"),
+                                                     " " + EXTRA_ARGS if EXTRA_ARGS else "",
+                                                     "workload arguments `%s`" % EXTRA_ARGS if EXTRA_ARGS else
+                                                     "BASELINE.json configs[1] (bg 512^3 + 4 obj 128^3, 640x480)"), ""]
 con = db("trace")
 stats = {}
 if con:
@@ -72,6 +77,12 @@ if con:
         stats[short(name)] = dict(kernel=name.split("(")[0], launches=n, avg_us=avg / 1e3,
                                   total_ms=tot / 1e6, timed_launches=len(timed), timed_avg_us=tavg / 1e3)
     out_md.append("")
+
+workload_key = None
+try:
+    workload_key = json.loads(open(f"{src}/bench_under_trace.json").read().strip())["config"].get("workload_key")
+except (OSError, ValueError, KeyError):
+    pass
 
 traffic = defaultdict(dict)
 for pas in ("pmc_rd", "pmc_wr", "pmc_fetch", "pmc_write"):
@@ -109,7 +120,7 @@ if traffic:
                       f"{wr / 1e6:.1f} | {ws[0] * 1024 / (ws[1] or 1) / 1e6:.1f} | {hr:.2f} |")
         tj[k] = dict(read_bytes_per_launch=rd, write_bytes_per_launch=wr,
                      hbm_bytes_per_launch=rd + wr, l2_hit_rate=hr, launches=nd)
-    json.dump(dict(tag=tag, source="rocprofv3 --pmc TCC_EA0_* (scripts/profile_round.sh)",
+    json.dump(dict(tag=tag, workload_key=workload_key, source="rocprofv3 --pmc TCC_EA0_* (scripts/profile_round.sh)",
                    kernels=tj, trace=stats), open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
     out_md.append("")
 # ---- issue / L1 / L2 counters of the timed launches (what bench.py's roofline prices the kernels against) ----
@@ -136,7 +147,8 @@ for pas in ("pmc_sq", "pmc_sq2", "pmc_tcp", "pmc_tcc", "pmc_rd", "pmc_wr"):
 if counters:
     # durations of the same launches from the kernel trace of the PMC passes are perturbed by the counters; the
     # un-perturbed durations are those of the trace pass (`trace` in *_traffic.json) and of bench.py's HIP events
-    json.dump(dict(tag=tag, protocol=f"python bench.py --steps {STEPS} --warmup {WARMUP} (timed launches only)",
+    json.dump(dict(tag=tag, workload_key=workload_key,
+                   protocol=f"python bench.py --steps {STEPS} --warmup {WARMUP}{' ' + EXTRA_ARGS if EXTRA_ARGS else ''} (timed launches only)",
                    source="rocprofv3 --pmc, one pass per counter group (scripts/profile_round.sh)",
                    kernels=counters), open(f"{dst}/{tag}_counters.json", "w"), indent=1)
     out_md += ["## Issue / L1 / L2 counters per timed launch", "",

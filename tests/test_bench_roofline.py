@@ -21,7 +21,7 @@ def bench():
 
 def test_committed_profile_is_found_and_complete(bench):
     prof = bench.committed_profile()
-    assert prof["tag"] and prof["tag"].startswith("r03"), prof["tag"]
+    assert prof["tag"] and prof["tag"][:3] in ("r03", "r04", "r05", "r06"), prof["tag"]
     assert "--steps 20 --warmup 5" in prof["protocol"]  # the driver's protocol, timed launches only
     for kind in ("raycast", "integrate_bg", "integrate", "assoc", "stream_copy"):
         c = prof["counters"][kind]
@@ -55,7 +55,7 @@ def test_roofline_object_of_a_bench_line(bench):
     fr = {k: v["frac"] for k, v in roof["resources"].items() if isinstance(v, dict)}
     assert roof["frac"] == max(fr.values()) and roof["bound"] == max(fr, key=fr.get) and roof["frac"] <= 1.0
     assert roof["achieved"] / roof["peak"] == pytest.approx(roof["frac"], abs=1e-3)
-    assert roof["traffic"] > 1e7 and "profiles/r03" in roof["counters_from"]
+    assert roof["traffic"] > 1e7 and "profiles/r0" in roof["counters_from"]
     assert roof["model_GBs"] > 8000 and "not a roofline fraction" in roof["model_note"]  # the byte model: a rate, kept apart
     integ = roof["integrate_stream"]
     assert integ["concurrent_with_raycast"] and 0 < integ["frac"] <= 1.0
@@ -65,6 +65,36 @@ def test_roofline_object_of_a_bench_line(bench):
     # another workload than the profiled one: nothing to price the kernel against, and the line says so
     roof2, _ = bench.roofline(kern, None, 307200, None, False)
     assert roof2["bound"] is None and roof2["frac"] is None and roof2["traffic"] is None and "none committed" in roof2["counters_from"]
+
+
+def test_profiles_are_selected_by_workload(bench):
+    """A run is priced by counters taken on ITS workload: the headline's key finds the configs[1] profile, the
+    configs[4] share its own (profiles/r04_cfg4_*), an unprofiled workload nothing."""
+    assert bench.committed_profile(bench.HEADLINE_KEY)["tag"]
+    assert bench.committed_profile("640x480_bg64_obj1x32")["tag"] is None
+    cfg4 = bench.committed_profile(bench.workload_key(1280, 960, 1024, 256, 2))
+    assert cfg4["tag"] and "cfg4" in cfg4["tag"] and cfg4["counters"]["integrate_bg"]["SQ_INSTS_VALU"]["per_launch"] > 0
+    assert cfg4["traffic"]["integrate_bg"]["hbm_bytes_per_launch"] > 1e8
+
+
+def test_the_committed_counters_are_not_older_than_the_kernels_they_price(bench):
+    """roofline divides THIS run's launch durations into counters of a committed profiler run: a change to the frame's
+    kernels without a new profile would price new time with old counts.  The newest configs[1] profile must have been
+    committed no earlier than the last commit that touched the sources of the frame's kernels."""
+    import subprocess
+    if not (ROOT / ".git").exists():
+        pytest.skip("no git history here (the GPU box gets a snapshot of the tree)")
+
+    def last_commit_time(paths):
+        out = subprocess.run(["git", "log", "-1", "--format=%ct", "--"] + paths, cwd=ROOT, capture_output=True, text=True)
+        return int(out.stdout.strip() or 0)
+    prof = bench.committed_profile()
+    kernels = [f"emfusion_amd/csrc/{f}" for f in ("batched.hip", "march_wave.hpp", "device_core.hpp", "volume_sweep.hip",
+                                                  "raycast.hip", "pixel_ops.hip", "common.hpp")]
+    t_prof, t_src = last_commit_time([f"profiles/{prof['file']}"]), last_commit_time(kernels)
+    assert t_prof > 0, f"profiles/{prof['file']} is not committed"
+    assert t_prof >= t_src, (f"profiles/{prof['file']} was committed before the last change to the frame's kernels: "
+                             "run scripts/profile_round.sh and commit the new summaries")
 
 
 def test_host_thread_count_respects_affinity_and_quota(monkeypatch, tmp_path):
