@@ -4,31 +4,97 @@
 //
 //   emfusion_synth [--frames N] [--objects K] [--bg-res R] [--obj-res R] [--width W --height H]
 //                  [--materialize-gradients] [--autonomous] [--out DIR]
+//   emfusion_synth --sequence DIR/ [--masks DIR] [--mask-frames N] [--visibility-thresh N] [--frames N]
+//                  [--bg-res R] [--bg-voxel M] [--obj-res R] [--volumes] --out DIR
+// --sequence: the reference's loop itself (apps/EM-Fusion.cpp:100-156) on a TUM RGB-D sequence: TUMRGBDReader
+// (core/Readers.hpp) -> emf.usePreprocMasks(masks) -> processFrame(frame) with camera and object tracking from the
+// second frame on -> writeResults.  What apps/run_tum.py does from Python, without Python.
 // --out DIR: keep the pose log and write the reference's result files at the end (writeResults:
 // poses-*.txt, mesh_*.ply, tsdfs/*.bin; EMFusion.cpp:258-292) into the existing directory DIR.
 // --autonomous: nothing but depth and instance masks go in, as in the reference's own loop -- objects
 // are spawned from the masks of frame 0 (initNewObjVolume), camera and object poses are tracked
 // (performTracking), later masks are matched to the models (matchSegmentation); the ground-truth
 // poses of the stream are only used to report the tracking error at the end.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "EMFusion.hpp"
+#include "Readers.hpp"
 #include "SyntheticScene.hpp"
+
+// The reference's main loop on a TUM sequence (apps/EM-Fusion.cpp:100-156)
+static int runSequence(const std::string& seq, const std::string& masks, const std::string& outDir, int frames, int bgRes,
+                       float bgVoxel, int objRes, int maskFrames, int visibilityThresh, bool volumes) {
+    emf::TUMRGBDReader reader(seq);  // "<dir>/associations.txt"
+    if (reader.getNumFrames() == 0) throw std::runtime_error("no frames in " + seq + "associations.txt");
+    const size_t n = frames > 0 ? std::min<size_t>(frames, reader.getNumFrames()) : reader.getNumFrames();
+    std::vector<float> depth;
+    const emf::Size size = reader.readDepth(0, depth);
+    emf::Params params;  // reference defaults (config/default.cfg)
+    params.frameSize = size;
+    params.setDefaultIntrinsics();
+    params.globalVolumeDims = emf::Vec3i::all(bgRes);
+    params.globalVoxelSize = bgVoxel;
+    params.volumePose = emf::Affine3f(emf::Matx33f::eye(), emf::Vec3f(0.f, 0.f, bgRes * bgVoxel / 2.f));
+    params.objVolumeDims = emf::Vec3i::all(objRes);
+    const float scale = static_cast<float>(size.width) / 640.f;
+    params.visibilityThresh = visibilityThresh > 0 ? visibilityThresh : static_cast<int>(std::lround(1600 * scale * scale));
+    params.boundary = static_cast<int>(std::lround(20 * scale));
+    params.maskRCNNFrames = maskFrames;
+    emf::EMFusion emf(params);
+    if (!masks.empty()) emf.usePreprocMasks(masks);   // apps/EM-Fusion.cpp:115
+    emf.setupOutput(false, volumes);                  // apps/EM-Fusion.cpp:112
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t f = 0; f < n; ++f) {                  // while (reader->moreFrames())
+        reader.readDepth(f, depth);                   // frame = reader->getNextFrame()
+        for (float& d : depth)
+            if (!std::isfinite(d)) d = 0.f;
+        emf::FrameInputs in;                          // frame 0 defines the world frame; then everything is tracked
+        in.trackCamera = in.trackObjects = f > 0;
+        in.cleanUp = true;
+        emf.setFrameInputs(in);
+        emf::RGBD frame;
+        frame.size = size;
+        frame.depth = depth.data();
+        emf.processFrame(frame);                      // apps/EM-Fusion.cpp:152
+        if (f % 50 == 0) {
+            std::vector<uint8_t> maskim;
+            const int inst = emf.getLastMasks(maskim);  // apps/EM-Fusion.cpp:162
+            std::printf("frame %zu/%zu: %zu visible objects, %d instances in the last mask frame\n", f, n,
+                        emf.visibleObjects().size(), inst);
+        }
+    }
+    emf.synchronize();
+    emf.writeResults(outDir, volumes);                // apps/EM-Fusion.cpp:204
+    std::printf("%zu frames of %s (%.1f Hz) in %.1f s incl. PNG decoding on the host; results in %s\n", n, seq.c_str(),
+                reader.getFrameRate(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), outDir.c_str());
+    return 0;
+}
 
 int main(int argc, char** argv) {
     int frames = 120, objects = 4, bgRes = 512, objRes = 128, width = 640, height = 480;
     bool materialize = false, autonomous = false;
-    std::string outDir;
+    std::string outDir, sequence, maskDir;
+    int maskFrames = 30, visThresh = 0, framesGiven = 0;
+    float bgVoxel = 0.f;
+    bool volumes = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() { return i + 1 < argc ? std::atoi(argv[++i]) : 0; };
-        if (a == "--frames") frames = next();
+        if (a == "--frames") frames = framesGiven = next();
+        else if (a == "--sequence" && i + 1 < argc) sequence = argv[++i];
+        else if (a == "--masks" && i + 1 < argc) maskDir = argv[++i];
+        else if (a == "--mask-frames") maskFrames = next();
+        else if (a == "--visibility-thresh") visThresh = next();
+        else if (a == "--bg-voxel" && i + 1 < argc) bgVoxel = static_cast<float>(std::atof(argv[++i]));
+        else if (a == "--volumes") volumes = true;
         else if (a == "--objects") objects = next();
         else if (a == "--bg-res") bgRes = next();
         else if (a == "--obj-res") objRes = next();
@@ -43,6 +109,11 @@ int main(int argc, char** argv) {
         }
     }
     try {
+        if (!sequence.empty()) {
+            if (outDir.empty()) throw std::runtime_error("--sequence needs --out DIR");
+            return runSequence(sequence, maskDir, outDir, framesGiven, bgRes, bgVoxel > 0 ? bgVoxel : 5.12f / static_cast<float>(bgRes),
+                               objRes, maskFrames, visThresh, volumes);
+        }
         emf::Params params;  // reference defaults (config/default.cfg)
         params.frameSize = emf::Size(width, height);
         params.setDefaultIntrinsics();

@@ -8,6 +8,7 @@
 //            4, materialised gradient volumes, or EMF_PER_VOLUME=1)  the reference's structure:
 //            one HIP stream per volume joined by events, host-side visibility gate
 #include "EMFusion.hpp"
+#include "Readers.hpp"
 
 #include <sys/stat.h>
 
@@ -17,6 +18,7 @@
 
 #include <algorithm>
 #include <exception>
+#include <fstream>
 #include <chrono>
 #include <cmath>
 #include <cmath>
@@ -464,7 +466,51 @@ void EMFusion::processFrame(const RGBD& frame) {
     depthUpload.upload(frame.depth, main);  // reference EMFusion.cpp:72
     FrameInputs in = pending;
     in.preprocessDepth = true;              // reference EMFusion.cpp:74
+    if (!maskPath.empty() && frameCount % params.maskRCNNFrames == 0) loadPreprocMasks(in);  // EMFusion.cpp:99-101, 375-395
     runSchedule(depthUpload.view(), in);
+}
+
+// runMaskRCNN with a mask path (reference EMFusion.cpp:383-389) + the label image getLastMasks hands out
+void EMFusion::loadPreprocMasks(FrameInputs& in) {
+    char name[32];
+    std::snprintf(name, sizeof(name), "Mask%04d.plk", frameCount);
+    PreprocMasks pm;
+    int n = 0;
+    {
+        std::ifstream probe(maskPath + "/" + name, std::ios::binary);
+        if (probe.good()) n = loadPreprocessedMasks(maskPath + "/" + name, pm);
+    }
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    if (n > 0 && (pm.width != w || pm.height != h))
+        throw HipError(std::string("EMFusion::usePreprocMasks: ") + name + " holds masks of another size than the frames",
+                       EMF_E_SHAPE);
+    main.waitForCompletion();  // the previous mask frame's device copies are being replaced
+    preprocMaskDev.clear();
+    in.instanceMasks.clear();
+    in.instanceScores.clear();
+    // the reference's instance colours (MaskRCNN.cpp:290-301), index 0 = no instance
+    static const unsigned char colors[31][3] = {
+        {0, 0, 0},       {0, 0, 255},     {255, 0, 0},    {0, 255, 0},     {255, 26, 184},  {255, 211, 0},   {0, 131, 246},
+        {0, 140, 70},    {167, 96, 61},   {79, 0, 105},   {0, 255, 246},   {61, 123, 140},  {237, 167, 255}, {211, 255, 149},
+        {184, 79, 255},  {228, 26, 87},   {131, 131, 0},  {0, 255, 149},   {96, 0, 43},     {246, 131, 17},  {202, 255, 0},
+        {43, 61, 0},     {0, 52, 193},    {255, 202, 131}, {0, 43, 96},    {158, 114, 140}, {79, 184, 17},   {158, 193, 255},
+        {149, 158, 123}, {255, 123, 175}, {158, 8, 0}};
+    lastMaskVis.assign(static_cast<size_t>(w) * h * 3, 0);
+    lastMaskInstances = n;
+    for (int k = 0; k < n; ++k) {
+        preprocMaskDev.emplace_back(params.frameSize);
+        preprocMaskDev.back().upload(pm.masks[k].data(), main);
+        const unsigned char* c = colors[1 + k % 30];
+        for (size_t i = 0; i < pm.masks[k].size(); ++i)
+            if (pm.masks[k][i]) {
+                lastMaskVis[3 * i] = c[0];
+                lastMaskVis[3 * i + 1] = c[1];
+                lastMaskVis[3 * i + 2] = c[2];
+            }
+    }
+    main.waitForCompletion();  // (pm's host buffers go out of scope)
+    for (auto& m : preprocMaskDev) in.instanceMasks.push_back(m.view());
+    in.instanceScores = pm.scores;
 }
 
 void EMFusion::processFrame(const emf_image_t& depthDev, const FrameInputs& in) {

@@ -172,6 +172,23 @@ public:
      * tsdfs/ dumps only with `volumes` (or setupOutput's exp_vols).
      */
     void writeResults(const std::string& dir, bool volumes);
+    /**
+     * Prepare for using preprocessed masks (reference EMFusion.h:98, EMFusion.cpp:249-251): from now on
+     * processFrame(const RGBD&) reads `<path>/Mask%04d.plk` (numbered by the frame count, EMFusion.cpp:383-389) on
+     * every maskRCNNFrames-th frame and runs its instances through initOrMatchObjs, as runMaskRCNN does with a
+     * mask path set.  A missing file counts as "no instances" (the reference's loadPreprocessed returns -1).
+     */
+    void usePreprocMasks(const std::string& path) { maskPath = path; }
+    /**
+     * Get the last Mask R-CNN segmentation image (reference EMFusion.h:83, EMFusion.cpp:237-240: the visualisation
+     * of the last mask frame).  Without the colour frame the instances are drawn in the reference's instance colours
+     * (MaskRCNN.cpp:290-301) on black: rgb = W x H x 3 bytes; empty before the first mask frame.  Returns the number
+     * of instances of that frame.
+     */
+    int getLastMasks(std::vector<uint8_t>& rgb) const {
+        rgb = lastMaskVis;
+        return lastMaskInstances;
+    }
     /** Ids returned by initNewObjVolume for FrameInputs::newObjectMasks of the last frame (-1: none). */
     const std::vector<int>& lastCreatedObjects() const { return lastCreated; }
     Affine3f getCameraPose() const { return pose; }
@@ -205,6 +222,7 @@ public:
 
     /** Poses / masks the next processFrame(RGBD) call consumes. */
     void setFrameInputs(const FrameInputs& in) { pending = in; }
+    void loadPreprocMasks(FrameInputs& in);
 
     /** Reference entry point (EMFusion.cpp:70): uploads the depth map, then runs the schedule. */
     void processFrame(const RGBD& frame);
@@ -324,6 +342,10 @@ private:
     // frame-sized device images (reference EMFusion.h:447-489)
     emf_image_t depth{};  // view of the current depth map
     DeviceImage<float> depthUpload;
+    std::string maskPath;                              // usePreprocMasks
+    std::vector<DeviceImage<uint8_t>> preprocMaskDev;  // the instances of the last mask frame (device copies)
+    std::vector<uint8_t> lastMaskVis;
+    int lastMaskInstances = 0;
     DeviceImage<float> depthFiltered;  // output of preprocessDepth
     DeviceImage<float> invLambda;  // per-pixel 1 / lambda of the integration, fixed by the intrinsics
     bool useLambdaTable = true;

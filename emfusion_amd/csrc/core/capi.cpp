@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "EMFusion.hpp"
+#include "Readers.hpp"
 #include "Output.hpp"
 #include "SyntheticScene.hpp"
 #include "emf_fusion.h"
@@ -178,6 +179,92 @@ int emf_fusion_process_frame(emf_fusion_t* h, const emf_image_t* depth_dev, cons
         in.instanceMasks.swap(h->queuedInstances);
         in.instanceScores.swap(h->queuedScores);
         h->impl->processFrame(*depth_dev, in);
+    });
+}
+
+int emf_fusion_process_rgbd(emf_fusion_t* h, const float* depth_host, int32_t width, int32_t height) {
+    REQ(h);
+    REQ(depth_host);
+    return guarded([&] {
+        FrameInputs in;  // poses stay as tracked (or identity): the reference's entry takes nothing but the frame
+        in.cam_pose = h->impl->getCameraPose();
+        in.trackCamera = h->trackCamera;
+        in.trackObjects = h->trackObjects;
+        in.cleanUp = h->cleanUp;
+        in.newObjectMasks.swap(h->queuedMasks);
+        in.instanceMasks.swap(h->queuedInstances);
+        in.instanceScores.swap(h->queuedScores);
+        h->impl->setFrameInputs(in);
+        RGBD frame;
+        frame.size = Size(width, height);
+        frame.depth = depth_host;
+        h->impl->processFrame(frame);
+    });
+}
+
+int emf_fusion_use_preproc_masks(emf_fusion_t* h, const char* path) {
+    REQ(h);
+    REQ(path);
+    return guarded([&] { h->impl->usePreprocMasks(path); });
+}
+
+int emf_fusion_get_last_masks(emf_fusion_t* h, uint8_t* rgb, size_t capacity, int32_t* instances) {
+    REQ(h);
+    return guarded([&] {
+        std::vector<uint8_t> img;
+        const int n = h->impl->getLastMasks(img);
+        if (instances) *instances = n;
+        if (rgb && capacity >= img.size() && !img.empty()) std::memcpy(rgb, img.data(), img.size());
+    });
+}
+
+int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capacity, int32_t* width, int32_t* height) {
+    REQ(path);
+    return guarded([&] {
+        std::vector<uint16_t> px;
+        int w = 0, hgt = 0;
+        readPngGray(path, px, w, hgt);
+        if (width) *width = w;
+        if (height) *height = hgt;
+        if (out) {
+            if (capacity < px.size()) throw HipError("emf_io_read_depth_png: buffer too small", EMF_E_ARG);
+            for (size_t i = 0; i < px.size(); ++i) out[i] = static_cast<float>(px[i]) * scale;
+        }
+    });
+}
+
+int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count) {
+    REQ(file);
+    return guarded([&] {
+        std::vector<std::string> rgb, depth;
+        std::vector<double> stamps;
+        TUMRGBDReader::readFileAssociations(file, rgb, depth, &stamps);
+        if (count) *count = static_cast<int32_t>(depth.size());
+        if (index >= 0 && index < static_cast<int>(depth.size())) {
+            if (depth_name && name_capacity > 0) std::snprintf(depth_name, static_cast<size_t>(name_capacity), "%s", depth[index].c_str());
+            if (stamp) *stamp = stamps[index];
+        }
+    });
+}
+
+int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int32_t* height, uint8_t* masks,
+                              size_t mask_capacity, double* boxes, double* scores, size_t score_capacity, int32_t* nscores) {
+    REQ(path);
+    return guarded([&] {
+        PreprocMasks pm;
+        const int k = loadPreprocessedMasks(path, pm);
+        if (n) *n = k;
+        if (width) *width = pm.width;
+        if (height) *height = pm.height;
+        const size_t per = static_cast<size_t>(pm.width) * pm.height;
+        const size_t ns = pm.scores.empty() ? 0 : pm.scores[0].size();
+        if (nscores) *nscores = static_cast<int32_t>(ns);
+        if (masks && mask_capacity >= per * k)
+            for (int i = 0; i < k; ++i) std::memcpy(masks + per * i, pm.masks[i].data(), per);
+        if (boxes)
+            for (int i = 0; i < k; ++i) std::memcpy(boxes + 4 * i, pm.boxes[i].data(), 4 * sizeof(double));
+        if (scores && score_capacity >= ns * pm.scores.size())
+            for (size_t i = 0; i < pm.scores.size(); ++i) std::memcpy(scores + ns * i, pm.scores[i].data(), ns * sizeof(double));
     });
 }
 

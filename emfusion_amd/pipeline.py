@@ -93,6 +93,13 @@ def load() -> C.CDLL:
         "emf_fusion_destroy": [vp],
         "emf_fusion_reset": [vp],
         "emf_fusion_trim_pool": [C.POINTER(C.c_uint64)],
+        "emf_fusion_process_rgbd": [vp, fp, C.c_int32, C.c_int32],
+        "emf_fusion_use_preproc_masks": [vp, C.c_char_p],
+        "emf_fusion_get_last_masks": [vp, C.c_void_p, C.c_size_t, ip],
+        "emf_io_read_depth_png": [C.c_char_p, C.c_float, fp, C.c_size_t, ip, ip],
+        "emf_io_tum_associations": [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), ip],
+        "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.c_size_t, ip],
         "emf_fusion_add_object": [vp, fp, C.c_float, ip],
         "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
                                      C.c_int],
@@ -431,6 +438,23 @@ class Fusion:
                                                _farr(cam_t, 3), n, ids, Rs, ts, m, mids, mviews,
                                                int(run_masks)))
 
+    def process_rgbd(self, depth: np.ndarray):
+        """EMFusion::processFrame(const RGBD&): a host depth image in metres (uploaded, filtered, fused)."""
+        d = np.ascontiguousarray(depth, np.float32)
+        _check("emf_fusion_process_rgbd",
+               load().emf_fusion_process_rgbd(self._h, d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[1], d.shape[0]))
+
+    def use_preproc_masks(self, path):
+        """EMFusion::usePreprocMasks: <path>/Mask%04d.plk on every mask frame of process_rgbd."""
+        _check("emf_fusion_use_preproc_masks", load().emf_fusion_use_preproc_masks(self._h, os.fspath(path).encode()))
+
+    def last_masks(self):
+        """EMFusion::getLastMasks: (instances, (H, W, 3) u8 image or None before the first mask frame)."""
+        n = C.c_int32(0)
+        img = np.zeros((self.params.height, self.params.width, 3), np.uint8)
+        _check("emf_fusion_get_last_masks", load().emf_fusion_get_last_masks(self._h, img.ctypes.data, img.nbytes, C.byref(n)))
+        return n.value, img
+
     def set_tracking(self, camera=True, objects=True):
         """From the next frame on, track the camera / object poses instead of taking them as inputs."""
         _check("emf_fusion_set_tracking", load().emf_fusion_set_tracking(self._h, int(camera), int(objects)))
@@ -665,6 +689,41 @@ class Fusion:
 
     def owns_object(self, obj_id: int) -> bool:
         return bool(load().emf_fusion_owns_object(self._h, obj_id))
+
+
+def read_depth_png(path, scale=1.0 / 5000.0) -> np.ndarray:
+    """core/Readers.cpp readPngGray through the C API: float32 (H, W) = raw * scale."""
+    w, h = C.c_int32(), C.c_int32()
+    _check("emf_io_read_depth_png", load().emf_io_read_depth_png(os.fspath(path).encode(), scale, None, 0, C.byref(w), C.byref(h)))
+    out = np.empty((h.value, w.value), np.float32)
+    _check("emf_io_read_depth_png", load().emf_io_read_depth_png(os.fspath(path).encode(), scale,
+                                                               out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(w), C.byref(h)))
+    return out
+
+
+def tum_associations(path):
+    """[(depth file name, time stamp)] of a TUM associations.txt, as the C++ TUMRGBDReader parses it."""
+    n, out = C.c_int32(), []
+    _check("emf_io_tum_associations", load().emf_io_tum_associations(os.fspath(path).encode(), -1, None, 0, None, C.byref(n)))
+    for i in range(n.value):
+        name, stamp = C.create_string_buffer(512), C.c_double()
+        _check("emf_io_tum_associations", load().emf_io_tum_associations(os.fspath(path).encode(), i, name, 512, C.byref(stamp), C.byref(n)))
+        out.append((name.value.decode(), stamp.value))
+    return out
+
+
+def load_preproc_masks(path):
+    """core/Readers.cpp loadPreprocessedMasks through the C API: (boxes (N, 4), masks (N, H, W) u8, scores (N, S))."""
+    n, w, h, ns = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    f = load().emf_io_load_preproc_masks
+    _check("emf_io_load_preproc_masks", f(os.fspath(path).encode(), C.byref(n), C.byref(w), C.byref(h), None, 0, None, None, 0, C.byref(ns)))
+    masks = np.zeros((n.value, h.value, w.value), np.uint8)
+    boxes = np.zeros((n.value, 4), np.float64)
+    scores = np.zeros((n.value, ns.value), np.float64)
+    _check("emf_io_load_preproc_masks", f(os.fspath(path).encode(), C.byref(n), C.byref(w), C.byref(h), masks.ctypes.data, masks.nbytes,
+                                          boxes.ctypes.data_as(C.POINTER(C.c_double)), scores.ctypes.data_as(C.POINTER(C.c_double)),
+                                          scores.size, C.byref(ns)))
+    return boxes, masks, scores
 
 
 def trim_pool() -> int:

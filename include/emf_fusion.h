@@ -77,6 +77,14 @@ int emf_fusion_reset(emf_fusion_t* h);
  * hipFree (which synchronises the device; EMF_POOL_MIB caps the pool, default 16 GiB).  This really frees them
  * -- it waits for the device -- and reports how many bytes were held (bytes_freed may be NULL). */
 int emf_fusion_trim_pool(uint64_t* bytes_freed);
+/* emf::EMFusion::processFrame(const RGBD&) -- the reference's entry (EMFusion.h:66): a HOST depth image in metres
+ * (width x height floats), uploaded, bilateral-filtered and run through the schedule with the frame inputs set by the
+ * emf_fusion_set_* / queue_* calls; with emf_fusion_use_preproc_masks the instance masks of every mask frame come
+ * from <path>/Mask%04d.plk (EMFusion::usePreprocMasks, EMFusion.h:98).  emf_fusion_get_last_masks: EMFusion::
+ * getLastMasks (EMFusion.h:83) -- W x H x 3 bytes (may be NULL), *instances of the last mask frame. */
+int emf_fusion_process_rgbd(emf_fusion_t* h, const float* depth_host, int32_t width, int32_t height);
+int emf_fusion_use_preproc_masks(emf_fusion_t* h, const char* path);
+int emf_fusion_get_last_masks(emf_fusion_t* h, uint8_t* rgb, size_t capacity, int32_t* instances);
 
 /* Create an object volume (edge vol_size metres, obj_res voxels) centred at `center` in world
  * coordinates; every rank issues the same calls.  *id_out = object id (1-based). */
@@ -160,6 +168,18 @@ int emf_io_write_pose_file(const char* filename, int n, const int32_t* frames, c
  * TUMRGBDReader.cpp for the depth images): rows = height x (1 + stride) bytes, each line preceded by
  * its filter type 0..4; out = height x stride reconstructed bytes; bpp = bytes per pixel (1 or 2). */
 int emf_io_png_unfilter(const uint8_t* rows, int height, int stride, int bpp, uint8_t* out);
+/* The C++ dataset readers behind apps/emfusion_synth --sequence (core/Readers.hpp; reference
+ * src/utils/TUMRGBDReader.cpp, src/core/MaskRCNN.cpp:250-282), exposed for tests and FFI users.
+ *   read_depth_png     an 8/16-bit grayscale PNG as float = raw * scale (TUM: 1 / 5000); out may be NULL to ask
+ *                      for the size only; capacity in floats
+ *   tum_associations   entry `index` of <file>: depth file name and time stamp; *count = number of entries
+ *   load_preproc_masks a Mask%04d.plk of the reference's preprocessing: *n instances of *width x *height; masks
+ *                      (n * height * width bytes, 0/1), boxes (n * 4) and scores (n * *nscores) are filled when
+ *                      not NULL and large enough (mask_capacity in bytes, score_capacity in doubles) */
+int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capacity, int32_t* width, int32_t* height);
+int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count);
+int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int32_t* height, uint8_t* masks,
+                              size_t mask_capacity, double* boxes, double* scores, size_t score_capacity, int32_t* nscores);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);

@@ -1,0 +1,74 @@
+"""The C++ dataset readers behind apps/emfusion_synth --sequence and EMFusion::usePreprocMasks (core/Readers.cpp;
+reference src/utils/TUMRGBDReader.cpp, src/core/MaskRCNN.cpp:250-282 + apps/maskrcnn.in.py:188-268), through the C API,
+against files this test writes and against the Python readers (emfusion_amd/readers.py).  No dataset exists here."""
+import pickle
+
+import numpy as np
+import pytest
+
+from emfusion_amd import pipeline, readers
+
+
+def test_png_decoder_handles_every_filter_type_and_both_depths(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 65535, (48, 64)).astype(np.uint16)
+    for k, filters in enumerate((None, rng.integers(0, 5, 48), np.full(48, 4), np.full(48, 3))):
+        readers.write_png_gray16(tmp_path / f"a{k}.png", img, filters=filters)
+        got = pipeline.read_depth_png(tmp_path / f"a{k}.png", 1.0)
+        assert got.dtype == np.float32 and np.array_equal(got, img.astype(np.float32))
+        assert np.array_equal(readers.read_png_gray(tmp_path / f"a{k}.png"), img)
+    tum = pipeline.read_depth_png(tmp_path / "a1.png")  # TUM scale: raw / 5000, the same float as the Python reader's
+    assert np.array_equal(tum, img.astype(np.float32) * np.float32(1 / 5000.0))
+    (tmp_path / "bad.png").write_bytes(b"not a png")
+    with pytest.raises(pipeline.FusionError, match="not a PNG"):
+        pipeline.read_depth_png(tmp_path / "bad.png")
+
+
+def test_associations_are_parsed_like_the_reference_reader(tmp_path):
+    (tmp_path / "associations.txt").write_text("# comment line\n0.100 rgb/0.png 0.110 depth/0.png\n0.200 rgb/1.png 0.210 depth/1.png\n"
+                                               "short line\n")
+    assert pipeline.tum_associations(tmp_path / "associations.txt") == [("depth/0.png", 0.1), ("depth/1.png", 0.2)]
+    # depth first: decided by the first line (TUMRGBDReader::readFileAssociations)
+    (tmp_path / "b.txt").write_text("0.1 depth/a.png 0.1 rgb/a.png\n0.2 depth/b.png 0.2 rgb/b.png\n")
+    assert [n for n, _ in pipeline.tum_associations(tmp_path / "b.txt")] == ["depth/a.png", "depth/b.png"]
+    py = readers.read_associations(tmp_path / "associations.txt")
+    assert py[1] == ["depth/0.png", "depth/1.png"]
+
+
+@pytest.mark.parametrize("protocol", [0, 1, 2, 3, 4, 5])
+def test_mask_pickles_of_every_protocol(tmp_path, protocol):
+    """generate_result() pickles three parallel lists: boxes (lists of numbers), masks (2-D slices of an (H, W, N)
+    bool array: non-contiguous views) and the 81 class scores (lists of floats); HIGHEST_PROTOCOL of the writing
+    interpreter -- 2 for Python 2, 4 or 5 for Python 3."""
+    rng = np.random.default_rng(protocol)
+    seg = np.zeros((48, 64, 2), bool)
+    seg[5:9, 7:9, 0] = True
+    seg[10:20, 30:40, 1] = True
+    boxes, scores = [[1, 2, 3, 4], [5, 6, 7, 8]], rng.random((2, 81))
+    with open(tmp_path / "Mask0000.plk", "wb") as f:
+        pickle.dump((boxes, [seg[:, :, 0], seg[:, :, 1]], scores.tolist()), f, protocol=protocol)
+    b, m, s = pipeline.load_preproc_masks(tmp_path / "Mask0000.plk")
+    assert np.array_equal(b, np.array(boxes, float)) and np.array_equal(s, scores)
+    assert m.dtype == np.uint8 and np.array_equal(m[0], seg[:, :, 0]) and np.array_equal(m[1], seg[:, :, 1])
+    pb, pm, ps = readers.load_preprocessed_masks(tmp_path / "Mask0000.plk")  # the Python reader agrees
+    assert np.array_equal(pb, b) and np.array_equal(np.stack(pm), m) and np.array_equal(ps, s)
+
+
+def test_mask_pickles_in_other_shapes(tmp_path):
+    m0 = np.zeros((48, 64), np.uint8)
+    m0[1:3, 2:5] = 1
+    boxes, scores = np.array([[1, 2, 3, 4], [5, 6, 7, 8]]), np.random.default_rng(1).random((2, 81))
+    with open(tmp_path / "a.plk", "wb") as f:  # arrays instead of lists: int64 boxes, an (N, H, W) stack, float64 scores
+        pickle.dump((boxes, np.stack([m0, m0.astype(bool)]), scores), f, protocol=2)
+    b, m, s = pipeline.load_preproc_masks(tmp_path / "a.plk")
+    assert m.sum() == 12 and np.array_equal(b, boxes.astype(float)) and np.array_equal(s, scores)
+    with open(tmp_path / "b.plk", "wb") as f:  # a frame without detections
+        pickle.dump(([], [], []), f, protocol=4)
+    assert len(pipeline.load_preproc_masks(tmp_path / "b.plk")[1]) == 0
+    with open(tmp_path / "c.plk", "wb") as f:  # Fortran-ordered masks, float32 values
+        pickle.dump(([[0, 0, 1, 1]], [np.asfortranarray(m0.astype(np.float32))], [[0.0] * 81]), f, protocol=4)
+    assert np.array_equal(pipeline.load_preproc_masks(tmp_path / "c.plk")[1][0], m0)
+    with open(tmp_path / "d.plk", "wb") as f:
+        pickle.dump({"not": "a tuple"}, f, protocol=2)
+    with pytest.raises(pipeline.FusionError, match="tuple"):
+        pipeline.load_preproc_masks(tmp_path / "d.plk")

@@ -38,3 +38,27 @@ def test_autonomous_loop(dev):
     m = re.search(r"autonomous: (\d+) objects spawned from masks; camera position error after 11 tracked frames: ([0-9.]+) mm", out)
     assert m, out
     assert int(m.group(1)) == 2 and float(m.group(2)) < 25.0
+
+
+def test_sequence_mode_equals_the_python_driver(dev, tmp_path):
+    """apps/emfusion_synth --sequence -- TUMRGBDReader, EMFusion::usePreprocMasks, processFrame(frame), getLastMasks,
+    writeResults, all in C++ (reference apps/EM-Fusion.cpp:100-204) -- on a staged TUM sequence: the pose files must equal
+    those of apps/run_tum.py (the Python readers, the C handle API) byte for byte, and the volume dumps too."""
+    import sys
+    from tests import tum_staging as T
+    seq, masks, truth = T.stage(tmp_path)
+    out_cpp, out_py = tmp_path / "out_cpp", tmp_path / "out_py"
+    p = subprocess.run([str(APP), "--sequence", seq, "--masks", masks, "--out", str(out_cpp), "--volumes", *T.SMALL],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "2 instances in the last mask frame" in p.stdout
+    q = subprocess.run([sys.executable, str(ROOT / "apps" / "run_tum.py"), seq, "--masks", masks, "--out", str(out_py), "--volumes",
+                        *T.SMALL], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout[-1500:] + q.stderr[-1500:]
+    names = sorted(f.name for f in out_py.glob("poses-*.txt"))
+    assert "poses-cam.txt" in names and "poses-1.txt" in names and names == sorted(f.name for f in out_cpp.glob("poses-*.txt"))
+    for name in names:
+        assert (out_cpp / name).read_bytes() == (out_py / name).read_bytes(), name
+    assert len((out_cpp / "poses-cam.txt").read_text().splitlines()) == T.N
+    for name in ("bg_tsdf.bin", "tsdf_1.bin", "fgProbs_1.bin"):
+        assert (out_cpp / "tsdfs" / name).read_bytes() == (out_py / "tsdfs" / name).read_bytes(), name

@@ -13,27 +13,13 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_run_tum_on_a_staged_synthetic_sequence(tmp_path, dev):
-    from emfusion_amd import pipeline, readers
-    W, H, N = 160, 120, 6
-    prm = pipeline.make_params(W, H, 64, 0.04, 32)
-    synth = pipeline.SyntheticStream(W, H, np.array(prm.K, np.float32), 2, seed=0xE3F5)
-    seq, masks = tmp_path / "seq", tmp_path / "masks"
-    (seq / "depth").mkdir(parents=True)
-    masks.mkdir()
-    lines, truth = [], []
-    for f in range(N):
-        depth, sid = synth.render(f)
-        truth.append(synth.camera_pose(f)[1])
-        readers.write_png_gray16(seq / "depth" / f"{f:04d}.png", np.round(depth * 5000).astype(np.uint16))
-        lines.append(f"{f / 30:.6f} rgb/{f:04d}.png {f / 30:.6f} depth/{f:04d}.png")
-        if f % 2 == 0:
-            m = [(sid == 1).astype(np.uint8), (sid == 2).astype(np.uint8)]  # generate_result's lists
-            with open(masks / f"Mask{f:04d}.plk", "wb") as fh:
-                pickle.dump(([[0, 0, 1, 1]] * 2, m, np.zeros((2, 81)).tolist()), fh, protocol=2)
-    (seq / "associations.txt").write_text("\n".join(lines) + "\n")
-    synth.close()
+    from tests import tum_staging as T
+    seq_dir, masks, truth = T.stage(tmp_path)
+    N = T.N
+    from pathlib import Path as _P
+    seq = _P(seq_dir)
     out = tmp_path / "out"
-    r = subprocess.run([sys.executable, str(ROOT / "apps" / "run_tum.py"), str(seq) + "/", "--masks", str(masks),
+    r = subprocess.run([sys.executable, str(ROOT / "apps" / "run_tum.py"), seq_dir, "--masks", str(masks),
                         "--out", str(out), "--bg-res", "64", "--bg-voxel", "0.04", "--obj-res", "32",
                         "--visibility-thresh", "100", "--mask-frames", "2", "--volumes"],
                        capture_output=True, text=True, timeout=300)
