@@ -757,6 +757,13 @@ int EMFusion::matchSegmentation(const emf_image_t& mask, float& match_iou) {
 
 void EMFusion::writeResults(const std::string& dir, bool volumes) {
     synchronize();
+    // boost::filesystem::create_directories(p) (EMFusion.cpp:254-255): every missing component of the path
+    for (size_t k = 1; k <= dir.size(); ++k)
+        if (k == dir.size() || dir[k] == '/') {
+            const std::string part = dir.substr(0, k);
+            if (!part.empty() && mkdir(part.c_str(), 0777) != 0 && errno != EEXIST)
+                throw std::runtime_error("EMFusion::writeResults: cannot create " + part);
+        }
     io::writePoseFile(dir + "/poses-cam.txt", poses);
     for (const auto& op : obj_poses)
         io::writePoseFile(dir + "/poses-" + std::to_string(op.first) + ".txt", op.second);

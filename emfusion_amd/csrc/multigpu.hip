@@ -597,7 +597,7 @@ int emf_hip_compositeFromKeysPeer(const emf_peer_t* group, uint32_t seq, int ban
     }
     EMF_TRY(peer_wait_in_front(group, seq, stream));
     const unsigned tiles = ceil_div(w, kTileX) * ceil_div(h, kTileY);
-    hipLaunchKernelGGL(k_composite_keys_peer, dim3(tiles < kPollGroups ? tiles : kPollGroups), pixel_block(), 0,
+    hipLaunchKernelGGL(k_composite_keys_peer, dim3(group->waitInFront || tiles < kPollGroups ? tiles : kPollGroups), pixel_block(), 0,
                        as_stream(stream), pa, seq, a, ids, loc, slots);
     return launch_status("compositeFromKeysPeer");
 }

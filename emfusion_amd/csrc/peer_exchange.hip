@@ -381,7 +381,9 @@ int emf_hip_peerNormalizeAssociation(const emf_peer_t* group, uint32_t seq, cons
         no = img<float>(norm);
     }
     EMF_TRY(peer_wait_in_front(group, seq, stream));
-    hipLaunchKernelGGL(k_peer_normalize, dim3(std::min<unsigned>(kPollGroups, ceil_div(w, 64) * ceil_div(h, 4))), dim3(64, 4), 0,
+    // a polling grid stays small (kPollGroups); behind the one-wave wait launch every tile gets its workgroup
+    const unsigned tiles = ceil_div(w, 64) * ceil_div(h, 4);
+    hipLaunchKernelGGL(k_peer_normalize, dim3(group->waitInFront ? tiles : std::min<unsigned>(kPollGroups, tiles)), dim3(64, 4), 0,
                        reinterpret_cast<hipStream_t>(stream), a, seq, t, so, no, w, h);
     return launch_status("peerNormalizeAssociation");
 }
