@@ -61,6 +61,7 @@ void ObjTSDF::computeAssociation(const emf_image_t& points, const Affine3f& cam_
 void ObjTSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_image_t& raylengths,
                       const emf_image_t& vertices, const emf_image_t& normals,
                       const emf_image_t& mask, Stream& stream, uint64_t* stats) {
+    pollReciprocal();  // (see TSDF::raycast)
     const Affine3f rel_pose_CO = pose.inv() * cam_pose;
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(),
                                  fgVolMask.as<uint8_t>(),

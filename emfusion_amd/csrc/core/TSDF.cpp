@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 namespace emf {
@@ -28,9 +29,10 @@ TSDF::TSDF(Vec3i _volumeRes, float _voxelSize, float _truncdist, Affine3f _pose,
 // Is 1 / voxelSize usable in place of the march's divisions?  An exhaustive device check per distinct
 // voxel size and process (emf_hip_voxelReciprocal*); EMF_VOXEL_RCP=0 keeps the divisions for A/B runs.
 namespace {
-bool g_deferReciprocal = false;
+std::atomic<bool> g_deferReciprocal{false};
 std::mutex g_rcpSlotMutex;
-unsigned long long* g_rcpSlots = nullptr;  // device-visible host words, allocated once, never freed
+unsigned long long* g_rcpSlots = nullptr;  // pinned host words the verdicts are COPIED to, allocated once, never freed
+unsigned long long* g_rcpSlotsDev = nullptr;  // the device counters the check adds into (no atomics across PCIe)
 constexpr int kRcpSlots = 256;
 bool g_rcpSlotUsed[kRcpSlots] = {};
 hipStream_t g_rcpStream = nullptr;         // lowest priority: the check must not delay a frame
@@ -44,6 +46,12 @@ int take_rcp_slot() {
             return -1;
         }
         g_rcpSlots = static_cast<unsigned long long*>(p);
+        void* dp = nullptr;
+        if (hipMalloc(&dp, sizeof(unsigned long long) * kRcpSlots) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        g_rcpSlotsDev = static_cast<unsigned long long*>(dp);
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&g_rcpStream, hipStreamNonBlocking, least) != hipSuccess) {
@@ -52,7 +60,7 @@ int take_rcp_slot() {
             return -1;
         }
     }
-    if (!g_rcpStream) return -1;
+    if (!g_rcpStream || !g_rcpSlotsDev) return -1;
     for (int i = 0; i < kRcpSlots; ++i)
         if (!g_rcpSlotUsed[i]) {
             g_rcpSlotUsed[i] = true;
@@ -97,8 +105,10 @@ void TSDF::obtainReciprocal() {
             std::unique_ptr<PendingReciprocal, PendingDeleter> p(new PendingReciprocal);
             p->slot = slot;
             if (hipEventCreateWithFlags(&p->done, hipEventDisableTiming) == hipSuccess &&
-                emf_hip_voxelReciprocalBegin(voxelSize, g_rcpSlots + slot,
+                emf_hip_voxelReciprocalBegin(voxelSize, g_rcpSlotsDev + slot,
                                              reinterpret_cast<emf_stream_t>(g_rcpStream)) == EMF_OK &&
+                hipMemcpyAsync(g_rcpSlots + slot, g_rcpSlotsDev + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               g_rcpStream) == hipSuccess &&
                 hipEventRecord(p->done, g_rcpStream) == hipSuccess) {
                 pendingRcp = std::move(p);
                 return;  // rcpVoxel stays 0 until pollReciprocal() sees the verdict
@@ -253,6 +263,7 @@ void TSDF::updateGradients(Stream& stream) {
 void TSDF::raycast(const Affine3f& cam_pose, const Matx33f& intr, const emf_image_t& raylengths,
                    const emf_image_t& vertices, const emf_image_t& normals,
                    const emf_image_t& mask, Stream& stream, uint64_t* stats) {
+    pollReciprocal();  // a volume used outside an emf::EMFusion adopts its deferred verdict here
     const Affine3f rel_pose_CO = pose.inv() * cam_pose;  // camera -> volume
     emfCheck(emf_hip_raycastTSDF(tsdfVol.as<float>(), gradsPtr(), tsdfWeights.as<float>(), nullptr,
                                  brickFlagMode() ? brickFlags.as<uint8_t>() : nullptr, &raylengths, &vertices, &normals, &mask,

@@ -345,6 +345,7 @@ int emf_hip_peerWaitCopyFromSlots(const emf_peer_t* group, uint32_t seq, int npa
         most = bytes_host[k] > most ? bytes_host[k] : most;
     }
     EMF_TRY(peer_wait_in_front(group, seq, stream));
+    if (parts.count == 0 && group->waitInFront) return EMF_OK;  // (a broadcast's root: the wait launch was all of it)
     hipLaunchKernelGGL(k_peer_wait_copy, dim3(grid_for(most / 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, seq,
                        parts);
     return launch_status("peerWaitCopyFromSlots");
