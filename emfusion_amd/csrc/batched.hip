@@ -152,10 +152,14 @@ constexpr int kRbTile = 16;
 struct RayTraceRec {
     unsigned long long t0, t1;
     unsigned hw, xcc, model, tile, wave, samplesMax, samplesSum, activeLanes;
+#ifdef EMF_MARCH_STAMP
+    unsigned long long ckIssue, ckWait, ckRest, lateIssue, lateWait, lateRest;
+    unsigned iters, hist[6], pad;
+#endif
 };
 __device__ RayTraceRec g_rayTrace[32768];
 __device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned samples, int m, int tile,
-                                           int wave, int lane) {
+                                           int wave, int lane, const MarchCount* mc = nullptr) {
     unsigned mx = samples, sm = samples;
     for (int o = 32; o > 0; o >>= 1) {
         mx = max(mx, static_cast<unsigned>(__shfl_xor(static_cast<int>(mx), o)));
@@ -175,6 +179,16 @@ __device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned sampl
         t.samplesMax = mx;
         t.samplesSum = sm;
         t.activeLanes = __popcll(lanes);
+#ifdef EMF_MARCH_STAMP
+        t.ckIssue = t.ckWait = t.ckRest = t.lateIssue = t.lateWait = t.lateRest = 0;
+        t.iters = t.pad = 0;
+        for (int k = 0; k < 6; ++k) t.hist[k] = 0;
+        if (mc) {  // (wave-uniform values: any lane that marched holds them; lanes that did not hold zeros)
+            t.ckIssue = mc->ckIssue; t.ckWait = mc->ckWait; t.ckRest = mc->ckRest; t.iters = mc->iters;
+            t.lateIssue = mc->lateIssue; t.lateWait = mc->lateWait; t.lateRest = mc->lateRest;
+            for (int k = 0; k < 6; ++k) t.hist[k] = mc->hist[k];
+        }
+#endif
         g_rayTrace[slot] = t;
     }
 }
@@ -328,7 +342,19 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
             md.hitMask[pix] = 0;
         }
         add_ray_stats(a.stats, c.samples, c.hit ? 1u : 0u, c.samples, 0u, lane);
+#ifdef EMF_MARCH_STAMP
+        {   // the stamps are the wave's, but only lanes that entered the march hold them: take the maximum over lanes
+            MarchCount cs = c;
+            auto wmax64 = [](unsigned long long v) { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w > v ? w : v; } return v; };
+            auto wmax32 = [](unsigned v) { for (int o = 32; o > 0; o >>= 1) { const unsigned w = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), o)); v = w > v ? w : v; } return v; };
+            cs.ckIssue = wmax64(c.ckIssue); cs.ckWait = wmax64(c.ckWait); cs.ckRest = wmax64(c.ckRest); cs.iters = wmax32(c.iters);
+            cs.lateIssue = wmax64(c.lateIssue); cs.lateWait = wmax64(c.lateWait); cs.lateRest = wmax64(c.lateRest);
+            for (int k = 0; k < 6; ++k) cs.hist[k] = wmax32(c.hist[k]);
+            trace_wave(trace_t0, c.samples, m, tile, wave, lane, &cs);
+        }
+#else
         trace_wave(trace_t0, c.samples, m, tile, wave, lane);
+#endif
         return;
     } else {
         r.hit = false;

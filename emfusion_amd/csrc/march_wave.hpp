@@ -128,7 +128,23 @@ __device__ __forceinline__ float trilinear_weights_g(const RayVolume& v, const C
 struct MarchCount {
     bool hit;
     unsigned samples;  // main-loop samples taken (byte-model statistic)
+#ifdef EMF_MARCH_STAMP
+    // attribution build only (scripts/raycast_attribution.py): shader clocks of the wave's loop iterations, split
+    // at the moment the four corner gathers have been issued and at the moment they have all returned
+    // (s_memtime; wave-uniform).  hist: iterations by the length of that wait.
+    unsigned long long ckIssue, ckWait, ckRest;
+    unsigned iters, hist[6];
+    unsigned long long lateIssue, lateWait, lateRest;  // the same sums over iterations 256.. only (the emptying chip)
+#endif
 };
+#ifdef EMF_MARCH_STAMP
+__device__ __forceinline__ unsigned long long march_clock() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return c;
+}
+#endif
 
 struct RayState {
     V3 dir;
@@ -262,6 +278,11 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
     float tmax = r.maxRay;
     float t = r.raylength, step = r.raystep, tsdf = r.tsdf;
     unsigned samples = 0;
+#ifdef EMF_MARCH_STAMP
+    unsigned long long ckIssue = 0, ckWait = 0, ckRest = 0, ckTop = march_clock();
+    unsigned long long lateIssue = 0, lateWait = 0, lateRest = 0;
+    unsigned iters = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+#endif
     for (;;) {
         t += step;
         if (!(t <= tmax)) break;
@@ -285,6 +306,20 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
                                        mad24(static_cast<unsigned>(ly), sy, static_cast<unsigned>(lx) << 2));
             const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off),
                          e = gload2(row11, off);
+#ifdef EMF_MARCH_STAMP
+            const unsigned long long ckSent = march_clock();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long ckBack = march_clock();
+            {
+                const unsigned wait = static_cast<unsigned>(ckBack - ckSent);
+                ckIssue += ckSent - ckTop;
+                ckWait += wait;
+                if (iters >= 256u) { lateIssue += ckSent - ckTop; lateWait += wait; }
+                h0 += wait < 200u; h1 += wait >= 200u && wait < 400u; h2 += wait >= 400u && wait < 700u;
+                h3 += wait >= 700u && wait < 1200u; h4 += wait >= 1200u && wait < 2500u; h5 += wait >= 2500u;
+                ++iters;
+            }
+#endif
             const float next = blend8(a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, fx, fy, fz);
             bool advance = true;  // reference: `tsdf = next_tsdf` at the end of the iteration
             if ((__float_as_int(tsdf) ^ __float_as_int(next)) < 0) {
@@ -317,9 +352,22 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
             if (fabsf(next) < 1.f) step = vs;  // (harmless for a lane that is done)
             if (fabsf(next) < .8f) step = hvs;
             if (advance) tsdf = next;
+#ifdef EMF_MARCH_STAMP
+            {
+                const unsigned long long ckEnd = march_clock();
+                ckRest += ckEnd - ckBack;
+                if (iters > 256u) lateRest += ckEnd - ckBack;
+                ckTop = ckEnd;
+            }
+#endif
         }
     }
     out.samples = samples;
+#ifdef EMF_MARCH_STAMP
+    out.ckIssue = ckIssue; out.ckWait = ckWait; out.ckRest = ckRest; out.iters = iters;
+    out.lateIssue = lateIssue; out.lateWait = lateWait; out.lateRest = lateRest;
+    out.hist[0] = h0; out.hist[1] = h1; out.hist[2] = h2; out.hist[3] = h3; out.hist[4] = h4; out.hist[5] = h5;
+#endif
 }
 
 #ifndef EMF_MARCH_LANE
@@ -336,6 +384,11 @@ __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid,
     MarchCount out;
     out.hit = false;
     out.samples = 0;
+#ifdef EMF_MARCH_STAMP
+    out.ckIssue = out.ckWait = out.ckRest = out.lateIssue = out.lateWait = out.lateRest = 0;
+    out.iters = 0;
+    for (int k = 0; k < 6; ++k) out.hist[k] = 0;
+#endif
     const V3 half = half_extent(v.n);
     const V3 nf = v3(static_cast<float>(v.n.x), static_cast<float>(v.n.y), static_cast<float>(v.n.z));
     RayState r;
