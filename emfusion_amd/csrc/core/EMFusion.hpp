@@ -351,6 +351,7 @@ private:
     bool useLambdaTable = true;
     DeviceBuffer integrateCullScratch;  // survivor list of emf_hip_integrateBatchedCulled (empty: plain launch)
     bool cullBoxes = true;               // EMF_INT_CULL=0 keeps the one-level launch (A/B measurements)
+    bool objCull = false;                // EMF_OBJ_CULL=1: two-level launch for the objects alone too (A/B)
     bool ignorePerson = false;
     int depthRoot = -1;  // sharded path: rank whose depth image is broadcast each frame (-1: none)
     bool bgBands = true;  // sharded path: split the background raycast into row bands per rank
