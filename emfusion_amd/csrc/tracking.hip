@@ -42,7 +42,9 @@ namespace emf_hip {
 namespace {
 
 #ifndef EMF_TRACK_BLOCK
-#define EMF_TRACK_BLOCK 1024  // 256: 1.64 ms per stage, 512: 1.51, 1024: 1.45 (fewer, fatter workgroups; 300 partial rows)
+#define EMF_TRACK_BLOCK 1024  // pixels per workgroup = per row of partial sums.  Round 4, resident grid, stage of the tracked bench
+                              // (scripts/ab_track_block.sh): 512: 1.34 ms, 640: 1.04, 768: 1.03, 1024: 0.96 -- fewer, fatter workgroups win:
+                              // every workgroup pays the prologue, and its cost grows with the number of rows
 #endif
 constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // pixels per workgroup
 constexpr int kCols = 30;          // partial-sum columns per workgroup: 21 (upper triangle of A) + 6 (b) + 1
@@ -485,13 +487,10 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #endif
     STAMP(0);
     const emf_track_state_t* in = state_buf(f, m, f.launch & 1);
-    // this wave's two columns of the previous launch's partial sums (c1: a sum, the maximum, or none)
-    static_assert(2 * kWaves >= kCols, "k_track_step: two columns of partial sums per wave");
-    const int c0 = wave, c1 = wave + kWaves;
-    const bool sum0 = c0 < kCols - 1, sum1 = c1 < kCols - 1, max1 = c1 == kCols - 1;
+    // this wave's columns of the previous launch's partial sums: wave, wave + kWaves, ... (a sum each; the last
+    // column is the maximum)
+    constexpr int kColsPerWave = (kCols + kWaves - 1) / kWaves;
     const float* const prev = scratch_partials(f, m, (f.launch + 1) & 1);
-    const float* const col0 = prev + static_cast<size_t>(sum0 ? c0 : 0) * f.nblocks;
-    const float* const col1 = prev + static_cast<size_t>(sum1 || max1 ? c1 : 0) * f.nblocks;
     // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
         if (blockIdx.x == 0) {
@@ -516,33 +515,42 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
         // The rows of a lane are loaded in batches of 8 before any of them is added: a plain
         // `acc += p[i]` loop is not pipelined by the compiler (the double add is a dependency chain)
         // and exposes one memory latency per element.  The maximum column likewise.
-        double a0 = 0.0, a1 = 0.0;
+        double acc[kColsPerWave];
         float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < kColsPerWave; ++q) acc[q] = 0.0;
         for (int i0 = lane; i0 < f.nblocks; i0 += 64 * 8) {
-            float v0[8], v1[8];
+            float v[kColsPerWave][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + 64 * j;
-                v0[j] = i < f.nblocks ? col0[i] : 0.f;
-                v1[j] = i < f.nblocks ? col1[i] : 0.f;
+            for (int q = 0; q < kColsPerWave; ++q) {
+                const int c = wave + q * kWaves;
+                const float* const col = prev + static_cast<size_t>(c < kCols ? c : 0) * f.nblocks;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = i0 + 64 * j;
+                    v[q][j] = i < f.nblocks ? col[i] : 0.f;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                a0 += static_cast<double>(v0[j]);
-                a1 += static_cast<double>(v1[j]);
-                mx = fmaxf(mx, v1[j]);
-            }
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int q = 0; q < kColsPerWave; ++q) {
+                    acc[q] += static_cast<double>(v[q][j]);
+                    if (wave + q * kWaves == kCols - 1) mx = fmaxf(mx, v[q][j]);
+                }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            a0 += __shfl_xor(a0, o);
-            a1 += __shfl_xor(a1, o);
-        }
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int q = 0; q < kColsPerWave; ++q) acc[q] += __shfl_xor(acc[q], o);
         mx = wave_max(mx);
         if (lane == 0) {
-            if (sum0) sums[c0] = a0;
-            if (sum1) sums[c1] = a1;
-            if (max1) sums[c1] = static_cast<double>(mx);
+#pragma unroll
+            for (int q = 0; q < kColsPerWave; ++q) {
+                const int c = wave + q * kWaves;
+                if (c < kCols - 1) sums[c] = acc[q];
+                else if (c == kCols - 1) sums[c] = static_cast<double>(mx);
+            }
         }
     }
     // the last wave has the fewest columns: two of its lanes take the poses' |log| off the solver's path
