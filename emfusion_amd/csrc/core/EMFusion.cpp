@@ -577,17 +577,24 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
             computeFarBounds(co);
         }
         computeAssociationWeights();
+        if (saveOutput) storeAssocs(bg_assocWeight_preTrack, obj_assocWeights_preTrack);  // EMFusion.cpp:80-83
         if (in.trackCamera) trackCamera();  // EMFusion.cpp:673-685
         else pose = in.cam_pose;            // ... or its result, supplied
+        if (saveOutput && in.trackCamera) storeTrackWeights(0, 1);
         computeAssociationWeights();
         if (in.trackObjects) trackObjects();  // EMFusion.cpp:689-723
         else applyObjectPoses();
+        if (saveOutput && in.trackObjects) storeTrackWeights(1, static_cast<int>(objects.size()));
         if (!posesKnown) {
             std::vector<emf_pose_t> co;
             posesCO(co);
             computeFarBounds(co);
         }
         computeAssociationWeights();
+        if (saveOutput) {
+            storeAssocs(bg_assocWeight_postTrack, obj_assocWeights_postTrack);  // EMFusion.cpp:88-91
+            storeFgProbs();  // what obj.getFgProbVals returns at the frame's end (EMFusion.cpp:120): this E-step's look-ups
+        }
         stamp(kEstep);
         integrateBackgroundAsync();  // runs beside the raycast (see there)
         joinFarBounds();
@@ -779,6 +786,21 @@ void EMFusion::writeResults(const std::string& dir, bool volumes) {
     for (auto& obj : objects)
         if (!(ignorePerson && isPerson(obj))) meshes[obj.getID()] = obj.getMesh();
     for (const auto& m : meshes) io::writeMesh(dir + "/mesh_" + std::to_string(m.first) + ".ply", m.second);
+    // writeRenderings / writeAssocs / writeHuberWeights / writeTrackWeights / writeFgProbs (EMFusion.cpp:1009-1145):
+    // directories are created whether or not the log holds anything, like the reference's
+    io::writeImageLog(dir + "/output", renderings);
+    io::writeImageLog(dir + "/assoc_weights/bg/preTrack", bg_assocWeight_preTrack);
+    io::writeImageLog(dir + "/assoc_weights/bg/postTrack", bg_assocWeight_postTrack);
+    for (const auto& o : obj_assocWeights_preTrack)
+        io::writeImageLog(dir + "/assoc_weights/" + std::to_string(o.first) + "/preTrack", o.second);
+    for (const auto& o : obj_assocWeights_postTrack)
+        io::writeImageLog(dir + "/assoc_weights/" + std::to_string(o.first) + "/postTrack", o.second);
+    io::writeImageLog(dir + "/huber_weights/bg", bg_huberWeights);
+    for (const auto& o : obj_huberWeights) io::writeImageLog(dir + "/huber_weights/" + std::to_string(o.first), o.second);
+    io::writeImageLog(dir + "/track_weights/bg", bg_trackWeights);
+    for (const auto& o : obj_trackWeights) io::writeImageLog(dir + "/track_weights/" + std::to_string(o.first), o.second);
+    io::createDirectories(dir + "/fg_probs");
+    for (const auto& o : obj_fgProbs) io::writeImageLog(dir + "/fg_probs/" + std::to_string(o.first), o.second);
     if (!(volumes || expVols)) return;  // `if ( expVols ) writeTSDFs ( p )` (EMFusion.cpp:290-291)
     const std::string t = dir + "/tsdfs";
     if (mkdir(t.c_str(), 0777) != 0 && errno != EEXIST)
@@ -1218,6 +1240,86 @@ void EMFusion::render(uint8_t* rgb) {
     emfCheck(emf_hip_renderPhong(&vv, &nv, &sv, colorMap.data(), light, &iv, main.abi()), "renderPhong");
     hipCheck(hipMemcpyAsync(rgb, image.ptr(), bytes, hipMemcpyDeviceToHost, main.get()), "render D2H");
     main.waitForCompletion();
+    if (saveOutput)  // `rendered.copyTo ( renderings[frameCount-1] )`, EMFusion.cpp:158-160
+        renderings[frameCount - 1] = io::encodePng(rgb, params.frameSize.width, params.frameSize.height, 3);
+}
+
+// ---- per-frame debug images (reference saveOutput mode) ---------------------------------------------------
+
+std::vector<uint8_t> EMFusion::pngOf(const float* dev, size_t pitchBytes) {
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    std::vector<float> host(static_cast<size_t>(w) * h);
+    hipCheck(hipMemcpy2DAsync(host.data(), static_cast<size_t>(w) * sizeof(float), dev, pitchBytes,
+                              static_cast<size_t>(w) * sizeof(float), static_cast<size_t>(h), hipMemcpyDeviceToHost,
+                              main.get()),
+             "hipMemcpy2DAsync(debug image)");
+    main.waitForCompletion();
+    const std::vector<uint8_t> u8 = io::toU8Times255(host.data(), w, h, static_cast<size_t>(w));
+    return io::encodePng(u8.data(), w, h, 1);
+}
+
+void EMFusion::storeAssocs(ImageLog& bg, std::map<int, ImageLog>& objs) {
+    if (sharded) return;  // (remote objects' maps are not on this rank; the reference is single-GPU)
+    const emf_image_t b = bg_associationWeights.view();
+    bg[frameCount] = pngOf(static_cast<const float*>(b.data), b.pitch);
+    for (const auto& obj : objects) {
+        const emf_image_t a = objImages.at(obj.getID()).associationWeights.view();
+        objs[obj.getID()][frameCount] = pngOf(static_cast<const float*>(a.data), a.pitch);
+    }
+}
+
+void EMFusion::storeTrackWeights(int first, int count) {
+    if (count <= 0 || trackStates.empty()) return;
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    const size_t px = static_cast<size_t>(w) * h, per = emf_hip_trackScratchBytes(w, h);
+    if (logScratch.empty()) logScratch = DeviceBuffer(2 * px * sizeof(float) * EMF_MAX_BATCH);
+    emf_track_params_t tp;
+    tp.huberThresh = params.tsdfParams.huberThresh;
+    tp.maxWeight = params.tsdfParams.maxTSDFWeight;
+    tp.tau = params.tsdfParams.tau;
+    tp.eps1 = params.tsdfParams.eps1;
+    tp.eps2 = params.tsdfParams.eps2;
+    tp.nuInit = params.tsdfParams.nu_init;
+    const emf_image_t pv = points.view();
+    float* huber = logScratch.as<float>();
+    float* track = huber + px * EMF_MAX_BATCH;
+    // the stage's states are final and the models' association maps are still the ones it tracked with
+    emfCheck(emf_hip_trackWeightImages(currentTable() + first, trackStates.as<emf_track_state_t>() + first, count, &pv, &tp,
+                                       static_cast<const char*>(trackScratch.data()) + per * first, per, huber, track,
+                                       main.abi()),
+             "trackWeightImages");
+    auto it = objects.begin();
+    for (int m = 0; m < count; ++m) {
+        const std::vector<uint8_t> hp = pngOf(huber + px * m, static_cast<size_t>(w) * sizeof(float));
+        const std::vector<uint8_t> tpng = pngOf(track + px * m, static_cast<size_t>(w) * sizeof(float));
+        if (first + m == 0) {
+            bg_huberWeights[frameCount] = hp;
+            bg_trackWeights[frameCount] = tpng;
+        } else {
+            const int id = (it++)->getID();
+            obj_huberWeights[id][frameCount] = hp;
+            obj_trackWeights[id][frameCount] = tpng;
+        }
+    }
+}
+
+void EMFusion::storeFgProbs() {
+    if (sharded || objects.empty()) return;
+    const int w = params.frameSize.width, h = params.frameSize.height;
+    const size_t px = static_cast<size_t>(w) * h;
+    if (logScratch.empty()) logScratch = DeviceBuffer(2 * px * sizeof(float) * EMF_MAX_BATCH);
+    const emf_image_t pv = points.view();
+    const emf_image_t out{logScratch.data(), static_cast<size_t>(w) * sizeof(float), w, h};
+    for (auto& obj : objects) {
+        // cuda::TSDF::getVolumeVals ( fgProbs, points, rel_pose_CO ... fgProbVals ), ObjTSDF.cpp:189-191
+        const Affine3f co = obj.getPose().inv() * pose;
+        const Vec3i res = obj.getVolumeRes();
+        const int32_t r[3] = {res[0], res[1], res[2]};
+        emfCheck(emf_hip_getVolumeVals(obj.fgProbsPtr(), 1, &pv, co.rotation().val, co.translation().val, r,
+                                       obj.getVoxelSize(), &out, main.abi()),
+                 "getVolumeVals(fgProbs)");
+        obj_fgProbs[obj.getID()][frameCount] = pngOf(logScratch.as<float>(), out.pitch);
+    }
 }
 
 Mesh EMFusion::getMesh(int id) {

@@ -161,10 +161,18 @@ public:
      * chooses whether the volumes are exported too.  With exp_vols the volumes of objects deleted
      * during the run are kept on the host like their mesh (EMFusion.cpp:966-973).  The per-frame
      * mesh export of exp_frame_meshes belongs to the viz path and is not kept.
+     * From here on every frame also keeps the reference's per-frame debug images (as PNG bytes, not as raw
+     * images): association weights before and after tracking (storeAssocs, EMFusion.cpp:79-91, 307-320), Huber
+     * and combined tracking weights of the stages that ran (EMFusion.cpp:110-118; TSDF.cpp:346-354), the
+     * objects' foreground-probability look-ups (ObjTSDF.cpp:237-240) and what render() produced
+     * (EMFusion.cpp:158-160); writeResults() writes them where writeRenderings / writeAssocs / writeHuberWeights
+     * / writeTrackWeights / writeFgProbs put them (EMFusion.cpp:1009-1145).  Each costs a device-to-host copy
+     * and a synchronisation per image: a debugging mode, as in the reference.  One-rank path only.
      */
     void setupOutput(bool expFrameMeshes, bool exp_vols) {
         (void)expFrameMeshes;
         poseLog = true;
+        saveOutput = true;
         expVols = exp_vols;
     }
     /**
@@ -368,6 +376,17 @@ private:
     DeviceImage<uint8_t, 3> image;  // rendering
     std::map<int, Mesh> meshes;                            // id -> last mesh (deleted objects keep theirs)
     bool expVols = false;                                  // setupOutput: keep / dump volumes too
+    // ---- per-frame debug images of the reference's saveOutput mode, kept as encoded PNGs ----
+    bool saveOutput = false;
+    using ImageLog = std::map<int, std::vector<uint8_t>>;  // frame -> PNG bytes
+    ImageLog renderings, bg_assocWeight_preTrack, bg_assocWeight_postTrack, bg_huberWeights, bg_trackWeights;
+    std::map<int, ImageLog> obj_assocWeights_preTrack, obj_assocWeights_postTrack, obj_huberWeights, obj_trackWeights,
+        obj_fgProbs;                                       // id -> frame -> PNG bytes
+    std::vector<uint8_t> pngOf(const float* dev, size_t pitchBytes);  // x 255 -> u8 -> PNG; synchronises `main`
+    void storeAssocs(ImageLog& bg, std::map<int, ImageLog>& objs);    // EMFusion.cpp:307-320
+    void storeTrackWeights(int first, int count);                     // behind a tracking stage
+    void storeFgProbs();                                              // behind the frame's last E-step
+    DeviceBuffer logScratch;                                          // 2 x EMF_MAX_BATCH float images
     struct SavedVolumes {                                  // tsdfs / intWeights / fgProbs / meta of the reference
         std::vector<float> tsdf, weights, fgProbs;
         Vec3i res;

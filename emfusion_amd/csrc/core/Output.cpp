@@ -7,6 +7,10 @@
 #include <fstream>
 #include <stdexcept>
 
+#include <sys/stat.h>
+#include <cerrno>
+#include <zlib.h>
+
 namespace emf {
 namespace io {
 
@@ -141,6 +145,87 @@ void writeMesh(const std::string& filename, const Mesh& mesh) {
         std::fprintf(file, "%d %d %d %d\n", t[0], t[1], t[2], t[3]);
     }
     if (std::fclose(file) != 0) throw std::runtime_error("emf::io::writeMesh: error writing " + filename);
+}
+
+std::vector<uint8_t> toU8Times255(const float* src, int width, int height, size_t pitchFloats) {
+    std::vector<uint8_t> out(static_cast<size_t>(width) * height);
+    for (int y = 0; y < height; ++y) {
+        const float* row = src + static_cast<size_t>(y) * pitchFloats;
+        uint8_t* o = out.data() + static_cast<size_t>(y) * width;
+        for (int x = 0; x < width; ++x) {
+            const float v = row[x] * 255.f;
+            // cvRound = lrint in the default rounding mode (ties to even); NaN and values beyond int saturate
+            int i = 0;
+            if (v >= 255.f) i = 255;
+            else if (v > 0.f) i = static_cast<int>(std::nearbyint(v));
+            o[x] = static_cast<uint8_t>(i < 0 ? 0 : (i > 255 ? 255 : i));
+        }
+    }
+    return out;
+}
+
+std::vector<uint8_t> encodePng(const uint8_t* pixels, int width, int height, int channels) {
+    if (width < 1 || height < 1 || (channels != 1 && channels != 3))
+        throw std::runtime_error("emf::io::encodePng: bad image shape");
+    const size_t stride = static_cast<size_t>(width) * channels;
+    std::vector<uint8_t> raw((stride + 1) * height);
+    for (int y = 0; y < height; ++y) {  // filter type 0 (None) in front of every scan line
+        raw[(stride + 1) * y] = 0;
+        std::copy(pixels + stride * y, pixels + stride * (y + 1), raw.begin() + (stride + 1) * y + 1);
+    }
+    uLongf zlen = compressBound(static_cast<uLong>(raw.size()));
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), static_cast<uLong>(raw.size()), 6) != Z_OK)
+        throw std::runtime_error("emf::io::encodePng: zlib failed");
+    z.resize(zlen);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    auto be32 = [&](uint32_t v) {
+        for (int k = 3; k >= 0; --k) out.push_back(static_cast<uint8_t>(v >> (8 * k)));
+    };
+    auto chunk = [&](const char kind[4], const uint8_t* body, size_t n) {
+        be32(static_cast<uint32_t>(n));
+        const size_t at = out.size();
+        out.insert(out.end(), kind, kind + 4);
+        out.insert(out.end(), body, body + n);
+        be32(static_cast<uint32_t>(crc32(0L, out.data() + at, static_cast<uInt>(4 + n))));
+    };
+    uint8_t ihdr[13];
+    for (int k = 0; k < 4; ++k) {
+        ihdr[k] = static_cast<uint8_t>(static_cast<uint32_t>(width) >> (8 * (3 - k)));
+        ihdr[4 + k] = static_cast<uint8_t>(static_cast<uint32_t>(height) >> (8 * (3 - k)));
+    }
+    ihdr[8] = 8;                       // bit depth
+    ihdr[9] = channels == 1 ? 0 : 2;   // colour type: grayscale / truecolour
+    ihdr[10] = ihdr[11] = ihdr[12] = 0;  // deflate, adaptive filtering, no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), z.size());
+    chunk("IEND", nullptr, 0);
+    return out;
+}
+
+void writeBytes(const std::string& filename, const std::vector<uint8_t>& bytes) {
+    std::ofstream f(filename, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(bytes.data()), static_cast<std::streamsize>(bytes.size()));
+    f.close();
+    if (!f.good()) throw std::runtime_error("emf::io::writeBytes: error writing " + filename);
+}
+
+void createDirectories(const std::string& dir) {
+    for (size_t k = 1; k <= dir.size(); ++k)
+        if (k == dir.size() || dir[k] == '/') {
+            const std::string part = dir.substr(0, k);
+            if (!part.empty() && mkdir(part.c_str(), 0777) != 0 && errno != EEXIST)
+                throw std::runtime_error("emf::io::createDirectories: cannot create " + part);
+        }
+}
+
+void writeImageLog(const std::string& dir, const std::map<int, std::vector<uint8_t>>& pngByFrame) {
+    createDirectories(dir);
+    for (const auto& e : pngByFrame) {
+        char name[32];
+        std::snprintf(name, sizeof(name), "/%04d.png", e.first);  // setfill('0') << setw(4) << id
+        writeBytes(dir + name, e.second);
+    }
 }
 
 }  // namespace io

@@ -47,5 +47,25 @@ std::array<uint8_t, 768> randomColors();
  */
 void writeMesh(const std::string& filename, const Mesh& mesh);
 
+/**
+ * cv::Mat::convertTo(CV_8U, 255) of a float image, the form in which the reference keeps its per-frame debug
+ * images (storeAssocs EMFusion.cpp:307-320; TSDF::getHuberWeights / getTrackingWeights TSDF.cpp:346-354;
+ * ObjTSDF::getFgProbVals ObjTSDF.cpp:237-240): saturate_cast<uchar>(v * 255) = round to nearest, ties to even,
+ * clamped to 0..255 (NaN -> 0).  `pitchFloats` = floats per source row.
+ */
+std::vector<uint8_t> toU8Times255(const float* src, int width, int height, size_t pitchFloats);
+
+/**
+ * An 8-bit PNG (channels = 1: grayscale, 3: RGB) as cv::imwrite would produce one for the reference's
+ * EMFusion::writeImage (EMFusion.cpp:1256-1261) -- same pixels; the compressed bytes are zlib's, not libpng's.
+ * encodePng returns the file's bytes (the per-frame log keeps those, not the raw images).
+ */
+std::vector<uint8_t> encodePng(const uint8_t* pixels, int width, int height, int channels);
+void writeBytes(const std::string& filename, const std::vector<uint8_t>& bytes);
+/** "<dir>/%04d.png" for every entry (EMFusion::writeImage's file names); creates <dir> and its parents. */
+void writeImageLog(const std::string& dir, const std::map<int, std::vector<uint8_t>>& pngByFrame);
+/** mkdir -p */
+void createDirectories(const std::string& dir);
+
 }  // namespace io
 }  // namespace emf

@@ -681,6 +681,33 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #undef STAMP
 }
 
+// The stage's Huber and combined weight images at its final pose (emf_hip_trackWeightImages): the body's
+// arithmetic for one pixel, nothing summed.
+__global__ __launch_bounds__(256) void k_track_weight_images(const TrackFrame f, float* huber, float* track) {
+    const int m = blockIdx.y;
+    const size_t px = static_cast<size_t>(f.w) * f.h;
+    const size_t pix = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (pix >= px) return;
+    const emf_track_state_t& st = f.states[m];
+    const emf_model_t& md = f.models[m];
+    const int y = static_cast<int>(pix / f.w), x = static_cast<int>(pix - static_cast<size_t>(y) * f.w);
+    const float* p = f.points.row(y) + 3 * x;
+    const float r = lookup1(md.tsdf, state_R(st.R), v3(st.t[0], st.t[1], st.t[2]), v3(p[0], p[1], p[2]),
+                            I3{md.res[0], md.res[1], md.res[2]}, md.voxelSize);
+    const float a = fabsf(r);
+    float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
+    tw = fminf(tw, 1.0f);
+    if (huber) huber[static_cast<size_t>(m) * px + pix] = tw;
+    if (track) {
+        const float mx = __uint_as_float(st.maxIwBits);
+        const float scale = static_cast<double>(mx) > 2.220446049250313e-16 ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f;
+        float w = scratch_iw(f, m, st.iwSel)[pix] * scale;
+        w = tw * w;
+        w = w * md.assoc[pix];
+        track[static_cast<size_t>(m) * px + pix] = w;
+    }
+}
+
 struct PrepareArgs {
     emf_track_state_t* states;
     emf_pose_t poses[EMF_MAX_BATCH];
@@ -856,6 +883,23 @@ int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_d
     f.seq = seq;
     enqueue_step(f, nmodels, launch, as_stream(stream));
     return launch_status("trackStep");
+}
+
+int emf_hip_trackWeightImages(const emf_model_t* models_dev, const emf_track_state_t* states_dev, int nmodels,
+                              const emf_image_t* points, const emf_track_params_t* params,
+                              const void* scratch_dev, size_t scratchBytesPerModel, float* huber_dev,
+                              float* track_dev, emf_stream_t stream) {
+    TrackFrame f;
+    EMF_TRY(fill_frame(f, models_dev, const_cast<emf_track_state_t*>(states_dev), nmodels, points, params,
+                       const_cast<void*>(scratch_dev), scratchBytesPerModel, "trackWeightImages"));
+    if (!huber_dev && !track_dev) return EMF_OK;
+    f.launch = f.iterations = 0;
+    f.watch = nullptr;
+    f.seq = 0;
+    const size_t px = static_cast<size_t>(f.w) * f.h;
+    hipLaunchKernelGGL(k_track_weight_images, dim3(static_cast<unsigned>(ceil_div(px, 256)), static_cast<unsigned>(nmodels)),
+                       dim3(256), 0, as_stream(stream), f, huber_dev, track_dev);
+    return launch_status("trackWeightImages");
 }
 
 int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const emf_image_t* points,

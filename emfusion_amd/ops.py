@@ -536,6 +536,17 @@ def track_step(models_dev, states_dev, nmodels, points, params, scratch, scratch
                                watch, seq, _stream(stream)))
 
 
+def track_weight_images(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model,
+                        huber=None, track=None, stream=None):
+    """Huber and combined tracking weights of a finished stage at its final pose (emf_hip_trackWeightImages);
+    huber / track: device arrays of nmodels x H x W floats or None."""
+    check("emf_hip_trackWeightImages",
+          _L.emf_hip_trackWeightImages(_ptr(models_dev), _ptr(states_dev), nmodels, C.byref(image_view(points)),
+                                       C.byref(params), _ptr(scratch), scratch_per_model,
+                                       _ptr(huber) if huber is not None else None,
+                                       _ptr(track) if track is not None else None, _stream(stream)))
+
+
 def read_track_states(states_dev, nmodels):
     """Synchronise and return the device LM states as a list of EmfTrackState."""
     raw = states_dev.numpy().tobytes()

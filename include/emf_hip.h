@@ -816,6 +816,18 @@ int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_d
                       void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
                       uint32_t* watch, uint32_t seq, emf_stream_t stream);
 
+/* The two weight images a stage leaves behind, as the reference's debug output reads them at the end of a frame
+ * (TSDF::getHuberWeights / getTrackingWeights, TSDF.cpp:346-354: `trackWeights` = min(huberThresh / |tsdf value|, 1)
+ * with x / 0 := 0, TSDF.cpp:222-231; `intWeights` = that x the clamped, NORM_INF-normalised integration weights x the
+ * association weights, TSDF.cpp:233-256) -- evaluated at the pose the stage ended with (states_dev[m].R / t), with the
+ * body's own arithmetic (k_track_step): the tracker itself never materialises the Huber image and keeps only the
+ * product.  Call it behind the stage's last launch and before anything overwrites the models' `assoc` maps.
+ * huber_dev / track_dev: nmodels dense width x height float images each (either may be NULL). */
+int emf_hip_trackWeightImages(const emf_model_t* models_dev, const emf_track_state_t* states_dev, int nmodels,
+                              const emf_image_t* points, const emf_track_params_t* params,
+                              const void* scratch_dev, size_t scratchBytesPerModel, float* huber_dev,
+                              float* track_dev, emf_stream_t stream);
+
 /* Level 1: replaces emf::cuda::TSDF::computePoseGradients (TSDF.cuh, TSDF.cu:603-660).
  * grads6: (W*H) x 6 f32, every row written (zeros where the reference leaves its setTo(0));
  * grads: N^3 x 3 gradient volume or NULL (forward differences blended on the fly, same values). */

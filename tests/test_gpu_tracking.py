@@ -319,3 +319,27 @@ def test_frame_without_valid_depth_converges_at_once(oracle, ops, dev, world):
         assert list(st.R) == [float(x) for x in np.asarray(R, np.float32).reshape(-1)]
         assert list(st.t) == [float(x) for x in np.asarray(t, np.float32)]
         assert list(st.b) == [0.0] * 6 and st.err == 0.0
+
+
+@pytest.mark.parametrize("k", [0, 1], ids=["background", "object"])
+def test_weight_images_of_a_finished_stage(oracle, ops, dev, world, k):
+    """emf_hip_trackWeightImages: what TSDF::getHuberWeights / getTrackingWeights download for the debug output
+    (reference TSDF.cpp:346-354; the images are made at TSDF.cpp:222-256) -- here evaluated at the pose the stage
+    ended with, against the oracle's per-pixel chain at that pose."""
+    dt = DeviceTracker(ops, world, [k])
+    st = dt.iterate(12)[0]
+    assert st.accepted >= 2
+    huber, track = dev_full((1, H, W), -1.0), dev_full((1, H, W), -1.0)
+    ops.track_weight_images(dt.table, dt.states, 1, dt.points, dt.params, dt.scratch, dt.per_model, huber, track)
+    v = world["vols"][k]
+    R, t = np.array(st.R, np.float32), np.array(st.t, np.float32)
+    vals = oracle.get_volume_vals(v["tsdf"], world["points"], R, t, v["vox"])
+    raw = oracle.get_volume_vals(v["wts"], world["points"], R, t, v["vox"])
+    tw, comb = oracle.tracking_weights(vals, raw, world["assoc"][k], 0.2, 64.0)
+    assert (tw.reshape(-1) > 0).sum() > 1000 and (comb.reshape(-1) > 0).sum() > 1000
+    assert_parity(to_np(huber)[0], tw.reshape(H, W), "Huber weights", exact=True)
+    assert_parity(to_np(track)[0], comb.reshape(H, W), "combined tracking weights", exact=True)
+    # either image alone
+    only = dev_full((1, H, W), -1.0)
+    ops.track_weight_images(dt.table, dt.states, 1, dt.points, dt.params, dt.scratch, dt.per_model, None, only)
+    assert np.array_equal(to_np(only), to_np(track))
