@@ -375,6 +375,12 @@ void EMFusion::adoptReciprocals() {
     for (auto& obj : objects) adopt(obj, slot++);
 }
 
+void EMFusion::settleReciprocals() {
+    background.settleReciprocal();
+    for (auto& obj : objects) obj.settleReciprocal();
+    adoptReciprocals();
+}
+
 void EMFusion::posesCO(std::vector<emf_pose_t>& out) const {
     out.clear();
     out.push_back(toPose(background.getPose().inv() * pose));  // reference TSDF.cpp:141,162

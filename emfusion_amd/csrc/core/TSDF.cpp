@@ -131,6 +131,10 @@ bool TSDF::pollReciprocal() {
     return rcpVoxel != 0.f;
 }
 
+void TSDF::settleReciprocal() {
+    if (pendingRcp && pendingRcp->done) (void)hipEventSynchronize(pendingRcp->done);
+}
+
 void TSDF::reset(const Affine3f& _pose) {
     Stream& s = Stream::Null();
     tsdfVol.setZero(s);

@@ -138,6 +138,8 @@ public:
     static void deferReciprocalChecks(bool on);
     /** True if the verdict arrived with this call (the owner refreshes its model table). */
     bool pollReciprocal();
+    /** Wait for a deferred check in flight (its 2.3 ms of device time end here); pollReciprocal() then adopts it. */
+    void settleReciprocal();
     float reciprocal() const { return rcpVoxel; }
 
 protected:

@@ -142,6 +142,7 @@ int emf_fusion_add_object(emf_fusion_t* h, const float center[3], float vol_size
     REQ(center);
     return guarded([&] {
         const int id = h->impl->addObject(Vec3f(center[0], center[1], center[2]), vol_size);
+        h->impl->settleReciprocals();  // an explicit call, outside any frame: the check ends here, not beside the first frames
         if (id_out) *id_out = id;
     });
 }
