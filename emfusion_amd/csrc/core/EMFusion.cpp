@@ -1278,7 +1278,7 @@ void EMFusion::storeTrackWeights(int first, int count) {
     if (count <= 0 || trackStates.empty()) return;
     const int w = params.frameSize.width, h = params.frameSize.height;
     const size_t px = static_cast<size_t>(w) * h, per = emf_hip_trackScratchBytes(w, h);
-    if (logScratch.empty()) logScratch = DeviceBuffer(2 * px * sizeof(float) * EMF_MAX_BATCH);
+    if (logScratch.bytes() < 2 * px * sizeof(float) * count) logScratch = DeviceBuffer(2 * px * sizeof(float) * count);
     emf_track_params_t tp;
     tp.huberThresh = params.tsdfParams.huberThresh;
     tp.maxWeight = params.tsdfParams.maxTSDFWeight;
@@ -1288,7 +1288,7 @@ void EMFusion::storeTrackWeights(int first, int count) {
     tp.nuInit = params.tsdfParams.nu_init;
     const emf_image_t pv = points.view();
     float* huber = logScratch.as<float>();
-    float* track = huber + px * EMF_MAX_BATCH;
+    float* track = huber + px * count;
     // the stage's states are final and the models' association maps are still the ones it tracked with
     emfCheck(emf_hip_trackWeightImages(currentTable() + first, trackStates.as<emf_track_state_t>() + first, count, &pv, &tp,
                                        static_cast<const char*>(trackScratch.data()) + per * first, per, huber, track,
@@ -1313,7 +1313,7 @@ void EMFusion::storeFgProbs() {
     if (sharded || objects.empty()) return;
     const int w = params.frameSize.width, h = params.frameSize.height;
     const size_t px = static_cast<size_t>(w) * h;
-    if (logScratch.empty()) logScratch = DeviceBuffer(2 * px * sizeof(float) * EMF_MAX_BATCH);
+    if (logScratch.bytes() < px * sizeof(float)) logScratch = DeviceBuffer(px * sizeof(float));
     const emf_image_t pv = points.view();
     const emf_image_t out{logScratch.data(), static_cast<size_t>(w) * sizeof(float), w, h};
     for (auto& obj : objects) {
