@@ -121,7 +121,6 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     hipCheck(hipHostMalloc(reinterpret_cast<void**>(&visibleHost),
                            sizeof(int32_t) * EMF_MAX_MODELS, hipHostMallocDefault),
              "hipHostMalloc");
-    hipCheck(hipEventCreateWithFlags(&visReady, hipEventDisableTiming), "hipEventCreate");
     stamps.resize(kNumStamps);
     for (auto& e : stamps) hipCheck(hipEventCreate(&e), "hipEventCreate");
     Stream& s = Stream::Null();
@@ -155,12 +154,10 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
 EMFusion::~EMFusion() {
     (void)hipDeviceSynchronize();
     for (auto& e : stamps) (void)hipEventDestroy(e);
-    if (visReady) (void)hipEventDestroy(visReady);
     if (visCountsHost) (void)hipHostFree(visCountsHost);
     if (visibleHost) (void)hipHostFree(visibleHost);
     if (trackStatesHost) (void)hipHostFree(trackStatesHost);
     if (trackWatch) (void)hipHostFree(trackWatch);
-    if (rayDone) (void)hipEventDestroy(rayDone);
     if (lifecycleHost) (void)hipHostFree(lifecycleHost);
 }
 
@@ -317,8 +314,8 @@ void EMFusion::rebuildModelTable() {
               static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
     farBounds = DeviceBuffer();
     if (batched && useFarBounds)
-        farBounds = DeviceBuffer(emf_hip_raycastFarBoundBytes(static_cast<int>(modelsHost.size()),
-                                                              params.frameSize.width, params.frameSize.height));
+        farBounds = DeviceBuffer(2 * emf_hip_raycastFarBoundBytes(static_cast<int>(modelsHost.size()),  // two halves, see computeFarBounds
+                                                                  params.frameSize.width, params.frameSize.height));
     if (batched && !integrateCullScratch.empty() && bgOverlap && bgCullScratch.empty()) {
         // the background gets its second copy the first time the two-level launch is usable
         background.enableDoubleBuffer();
@@ -452,11 +449,13 @@ uint64_t EMFusion::takeIntegratedVoxels() {
     return v;
 }
 
-// The batched path leaves the visibility counts in pinned memory behind an event instead of
+// The batched path leaves the visibility counts in pinned memory (stored by the kernel itself) instead of
 // stalling the frame; turn them into the host-side set when somebody asks.
 void EMFusion::refreshVisibleFromDevice() {
     if (!visPending) return;
-    hipCheck(hipEventSynchronize(visReady), "hipEventSynchronize");
+    // (round 4: no event behind the counts any more -- a record costs the critical stream ~8 us per frame whether
+    // or not anybody asks; whoever asks waits for the stream instead)
+    main.waitForCompletion();
     vis_objs.clear();
     for (size_t k = 0; k < visIds.size(); ++k)
         if (visibleHost[k] > params.visibilityThresh) vis_objs.insert(visIds[k]);
@@ -1441,17 +1440,12 @@ void EMFusion::raycastBatched() {
         // the bands are then gathered (1.5 MB at VGA).  Background vertices / normals stay
         // band-local: like the remote objects' they only feed rendering.
         const int band = sharded && bgBands ? bgBandRows(h, world) : 0;
-        const float* far = farBoundsReady && !flags ? farBounds.as<float>() : nullptr;
+        const float* far = farBoundsReady && !flags ? farBoundsHalf() : nullptr;
         farBoundsReady = false;
         emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
                                         flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
                                         band, far, useFootprints ? voxelHost.data() : nullptr, stats, main.abi()),
                  "raycastBatched");
-        if (far) {  // what the next frame's far bounds wait for before they overwrite the buffer
-            if (!rayDone) hipCheck(hipEventCreateWithFlags(&rayDone, hipEventDisableTiming), "hipEventCreate");
-            hipCheck(hipEventRecord(rayDone, main.get()), "hipEventRecord");
-            rayDoneValid = true;
-        }
         bandRowsPending = band;  // gathered together with the nearest-hit keys: one exchange (compositeAcrossRanks)
     }
     stamp(kRaycast);
@@ -1469,13 +1463,19 @@ void EMFusion::computeFarBounds(const std::vector<emf_pose_t>& co) {
     // background's list rebuilt on `lists` itself: the bounds need nothing of `main` but the previous raycast
     // to be through with the buffer -- they run beside the composite and the objects' integration instead of
     // beside the E-steps.
-    if (earlyFarBounds && scanMask == 0 && rayDoneValid && overlapUsable() && !bgBackStale)
-        hipCheck(hipStreamWaitEvent(lists.get(), rayDone, 0), "hipStreamWaitEvent");
+    // Round 4: the bounds alternate between two halves of the buffer, so the raycast of the PREVIOUS frame may
+    // still be reading its half while these are written; the last reader of this half is the raycast of two frames
+    // ago, and `main`'s event was re-recorded behind that one when the previous frame forked the background's
+    // integration (integrateBackgroundAsync: behind its last E-step).  No event of its own behind every raycast
+    // any more (a record costs the critical stream ~8 us per frame).
+    farSel ^= 1;
+    if (earlyFarBounds && scanMask == 0 && forkFrame == frameCount - 1 && overlapUsable() && !bgBackStale)
+        lists.waitOn(main);
     else
         lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
     emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
                                       params.frameSize.width, params.frameSize.height, params.intr.val, scanMask,
-                                      farBounds.as<float>(), lists.abi()),
+                                      farBoundsHalf(), lists.abi()),
              "raycastFarBounds");
     farBoundsReady = true;
 }
@@ -1539,6 +1539,7 @@ void EMFusion::integrateBackgroundAsync() {
     bgPrepared = true;
     bgInFlight = true;
     bgListPending = true;
+    forkFrame = frameCount;
 }
 
 // Join: the frame's later stages (and the next frame) see the integrated background.
@@ -1599,7 +1600,7 @@ void EMFusion::integrateBatched() {
 
 // Compositing in list (creation) order + visibility counts (reference EMFusion.cpp:760-794).
 // deviceGate: turn the counts into the integrate gate on the device and mirror them to pinned
-// memory behind an event; otherwise wait for them here (the reference's behaviour).
+// memory; otherwise wait for them here (the reference's behaviour).
 void EMFusion::compositeAndVisibility(bool deviceGate) {
     if (sharded) {
         compositeAcrossRanks(deviceGate);
@@ -1654,7 +1655,6 @@ void EMFusion::compositeAndVisibility(bool deviceGate) {
     visPending = false;
     if (nobj == 0) return;
     if (deviceGate) {
-        hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
         visIds = ids;
         visPending = true;
         return;
@@ -1769,7 +1769,6 @@ void EMFusion::compositeAcrossRanks(bool deviceGate) {
                  "visCounts D2H");
     }
     if (deviceGate) {
-        hipCheck(hipEventRecord(visReady, main.get()), "hipEventRecord");
         visIds = allIds;
         visPending = true;
         return;

@@ -448,11 +448,12 @@ private:
     // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
     bool useFootprints = true;  // objects are marched only where their volume box projects to
     bool useFarBounds = true;
-    DeviceBuffer farBounds;
+    DeviceBuffer farBounds;       // two halves, written alternately (computeFarBounds)
+    int farSel = 0;
+    float* farBoundsHalf() const { return farBounds.as<float>() + static_cast<size_t>(farSel) * (farBounds.bytes() / 2 / sizeof(float)); }
+    int forkFrame = -2;           // frame whose integrateBackgroundAsync forked `aux` (and re-recorded `main`'s event)
     bool farBoundsReady = false;
     bool earlyFarBounds = true;    // far bounds wait for the previous raycast only (EMF_EARLY_FAR_BOUNDS=0: for `main`)
-    hipEvent_t rayDone = nullptr;  // behind the last raycast that read farBounds
-    bool rayDoneValid = false;
     bool peerFused = false;     // sharded over a direct peer-write transport: exchanges fused into the path's kernels
     int bandRowsPending = 0;    // background raycast bands waiting for the raycast's exchange
     Stream lists{streamPriority("EMF_PRIO_LISTS", -1)};  // relevant-tile list rebuilds: behind the integrations, waited for by the next far bounds
@@ -472,7 +473,6 @@ private:
     DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device
     DeviceBuffer integrateStatsDev; // u64: voxels swept by integrateBatched
     int32_t* visibleHost = nullptr; // pinned mirror of visCounts for visibleObjects()
-    hipEvent_t visReady = nullptr;
     bool visPending = false;
     std::vector<int32_t> visIds;    // object ids in the order of the pending counts
 
