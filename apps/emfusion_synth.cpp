@@ -6,6 +6,9 @@
 //                  [--materialize-gradients] [--autonomous] [--out DIR]
 //   emfusion_synth --sequence DIR/ [--masks DIR] [--mask-frames N] [--visibility-thresh N] [--frames N]
 //                  [--bg-res R] [--bg-voxel M] [--obj-res R] [--volumes] --out DIR
+//   emfusion_synth --dir BASE/ [--colordir colour] [--depthdir depth] [--intrinsics fx fy cx cy] ... --out DIR
+// --dir: the same loop on a Co-Fusion style dataset (ColorNNNN.png + DepthNNNN.exr), the reference's ImageReader
+// (apps/EM-Fusion.cpp:118-126; core/Readers.hpp ImageReader + readExr).
 // --sequence: the reference's loop itself (apps/EM-Fusion.cpp:100-156) on a TUM RGB-D sequence: TUMRGBDReader
 // (core/Readers.hpp) -> emf.usePreprocMasks(masks) -> processFrame(frame) with camera and object tracking from the
 // second frame on -> writeResults.  What apps/run_tum.py does from Python, without Python.
@@ -21,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,17 +33,38 @@
 #include "Readers.hpp"
 #include "SyntheticScene.hpp"
 
-// The reference's main loop on a TUM sequence (apps/EM-Fusion.cpp:100-156)
-static int runSequence(const std::string& seq, const std::string& masks, const std::string& outDir, int frames, int bgRes,
+// The reference's main loop on a dataset (apps/EM-Fusion.cpp:100-156): a TUM sequence (`--sequence`, TUMRGBDReader) or a
+// Co-Fusion style directory (`--dir`, ImageReader: ColorNNNN.png + DepthNNNN.exr), as apps/EM-Fusion.cpp:118-131 chooses
+static int runSequence(const std::string& seq, bool cofusion, const std::string& colordir, const std::string& depthdir,
+                       const float* intrinsics, const std::string& masks, const std::string& outDir, int frames, int bgRes,
                        float bgVoxel, int objRes, int maskFrames, int visibilityThresh, bool volumes) {
-    emf::TUMRGBDReader reader(seq);  // "<dir>/associations.txt"
-    if (reader.getNumFrames() == 0) throw std::runtime_error("no frames in " + seq + "associations.txt");
-    const size_t n = frames > 0 ? std::min<size_t>(frames, reader.getNumFrames()) : reader.getNumFrames();
+    std::unique_ptr<emf::TUMRGBDReader> tum;
+    std::unique_ptr<emf::ImageReader> dir;
+    size_t available = 0;
+    if (cofusion) {
+        dir.reset(new emf::ImageReader(seq, colordir, depthdir));  // "<base><colordir>", "<base><depthdir>"
+        available = dir->getNumFrames();
+    } else {
+        tum.reset(new emf::TUMRGBDReader(seq));  // "<dir>/associations.txt"
+        available = tum->getNumFrames();
+    }
+    if (available == 0) throw std::runtime_error("no frames in " + seq);
+    const size_t n = frames > 0 ? std::min<size_t>(frames, available) : available;
     std::vector<float> depth;
-    const emf::Size size = reader.readDepth(0, depth);
+    auto readDepth = [&](size_t f) {
+        return cofusion ? dir->readDepth(dir->firstIndex() + static_cast<int>(f), depth) : tum->readDepth(f, depth);
+    };
+    const emf::Size size = readDepth(0);
     emf::Params params;  // reference defaults (config/default.cfg)
     params.frameSize = size;
     params.setDefaultIntrinsics();
+    if (intrinsics) {  // the reference takes them from its config file (data.h: intr)
+        params.intr = emf::Matx33f::eye();
+        params.intr(0, 0) = intrinsics[0];
+        params.intr(1, 1) = intrinsics[1];
+        params.intr(0, 2) = intrinsics[2];
+        params.intr(1, 2) = intrinsics[3];
+    }
     params.globalVolumeDims = emf::Vec3i::all(bgRes);
     params.globalVoxelSize = bgVoxel;
     params.volumePose = emf::Affine3f(emf::Matx33f::eye(), emf::Vec3f(0.f, 0.f, bgRes * bgVoxel / 2.f));
@@ -53,7 +78,7 @@ static int runSequence(const std::string& seq, const std::string& masks, const s
     emf.setupOutput(false, volumes);                  // apps/EM-Fusion.cpp:112
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t f = 0; f < n; ++f) {                  // while (reader->moreFrames())
-        reader.readDepth(f, depth);                   // frame = reader->getNextFrame()
+        readDepth(f);                                 // frame = reader->getNextFrame()
         for (float& d : depth)
             if (!std::isfinite(d)) d = 0.f;
         emf::FrameInputs in;                          // frame 0 defines the world frame; then everything is tracked
@@ -73,15 +98,18 @@ static int runSequence(const std::string& seq, const std::string& masks, const s
     }
     emf.synchronize();
     emf.writeResults(outDir, volumes);                // apps/EM-Fusion.cpp:204
-    std::printf("%zu frames of %s (%.1f Hz) in %.1f s incl. PNG decoding on the host; results in %s\n", n, seq.c_str(),
-                reader.getFrameRate(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), outDir.c_str());
+    std::printf("%zu frames of %s (%.1f Hz) in %.1f s incl. image decoding on the host; results in %s\n", n, seq.c_str(),
+                cofusion ? 30.0 : tum->getFrameRate(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                outDir.c_str());
     return 0;
 }
 
 int main(int argc, char** argv) {
     int frames = 120, objects = 4, bgRes = 512, objRes = 128, width = 640, height = 480;
     bool materialize = false, autonomous = false;
-    std::string outDir, sequence, maskDir;
+    std::string outDir, sequence, maskDir, dataDir, colordir = "colour", depthdir = "depth";
+    float intrinsics[4] = {0.f, 0.f, 0.f, 0.f};
+    bool haveIntrinsics = false;
     int maskFrames = 30, visThresh = 0, framesGiven = 0;
     float bgVoxel = 0.f;
     bool volumes = false;
@@ -91,6 +119,13 @@ int main(int argc, char** argv) {
         if (a == "--frames") frames = framesGiven = next();
         else if (a == "--sequence" && i + 1 < argc) sequence = argv[++i];
         else if (a == "--masks" && i + 1 < argc) maskDir = argv[++i];
+        else if (a == "--dir" && i + 1 < argc) dataDir = argv[++i];
+        else if (a == "--colordir" && i + 1 < argc) colordir = argv[++i];
+        else if (a == "--depthdir" && i + 1 < argc) depthdir = argv[++i];
+        else if (a == "--intrinsics" && i + 4 < argc) {
+            for (int k = 0; k < 4; ++k) intrinsics[k] = static_cast<float>(std::atof(argv[++i]));
+            haveIntrinsics = true;
+        }
         else if (a == "--mask-frames") maskFrames = next();
         else if (a == "--visibility-thresh") visThresh = next();
         else if (a == "--bg-voxel" && i + 1 < argc) bgVoxel = static_cast<float>(std::atof(argv[++i]));
@@ -109,9 +144,11 @@ int main(int argc, char** argv) {
         }
     }
     try {
-        if (!sequence.empty()) {
-            if (outDir.empty()) throw std::runtime_error("--sequence needs --out DIR");
-            return runSequence(sequence, maskDir, outDir, framesGiven, bgRes, bgVoxel > 0 ? bgVoxel : 5.12f / static_cast<float>(bgRes),
+        if (!sequence.empty() || !dataDir.empty()) {
+            if (outDir.empty()) throw std::runtime_error("--sequence / --dir need --out DIR");
+            const bool cofusion = !dataDir.empty();
+            return runSequence(cofusion ? dataDir : sequence, cofusion, colordir, depthdir, haveIntrinsics ? intrinsics : nullptr,
+                               maskDir, outDir, framesGiven, bgRes, bgVoxel > 0 ? bgVoxel : 5.12f / static_cast<float>(bgRes),
                                objRes, maskFrames, visThresh, volumes);
         }
         emf::Params params;  // reference defaults (config/default.cfg)

@@ -3,7 +3,11 @@
 // as the files of the reference's preprocessing need it.
 #include "Readers.hpp"
 
+#include <dirent.h>
+#include <sys/stat.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -136,6 +140,221 @@ Size TUMRGBDReader::readDepth(size_t i, std::vector<float>& depth) const {
     const float s = 1.f / 5000.f;  // TUM depth scale (TUMRGBDReader.cpp: convertTo(CV_32FC1, 1 / 5000.))
     for (size_t k = 0; k < px.size(); ++k) depth[k] = static_cast<float>(px[k]) * s;
     return Size(w, h);
+}
+
+// ---- OpenEXR scan-line files (the depth images of the Co-Fusion datasets) --------------------------------------------
+namespace {
+
+float halfToFloat(uint16_t h) {
+    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {  // subnormal half: normalise
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400u));
+            bits = sign | static_cast<uint32_t>(127 - 15 - e) << 23 | (man & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | man << 13;  // inf / NaN
+    else bits = sign | (exp + 127 - 15) << 23 | man << 13;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+uint32_t le32(const unsigned char* p) { return uint32_t(p[0]) | uint32_t(p[1]) << 8 | uint32_t(p[2]) << 16 | uint32_t(p[3]) << 24; }
+uint64_t le64(const unsigned char* p) { return uint64_t(le32(p)) | uint64_t(le32(p + 4)) << 32; }
+
+// -n literal bytes / the next byte n + 1 times (OpenEXR's run-length code)
+std::string exrUnRle(const unsigned char* d, size_t n, size_t want, const std::string& path) {
+    std::string out;
+    out.reserve(want);
+    size_t i = 0;
+    while (i < n) {
+        const int c = static_cast<signed char>(d[i++]);
+        if (c < 0) {
+            const size_t k = static_cast<size_t>(-c);
+            if (i + k > n) throw std::runtime_error(path + ": truncated RLE block");
+            out.append(reinterpret_cast<const char*>(d + i), k);
+            i += k;
+        } else {
+            if (i >= n) throw std::runtime_error(path + ": truncated RLE block");
+            out.append(static_cast<size_t>(c) + 1, static_cast<char>(d[i++]));
+        }
+    }
+    if (out.size() != want) throw std::runtime_error(path + ": EXR RLE block decodes to the wrong size");
+    return out;
+}
+
+// undo the byte predictor and the even / odd split OpenEXR applies before RLE / ZIP
+std::string exrUnpredict(const std::string& t) {
+    std::string d(t);
+    for (size_t k = 1; k < d.size(); ++k)
+        d[k] = static_cast<char>(static_cast<unsigned char>(d[k - 1]) + static_cast<unsigned char>(d[k]) - 128);
+    std::string out(d.size(), '\0');
+    const size_t half = (d.size() + 1) / 2;
+    for (size_t k = 0; k < d.size(); ++k) out[k] = (k & 1) ? d[half + k / 2] : d[k / 2];
+    return out;
+}
+
+}  // namespace
+
+Size readExr(const std::string& path, std::vector<float>& pixels, const std::string& channelIn) {
+    const std::string raw = slurp(path);
+    const unsigned char* r = reinterpret_cast<const unsigned char*>(raw.data());
+    if (raw.size() < 8 || le32(r) != 0x01312f76u) throw std::runtime_error(path + " is not an OpenEXR file");
+    const uint32_t version = le32(r + 4);
+    if ((version & 0xffu) != 2 || (version & 0x1a00u))  // tiled, deep, multi-part
+        throw std::runtime_error(path + ": only single-part scan-line EXR files are supported");
+    size_t pos = 8;
+    std::map<std::string, std::string> attrs;
+    auto cstr = [&](size_t& p) {
+        const size_t e = raw.find('\0', p);
+        if (e == std::string::npos) throw std::runtime_error(path + ": truncated EXR header");
+        std::string s = raw.substr(p, e - p);
+        p = e + 1;
+        return s;
+    };
+    while (pos < raw.size() && raw[pos] != '\0') {
+        const std::string name = cstr(pos);
+        cstr(pos);  // type name
+        if (pos + 4 > raw.size()) throw std::runtime_error(path + ": truncated EXR header");
+        const uint32_t size = le32(r + pos);
+        pos += 4;
+        if (pos + size > raw.size()) throw std::runtime_error(path + ": truncated EXR header");
+        attrs[name] = raw.substr(pos, size);
+        pos += size;
+    }
+    ++pos;
+    if (!attrs.count("channels") || !attrs.count("compression") || !attrs.count("dataWindow") || attrs["dataWindow"].size() != 16)
+        throw std::runtime_error(path + ": EXR header lacks channels / compression / dataWindow");
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    {
+        const std::string& c = attrs["channels"];
+        size_t i = 0;
+        while (i < c.size() && c[i] != '\0') {
+            const size_t e = c.find('\0', i);
+            if (e == std::string::npos || e + 17 > c.size()) throw std::runtime_error(path + ": bad EXR channel list");
+            const unsigned char* q = reinterpret_cast<const unsigned char*>(c.data()) + e + 1;
+            const int type = static_cast<int>(le32(q));
+            if (le32(q + 8) != 1 || le32(q + 12) != 1) throw std::runtime_error(path + ": sub-sampled EXR channels are not supported");
+            if (type < 0 || type > 2) throw std::runtime_error(path + ": unknown EXR pixel type");
+            chans.push_back({c.substr(i, e - i), type});
+            i = e + 17;
+        }
+    }
+    const int comp = static_cast<unsigned char>(attrs["compression"][0]);
+    if (comp > 3)
+        throw std::runtime_error(path + ": EXR compression " + std::to_string(comp) + " is not supported (NONE, RLE, ZIPS, ZIP are)");
+    const unsigned char* dw = reinterpret_cast<const unsigned char*>(attrs["dataWindow"].data());
+    const int xmin = static_cast<int>(le32(dw)), ymin = static_cast<int>(le32(dw + 4)), xmax = static_cast<int>(le32(dw + 8)),
+              ymax = static_cast<int>(le32(dw + 12));
+    const int w = xmax - xmin + 1, h = ymax - ymin + 1;
+    if (w < 1 || h < 1) throw std::runtime_error(path + ": empty EXR data window");
+    std::string channel = channelIn;
+    auto has = [&](const std::string& n) {
+        for (const Chan& c : chans)
+            if (c.name == n) return true;
+        return false;
+    };
+    if (channel.empty()) {
+        if (chans.size() == 1) channel = chans[0].name;
+        else
+            for (const char* n : {"Z", "Y", "R"})
+                if (has(n)) { channel = n; break; }
+    }
+    if (channel.empty() || !has(channel)) throw std::runtime_error(path + ": no channel '" + channel + "' in the EXR file");
+    static const size_t pixelBytes[3] = {4, 2, 4};  // UINT, HALF, FLOAT
+    size_t lineBytes = 0, offsetInLine = 0;
+    int type = 2;
+    bool found = false;
+    for (const Chan& c : chans) {  // channels are stored in the order of the list (alphabetical)
+        if (c.name == channel) { type = c.type; found = true; }
+        if (!found) offsetInLine += pixelBytes[c.type] * w;
+        lineBytes += pixelBytes[c.type] * w;
+    }
+    const int perBlock = comp == 3 ? 16 : 1;
+    const int nblocks = (h + perBlock - 1) / perBlock;
+    if (pos + 8 * static_cast<size_t>(nblocks) > raw.size()) throw std::runtime_error(path + ": truncated EXR offset table");
+    pixels.assign(static_cast<size_t>(w) * h, 0.f);
+    for (int b = 0; b < nblocks; ++b) {
+        const uint64_t off = le64(r + pos + 8 * static_cast<size_t>(b));
+        if (off + 8 > raw.size()) throw std::runtime_error(path + ": EXR block offset beyond the file");
+        const int y = static_cast<int>(le32(r + off));
+        const uint32_t size = le32(r + off + 4);
+        if (off + 8 + size > raw.size() || y < ymin || y > ymax) throw std::runtime_error(path + ": bad EXR block");
+        const int lines = std::min(perBlock, ymax - y + 1);
+        const size_t want = static_cast<size_t>(lines) * lineBytes;
+        std::string data(raw, off + 8, size);
+        if (comp != 0 && size < want) {  // a block that does not shrink is stored as it is
+            if (comp == 1) data = exrUnRle(r + off + 8, size, want, path);
+            else {
+                std::string z(want, '\0');
+                uLongf got = static_cast<uLongf>(want);
+                if (uncompress(reinterpret_cast<Bytef*>(&z[0]), &got, r + off + 8, size) != Z_OK || got != want)
+                    throw std::runtime_error(path + ": cannot inflate an EXR block");
+                data.swap(z);
+            }
+            data = exrUnpredict(data);
+        }
+        if (data.size() != want) throw std::runtime_error(path + ": EXR block has the wrong size");
+        for (int l = 0; l < lines; ++l) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(data.data()) + l * lineBytes + offsetInLine;
+            float* dst = pixels.data() + static_cast<size_t>(y - ymin + l) * w;
+            for (int x = 0; x < w; ++x) {
+                if (type == 1) dst[x] = halfToFloat(static_cast<uint16_t>(src[2 * x] | src[2 * x + 1] << 8));
+                else if (type == 2) { const uint32_t u = le32(src + 4 * x); std::memcpy(&dst[x], &u, 4); }
+                else dst[x] = static_cast<float>(le32(src + 4 * x));
+            }
+        }
+    }
+    return Size(w, h);
+}
+
+// ---- ImageReader (reference src/utils/ImageReader.cpp) -----------------------------------------------------------------
+namespace {
+int countWithExtension(const std::string& dir, const char* ext) {
+    DIR* d = opendir(dir.c_str());
+    if (!d) return -1;
+    int n = 0;
+    const size_t el = std::strlen(ext);
+    while (const dirent* e = readdir(d)) {
+        const size_t l = std::strlen(e->d_name);
+        if (l > el && std::strcmp(e->d_name + l - el, ext) == 0) ++n;
+    }
+    closedir(d);
+    return n;
+}
+bool fileExists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+std::string indexed(const std::string& dir, const char* stem, int i, const char* ext) {
+    char name[64];
+    std::snprintf(name, sizeof(name), "/%s%04d%s", stem, i, ext);  // setfill('0') << setw(4)
+    return dir + name;
+}
+}  // namespace
+
+ImageReader::ImageReader(std::string basepath, std::string colordir, std::string depthdir)
+    : colorpath(basepath + colordir), depthpath(basepath + depthdir) {
+    const int rgbs = countWithExtension(colorpath, ".png"), depths = countWithExtension(depthpath, ".exr");
+    if (rgbs < 0 || depths < 0) throw std::runtime_error("Could not read color or depth dir!");
+    if (rgbs != depths) throw std::runtime_error("Different number of rgb and depth files!");
+    numFrames = static_cast<size_t>(rgbs);
+    while (!(fileExists(colorFileName(first)) && fileExists(depthFileName(first)))) {  // ImageReader.cpp:79-94
+        ++first;
+        if (first >= rgbs) throw std::runtime_error("Could not find starting index!");
+    }
+}
+std::string ImageReader::depthFileName(int index) const { return indexed(depthpath, "Depth", index, ".exr"); }
+std::string ImageReader::colorFileName(int index) const { return indexed(colorpath, "Color", index, ".png"); }
+Size ImageReader::readDepth(int index, std::vector<float>& depth) const {
+    const Size s = readExr(depthFileName(index), depth);
+    for (float& d : depth)
+        if (d > 100.f) d = 0.f;  // depth.setTo ( 0, depth > 100 )
+    return s;
 }
 
 // ---- a small unpickler ---------------------------------------------------------------------------------------------

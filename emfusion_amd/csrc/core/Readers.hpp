@@ -39,6 +39,37 @@ private:
     double frameRate = 0.0;
 };
 
+/**
+ * One channel of a single-part scan-line OpenEXR file as float, row-major: what cv::imread(IMREAD_UNCHANGED) hands the
+ * reference for the Co-Fusion depth files (reference src/utils/ImageReader.cpp:105-110).  Compression NONE, RLE, ZIPS
+ * and ZIP; HALF, FLOAT and UINT pixels; PIZ / PXR24 / B44 / DWA, tiled, deep and multi-part files are rejected with a
+ * message.  channel: name to read; empty = the only channel, else the first of Z, Y, R that exists.  Written from the
+ * published file layout ("OpenEXR File Layout", openexr.com); the same decoder as emfusion_amd/readers.py read_exr.
+ */
+Size readExr(const std::string& path, std::vector<float>& pixels, const std::string& channel = std::string());
+
+/**
+ * Keeps the reference's class name: depth frames of a Co-Fusion style dataset, <base><colordir>/ColorNNNN.png and
+ * <base><depthdir>/DepthNNNN.exr (reference src/utils/ImageReader.cpp; base with a trailing separator, as the reference
+ * concatenates).  The two directories must hold the same number of .png / .exr files; frames start at the first index
+ * for which both files exist; depth in metres, values above 100 set to 0 (ImageReader.cpp:112).
+ */
+class ImageReader {
+public:
+    ImageReader(std::string basepath, std::string colordir, std::string depthdir);
+    size_t getNumFrames() const { return numFrames; }
+    int firstIndex() const { return first; }
+    std::string depthFileName(int index) const;
+    std::string colorFileName(int index) const;
+    /** depth of file index `index` (firstIndex() ... ); returns its size */
+    Size readDepth(int index, std::vector<float>& depth) const;
+
+private:
+    std::string colorpath, depthpath;
+    size_t numFrames = 0;
+    int first = 0;
+};
+
 /** What MaskRCNN::loadPreprocessed hands to EMFusion::initOrMatchObjs. */
 struct PreprocMasks {
     int width = 0, height = 0;

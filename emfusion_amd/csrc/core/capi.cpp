@@ -234,6 +234,31 @@ int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capa
     });
 }
 
+int emf_io_read_exr(const char* path, const char* channel, float* out, size_t capacity, int32_t* width, int32_t* height) {
+    REQ(path);
+    return guarded([&] {
+        std::vector<float> px;
+        const Size s = readExr(path, px, channel ? channel : "");
+        if (width) *width = s.width;
+        if (height) *height = s.height;
+        if (out) {
+            if (capacity < px.size()) throw HipError("emf_io_read_exr: buffer too small", EMF_E_ARG);
+            std::copy(px.begin(), px.end(), out);
+        }
+    });
+}
+
+int emf_io_image_reader(const char* base, const char* colordir, const char* depthdir, int32_t* num_frames, int32_t* first) {
+    REQ(base);
+    REQ(colordir);
+    REQ(depthdir);
+    return guarded([&] {
+        const ImageReader r(base, colordir, depthdir);
+        if (num_frames) *num_frames = static_cast<int32_t>(r.getNumFrames());
+        if (first) *first = r.firstIndex();
+    });
+}
+
 int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count) {
     REQ(file);
     return guarded([&] {

@@ -97,6 +97,8 @@ def load() -> C.CDLL:
         "emf_fusion_use_preproc_masks": [vp, C.c_char_p],
         "emf_fusion_get_last_masks": [vp, C.c_void_p, C.c_size_t, ip],
         "emf_io_read_depth_png": [C.c_char_p, C.c_float, fp, C.c_size_t, ip, ip],
+        "emf_io_read_exr": [C.c_char_p, C.c_char_p, fp, C.c_size_t, ip, ip],
+        "emf_io_image_reader": [C.c_char_p, C.c_char_p, C.c_char_p, ip, ip],
         "emf_io_tum_associations": [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), ip],
         "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_size_t, ip],
@@ -699,6 +701,25 @@ def read_depth_png(path, scale=1.0 / 5000.0) -> np.ndarray:
     _check("emf_io_read_depth_png", load().emf_io_read_depth_png(os.fspath(path).encode(), scale,
                                                                out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(w), C.byref(h)))
     return out
+
+
+def read_exr(path, channel=None) -> np.ndarray:
+    """core/Readers.cpp readExr through the C API: one channel of a scan-line OpenEXR file as float32 (H, W)."""
+    w, h = C.c_int32(), C.c_int32()
+    ch = channel.encode() if channel else None
+    _check("emf_io_read_exr", load().emf_io_read_exr(os.fspath(path).encode(), ch, None, 0, C.byref(w), C.byref(h)))
+    out = np.empty((h.value, w.value), np.float32)
+    _check("emf_io_read_exr", load().emf_io_read_exr(os.fspath(path).encode(), ch, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                     out.size, C.byref(w), C.byref(h)))
+    return out
+
+
+def image_reader(base, colordir="colour", depthdir="depth"):
+    """(number of frames, first index) of a Co-Fusion style dataset, as the C++ emf::ImageReader sees it."""
+    n, first = C.c_int32(), C.c_int32()
+    _check("emf_io_image_reader", load().emf_io_image_reader((os.fspath(base) + os.sep).encode(), colordir.encode(),
+                                                            depthdir.encode(), C.byref(n), C.byref(first)))
+    return n.value, first.value
 
 
 def tum_associations(path):

@@ -177,6 +177,13 @@ int emf_io_png_unfilter(const uint8_t* rows, int height, int stride, int bpp, ui
  *                      (n * height * width bytes, 0/1), boxes (n * 4) and scores (n * *nscores) are filled when
  *                      not NULL and large enough (mask_capacity in bytes, score_capacity in doubles) */
 int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capacity, int32_t* width, int32_t* height);
+/*   read_exr           one channel (NULL / "": the only one, else the first of Z, Y, R) of a single-part scan-line
+ *                      OpenEXR file as float (emf::readExr; reference src/utils/ImageReader.cpp:105-110 reads its
+ *                      depth files with cv::imread); out may be NULL to ask for the size only
+ *   image_reader       emf::ImageReader on <base><colordir> / <base><depthdir> (ColorNNNN.png / DepthNNNN.exr):
+ *                      number of frames and first index; the reference's error messages for unusable directories */
+int emf_io_read_exr(const char* path, const char* channel, float* out, size_t capacity, int32_t* width, int32_t* height);
+int emf_io_image_reader(const char* base, const char* colordir, const char* depthdir, int32_t* num_frames, int32_t* first);
 int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count);
 int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int32_t* height, uint8_t* masks,
                               size_t mask_capacity, double* boxes, double* scores, size_t score_capacity, int32_t* nscores);

@@ -72,3 +72,78 @@ def test_mask_pickles_in_other_shapes(tmp_path):
         pickle.dump({"not": "a tuple"}, f, protocol=2)
     with pytest.raises(pipeline.FusionError, match="tuple"):
         pipeline.load_preproc_masks(tmp_path / "d.plk")
+
+
+# ---- OpenEXR depth files and the Co-Fusion directory layout in C++ (reference src/utils/ImageReader.cpp) --------------
+
+def test_cpp_exr_reader_on_a_real_file():
+    """tests/golden/python_logo.exr was written by the OpenEXR library (CPython's test data): the C++ decoder must give
+    what the Python one gives, channel by channel, and the committed pixels."""
+    from pathlib import Path
+    gold = Path(__file__).parent / "golden"
+    want = np.load(gold / "python_logo_rgba.npy")
+    for k, c in enumerate("RGBA"):
+        got = pipeline.read_exr(gold / "python_logo.exr", c)
+        assert got.dtype == np.float32 and np.array_equal(got, readers.read_exr(gold / "python_logo.exr", c))
+        assert np.abs(got - want[..., k].astype(np.float32) / 255).max() < 2e-3
+    assert np.array_equal(pipeline.read_exr(gold / "python_logo.exr"), pipeline.read_exr(gold / "python_logo.exr", "R"))
+    with pytest.raises(pipeline.FusionError, match="no channel"):
+        pipeline.read_exr(gold / "python_logo.exr", "Z")
+    with pytest.raises(pipeline.FusionError, match="not an OpenEXR"):
+        pipeline.read_exr(gold / "python_logo_rgba.npy")
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3], ids=["none", "rle", "zips", "zip"])
+@pytest.mark.parametrize("pixel", ["f", "h", "u"])
+def test_cpp_exr_reader_against_written_files(tmp_path, compression, pixel):
+    from tests.test_readers import write_exr
+    rng = np.random.default_rng(10 * compression + ord(pixel))
+    if pixel == "u":
+        z = rng.integers(0, 70000, (37, 53)).astype(np.float32)
+    else:
+        z = rng.uniform(0.3, 6.0, (37, 53)).astype(np.float16 if pixel == "h" else np.float32).astype(np.float32)
+    z[5:20, 7:30] = z[5, 7]  # runs, so that RLE / ZIP blocks really shrink
+    other = np.full_like(z, 3.0)
+    f = tmp_path / "Depth0000.exr"
+    write_exr(f, {"Z": z}, compression, pixel)
+    assert np.array_equal(pipeline.read_exr(f), z) and np.array_equal(readers.read_exr(f), z)
+    write_exr(f, {"A": other, "Z": z, "R": other * 2}, compression, pixel)  # stored alphabetically: A, R, Z
+    assert np.array_equal(pipeline.read_exr(f), z) and np.array_equal(pipeline.read_exr(f, "A"), other)
+    raw = bytearray(f.read_bytes())
+    (tmp_path / "cut.exr").write_bytes(raw[:len(raw) - 40])
+    with pytest.raises(pipeline.FusionError):
+        pipeline.read_exr(tmp_path / "cut.exr")
+
+
+def test_cpp_exr_reader_rejects_what_it_cannot_decode(tmp_path):
+    from tests.test_readers import write_exr
+    z = np.ones((16, 16), np.float32)
+    write_exr(tmp_path / "a.exr", {"Z": z}, 0, "f")
+    raw = bytearray((tmp_path / "a.exr").read_bytes())
+    at = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[at] = 4  # PIZ
+    (tmp_path / "piz.exr").write_bytes(raw)
+    with pytest.raises(pipeline.FusionError, match="compression 4 is not supported"):
+        pipeline.read_exr(tmp_path / "piz.exr")
+    raw[at] = 0
+    raw[5] |= 0x02  # tiled
+    (tmp_path / "tiled.exr").write_bytes(raw)
+    with pytest.raises(pipeline.FusionError, match="single-part scan-line"):
+        pipeline.read_exr(tmp_path / "tiled.exr")
+
+
+def test_cpp_image_reader_directory_layout(tmp_path):
+    from tests.test_readers import write_exr
+    (tmp_path / "colour").mkdir()
+    (tmp_path / "depth").mkdir()
+    for i in range(3, 7):  # the Co-Fusion sequences do not start at 0
+        readers.write_png_gray16(tmp_path / "colour" / ("Color%04d.png" % i), np.zeros((4, 4), np.uint16))
+        write_exr(tmp_path / "depth" / ("Depth%04d.exr" % i), {"Z": np.full((4, 4), float(i), np.float32)}, 3, "f")
+    assert pipeline.image_reader(tmp_path) == (4, 3)
+    py = readers.ImageReader(tmp_path)
+    assert (len(py), py.first) == (4, 3)
+    (tmp_path / "depth" / "Depth0006.exr").unlink()
+    with pytest.raises(pipeline.FusionError, match="Different number of rgb and depth files"):
+        pipeline.image_reader(tmp_path)
+    with pytest.raises(pipeline.FusionError, match="Could not read color or depth dir"):
+        pipeline.image_reader(tmp_path / "nowhere")

@@ -62,3 +62,38 @@ def test_sequence_mode_equals_the_python_driver(dev, tmp_path):
     assert len((out_cpp / "poses-cam.txt").read_text().splitlines()) == T.N
     for name in ("bg_tsdf.bin", "tsdf_1.bin", "fgProbs_1.bin"):
         assert (out_cpp / "tsdfs" / name).read_bytes() == (out_py / "tsdfs" / name).read_bytes(), name
+
+
+def test_dir_mode_reads_a_cofusion_layout_like_the_tum_one(dev, tmp_path):
+    """apps/emfusion_synth --dir -- emf::ImageReader + readExr (reference src/utils/ImageReader.cpp, apps/EM-Fusion.cpp:
+    118-126) -- on the staged sequence re-written as ColorNNNN.png + DepthNNNN.exr (ZIP, float; starting at index 3, as
+    the Co-Fusion sequences do not start at 0): the same depth values as the PNGs hold, so every result file must equal
+    the --sequence run's byte for byte."""
+    import numpy as np
+    from emfusion_amd import readers
+    from tests import tum_staging as T
+    from tests.test_readers import write_exr
+    seq, masks, _ = T.stage(tmp_path)
+    base = tmp_path / "cofusion"
+    (base / "colour").mkdir(parents=True)
+    (base / "depth").mkdir()
+    for f in range(T.N):
+        d = readers.read_png_gray(tmp_path / "seq" / "depth" / f"{f:04d}.png").astype(np.float32) * np.float32(1 / 5000.0)
+        write_exr(base / "depth" / f"Depth{f + 3:04d}.exr", {"Z": d}, 3 if f % 2 else 1, "f")
+        readers.write_png_gray16(base / "colour" / f"Color{f + 3:04d}.png", np.zeros((T.H, T.W), np.uint16))
+    # the mask files are numbered by the frame count, not by the file index (EMFusion.cpp:383-389)
+    outs = {}
+    for name, args in (("tum", ["--sequence", seq]), ("dir", ["--dir", str(base) + "/"])):
+        outs[name] = tmp_path / ("out_" + name)
+        p = subprocess.run([str(APP), *args, "--masks", masks, "--out", str(outs[name]), "--volumes", *T.SMALL],
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    names = sorted(f.name for f in outs["tum"].glob("poses-*.txt"))
+    assert "poses-cam.txt" in names and names == sorted(f.name for f in outs["dir"].glob("poses-*.txt"))
+    for name in names:
+        assert (outs["dir"] / name).read_bytes() == (outs["tum"] / name).read_bytes(), name
+    for name in ("bg_tsdf.bin", "tsdf_1.bin"):
+        assert (outs["dir"] / "tsdfs" / name).read_bytes() == (outs["tum"] / "tsdfs" / name).read_bytes(), name
+    # and the debug images of --save-output (setupOutput is on in this mode): one per tracked frame
+    assert len(list((outs["dir"] / "huber_weights" / "bg").glob("*.png"))) == T.N - 1
+    assert len(list((outs["dir"] / "assoc_weights" / "bg" / "postTrack").glob("*.png"))) == T.N - 1
