@@ -7,6 +7,8 @@
 //   emfusion_synth --sequence DIR/ [--masks DIR] [--mask-frames N] [--visibility-thresh N] [--frames N]
 //                  [--bg-res R] [--bg-voxel M] [--obj-res R] [--volumes] --out DIR
 //   emfusion_synth --dir BASE/ [--colordir colour] [--depthdir depth] [--intrinsics fx fy cx cy] ... --out DIR
+// --configfile FILE (-c): with --sequence / --dir, take every parameter from one of the reference's configuration files
+// (config/default.cfg, tum.cfg ...; core/Config.hpp) instead of the sizing options above.
 // --dir: the same loop on a Co-Fusion style dataset (ColorNNNN.png + DepthNNNN.exr), the reference's ImageReader
 // (apps/EM-Fusion.cpp:118-126; core/Readers.hpp ImageReader + readExr).
 // --sequence: the reference's loop itself (apps/EM-Fusion.cpp:100-156) on a TUM RGB-D sequence: TUMRGBDReader
@@ -29,6 +31,7 @@
 #include <string>
 #include <vector>
 
+#include "Config.hpp"
 #include "EMFusion.hpp"
 #include "Readers.hpp"
 #include "SyntheticScene.hpp"
@@ -36,8 +39,9 @@
 // The reference's main loop on a dataset (apps/EM-Fusion.cpp:100-156): a TUM sequence (`--sequence`, TUMRGBDReader) or a
 // Co-Fusion style directory (`--dir`, ImageReader: ColorNNNN.png + DepthNNNN.exr), as apps/EM-Fusion.cpp:118-131 chooses
 static int runSequence(const std::string& seq, bool cofusion, const std::string& colordir, const std::string& depthdir,
-                       const float* intrinsics, const std::string& masks, const std::string& outDir, int frames, int bgRes,
-                       float bgVoxel, int objRes, int maskFrames, int visibilityThresh, bool volumes) {
+                       const float* intrinsics, const std::string& configFile, const std::string& masks,
+                       const std::string& outDir, int frames, int bgRes, float bgVoxel, int objRes, int maskFrames,
+                       int visibilityThresh, bool volumes) {
     std::unique_ptr<emf::TUMRGBDReader> tum;
     std::unique_ptr<emf::ImageReader> dir;
     size_t available = 0;
@@ -56,8 +60,20 @@ static int runSequence(const std::string& seq, bool cofusion, const std::string&
     };
     const emf::Size size = readDepth(0);
     emf::Params params;  // reference defaults (config/default.cfg)
-    params.frameSize = size;
-    params.setDefaultIntrinsics();
+    const bool configured = !configFile.empty();
+    if (configured) {
+        // --configfile: everything comes from the reference's configuration file (apps/EM-Fusion.cpp:268-371) and, for
+        // --dir, from <base>calibration.txt (:399-410); the sizing options of this command line are not applied
+        emf::loadConfigFile(params, configFile);
+        if (cofusion) emf::loadCalibrationFile(params, seq + "calibration.txt");
+        if (params.frameSize.width != size.width || params.frameSize.height != size.height)
+            throw std::runtime_error("the configuration says " + std::to_string(params.frameSize.width) + " x " +
+                                     std::to_string(params.frameSize.height) + ", the images are " + std::to_string(size.width) +
+                                     " x " + std::to_string(size.height));
+    } else {
+        params.frameSize = size;
+        params.setDefaultIntrinsics();
+    }
     if (intrinsics) {  // the reference takes them from its config file (data.h: intr)
         params.intr = emf::Matx33f::eye();
         params.intr(0, 0) = intrinsics[0];
@@ -65,14 +81,16 @@ static int runSequence(const std::string& seq, bool cofusion, const std::string&
         params.intr(0, 2) = intrinsics[2];
         params.intr(1, 2) = intrinsics[3];
     }
-    params.globalVolumeDims = emf::Vec3i::all(bgRes);
-    params.globalVoxelSize = bgVoxel;
-    params.volumePose = emf::Affine3f(emf::Matx33f::eye(), emf::Vec3f(0.f, 0.f, bgRes * bgVoxel / 2.f));
-    params.objVolumeDims = emf::Vec3i::all(objRes);
-    const float scale = static_cast<float>(size.width) / 640.f;
-    params.visibilityThresh = visibilityThresh > 0 ? visibilityThresh : static_cast<int>(std::lround(1600 * scale * scale));
-    params.boundary = static_cast<int>(std::lround(20 * scale));
-    params.maskRCNNFrames = maskFrames;
+    if (!configured) {
+        params.globalVolumeDims = emf::Vec3i::all(bgRes);
+        params.globalVoxelSize = bgVoxel;
+        params.volumePose = emf::Affine3f(emf::Matx33f::eye(), emf::Vec3f(0.f, 0.f, bgRes * bgVoxel / 2.f));
+        params.objVolumeDims = emf::Vec3i::all(objRes);
+        const float scale = static_cast<float>(size.width) / 640.f;
+        params.visibilityThresh = visibilityThresh > 0 ? visibilityThresh : static_cast<int>(std::lround(1600 * scale * scale));
+        params.boundary = static_cast<int>(std::lround(20 * scale));
+        params.maskRCNNFrames = maskFrames;
+    }
     emf::EMFusion emf(params);
     if (!masks.empty()) emf.usePreprocMasks(masks);   // apps/EM-Fusion.cpp:115
     emf.setupOutput(false, volumes);                  // apps/EM-Fusion.cpp:112
@@ -107,7 +125,7 @@ static int runSequence(const std::string& seq, bool cofusion, const std::string&
 int main(int argc, char** argv) {
     int frames = 120, objects = 4, bgRes = 512, objRes = 128, width = 640, height = 480;
     bool materialize = false, autonomous = false;
-    std::string outDir, sequence, maskDir, dataDir, colordir = "colour", depthdir = "depth";
+    std::string outDir, sequence, maskDir, dataDir, colordir = "colour", depthdir = "depth", configFile;
     float intrinsics[4] = {0.f, 0.f, 0.f, 0.f};
     bool haveIntrinsics = false;
     int maskFrames = 30, visThresh = 0, framesGiven = 0;
@@ -120,6 +138,7 @@ int main(int argc, char** argv) {
         else if (a == "--sequence" && i + 1 < argc) sequence = argv[++i];
         else if (a == "--masks" && i + 1 < argc) maskDir = argv[++i];
         else if (a == "--dir" && i + 1 < argc) dataDir = argv[++i];
+        else if ((a == "--configfile" || a == "-c") && i + 1 < argc) configFile = argv[++i];
         else if (a == "--colordir" && i + 1 < argc) colordir = argv[++i];
         else if (a == "--depthdir" && i + 1 < argc) depthdir = argv[++i];
         else if (a == "--intrinsics" && i + 4 < argc) {
@@ -148,7 +167,7 @@ int main(int argc, char** argv) {
             if (outDir.empty()) throw std::runtime_error("--sequence / --dir need --out DIR");
             const bool cofusion = !dataDir.empty();
             return runSequence(cofusion ? dataDir : sequence, cofusion, colordir, depthdir, haveIntrinsics ? intrinsics : nullptr,
-                               maskDir, outDir, framesGiven, bgRes, bgVoxel > 0 ? bgVoxel : 5.12f / static_cast<float>(bgRes),
+                               configFile, maskDir, outDir, framesGiven, bgRes, bgVoxel > 0 ? bgVoxel : 5.12f / static_cast<float>(bgRes),
                                objRes, maskFrames, visThresh, volumes);
         }
         emf::Params params;  // reference defaults (config/default.cfg)

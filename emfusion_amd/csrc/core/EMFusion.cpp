@@ -74,6 +74,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
         world = comm->size();
         hitKeys = DeviceBuffer(params.frameSize.area() * sizeof(uint64_t));
     }
+    ignorePerson = params.ignore_person;  // data.h:198; config/tum.cfg sets it
     const char* env = std::getenv("EMF_PER_VOLUME");
     forceLegacy = env && env[0] == '1';
     // EMF_LAMBDA_TABLE=0: integrate with the inline 1 / lambda (A/B measurements; same results)

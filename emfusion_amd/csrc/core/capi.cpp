@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "EMFusion.hpp"
+#include "Config.hpp"
 #include "Readers.hpp"
 #include "Output.hpp"
 #include "SyntheticScene.hpp"
@@ -231,6 +232,37 @@ int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capa
             if (capacity < px.size()) throw HipError("emf_io_read_depth_png: buffer too small", EMF_E_ARG);
             for (size_t i = 0; i < px.size(); ++i) out[i] = static_cast<float>(px[i]) * scale;
         }
+    });
+}
+
+int emf_io_load_config(const char* path, const char* calibration, emf_fusion_params_t* p, char* dump, size_t dump_capacity) {
+    return guarded([&] {
+        Params q;
+        if (path && path[0]) loadConfigFile(q, path);
+        if (calibration && calibration[0]) loadCalibrationFile(q, calibration);
+        if (p) {
+            emf_fusion_default_params(p);
+            p->width = q.frameSize.width;
+            p->height = q.frameSize.height;
+            for (int k = 0; k < 9; ++k) p->K[k] = q.intr.val[k];
+            for (int k = 0; k < 3; ++k) {
+                p->bg_res[k] = q.globalVolumeDims[k];
+                p->obj_res[k] = q.objVolumeDims[k];
+                p->volume_pose_t[k] = q.volumePose.translation()[k];
+            }
+            p->bg_voxel_size = q.globalVoxelSize;
+            p->bg_rel_truncdist = q.globalRelTruncDist;
+            p->obj_rel_truncdist = q.objRelTruncDist;
+            p->max_tsdf_weight = q.tsdfParams.maxTSDFWeight;
+            p->assoc_sigma = q.tsdfParams.assocSigma;
+            p->alpha = q.tsdfParams.alpha;
+            p->uni_prior = q.tsdfParams.uniPrior;
+            p->visibility_thresh = q.visibilityThresh;
+            p->boundary = q.boundary;
+            p->mask_frames = q.maskRCNNFrames;
+            p->max_tracking_iter = q.maxTrackingIter;
+        }
+        if (dump && dump_capacity) std::snprintf(dump, dump_capacity, "%s", dumpConfig(q).c_str());
     });
 }
 

@@ -98,6 +98,7 @@ def load() -> C.CDLL:
         "emf_fusion_get_last_masks": [vp, C.c_void_p, C.c_size_t, ip],
         "emf_io_read_depth_png": [C.c_char_p, C.c_float, fp, C.c_size_t, ip, ip],
         "emf_io_read_exr": [C.c_char_p, C.c_char_p, fp, C.c_size_t, ip, ip],
+        "emf_io_load_config": [C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t],
         "emf_io_image_reader": [C.c_char_p, C.c_char_p, C.c_char_p, ip, ip],
         "emf_io_tum_associations": [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), ip],
         "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
@@ -701,6 +702,26 @@ def read_depth_png(path, scale=1.0 / 5000.0) -> np.ndarray:
     _check("emf_io_read_depth_png", load().emf_io_read_depth_png(os.fspath(path).encode(), scale,
                                                                out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(w), C.byref(h)))
     return out
+
+
+def load_config(path=None, calibration=None):
+    """The reference's configuration file (config/*.cfg, apps/EM-Fusion.cpp:268-371) and / or a Co-Fusion
+    calibration.txt applied to the reference defaults (core/Config.cpp): (FusionParams for Fusion(...), {key: value
+    string or list of strings} of every configurable field)."""
+    prm = FusionParams()
+    buf = C.create_string_buffer(1 << 14)
+    _check("emf_io_load_config",
+           load().emf_io_load_config(os.fspath(path).encode() if path else None,
+                                     os.fspath(calibration).encode() if calibration else None,
+                                     C.byref(prm), buf, len(buf)))
+    fields: Dict[str, object] = {}
+    for line in buf.value.decode().splitlines():
+        k, v = [t.strip() for t in line.split("=", 1)]
+        if k.startswith("Params.MaskRCNNParams."):
+            fields.setdefault(k, []).append(v)
+        else:
+            fields[k] = v
+    return prm, fields
 
 
 def read_exr(path, channel=None) -> np.ndarray:

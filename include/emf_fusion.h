@@ -182,6 +182,12 @@ int emf_io_read_depth_png(const char* path, float scale, float* out, size_t capa
  *                      depth files with cv::imread); out may be NULL to ask for the size only
  *   image_reader       emf::ImageReader on <base><colordir> / <base><depthdir> (ColorNNNN.png / DepthNNNN.exr):
  *                      number of frames and first index; the reference's error messages for unusable directories */
+/*   load_config        emf::loadConfigFile (core/Config.hpp): the reference's config files (config/default.cfg ...;
+ *                      apps/EM-Fusion.cpp:268-371) applied to the reference defaults, then -- if calibration is not
+ *                      NULL and the file exists -- <dir>/calibration.txt (EM-Fusion.cpp:399-410); the fields the
+ *                      volumetric path reads come back in *p (may be NULL), every configurable field as
+ *                      "Section.key = value" lines in dump (may be NULL; truncated to dump_capacity - 1 characters) */
+int emf_io_load_config(const char* path, const char* calibration, emf_fusion_params_t* p, char* dump, size_t dump_capacity);
 int emf_io_read_exr(const char* path, const char* channel, float* out, size_t capacity, int32_t* width, int32_t* height);
 int emf_io_image_reader(const char* base, const char* colordir, const char* depthdir, int32_t* num_frames, int32_t* first);
 int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count);

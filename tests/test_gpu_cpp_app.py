@@ -97,3 +97,43 @@ def test_dir_mode_reads_a_cofusion_layout_like_the_tum_one(dev, tmp_path):
     # and the debug images of --save-output (setupOutput is on in this mode): one per tracked frame
     assert len(list((outs["dir"] / "huber_weights" / "bg").glob("*.png"))) == T.N - 1
     assert len(list((outs["dir"] / "assoc_weights" / "bg" / "postTrack").glob("*.png"))) == T.N - 1
+
+
+def test_configfile_drives_the_sequence_mode(dev, tmp_path):
+    """--configfile: the reference's configuration syntax (core/Config.cpp; apps/EM-Fusion.cpp:268-371) instead of the
+    sizing options -- a file that says what tests/tum_staging.SMALL says must give the same result files."""
+    from tests import tum_staging as T
+    seq, masks, _ = T.stage(tmp_path)
+    f = 525.0 * T.W / 640
+    (tmp_path / "small.cfg").write_text(f"""\
+[Params]
+frameSize = {T.W} {T.H}
+[Params.intr]
+fx = {f}
+fy = {f}
+cx = {T.W // 2 - 0.5}
+cy = {T.H // 2 - 0.5}
+[Params]
+globalVolumeDims = 64 64 64
+globalVoxelSize = 0.04
+volumePose = 0 0 1.28
+objVolumeDims = 32 32 32
+visibilityThresh = 100
+boundary = {round(20 * T.W / 640)}
+maskRCNNFrames = {T.MASK_EVERY}
+""")
+    outs = {}
+    for name, args in (("cli", T.SMALL), ("cfg", ["--configfile", str(tmp_path / "small.cfg")])):
+        outs[name] = tmp_path / ("out_" + name)
+        p = subprocess.run([str(APP), "--sequence", seq, "--masks", masks, "--out", str(outs[name]), "--volumes", *args],
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    names = sorted(f.name for f in outs["cli"].glob("poses-*.txt"))
+    assert len(names) >= 2 and names == sorted(f.name for f in outs["cfg"].glob("poses-*.txt"))
+    for name in names:
+        assert (outs["cfg"] / name).read_bytes() == (outs["cli"] / name).read_bytes(), name
+    assert (outs["cfg"] / "tsdfs" / "bg_tsdf.bin").read_bytes() == (outs["cli"] / "tsdfs" / "bg_tsdf.bin").read_bytes()
+    (tmp_path / "wrong.cfg").write_text("[Params]\nframeSize = 640 480\n")
+    p = subprocess.run([str(APP), "--sequence", seq, "--out", str(tmp_path / "o"), "--configfile", str(tmp_path / "wrong.cfg")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "the images are" in (p.stdout + p.stderr)
