@@ -250,8 +250,9 @@ Size readExr(const std::string& path, std::vector<float>& pixels, const std::str
     const unsigned char* dw = reinterpret_cast<const unsigned char*>(attrs["dataWindow"].data());
     const int xmin = static_cast<int>(le32(dw)), ymin = static_cast<int>(le32(dw + 4)), xmax = static_cast<int>(le32(dw + 8)),
               ymax = static_cast<int>(le32(dw + 12));
-    const int w = xmax - xmin + 1, h = ymax - ymin + 1;
-    if (w < 1 || h < 1) throw std::runtime_error(path + ": empty EXR data window");
+    const long long wl = static_cast<long long>(xmax) - xmin + 1, hl = static_cast<long long>(ymax) - ymin + 1;
+    if (wl < 1 || hl < 1 || wl > 65536 || hl > 65536) throw std::runtime_error(path + ": empty or implausible EXR data window");
+    const int w = static_cast<int>(wl), h = static_cast<int>(hl);
     std::string channel = channelIn;
     auto has = [&](const std::string& n) {
         for (const Chan& c : chans)
