@@ -1129,27 +1129,41 @@ void EMFusion::trackModels(int first, int count) {
             const int maxLaunches = 2 * params.maxTrackingIter + 4;  // (every step a speculation miss)
             const auto t0 = std::chrono::steady_clock::now();
             int launch = 0;
+            bool lookAhead = false;
             for (; launch < maxLaunches; ++launch) {
                 for (unsigned spins = 0; launch - static_cast<int>(watch[0]) >= trackWindow; ++spins)
                     if ((spins & 0xffffu) == 0xffffu &&
                         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
                         throw HipError("EMFusion: the tracking launches make no progress", EMF_E_ARG);
                 bool all = launch > 0;
-                for (int m = 0; m < count && all; ++m) all = watch[1 + m] != 0u;
+                for (int m = 0; m < count && all; ++m) all = (watch[1 + m] & 3u) != 0u;
                 if (all) break;
+                // look-ahead past rejected steps from a stage's first rejection on (the launch that can is the
+                // slower one per launch; until then every step is accepted and there is nothing to look past)
+                if (!lookAhead)
+                    for (int m = 0; m < count; ++m) lookAhead = lookAhead || (watch[1 + m] & 4u) != 0u;
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, trackWatchDev, static_cast<uint32_t>(launch + 1),
-                                           main.abi()),
+                                           params.maxTrackingIter, lookAhead ? EMF_TRACK_AHEAD : 0, trackWatchDev,
+                                           static_cast<uint32_t>(launch + 1), main.abi()),
                          "trackStep");
             }
             if (launch & 1)  // an even number of launches leaves the state in `states`
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, nullptr, 0u, main.abi()),
+                                           params.maxTrackingIter, 0, nullptr, 0u, main.abi()),
                          "trackStep");
             hipCheck(hipMemcpyAsync(trackStatesHost + first, states, sizeof(emf_track_state_t) * count,
                                     hipMemcpyDeviceToHost, main.get()),
                      "hipMemcpyAsync");
             main.waitForCompletion();
+            if (std::getenv("EMF_TRACK_LOG")) {  // diagnosis: launches against judged steps
+                int it = 0, acc = 0;
+                for (int m = first; m < first + count; ++m) {
+                    it = std::max(it, trackStatesHost[m].iterations);
+                    acc = std::max(acc, trackStatesHost[m].accepted);
+                }
+                std::fprintf(stderr, "track stage first %d count %d: launches %d, most steps %d, most accepted %d\n", first, count,
+                             launch, it, acc);
+            }
             return;
         }
         // Without the progress words (EMF_TRACK_WINDOW=0): iterations are enqueued in chunks and the
@@ -1162,8 +1176,10 @@ void EMFusion::trackModels(int first, int count) {
         const int chunk = trackChunk > 0 ? trackChunk : params.maxTrackingIter;
         int& predicted = trackPredicted[first == 0 ? 0 : 1];
         int taken = 0;
+        // diagnosis (scripts/track_verdict_sequences.py): one line per poll and model, every chunk as long as asked
+        static const bool logVerdicts = std::getenv("EMF_TRACK_LOG") != nullptr;
         for (int done = 0; done < params.maxTrackingIter;) {
-            const int want = done == 0 && predicted > 0 && trackChunk > 0 ? std::max(chunk, predicted + 8) : chunk;
+            const int want = done == 0 && predicted > 0 && trackChunk > 0 && !logVerdicts ? std::max(chunk, predicted + 8) : chunk;
             const int n = std::min(want, params.maxTrackingIter - done);
             emfCheck(emf_hip_trackIterate(currentTable() + first, states, count, &pv, &tp, scratch, per, n,
                                           main.abi()),
@@ -1177,6 +1193,9 @@ void EMFusion::trackModels(int first, int count) {
             done = params.maxTrackingIter;
             for (int m = first; m < first + count; ++m) {
                 const emf_track_state_t& st = trackStatesHost[m];
+                if (logVerdicts)
+                    std::fprintf(stderr, "track model %d: iterations %d accepted %d rho %g mu %g nu %g converged %d\n", m,
+                                 st.iterations, st.accepted, st.rho, st.mu, st.nu, st.converged);
                 taken = std::max(taken, st.iterations);
                 if (st.converged) continue;
                 all = false;

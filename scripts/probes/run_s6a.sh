@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box: phase stamps of k_track_step for several workgroups (first / second on their CU), camera stage at 640x480
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+for WG in ${WGS:-0 100 260 280 299}; do
+  touch emfusion_amd/csrc/tracking.hip
+  make -s -C emfusion_amd/csrc -j8 EXTRA="-DEMF_TRACK_TRACE=$WG $TRACK_EXTRA" > /tmp/tb.log 2>&1 || { tail -5 /tmp/tb.log; exit 1; }
+  for A in ${AHEADS:-2}; do
+  echo "== EMF_TRACK_TRACE=$WG EMF_TRACK_AHEAD=$A"
+  EMF_TRACK_AHEAD=$A python scripts/track_step_trace.py 2>&1 | tail -${TAIL:-16}
+  done
+done
+touch emfusion_amd/csrc/tracking.hip
+make -s -C emfusion_amd/csrc -j8 > /tmp/tb.log 2>&1

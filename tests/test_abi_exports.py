@@ -61,5 +61,5 @@ def test_struct_mirrors_have_the_sizes_the_library_asserts():
     matching static_asserts (168 and 484 bytes)."""
     import ctypes as C
     assert C.sizeof(_lib.EmfModel) == 168
-    assert C.sizeof(_lib.EmfTrackState) == 484
+    assert C.sizeof(_lib.EmfTrackState) == 652
     assert C.sizeof(_lib.EmfVolumeOut) == 32
