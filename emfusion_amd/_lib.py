@@ -120,7 +120,7 @@ SIGNATURES = {
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
                              C.c_int, _STREAM],
     "emf_hip_trackStep": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
-                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, _STREAM],
+                          C.c_int, C.c_int, C.c_void_p, C.c_uint32, _STREAM],
     "emf_hip_trackWeightImages": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t, _FP, _FP, _STREAM],
     "emf_hip_computePoseGradients": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, _FP, _STREAM],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_int, _FP,
@@ -190,9 +190,7 @@ class EmfTrackState(C.Structure):
                 ("wSel", C.c_int32), ("needAccum", C.c_int32), ("haveSpec", C.c_int32),
                 ("spec", C.c_float * 28), ("checkB", C.c_int32),
                 ("pending", C.c_int32), ("body", C.c_int32), ("iterTarget", C.c_int32),
-                ("logCur", C.c_float), ("logTrial", C.c_float), ("sawReject", C.c_int32),
-                ("nAhead", C.c_int32), ("aheadX", C.c_float * 6 * 2), ("aheadR", C.c_float * 9 * 2),
-                ("aheadT", C.c_float * 3 * 2), ("aheadConv", C.c_int32 * 2)]
+                ("logCur", C.c_float), ("logTrial", C.c_float)]
 
 _lib = None
 

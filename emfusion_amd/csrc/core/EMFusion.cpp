@@ -1129,27 +1129,22 @@ void EMFusion::trackModels(int first, int count) {
             const int maxLaunches = 2 * params.maxTrackingIter + 4;  // (every step a speculation miss)
             const auto t0 = std::chrono::steady_clock::now();
             int launch = 0;
-            bool lookAhead = false;
             for (; launch < maxLaunches; ++launch) {
                 for (unsigned spins = 0; launch - static_cast<int>(watch[0]) >= trackWindow; ++spins)
                     if ((spins & 0xffffu) == 0xffffu &&
                         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
                         throw HipError("EMFusion: the tracking launches make no progress", EMF_E_ARG);
                 bool all = launch > 0;
-                for (int m = 0; m < count && all; ++m) all = (watch[1 + m] & 3u) != 0u;
+                for (int m = 0; m < count && all; ++m) all = watch[1 + m] != 0u;
                 if (all) break;
-                // look-ahead past rejected steps from a stage's first rejection on (the launch that can is the
-                // slower one per launch; until then every step is accepted and there is nothing to look past)
-                if (!lookAhead)
-                    for (int m = 0; m < count; ++m) lookAhead = lookAhead || (watch[1 + m] & 4u) != 0u;
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, lookAhead ? EMF_TRACK_AHEAD : 0, trackWatchDev,
-                                           static_cast<uint32_t>(launch + 1), main.abi()),
+                                           params.maxTrackingIter, trackWatchDev, static_cast<uint32_t>(launch + 1),
+                                           main.abi()),
                          "trackStep");
             }
             if (launch & 1)  // an even number of launches leaves the state in `states`
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, 0, nullptr, 0u, main.abi()),
+                                           params.maxTrackingIter, nullptr, 0u, main.abi()),
                          "trackStep");
             hipCheck(hipMemcpyAsync(trackStatesHost + first, states, sizeof(emf_track_state_t) * count,
                                     hipMemcpyDeviceToHost, main.get()),

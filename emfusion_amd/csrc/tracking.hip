@@ -34,11 +34,8 @@
 // but fixed, run-to-run deterministic -- order than cv::cuda::reduce's unspecified one, and the
 // SE(3) exponential / QR re-orthonormalisation restate Sophus / Eigen (absent from the reference
 // tree, versions unpinned): these agree with the oracle to float rounding, not bit for bit.
-#include <algorithm>
 #include <atomic>
 #include <cstddef>
-#include <cstdlib>
-#include <type_traits>
 
 #include "device_core.hpp"
 
@@ -51,13 +48,9 @@ namespace {
                               // every workgroup pays the prologue, and its cost grows with the number of rows
 #endif
 constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // pixels per workgroup
-constexpr int kAhead = EMF_TRACK_AHEAD;  // look-ahead poses per launch (k_track_step)
-constexpr int kCols = 30 + kAhead; // partial-sum columns per workgroup: 21 (upper triangle of A) + 6 (b) + 1
+constexpr int kCols = 30;          // partial-sum columns per workgroup: 21 (upper triangle of A) + 6 (b) + 1
                                    // (error), + the trial step's error + max |integration weight| at the
-                                   // trial pose + the errors at the look-ahead poses (k_track_step)
-constexpr int kColErrTrial = 28, kColMax = 29, kColAhead = 30;
-static_assert(kAhead == 2, "the column layout (two columns per wave of a 1024-thread workgroup, the look-ahead errors in "
-                           "the two spare slots of the second wave_sum16) is laid out for two look-ahead poses");
+                                   // trial pose (k_track_step)
 
 struct TrackFrame {
     const emf_model_t* models;
@@ -70,7 +63,6 @@ struct TrackFrame {
     size_t scratchStride;   // bytes per model
     int launch;             // index of the launch within the trackIterate call (parity of the double buffers)
     int iterations;         // LM iterations the call asks for
-    int ahead;              // look-ahead poses a launch may evaluate (0: every trial step gets its own launch)
     uint32_t* watch;        // host memory (or null): [0] <- seq, [1 + m] <- model m is done (emf_hip_trackStep)
     uint32_t seq;
 };
@@ -361,55 +353,31 @@ __device__ __forceinline__ void adopt_sums(emf_track_state_t& st, const float* s
     st.checkB = 1;
 }
 
-// Lane 0 of a workgroup: everything between two per-pixel passes up to the next solve.  Sets st.body (what
-// this launch does per pixel) and st.pending (what the next launch will find in the partial sums); returns
-// true if a trial step is to be solved for (lm_solve).
-//
-// Look-ahead.  A rejected step changes nothing but the damping (mu *= nu, nu *= nu_init, TSDF.cpp:328-336): the
-// solves and trial poses of the NEXT damping values depend on nothing a per-pixel pass produces, so lm_solve
-// makes them together with the trial's (other lanes, same instructions) and the launch that evaluates the
-// trial also sums the error at each of them (8 gathers and one column per pose).  Here the run is judged
-// in the reference's order: trial rejected -> the first look-ahead pose IS the next trial and its error is at
-// hand -> rejected again -> the second.  A look-ahead pose whose step would be ACCEPTED needs the full pass
-// (weights, Hessian sums): it becomes this launch's ordinary trial and is judged again, identically, by the
-// next launch -- only rejected steps are passed over.  Every field the reference's flow keeps (pose, A, b, x,
-// mu, nu, rho, err, errNew, counters, flags) goes through the same values in the same order as with a launch
-// per step (tests/test_gpu_tracking.py compares the two flows bit for bit); maxIwTrialBits, which only an
-// accepted step reads, is that of the last FULLY evaluated trial.  Look-ahead starts with a stage's first
-// rejection (the first 8-12 steps of a stage are accepted one after the other; from then on 30-45 % are
-// rejected, in runs of 2-6: scripts/track_verdict_sequences.py).
-__device__ bool lm_verdict(emf_track_state_t& st, const double* sums, const TrackFrame& f) {
+// One lane: everything between two per-pixel passes.  Sets st.body (what this launch does per
+// pixel) and st.pending (what the next launch will find in the partial sums).
+// st.logCur / st.logTrial: |log| of the current and of the trial pose (the step-size test needs the one of the
+// pose the verdict leaves current); the trial's is made beside the per-pixel pass of the launch that made the pose.
+__device__ void lm_advance(emf_track_state_t& st, const double* sums, const TrackFrame& f) {
     if (f.launch == 0) st.iterTarget = st.iterations + f.iterations;
     st.body = kBodyNone;
     if (st.converged) {
         st.pending = 0;
-        return false;
+        return;
     }
-    // mu *= nu; nu *= nu_init (TSDF.cpp:328-336)
-    const auto reject = [&]() {
-        st.mu *= st.nu;
-        st.nu *= f.prm.nuInit;
-        st.evaluateGradient = 0;
-        st.haveTrial = 0;
-        st.sawReject = 1;
-    };
-    // gain = 0.5 * -x^T (mu * -x - b), rho = (err - errNew) / gain  (TSDF.cpp:319-320)
-    const auto gain_ratio = [&](float errNew) {
-        float gain = 0.f;
-        for (int j = 0; j < 6; ++j) gain += -st.x[j] * (st.mu * -st.x[j] - st.b[j]);
-        gain = 0.5f * gain;
-        return (st.err - errNew) / gain;
-    };
     if (st.pending == kBodyAccum) {
         for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
         st.needAccum = 0;
         st.haveSpec = 1;
     } else if (st.pending == kBodyTrial) {
         // ---- computePoseUpdate, second half (TSDF.cpp:315-337) ----
-        const float errNew = static_cast<float>(sums[kColErrTrial]);
+        const float errNew = static_cast<float>(sums[28]);
         st.errNew = errNew;
-        st.maxIwTrialBits = __float_as_uint(static_cast<float>(sums[kColMax]));
-        const float rho = gain_ratio(errNew);
+        st.maxIwTrialBits = __float_as_uint(static_cast<float>(sums[29]));
+        // gain = 0.5 * -x^T (mu * -x - b)  (TSDF.cpp:319)
+        float gain = 0.f;
+        for (int j = 0; j < 6; ++j) gain += -st.x[j] * (st.mu * -st.x[j] - st.b[j]);
+        gain = 0.5f * gain;
+        const float rho = (st.err - errNew) / gain;
         st.rho = rho;
         st.iterations += 1;
         if (rho > 0) {  // accept (TSDF.cpp:322-327)
@@ -431,42 +399,18 @@ __device__ bool lm_verdict(emf_track_state_t& st, const double* sums, const Trac
                 st.needAccum = 1;
             }
             st.maxIwBits = st.maxIwTrialBits;
-            st.haveTrial = 0;
-        } else {  // reject (TSDF.cpp:328-336), and on through the look-ahead poses
-            reject();
-            const int nAhead = st.nAhead;
-            for (int j = 0; j < nAhead; ++j) {
-                if (st.iterations >= st.iterTarget) break;  // (the call's budget ends in front of this step)
-                for (int k = 0; k < 6; ++k) st.x[k] = st.aheadX[j][k];  // the solve at the damping value now current
-                if (st.aheadConv[j]) {  // its step-size test (TSDF.cpp:292-296)
-                    st.converged = 1;
-                    st.pending = 0;
-                    st.nAhead = 0;
-                    return false;
-                }
-                for (int k = 0; k < 9; ++k) st.Rtrial[k] = st.aheadR[j][k];
-                for (int k = 0; k < 3; ++k) st.ttrial[k] = st.aheadT[j][k];
-                st.haveTrial = 1;
-                const float errJ = static_cast<float>(sums[kColAhead + j]);
-                const float rhoJ = gain_ratio(errJ);
-                if (rhoJ > 0) {  // this one counts: the full pass at its pose, the verdict behind it
-                    st.nAhead = 0;
-                    st.body = st.pending = kBodyTrial;
-                    return false;
-                }
-                st.errNew = errJ;
-                st.rho = rhoJ;
-                st.iterations += 1;
-                reject();
-            }
+        } else {  // reject (TSDF.cpp:328-336)
+            st.mu *= st.nu;
+            st.nu *= f.prm.nuInit;
+            st.evaluateGradient = 0;
         }
+        st.haveTrial = 0;
     }
-    st.nAhead = 0;
     st.pending = 0;
-    if (st.iterations >= st.iterTarget) return false;
+    if (st.iterations >= st.iterTarget) return;
     if (st.needAccum) {
         st.body = st.pending = kBodyAccum;
-        return false;
+        return;
     }
     // the iteration proper starts here: its A, b, err (TSDF.cpp:264-275) are the sums made ahead of it
     if (st.haveSpec) adopt_sums(st, st.spec);
@@ -476,71 +420,49 @@ __device__ bool lm_verdict(emf_track_state_t& st, const double* sums, const Trac
         for (int j = 0; j < 6; ++j) maxB = fmaxf(maxB, fabsf(st.b[j]));
         if (maxB < f.prm.eps1) {
             st.converged = 1;
-            return false;
+            return;
         }
     }
-    // ---- computePoseUpdate, first half (TSDF.cpp:281-313): the damping; the solve is lm_solve ----
+    // ---- computePoseUpdate, first half (TSDF.cpp:281-313) ----
     if (st.firstIteration) {
         float maxA = st.A[0];
         for (int j = 1; j < 6; ++j) maxA = fmaxf(maxA, st.A[7 * j]);
         st.mu = f.prm.tau * maxA;
         st.firstIteration = 0;
     }
-    return true;
-}
-
-// Lanes 0 .. nAhead of a workgroup's first wave, in lock-step: lane 0 the trial step at the current damping
-// (TSDF.cpp:281-313), lane j the step that j rejections from now would ask for -- the same instructions on
-// another mu.  (A + mu I) x = b, the step-size test, the trial pose exp(-x) * pose.
-__device__ void lm_solve(emf_track_state_t& st, int lane, int nAhead, const TrackFrame& f) {
-    float mu = st.mu, nu = st.nu;
-    for (int k = 0; k < lane; ++k) {
-        mu *= nu;
-        nu *= f.prm.nuInit;
-    }
     float M[6][6], rhs[6], x[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? mu : 0.f);
+        for (int k = 0; k < 6; ++k) M[j][k] = st.A[6 * j + k] + (j == k ? st.mu : 0.f);
         rhs[j] = st.b[j];
     }
     solve6(M, rhs, x);
     float nx = 0.f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) nx += x[j] * x[j];
+    for (int j = 0; j < 6; ++j) {
+        st.x[j] = x[j];
+        nx += x[j] * x[j];
+    }
     nx = sqrtf(nx);
-    const bool small = nx < f.prm.eps2 * (st.logCur + f.prm.eps2);  // |log| of the current pose: se3_log_norm(R, t)
+    const M33 R = state_R(st.R);
+    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
+    if (nx < f.prm.eps2 * (st.logCur + f.prm.eps2)) {  // se3_log_norm(R, t)
+        st.converged = 1;
+        return;
+    }
     float mx[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) mx[j] = -x[j];
     const Se3 inc = se3_exp(mx);  // pose_incr = exp(-x); rel_pose_CO = pose_incr * rel_pose_CO
-    const M33 R = state_R(st.R);
-    const V3 t = v3(st.t[0], st.t[1], st.t[2]);
     const M33 Rn = mat_mul(inc.R, R);
     const V3 tn = mul(inc.R, t) + inc.t;
-    const float Rt[12] = {Rn.r0.x, Rn.r0.y, Rn.r0.z, Rn.r1.x, Rn.r1.y, Rn.r1.z, Rn.r2.x, Rn.r2.y, Rn.r2.z, tn.x, tn.y, tn.z};
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) st.x[j] = x[j];
-        if (small) {
-            st.converged = 1;
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) st.Rtrial[k] = Rt[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) st.ttrial[k] = Rt[9 + k];
-        st.haveTrial = 1;
-        st.body = st.pending = kBodyTrial;
-        st.nAhead = nAhead;
-    } else {
-        const int j = lane - 1;
-        for (int k = 0; k < 6; ++k) st.aheadX[j][k] = x[k];
-        for (int k = 0; k < 9; ++k) st.aheadR[j][k] = Rt[k];
-        for (int k = 0; k < 3; ++k) st.aheadT[j][k] = Rt[9 + k];
-        st.aheadConv[j] = small ? 1 : 0;
-    }
+    st.Rtrial[0] = Rn.r0.x; st.Rtrial[1] = Rn.r0.y; st.Rtrial[2] = Rn.r0.z;
+    st.Rtrial[3] = Rn.r1.x; st.Rtrial[4] = Rn.r1.y; st.Rtrial[5] = Rn.r1.z;
+    st.Rtrial[6] = Rn.r2.x; st.Rtrial[7] = Rn.r2.y; st.Rtrial[8] = Rn.r2.z;
+    st.ttrial[0] = tn.x; st.ttrial[1] = tn.y; st.ttrial[2] = tn.z;
+    st.haveTrial = 1;
+    st.body = st.pending = kBodyTrial;
 }
 
 // progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
@@ -548,14 +470,10 @@ __device__ void lm_solve(emf_track_state_t& st, int lane, int nAhead, const Trac
 __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st) {
     if (!f.watch) return;
     const uint32_t done = st.converged ? 1u : (st.pending == 0 && st.iterations >= st.iterTarget ? 2u : 0u);
-    __hip_atomic_store(f.watch + 1 + m, done | (st.sawReject ? 4u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(f.watch + 1 + m, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// kA: look-ahead poses the launch can take (0 or kAhead).  Two kernels, not two paths in one: with both copies of
-// the per-pixel loop in one kernel the plain path loses 1.5 us per launch (registers, instruction cache); the host
-// launches k_track_step<kAhead> once a model of the stage reports its first rejection (emf_hip_trackStep).
-template <int kA>
 __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame f) {  // 8 waves per SIMD: two workgroups per CU
     constexpr int kWaves = kTrackBlock / 64;
     __shared__ double sums[kCols];
@@ -622,7 +540,7 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #pragma unroll
                 for (int q = 0; q < kColsPerWave; ++q) {
                     acc[q] += static_cast<double>(v[q][j]);
-                    if (wave + q * kWaves == kColMax) mx = fmaxf(mx, v[q][j]);
+                    if (wave + q * kWaves == kCols - 1) mx = fmaxf(mx, v[q][j]);
                 }
         }
 #pragma unroll
@@ -634,25 +552,17 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
 #pragma unroll
             for (int q = 0; q < kColsPerWave; ++q) {
                 const int c = wave + q * kWaves;
-                if (c == kColMax) sums[c] = static_cast<double>(mx);
-                else if (c < kCols) sums[c] = acc[q];
+                if (c < kCols - 1) sums[c] = acc[q];
+                else if (c == kCols - 1) sums[c] = static_cast<double>(mx);
             }
         }
     }
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    if (wave == 0) {  // (wave-uniform: lane 0 judges, lanes 0 .. nAhead solve in lock-step)
-        int go = 0;
-        if (lane == 0) go = lm_verdict(st, sums, f) ? 1 : 0;
-        go = __builtin_amdgcn_readfirstlane(go);
-        if (go) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // lane 0's stores to the LDS copy, read by the other lanes
-            const int nAhead = kA > 0 && __builtin_amdgcn_readfirstlane(st.sawReject) ? min(f.ahead, kA) : 0;
-            if (lane <= nAhead) lm_solve(st, lane, nAhead, f);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (lane == 0 && blockIdx.x == 0) report(f, m, st);
+    if (threadIdx.x == 0) {
+        lm_advance(st, sums, f);
+        if (blockIdx.x == 0) report(f, m, st);
     }
     STAMP(3);
     __syncthreads();
@@ -660,8 +570,9 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     if (blockIdx.x == 0) {
         emf_track_state_t* const out = state_buf(f, m, (f.launch + 1) & 1);
         state_copy<true>(reinterpret_cast<unsigned*>(out), reinterpret_cast<const unsigned*>(&st), threadIdx.x, kTrackBlock);
-        // the new trial pose's |log| (the step-size test needs it once the pose is the current one): one lane
-        // of one workgroup, beside the per-pixel pass instead of in front of the solve
+        // the new trial pose's |log| (the step-size test needs it once the pose is the current one): one lane of one
+        // workgroup, beside the per-pixel pass -- not two lanes of every workgroup in front of the solve (the barrier
+        // behind the column sums waited 1.8 us for them; round 4)
         if (threadIdx.x == kTrackBlock - 1)
             out->logTrial = body == kBodyTrial
                                 ? se3_log_norm(state_R(st.Rtrial), v3(st.ttrial[0], st.ttrial[1], st.ttrial[2]))
@@ -686,13 +597,6 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     const int iwSel = __builtin_amdgcn_readfirstlane(st.iwSel), wSel = __builtin_amdgcn_readfirstlane(st.wSel);
     float* const wOut = scratch_w(f, m, trial ? 1 - wSel : wSel);
     float* const mine = scratch_partials(f, m, f.launch & 1);
-    // look-ahead poses (lm_verdict): only their error under the current weights is summed
-    const int nAhead = kA > 0 && trial ? __builtin_amdgcn_readfirstlane(st.nAhead) : 0;
-    const auto ahead_R = [&](int j) {
-        const float* a = st.aheadR[j];
-        return M33{{uni(a[0]), uni(a[1]), uni(a[2])}, {uni(a[3]), uni(a[4]), uni(a[5])}, {uni(a[6]), uni(a[7]), uni(a[8])}};
-    };
-    const auto ahead_t = [&](int j) { return v3(uni(st.aheadT[j][0]), uni(st.aheadT[j][1]), uni(st.aheadT[j][2])); };
     // The image in blocks of kTrackBlock pixels, one row of partial sums each -- however many of them
     // a workgroup takes (the launch sizes the grid so that all workgroups are resident at once and
     // the prologue is paid once per workgroup): the sums do not depend on the grid.
@@ -704,58 +608,22 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     // A pixel whose point is invalid or falls outside the volume's interpolation range contributes
     // exact zeros to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such
     // pixels -- most of the image, for an object -- stores its zeros and skips the arithmetic.
-    bool alive = valid && pc.z > 0 && !outside(to_voxel(mul(R, pc) + t, voxelSize, half_extent(n)), 1.f, n);
-    if constexpr (kA > 0)
-        for (int j = 0; j < nAhead; ++j)  // (a pixel may enter the volume at a look-ahead pose)
-            alive = alive || (valid && pc.z > 0 && !outside(to_voxel(mul(ahead_R(j), pc) + ahead_t(j), voxelSize, half_extent(n)), 1.f, n));
+    const bool alive = valid && pc.z > 0 && !outside(to_voxel(mul(R, pc) + t, voxelSize, half_extent(n)), 1.f, n);
     if (__ballot(alive) == 0ull) {
         if (valid) {
             if (trial) scratch_iw(f, m, 1 - iwSel)[pix] = 0.f;
             wOut[pix] = 0.f;
         }
-        if (lane < 32) red[wave][lane] = 0.f;
+        if (lane < kCols - 1) red[wave][lane] = 0.f;
         if (lane == 0) redMax[wave] = 0.f;
     } else {
-        float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f, e = 0.f, iw = 0.f, eAhead[kAhead] = {0.f, 0.f};
+        float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f, e = 0.f, iw = 0.f;
         if (valid) {
             pose_gradient(tsdf, md.grads, R, t, pc, n, voxelSize, g);
-            // getVolumeVals at the pose (lookup1); with look-ahead poses the cell's eight corners are kept for them
-            [[maybe_unused]] float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            [[maybe_unused]] size_t base = ~static_cast<size_t>(0);
-            if constexpr (kA == 0) {
-                r = lookup1(tsdf, R, t, pc, n, voxelSize);
-            } else if (pc.z > 0) {
-                const V3 v = to_voxel(mul(R, pc) + t, voxelSize, half_extent(n));
-                if (!outside(v, 1.f, n)) {
-                    const Cell c = cell_of(v, n);
-                    const size_t sy = static_cast<size_t>(n.x), sz = static_cast<size_t>(n.x) * n.y;
-                    const float* p = tsdf + c.base;
-                    c8[0] = p[0]; c8[1] = p[1]; c8[2] = p[sy]; c8[3] = p[sy + 1];
-                    c8[4] = p[sz]; c8[5] = p[sz + 1]; c8[6] = p[sz + sy]; c8[7] = p[sz + sy + 1];
-                    base = c.base;
-                    r = blend8(c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7], c.fx, c.fy, c.fz);
-                }
-            }
+            r = lookup1(tsdf, R, t, pc, n, voxelSize);
             if (trial) {
                 // computeError at the trial pose under the current weights (TSDF.cpp:390-394) ...
-                const float wCur = scratch_w(f, m, wSel)[pix];
-                e = (r * r) * wCur;
-                // ... and at the look-ahead poses: a few 1e-3 voxels from the trial's, nearly always in the
-                // same cell -- the same eight corners under other fractions; gathered anew where not
-                if constexpr (kA > 0) {
-#pragma unroll
-                    for (int j = 0; j < kA; ++j)
-                        if (j < nAhead && pc.z > 0) {
-                            const V3 vj = to_voxel(mul(ahead_R(j), pc) + ahead_t(j), voxelSize, half_extent(n));
-                            if (!outside(vj, 1.f, n)) {
-                                const Cell cj = cell_of(vj, n);
-                                const float rj = cj.base == base
-                                                     ? blend8(c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7], cj.fx, cj.fy, cj.fz)
-                                                     : trilinear1(tsdf, cj, n);
-                                eAhead[j] = (rj * rj) * wCur;
-                            }
-                        }
-                }
+                e = (r * r) * scratch_w(f, m, wSel)[pix];
                 // ... and the clamped integration weights there: the next iteration's if the step is accepted
                 iw = fminf(lookup1(weights, R, t, pc, n, voxelSize), f.prm.maxWeight);  // TSDF.cpp:234
                 scratch_iw(f, m, 1 - iwSel)[pix] = iw;
@@ -796,26 +664,23 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
             for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
             s[q++] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
             s[q++] = e;
-            s[13] = eAhead[0];
-            s[14] = eAhead[1];
-            s[15] = 0.f;
+            s[13] = s[14] = s[15] = 0.f;
             wave_sum16(s, lane);
-            // values 0..12 are columns 16..28; 13 and 14 the look-ahead columns behind the maximum's
-            if (!(lane & 3) && (lane >> 2) < 15) red[wave][(lane >> 2) < 13 ? 16 + (lane >> 2) : kColAhead - 13 + (lane >> 2)] = s[0];
+            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) red[wave][16 + (lane >> 2)] = s[0];
         }
         const float wmx = wave_max(fabsf(iw));
         if (lane == 0) redMax[wave] = wmx;
     }
     __syncthreads();
-    if (threadIdx.x == kColMax) {
-        float v = redMax[0];
-        for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
-        mine[static_cast<size_t>(kColMax) * f.nblocks + blk] = v;
-    } else if (threadIdx.x < kCols) {
+    if (threadIdx.x < kCols - 1) {
         float v = red[0][threadIdx.x];
         for (int i = 1; i < kWaves; ++i) v += red[i][threadIdx.x];
         // component-major: the next prologue reads each component contiguously
         mine[static_cast<size_t>(threadIdx.x) * f.nblocks + blk] = v;
+    } else if (threadIdx.x == kCols - 1) {
+        float v = redMax[0];
+        for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
+        mine[static_cast<size_t>(kCols - 1) * f.nblocks + blk] = v;
     }
     }
     STAMP(6);
@@ -882,15 +747,7 @@ __global__ void k_track_prepare(const PrepareArgs a) {
     st.checkB = 0;
     st.pending = st.body = 0;
     st.iterTarget = 0;
-    st.logCur = se3_log_norm(state_R(st.R), v3(st.t[0], st.t[1], st.t[2]));
-    st.logTrial = st.logCur;
-    st.sawReject = st.nAhead = 0;
-    for (int j = 0; j < kAhead; ++j) {
-        for (int k = 0; k < 6; ++k) st.aheadX[j][k] = 0.f;
-        for (int k = 0; k < 9; ++k) st.aheadR[j][k] = 0.f;
-        for (int k = 0; k < 3; ++k) st.aheadT[j][k] = 0.f;
-        st.aheadConv[j] = 0;
-    }
+    st.logCur = st.logTrial = se3_log_norm(state_R(st.R), v3(st.t[0], st.t[1], st.t[2]));
     a.states[m] = st;
 }
 
@@ -949,10 +806,6 @@ int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* 
     f.prm = *prm;
     f.scratch = static_cast<char*>(scratch_dev);
     f.scratchStride = scratchBytesPerModel;
-    // EMF_TRACK_AHEAD=0: every trial step gets its own launch (A/B and the flow test; read per call)
-    const char* const ah = std::getenv("EMF_TRACK_AHEAD");
-    f.ahead = ah ? std::max(0, std::min(kAhead, std::atoi(ah))) : kAhead;  // (emf_hip_trackStep: at most its argument)
-
     if (scratchBytesPerModel < emf_hip_trackScratchBytes(f.w, f.h) || scratchBytesPerModel % 16)
         return fail(EMF_E_ARG, "%s: scratch of %zu bytes per model, need %zu (multiple of 16)", fn,
                     scratchBytesPerModel, emf_hip_trackScratchBytes(f.w, f.h));
@@ -1000,9 +853,8 @@ void enqueue_step(TrackFrame& f, int nmodels, int launch, hipStream_t s) {
     // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
     const int perModel = std::max(1, std::min(f.nblocks, 2 * compute_units() / nmodels));
     f.launch = launch;
-    const dim3 grid(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels));
-    if (f.ahead > 0) hipLaunchKernelGGL(k_track_step<kAhead>, grid, dim3(kTrackBlock), 0, s, f);
-    else hipLaunchKernelGGL(k_track_step<0>, grid, dim3(kTrackBlock), 0, s, f);
+    hipLaunchKernelGGL(k_track_step, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
+                       dim3(kTrackBlock), 0, s, f);
 }
 }  // namespace
 
@@ -1027,14 +879,12 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
 
 int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                       const emf_image_t* points, const emf_track_params_t* params,
-                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations, int ahead,
+                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
                       uint32_t* watch, uint32_t seq, emf_stream_t stream) {
     TrackFrame f;
     EMF_TRY(fill_frame(f, models_dev, states_dev, nmodels, points, params, scratch_dev,
                        scratchBytesPerModel, "trackStep"));
     if (launch < 0 || iterations < 0) return fail(EMF_E_ARG, "trackStep: launch = %d, iterations = %d", launch, iterations);
-    if (ahead < 0 || ahead > EMF_TRACK_AHEAD) return fail(EMF_E_ARG, "trackStep: ahead = %d, expected 0..%d", ahead, EMF_TRACK_AHEAD);
-    f.ahead = std::min(f.ahead, ahead);
     f.iterations = iterations;
     f.watch = watch;
     f.seq = seq;
@@ -1088,5 +938,5 @@ int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const em
 
 }  // extern "C"
 
-static_assert(sizeof(emf_track_state_t) == 652, "emf_track_state_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_track_state_t) == 492, "emf_track_state_t layout is mirrored in _lib.py");
 static_assert(sizeof(emf_model_t) == 168, "emf_model_t layout is mirrored in _lib.py");

@@ -528,12 +528,11 @@ def track_iterate(models_dev, states_dev, nmodels, points, params, scratch, scra
 
 
 def track_step(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model, launch,
-               iterations, watch=None, seq=0, stream=None, ahead=0):
-    """One launch of the LM step kernel (emf_hip_trackStep); watch: address of host-pinned uint32s or None;
-    ahead: look-ahead poses the launch may evaluate (0..2)."""
+               iterations, watch=None, seq=0, stream=None):
+    """One launch of the LM step kernel (emf_hip_trackStep); watch: address of host-pinned uint32s or None."""
     check("emf_hip_trackStep",
           _L.emf_hip_trackStep(_ptr(models_dev), _ptr(states_dev), nmodels, C.byref(image_view(points)),
-                               C.byref(params), _ptr(scratch), scratch_per_model, launch, iterations, ahead,
+                               C.byref(params), _ptr(scratch), scratch_per_model, launch, iterations,
                                watch, seq, _stream(stream)))
 
 

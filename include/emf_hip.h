@@ -746,7 +746,6 @@ typedef struct emf_track_params {
 /* Per-model Levenberg-Marquardt state (device memory; read it back after synchronising).
  * R, t = rel_pose_CO (camera -> volume), the quantity TSDF::prepareTracking sets up and
  * TSDF::syncTrack converts back: cam_pose = pose * rel_pose_CO. */
-#define EMF_TRACK_AHEAD 2
 typedef struct emf_track_state {
     float R[9], t[3];
     float Rtrial[9], ttrial[3];
@@ -772,16 +771,8 @@ typedef struct emf_track_state {
     int32_t body;              /* what the current launch does per pixel (same codes) */
     int32_t iterTarget;        /* `iterations` at which the current trackIterate call stops */
     /* |log| of the two poses (the step-size test of TSDF.cpp:292-296 needs the current pose's): kept with
-     * the poses so that no launch has to make them in front of its solve */
+     * the poses, so that no launch has to make them in front of its solve */
     float logCur, logTrial;
-    /* look-ahead past a rejected step: a rejection changes nothing but the damping, so the trial poses of
-     * the next EMF_TRACK_AHEAD damping values are known together with the trial's; the launch that evaluates
-     * the trial also sums their errors, and the next launch judges the whole run (see k_track_step) */
-    int32_t sawReject;         /* a step of this stage has been rejected: look-ahead is on from then */
-    int32_t nAhead;            /* look-ahead poses the pending launch evaluates (0..EMF_TRACK_AHEAD) */
-    float aheadX[EMF_TRACK_AHEAD][6];
-    float aheadR[EMF_TRACK_AHEAD][9], aheadT[EMF_TRACK_AHEAD][3];
-    int32_t aheadConv[EMF_TRACK_AHEAD]; /* the step-size test ends the stage at this damping value */
 } emf_track_state_t;
 
 /* bytes of scratch per model for emf_hip_trackIterate on a width x height image */
@@ -817,22 +808,15 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
  * maximum pass and lets every model do `iterations` more iterations) and has the device report to
  * `watch`, which must be host memory the device can write (hipHostMalloc, coherent):
  *   watch[0]      <- seq when the launch has begun (any nonzero number the caller increases per launch),
- *   watch[1 + m]  <- bits 0-1: 1 when model m has converged, 2 when it has done its iterations, else 0;
- *                    bit 2 (value 4): a step of model m has been rejected in this stage.
+ *   watch[1 + m]  <- 1 when model m has converged, 2 when it has done its iterations, else 0.
  * These are hints to stop enqueuing (written with system-scope stores while the stream runs: keep a
- * few launches ahead of watch[0], stop when every watch[1 + m] & 3 != 0); the states are read as usual.
- * ahead: look-ahead poses the launch may evaluate, 0..EMF_TRACK_AHEAD (see emf_track_state_t): a rejected
- * step's successors are judged by the same launch, a run of rejections costs one launch instead of one per
- * step.  Any value, changing from launch to launch, gives the same states; the launch that can look ahead is
- * the slower one per launch, so pass 0 until some watch[1 + m] & 4 is set (an LM stage accepts its first
- * 8-12 steps one after the other and meets rejections, in runs, from then on), EMF_TRACK_AHEAD after that.
- * (emf_hip_trackIterate always looks ahead.  EMF_TRACK_AHEAD=0 in the environment: never.)
+ * few launches ahead of watch[0], stop when every watch[1 + m] != 0); the states are read as usual.
  * The number of launches of a stage must be even (the state alternates between the caller's array
  * and a shadow in the scratch): end with one more launch if it is not -- a launch with nothing to
  * do returns at once.  watch may be NULL. */
 int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                       const emf_image_t* points, const emf_track_params_t* params,
-                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations, int ahead,
+                      void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
                       uint32_t* watch, uint32_t seq, emf_stream_t stream);
 
 /* The two weight images a stage leaves behind, as the reference's debug output reads them at the end of a frame

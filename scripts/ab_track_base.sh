@@ -14,7 +14,6 @@ print('$1: %.1f frames/s  %.4f ms/frame%s' % (d['value'], d['ms_per_step'], '  s
 }
 for rep in 1 2 ${REPS}; do
   cp build_tmp/base/$P/*.so $P/; run "base       "
-  cp /tmp/ab_new/*.so $P/
-  for A in ${AHEADS:-0 2}; do EMF_TRACK_AHEAD=$A run "new ahead=$A"; done
+  cp /tmp/ab_new/*.so $P/; run "tree       "
 done
 cp /tmp/ab_new/*.so $P/

@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: launches of every tracking stage of the tracked bench against the LM steps it judged (EMF_TRACK_LOG), in tens of frames
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 EMF_TRACK_LOG=1 python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-stats-replay --no-target --track 2>&1 | grep "track stage" > /tmp/stages.txt
 python - <<'PY'

@@ -4,10 +4,8 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 for WG in ${WGS:-0 100 260 280 299}; do
   touch emfusion_amd/csrc/tracking.hip
   make -s -C emfusion_amd/csrc -j8 EXTRA="-DEMF_TRACK_TRACE=$WG $TRACK_EXTRA" > /tmp/tb.log 2>&1 || { tail -5 /tmp/tb.log; exit 1; }
-  for A in ${AHEADS:-2}; do
-  echo "== EMF_TRACK_TRACE=$WG EMF_TRACK_AHEAD=$A"
-  EMF_TRACK_AHEAD=$A python scripts/track_step_trace.py 2>&1 | tail -${TAIL:-16}
-  done
+  echo "== EMF_TRACK_TRACE=$WG"
+  python scripts/track_step_trace.py 2>&1 | tail -${TAIL:-16}
 done
 touch emfusion_amd/csrc/tracking.hip
 make -s -C emfusion_amd/csrc -j8 > /tmp/tb.log 2>&1

@@ -204,43 +204,6 @@ def test_split_calls_equal_one_call(ops, dev, world):
         assert _fields(one[k]) == _fields(parts[k]), k
 
 
-FLOW = LEGACY + ("wSel", "needAccum", "haveSpec", "spec", "checkB", "pending", "body", "logCur", "sawReject")
-
-
-@pytest.mark.parametrize("chunks", [(100,), (7,) * 15, (1,) * 40, (3, 1, 30, 2, 64)], ids=["one", "7s", "1s", "mixed"])
-def test_look_ahead_past_rejected_steps_equals_a_launch_per_step(ops, dev, world, monkeypatch, chunks):
-    """A launch also sums the error at the poses the next damping values of a rejected step would give and the
-    next launch judges the whole run of rejections (k_track_step, lm_verdict): every field the reference's flow
-    keeps goes through the same values as with one launch per trial step (EMF_TRACK_AHEAD=0) -- after every
-    call, whatever the calls' budgets (a budget may end inside a run).  (Not compared: maxIwTrialBits and logTrial,
-    which belong to the last trial that got a full pass and are read only once such a trial is accepted.)"""
-    def run(ahead, w, which):
-        monkeypatch.setenv("EMF_TRACK_AHEAD", str(ahead))
-        dt = DeviceTracker(ops, w, which)
-        out, want = [], 0
-        for n in chunks:
-            # a call's launches cover its budget unless speculation misses took some (the ramped world): call again,
-            # so that both flows are compared where the budget ends and not where the launches ran out
-            want += n
-            for _ in range(40):
-                sts = dt.iterate(max(0, want - min(st.iterations for st in sts)) if _ else n)
-                if all(st.converged or (st.iterations >= want and st.pending == 0) for st in sts):
-                    break
-            else:
-                raise AssertionError("the stage does not advance")
-            out.append([{k: (np.array(v).tolist() if hasattr(v, "__len__") else v) for k in FLOW for v in [getattr(st, k)]}
-                        for st in sts])
-        return out
-    for w, which in ((world, [0, 1]), (_ramped(world), [0])):
-        plain, ahead = run(0, w, which), run(2, w, which)
-        for call, (a, b) in enumerate(zip(plain, ahead)):
-            for k in range(len(which)):
-                assert a[k] == b[k], (call, k, [n for n in FLOW if a[k][n] != b[k][n]])
-        # the stage met rejections (so there was something to look past) and ended
-        assert all(st["sawReject"] == 1 for st in plain[-1]), [st["iterations"] for st in plain[-1]]
-        assert all(st["iterations"] > st["accepted"] + 1 for st in plain[-1])
-
-
 def _ramped(world):
     """The same world with integration weights that grow along x: their maximum over the image
     changes with the pose, so the speculative Hessian sums of every accepted step are normalised
@@ -310,30 +273,24 @@ def test_launch_by_launch_with_progress_words(ops, dev, world):
     states say (here in device memory and read back; EMFusion::trackModels points them at pinned host
     memory and reads them while the stream runs)."""
     ref = DeviceTracker(ops, world, [0, 1]).iterate(100)
-    counts = {}
-    for policy in ("never", "always", "as the host does"):
-        dt = DeviceTracker(ops, world, [0, 1])
-        watch = dev_full((3,), 0, np.uint32)
-        launch, ahead = 0, 2 if policy == "always" else 0
-        while True:
-            for _ in range(8):
-                ops.track_step(dt.table, dt.states, dt.n, dt.points, dt.params, dt.scratch, dt.per_model, launch, 100,
-                               watch.ptr, launch + 1, ahead=ahead)
-                launch += 1
-            w = to_np(watch)
-            assert w[0] == launch
-            if policy == "as the host does" and ((w[1] | w[2]) & 4):  # a model has met its first rejection
-                ahead = 2
-            if (w[1] & 3) and (w[2] & 3):
-                break
-            assert launch < 220
-        sts = ops.read_track_states(dt.states, 2)  # (an even number of launches: the state is in the caller's array)
-        for k in (0, 1):
-            assert _fields(sts[k]) == _fields(ref[k]), policy
-            assert (w[1 + k] & 3) == (1 if sts[k].converged else 2)
-            assert bool(w[1 + k] & 4) == bool(sts[k].sawReject)
-        assert launch < 100  # both converge long before the iteration budget
-        counts[policy] = launch
+    dt = DeviceTracker(ops, world, [0, 1])
+    watch = dev_full((3,), 0, np.uint32)
+    launch = 0
+    while True:
+        for _ in range(8):
+            ops.track_step(dt.table, dt.states, dt.n, dt.points, dt.params, dt.scratch, dt.per_model, launch, 100,
+                           watch.ptr, launch + 1)
+            launch += 1
+        w = to_np(watch)
+        assert w[0] == launch
+        if w[1] and w[2]:
+            break
+        assert launch < 220
+    sts = ops.read_track_states(dt.states, 2)  # (an even number of launches: the state is in the caller's array)
+    for k in (0, 1):
+        assert _fields(sts[k]) == _fields(ref[k])
+        assert w[1 + k] == (1 if sts[k].converged else 2)
+    assert launch < 100  # both converge long before the iteration budget
 
 
 def test_gradient_volume_gives_the_same_states(oracle, ops, dev, world):
