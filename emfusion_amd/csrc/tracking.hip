@@ -36,6 +36,8 @@
 // tree, versions unpinned): these agree with the oracle to float rounding, not bit for bit.
 #include <atomic>
 #include <cstddef>
+#include <cstdlib>
+#include <algorithm>
 
 #include "device_core.hpp"
 
@@ -47,7 +49,15 @@ namespace {
                               // (scripts/ab_track_block.sh): 512: 1.34 ms, 640: 1.04, 768: 1.03, 1024: 0.96 -- fewer, fatter workgroups win:
                               // every workgroup pays the prologue, and its cost grows with the number of rows
 #endif
-constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // pixels per workgroup
+constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // threads per workgroup
+#ifndef EMF_TRACK_ROW_EXTRA
+#define EMF_TRACK_ROW_EXTRA 192  // 640 x 480 pixels in rows of 1024 are 300 rows for 256 CUs: 44 CUs carry two workgroups and the
+                                 // launch ends with them (20.4 us against 16.3).  Rows of 1024 + 192 pixels are 253: a workgroup
+                                 // per CU, the first three waves take a second pixel
+#endif
+constexpr int kRowExtra = EMF_TRACK_ROW_EXTRA;          // pixels of a row beyond the workgroup's lanes (whole waves)
+constexpr int kRowPixels = kTrackBlock + kRowExtra;     // pixels per row of partial sums
+static_assert(kRowExtra % 64 == 0 && kRowExtra >= 0 && kRowExtra <= kTrackBlock, "whole waves take a second pixel");
 constexpr int kCols = 30;          // partial-sum columns per workgroup: 21 (upper triangle of A) + 6 (b) + 1
                                    // (error), + the trial step's error + max |integration weight| at the
                                    // trial pose (k_track_step)
@@ -94,9 +104,11 @@ __device__ __forceinline__ M33 state_R(const float* R) {
     return M33{{R[0], R[1], R[2]}, {R[3], R[4], R[5]}, {R[6], R[7], R[8]}};
 }
 
-// pixel of this lane: blockIdx.x covers the image in runs of kTrackBlock pixels, blockIdx.y = model
-__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc, unsigned block = blockIdx.x) {
-    pix = static_cast<size_t>(block) * kTrackBlock + threadIdx.x;
+// pixel of this lane: the image in runs of `run` pixels (rows of partial sums: kRowPixels, the lanes' first pixel
+// at offset 0, the second one of the first waves at kTrackBlock), blockIdx.y = model
+__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc, unsigned block = blockIdx.x,
+                                           int run = kTrackBlock, int offset = 0) {
+    pix = static_cast<size_t>(block) * run + offset + threadIdx.x;
     pc = v3(0.f, 0.f, 0.f);
     if (pix >= static_cast<size_t>(f.w) * f.h) return false;
     const int y = static_cast<int>(pix / f.w), x = static_cast<int>(pix - static_cast<size_t>(y) * f.w);
@@ -465,6 +477,121 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
     st.body = st.pending = kBodyTrial;
 }
 
+// ---- the per-pixel pass of k_track_step -----------------------------------------------------------
+// What a pixel contributes: pose gradient (6), residual, combined weight, the trial step's error term, the clamped
+// integration weight.
+struct PixelTerms {
+    float g[6], r, w, e, iw;
+};
+struct PixelPass {  // (wave-uniform)
+    const float* tsdf;
+    const float* weights;
+    const float* grads;
+    const float* assoc;
+    I3 n;
+    float voxelSize;
+    M33 R;
+    V3 t;
+    bool trial;
+    float scale, huberThresh, maxWeight;
+    const float* wCur;   // the weight image of the current pose (trial: read for the step's error)
+    float* wOut;         // the weight image this pass fills
+    const float* iwCur;  // clamped integration weights at the current pose (read when the pass is at that pose)
+    float* iwOut;        // ... at the trial pose (filled by a trial pass)
+};
+
+// One pixel, the reference's operators one by one (TSDF.cu:603-637, 662-688; TSDF.cpp:212-262, 390-394), each lookup
+// behind its own tests: three dependent rounds of gathers.  The form the 64-register kernel can afford.
+__device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid, size_t pix, const V3& pc) {
+    PixelTerms o;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.g[k] = 0.f;
+    o.r = o.w = o.e = o.iw = 0.f;
+    if (!valid) return o;
+    pose_gradient(a.tsdf, a.grads, a.R, a.t, pc, a.n, a.voxelSize, o.g);
+    o.r = lookup1(a.tsdf, a.R, a.t, pc, a.n, a.voxelSize);
+    if (a.trial) {
+        // computeError at the trial pose under the current weights (TSDF.cpp:390-394) ...
+        o.e = (o.r * o.r) * a.wCur[pix];
+        // ... and the clamped integration weights there: the next iteration's if the step is accepted
+        o.iw = fminf(lookup1(a.weights, a.R, a.t, pc, a.n, a.voxelSize), a.maxWeight);  // TSDF.cpp:234
+        a.iwOut[pix] = o.iw;
+    } else {
+        o.iw = a.iwCur[pix];
+    }
+    const float ab = fabsf(o.r);
+    float tw = ab != 0.f ? a.huberThresh / ab : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
+    tw = fminf(tw, 1.0f);
+    float w = o.iw * a.scale;
+    w = tw * w;              // multiply(trackWeights, intWeights)
+    w = w * a.assoc[pix];    // multiply(intWeights, associationWeights)
+    a.wOut[pix] = w;
+    o.w = w;
+    return o;
+}
+
+// The same values with every load in front of every use: the tests become selects, a pixel outside the volume (or the
+// image) reads voxel 0 / pixel 0 and drops what it read, the 20 tsdf values of the cell and its forward differences,
+// the 8 weights and the three per-pixel images are requested in one batch -- one round trip instead of three.  Needs
+// the registers of the kernel that runs one workgroup per CU (k_track_step<true>); on-the-fly gradients only.
+__device__ __forceinline__ PixelTerms pixel_terms_batched(const PixelPass& a, bool valid, size_t pix, const V3& pc) {
+    const bool zpos = valid && pc.z > 0;
+    const V3 p = mul(a.R, pc) + a.t;
+    const V3 v = to_voxel(p, a.voxelSize, half_extent(a.n));
+    const bool in1 = zpos && !outside(v, 1.f, a.n);  // getVolumeVals' range (TSDF.cu:676-683)
+    const bool in2 = zpos && !outside(v, 2.f, a.n);  // computePoseGradients' (TSDF.cu:617-624)
+    const Cell c = cell_of(in1 ? v : v3(0.f, 0.f, 0.f), a.n);
+    const size_t sy = static_cast<size_t>(a.n.x), sz = sy * a.n.y;
+    const size_t x2 = in2 ? 2 : 0, y2 = in2 ? 2 * sy : 0, z2 = in2 ? 2 * sz : 0;
+    const float* q = a.tsdf + c.base;
+    // the cell's corners (z, y, x) ...
+    const float c000 = q[0], c001 = q[1], c010 = q[sy], c011 = q[sy + 1];
+    const float c100 = q[sz], c101 = q[sz + 1], c110 = q[sz + sy], c111 = q[sz + sy + 1];
+    // ... and the voxels one further along each axis
+    const float x00 = q[x2], x01 = q[sy + x2], x10 = q[sz + x2], x11 = q[sz + sy + x2];
+    const float y00 = q[y2], y01 = q[y2 + 1], y10 = q[sz + y2], y11 = q[sz + y2 + 1];
+    const float z00 = q[z2], z01 = q[z2 + 1], z10 = q[z2 + sy], z11 = q[z2 + sy + 1];
+    const float* qw = a.weights + c.base;
+    const float w000 = qw[0], w001 = qw[1], w010 = qw[sy], w011 = qw[sy + 1];
+    const float w100 = qw[sz], w101 = qw[sz + 1], w110 = qw[sz + sy], w111 = qw[sz + sy + 1];
+    const size_t pp = valid ? pix : 0;
+    const float wCur = a.wCur[pp], iwCur = a.iwCur[pp], assoc = a.assoc[pp];
+    PixelTerms o;
+    // forward differences at the eight corners, blended (gradient_at), / voxelSize (TSDF.cu:626-630)
+    const float gx = blend8(c001 - c000, x00 - c001, c011 - c010, x01 - c011, c101 - c100, x10 - c101, c111 - c110, x11 - c111,
+                            c.fx, c.fy, c.fz);
+    const float gy = blend8(c010 - c000, c011 - c001, y00 - c010, y01 - c011, c110 - c100, c111 - c101, y10 - c110, y11 - c111,
+                            c.fx, c.fy, c.fz);
+    const float gz = blend8(c100 - c000, c101 - c001, c110 - c010, c111 - c011, z00 - c100, z01 - c101, z10 - c110, z11 - c111,
+                            c.fx, c.fy, c.fz);
+    const V3 gt = v3(gx, gy, gz) / a.voxelSize;
+    const M33 S{{0.f, -p.z, p.y}, {p.z, 0.f, -p.x}, {-p.y, p.x, 0.f}};
+    const V3 gr = mul(S, gt);
+    o.g[0] = in2 ? gt.x : 0.f; o.g[1] = in2 ? gt.y : 0.f; o.g[2] = in2 ? gt.z : 0.f;
+    o.g[3] = in2 ? gr.x : 0.f; o.g[4] = in2 ? gr.y : 0.f; o.g[5] = in2 ? gr.z : 0.f;
+    const float rIn = blend8(c000, c001, c010, c011, c100, c101, c110, c111, c.fx, c.fy, c.fz);
+    o.r = in1 ? rIn : 0.f;
+    const float iwIn = blend8(w000, w001, w010, w011, w100, w101, w110, w111, c.fx, c.fy, c.fz);
+    o.e = a.trial ? (o.r * o.r) * wCur : 0.f;
+    o.iw = a.trial ? fminf(in1 ? iwIn : 0.f, a.maxWeight) : iwCur;
+    const float ab = fabsf(o.r);
+    float tw = ab != 0.f ? a.huberThresh / ab : 0.f;
+    tw = fminf(tw, 1.0f);
+    float w = o.iw * a.scale;
+    w = tw * w;
+    w = w * assoc;
+    o.w = w;
+    if (valid) {
+        if (a.trial) a.iwOut[pix] = o.iw;
+        a.wOut[pix] = w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o.g[k] = 0.f;
+        o.r = o.w = o.e = o.iw = 0.f;
+    }
+    return o;
+}
+
 // progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
 // go to the host's memory while the kernel runs
 __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st) {
@@ -474,7 +601,11 @@ __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_tra
     if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame f) {  // 8 waves per SIMD: two workgroups per CU
+// kWide: the launch has at most one workgroup per CU (a single model: the camera stage): 128 registers instead of 64,
+// every load of a pixel in one batch (pixel_terms_batched), the two pixels of a wave that has two side by side.
+// Same values, same sums: which kernel runs is the host's choice and changes no bit of the state.
+template <bool kWide>
+__global__ __launch_bounds__(kTrackBlock, kWide ? 4 : 8) void k_track_step(const TrackFrame f) {  // waves per SIMD: one / two workgroups per CU
     constexpr int kWaves = kTrackBlock / 64;
     __shared__ double sums[kCols];
     __shared__ emf_track_state_t st;
@@ -507,12 +638,9 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
     const emf_model_t& md = f.models[m];
     const I3 n{md.res[0], md.res[1], md.res[2]};
-    const float voxelSize = md.voxelSize;
-    const float* const tsdf = md.tsdf;
-    const float* const weights = md.weights;
     size_t pix;
     V3 pc;
-    bool valid = load_point(f, pix, pc);  // (the first block's points: fetched under the prologue)
+    bool valid = load_point(f, pix, pc, blockIdx.x, kRowPixels, 0);  // (the first row's points: fetched under the prologue)
     // ---- prologue ----
     if (in->pending != 0) {  // (uniform: read from global memory, not from the copy in flight)
         // lane-strided partial sums in double, then a fixed xor tree -- the same order on every run.
@@ -586,102 +714,131 @@ __global__ __launch_bounds__(kTrackBlock, 8) void k_track_step(const TrackFrame 
     const bool trial = body == kBodyTrial;
     const float* Rp = trial ? st.Rtrial : st.R;
     const float* tp = trial ? st.ttrial : st.t;
-    const M33 R{{uni(Rp[0]), uni(Rp[1]), uni(Rp[2])}, {uni(Rp[3]), uni(Rp[4]), uni(Rp[5])}, {uni(Rp[6]), uni(Rp[7]), uni(Rp[8])}};
-    const V3 t = v3(uni(tp[0]), uni(tp[1]), uni(tp[2]));
+    PixelPass a;
+    a.tsdf = md.tsdf;
+    a.weights = md.weights;
+    a.grads = md.grads;
+    a.assoc = md.assoc;
+    a.n = n;
+    a.voxelSize = md.voxelSize;
+    a.R = M33{{uni(Rp[0]), uni(Rp[1]), uni(Rp[2])}, {uni(Rp[3]), uni(Rp[4]), uni(Rp[5])}, {uni(Rp[6]), uni(Rp[7]), uni(Rp[8])}};
+    a.t = v3(uni(tp[0]), uni(tp[1]), uni(tp[2]));
+    a.trial = trial;
     // cv::cuda::normalize(NORM_INF, alpha = 1): scale = norm > DBL_EPSILON ? 1 / norm : 0
     // (trial: the current pose's maximum, assumed to hold at the trial pose as well -- checked by
     // the next prologue)
     const float mx = __uint_as_float(__builtin_amdgcn_readfirstlane(st.maxIwBits));
-    const float scale = uni(static_cast<double>(mx) > 2.220446049250313e-16
-                                ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f);
+    a.scale = uni(static_cast<double>(mx) > 2.220446049250313e-16 ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f);
+    a.huberThresh = f.prm.huberThresh;
+    a.maxWeight = f.prm.maxWeight;
     const int iwSel = __builtin_amdgcn_readfirstlane(st.iwSel), wSel = __builtin_amdgcn_readfirstlane(st.wSel);
-    float* const wOut = scratch_w(f, m, trial ? 1 - wSel : wSel);
+    a.wCur = scratch_w(f, m, wSel);
+    a.wOut = scratch_w(f, m, trial ? 1 - wSel : wSel);
+    a.iwCur = scratch_iw(f, m, iwSel);
+    a.iwOut = scratch_iw(f, m, 1 - iwSel);
     float* const mine = scratch_partials(f, m, f.launch & 1);
-    // The image in blocks of kTrackBlock pixels, one row of partial sums each -- however many of them
-    // a workgroup takes (the launch sizes the grid so that all workgroups are resident at once and
-    // the prologue is paid once per workgroup): the sums do not depend on the grid.
-    for (unsigned blk = blockIdx.x; blk < static_cast<unsigned>(f.nblocks); blk += gridDim.x) {
-    if (blk != blockIdx.x) {
-        __syncthreads();  // red[] of the previous block has been read
-        valid = load_point(f, pix, pc, blk);
-    }
+    const bool batched = kWide && a.grads == nullptr;  // (uniform)
+    // A pixel's 28 products As = (g_j * g_k) * w, bs = (r * g_j) * w, r^2 w (computeAb / multSingletonCol; column
+    // order: the upper triangle of A row by row (21), b (6), err) and the trial step's error, summed over the wave
+    // into the wave's line of red[] (`first`: stored, else added to what the wave's first pixels left there)
+    const auto accumulate = [&](const PixelTerms& o, bool first) {
+        {
+            float s[16];
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = j; k < 6; ++k)
+                    if (6 * j - j * (j - 1) / 2 + (k - j) < 16) s[q++] = (o.g[j] * o.g[k]) * o.w;
+            wave_sum16(s, lane);
+            if (!(lane & 3)) red[wave][lane >> 2] = first ? s[0] : red[wave][lane >> 2] + s[0];
+        }
+        {
+            float s[16];
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int k = j; k < 6; ++k)
+                    if (6 * j - j * (j - 1) / 2 + (k - j) >= 16) s[q++] = (o.g[j] * o.g[k]) * o.w;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s[q++] = (o.r * o.g[j]) * o.w;
+            s[q++] = (o.r * o.r) * o.w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
+            s[q++] = o.e;
+            s[13] = s[14] = s[15] = 0.f;
+            wave_sum16(s, lane);
+            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1)
+                red[wave][16 + (lane >> 2)] = first ? s[0] : red[wave][16 + (lane >> 2)] + s[0];
+        }
+        const float wmx = wave_max(fabsf(o.iw));
+        if (lane == 0) redMax[wave] = first ? wmx : fmaxf(redMax[wave], wmx);
+    };
     // A pixel whose point is invalid or falls outside the volume's interpolation range contributes
     // exact zeros to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such
     // pixels -- most of the image, for an object -- stores its zeros and skips the arithmetic.
-    const bool alive = valid && pc.z > 0 && !outside(to_voxel(mul(R, pc) + t, voxelSize, half_extent(n)), 1.f, n);
-    if (__ballot(alive) == 0ull) {
-        if (valid) {
-            if (trial) scratch_iw(f, m, 1 - iwSel)[pix] = 0.f;
-            wOut[pix] = 0.f;
+    const auto alive_at = [&](bool valid_, const V3& pc_) {
+        return valid_ && pc_.z > 0 && !outside(to_voxel(mul(a.R, pc_) + a.t, a.voxelSize, half_extent(n)), 1.f, n);
+    };
+    const auto dead_wave = [&](bool valid_, size_t pix_, bool first) {
+        if (valid_) {
+            if (trial) a.iwOut[pix_] = 0.f;
+            a.wOut[pix_] = 0.f;
         }
-        if (lane < kCols - 1) red[wave][lane] = 0.f;
-        if (lane == 0) redMax[wave] = 0.f;
-    } else {
-        float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r = 0.f, w = 0.f, e = 0.f, iw = 0.f;
-        if (valid) {
-            pose_gradient(tsdf, md.grads, R, t, pc, n, voxelSize, g);
-            r = lookup1(tsdf, R, t, pc, n, voxelSize);
-            if (trial) {
-                // computeError at the trial pose under the current weights (TSDF.cpp:390-394) ...
-                e = (r * r) * scratch_w(f, m, wSel)[pix];
-                // ... and the clamped integration weights there: the next iteration's if the step is accepted
-                iw = fminf(lookup1(weights, R, t, pc, n, voxelSize), f.prm.maxWeight);  // TSDF.cpp:234
-                scratch_iw(f, m, 1 - iwSel)[pix] = iw;
+        if (first) {
+            if (lane < kCols - 1) red[wave][lane] = 0.f;
+            if (lane == 0) redMax[wave] = 0.f;
+        }
+    };
+    // The image in rows of kRowPixels pixels, one row of partial sums each -- however many of them a workgroup
+    // takes (the launch sizes the grid so that all workgroups are resident at once and the prologue is paid once
+    // per workgroup): the sums do not depend on the grid, nor on which of the two kernels runs.  A row is the
+    // workgroup's lanes once plus a second pixel for its first waves.
+    const bool second = wave < kRowExtra / 64;  // (uniform per wave)
+    for (unsigned blk = blockIdx.x; blk < static_cast<unsigned>(f.nblocks); blk += gridDim.x) {
+        if (blk != blockIdx.x) {
+            __syncthreads();  // red[] of the previous row has been read
+            valid = load_point(f, pix, pc, blk, kRowPixels, 0);
+        }
+        size_t pix2 = 0;
+        V3 pc2 = v3(0.f, 0.f, 0.f);
+        const bool valid2 = second && load_point(f, pix2, pc2, blk, kRowPixels, kTrackBlock);
+        const bool live1 = __ballot(alive_at(valid, pc)) != 0ull;
+        const bool live2 = second && __ballot(alive_at(valid2, pc2)) != 0ull;
+        if (kWide && live1 && live2) {
+            // both pixels' loads in flight together
+            const PixelTerms o1 = batched ? pixel_terms_batched(a, valid, pix, pc) : pixel_terms(a, valid, pix, pc);
+            const PixelTerms o2 = batched ? pixel_terms_batched(a, valid2, pix2, pc2) : pixel_terms(a, valid2, pix2, pc2);
+            STAMP(5);
+            accumulate(o1, true);
+            accumulate(o2, false);
+        } else {
+            if (live1) {
+                const PixelTerms o1 = batched ? pixel_terms_batched(a, valid, pix, pc) : pixel_terms(a, valid, pix, pc);
+                STAMP(5);
+                accumulate(o1, true);
             } else {
-                iw = scratch_iw(f, m, iwSel)[pix];
+                dead_wave(valid, pix, true);
             }
-            const float a = fabsf(r);
-            float tw = a != 0.f ? f.prm.huberThresh / a : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
-            tw = fminf(tw, 1.0f);
-            w = iw * scale;
-            w = tw * w;        // multiply(trackWeights, intWeights)
-            w = w * md.assoc[pix];  // multiply(intWeights, associationWeights)
-            wOut[pix] = w;
+            if (second) {
+                if (live2) {
+                    const PixelTerms o2 = batched ? pixel_terms_batched(a, valid2, pix2, pc2) : pixel_terms(a, valid2, pix2, pc2);
+                    accumulate(o2, false);
+                } else {
+                    dead_wave(valid2, pix2, false);
+                }
+            }
         }
-        STAMP(5);
-        // As = (g_j * g_k) * w, bs = (r * g_j) * w: the products of computeAb / multSingletonCol;
-        // column order: the upper triangle of A row by row (21), b (6), err, the trial step's error
-        {
-            float s[16];
-            int q = 0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int k = j; k < 6; ++k)
-                    if (6 * j - j * (j - 1) / 2 + (k - j) < 16) s[q++] = (g[j] * g[k]) * w;
-            wave_sum16(s, lane);
-            if (!(lane & 3)) red[wave][lane >> 2] = s[0];
+        __syncthreads();
+        if (threadIdx.x < kCols - 1) {
+            float v = red[0][threadIdx.x];
+            for (int i = 1; i < kWaves; ++i) v += red[i][threadIdx.x];
+            // component-major: the next prologue reads each component contiguously
+            mine[static_cast<size_t>(threadIdx.x) * f.nblocks + blk] = v;
+        } else if (threadIdx.x == kCols - 1) {
+            float v = redMax[0];
+            for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
+            mine[static_cast<size_t>(kCols - 1) * f.nblocks + blk] = v;
         }
-        {
-            float s[16];
-            int q = 0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int k = j; k < 6; ++k)
-                    if (6 * j - j * (j - 1) / 2 + (k - j) >= 16) s[q++] = (g[j] * g[k]) * w;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) s[q++] = (r * g[j]) * w;
-            s[q++] = (r * r) * w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
-            s[q++] = e;
-            s[13] = s[14] = s[15] = 0.f;
-            wave_sum16(s, lane);
-            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) red[wave][16 + (lane >> 2)] = s[0];
-        }
-        const float wmx = wave_max(fabsf(iw));
-        if (lane == 0) redMax[wave] = wmx;
-    }
-    __syncthreads();
-    if (threadIdx.x < kCols - 1) {
-        float v = red[0][threadIdx.x];
-        for (int i = 1; i < kWaves; ++i) v += red[i][threadIdx.x];
-        // component-major: the next prologue reads each component contiguously
-        mine[static_cast<size_t>(threadIdx.x) * f.nblocks + blk] = v;
-    } else if (threadIdx.x == kCols - 1) {
-        float v = redMax[0];
-        for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
-        mine[static_cast<size_t>(kCols - 1) * f.nblocks + blk] = v;
-    }
     }
     STAMP(6);
 #undef STAMP
@@ -802,7 +959,7 @@ int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* 
     f.points = img<const float>(points);
     f.w = points->width;
     f.h = points->height;
-    f.nblocks = static_cast<int>(ceil_div(static_cast<size_t>(f.w) * f.h, kTrackBlock));
+    f.nblocks = static_cast<int>(ceil_div(static_cast<size_t>(f.w) * f.h, kRowPixels));
     f.prm = *prm;
     f.scratch = static_cast<char*>(scratch_dev);
     f.scratchStride = scratchBytesPerModel;
@@ -821,7 +978,7 @@ extern "C" {
 
 size_t emf_hip_trackScratchBytes(int width, int height) {
     const size_t px = static_cast<size_t>(width) * height;
-    const size_t nblocks = ceil_div(px, kTrackBlock);
+    const size_t nblocks = ceil_div(px, kRowPixels);
     size_t bytes = (4 * px + 2 * nblocks * kCols) * sizeof(float) + sizeof(emf_track_state_t);
 #ifdef EMF_TRACK_TRACE
     bytes += (24 * 8 + 2 * nblocks) * sizeof(long long);
@@ -846,15 +1003,24 @@ int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO
 namespace {
 // launch `launch` of a stage (see emf_hip_trackStep)
 void enqueue_step(TrackFrame& f, int nmodels, int launch, hipStream_t s) {
-    const dim3 px(static_cast<unsigned>(f.nblocks), static_cast<unsigned>(nmodels));
+    const dim3 px(ceil_div(static_cast<size_t>(f.w) * f.h, kTrackBlock), static_cast<unsigned>(nmodels));
     // the weight maximum is looked up at the first pose of a stage only (device flag); in a later
     // call of the stage the kernel returns at once
     if (launch == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
     // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
-    const int perModel = std::max(1, std::min(f.nblocks, 2 * compute_units() / nmodels));
     f.launch = launch;
-    hipLaunchKernelGGL(k_track_step, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
-                       dim3(kTrackBlock), 0, s, f);
+    // a single model whose rows fit the CUs one each (the camera stage at 640 x 480: 253 rows): the kernel with the
+    // registers of a workgroup per CU; else two workgroups per CU, each taking its share of the rows
+    static const int wideMode = std::getenv("EMF_TRACK_WIDE") ? std::atoi(std::getenv("EMF_TRACK_WIDE")) : 1;  // (A/B)
+    if ((nmodels == 1 && wideMode == 1) || wideMode == 2) {
+        const int wgs = std::max(1, std::min(f.nblocks, compute_units() / nmodels));
+        hipLaunchKernelGGL(k_track_step<true>, dim3(static_cast<unsigned>(wgs), static_cast<unsigned>(nmodels)),
+                           dim3(kTrackBlock), 0, s, f);
+    } else {
+        const int perModel = std::max(1, std::min(f.nblocks, 2 * compute_units() / nmodels));
+        hipLaunchKernelGGL(k_track_step<false>, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
+                           dim3(kTrackBlock), 0, s, f);
+    }
 }
 }  // namespace
 

@@ -15,7 +15,7 @@ world = T.world.__wrapped__(binding)
 tr = T.DeviceTracker(ops, world, [int(a) for a in sys.argv[1:]] or [0])
 tr.iterate(20)
 raw = T.to_np(tr.scratch)[:tr.per_model]
-px, nb = T.W * T.H, -(-T.W * T.H // 1024)
+px, nb = T.W * T.H, -(-T.W * T.H // 1216)
 off = (4 * px + 2 * nb * 30) * 4 + C.sizeof(_lib.EmfTrackState)
 st = raw[off:off + 24 * 64].view(np.int64).reshape(24, 8)
 wg = raw[off + 24 * 64:off + 24 * 64 + 16 * nb].view(np.int64).reshape(nb, 2)
