@@ -500,41 +500,19 @@ struct PixelPass {  // (wave-uniform)
     float* iwOut;        // ... at the trial pose (filled by a trial pass)
 };
 
-// One pixel, the reference's operators one by one (TSDF.cu:603-637, 662-688; TSDF.cpp:212-262, 390-394), each lookup
-// behind its own tests: three dependent rounds of gathers.  The form the 64-register kernel can afford.
-__device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid, size_t pix, const V3& pc) {
-    PixelTerms o;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o.g[k] = 0.f;
-    o.r = o.w = o.e = o.iw = 0.f;
-    if (!valid) return o;
-    pose_gradient(a.tsdf, a.grads, a.R, a.t, pc, a.n, a.voxelSize, o.g);
-    o.r = lookup1(a.tsdf, a.R, a.t, pc, a.n, a.voxelSize);
-    if (a.trial) {
-        // computeError at the trial pose under the current weights (TSDF.cpp:390-394) ...
-        o.e = (o.r * o.r) * a.wCur[pix];
-        // ... and the clamped integration weights there: the next iteration's if the step is accepted
-        o.iw = fminf(lookup1(a.weights, a.R, a.t, pc, a.n, a.voxelSize), a.maxWeight);  // TSDF.cpp:234
-        a.iwOut[pix] = o.iw;
-    } else {
-        o.iw = a.iwCur[pix];
-    }
-    const float ab = fabsf(o.r);
-    float tw = ab != 0.f ? a.huberThresh / ab : 0.f;  // divide(scalar, mat): x / 0 := 0 (Q7)
-    tw = fminf(tw, 1.0f);
-    float w = o.iw * a.scale;
-    w = tw * w;              // multiply(trackWeights, intWeights)
-    w = w * a.assoc[pix];    // multiply(intWeights, associationWeights)
-    a.wOut[pix] = w;
-    o.w = w;
-    return o;
+// what a pass leaves per pixel: the combined weight, and at a trial pose the clamped integration weight
+__device__ __forceinline__ void store_terms(const PixelPass& a, bool valid, size_t pix, const PixelTerms& o) {
+    if (!valid) return;
+    if (a.trial) a.iwOut[pix] = o.iw;
+    a.wOut[pix] = o.w;
 }
 
-// The same values with every load in front of every use: the tests become selects, a pixel outside the volume (or the
-// image) reads voxel 0 / pixel 0 and drops what it read, the 20 tsdf values of the cell and its forward differences,
-// the 8 weights and the three per-pixel images are requested in one batch -- one round trip instead of three.  Needs
-// the registers of the kernel that runs one workgroup per CU (k_track_step<true>); on-the-fly gradients only.
-__device__ __forceinline__ PixelTerms pixel_terms_batched(const PixelPass& a, bool valid, size_t pix, const V3& pc) {
+// One pixel: the reference's operators one by one (computePoseGradients TSDF.cu:603-637, getVolumeVals 662-688,
+// TSDF.cpp:212-262, 390-394), but with every load in front of every use: the range tests become selects, a pixel outside
+// the volume (or the image) reads voxel 0 / pixel 0 and drops what it read, and the 20 tsdf values of the cell and of
+// its forward differences (or the 24 of the gradient volume), the 8 weights and the three per-pixel images are requested
+// in one batch -- one round trip instead of the three of "lookup, test, next lookup" (rounds 1-3, in 64 registers).
+__device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid, size_t pix, const V3& pc) {
     const bool zpos = valid && pc.z > 0;
     const V3 p = mul(a.R, pc) + a.t;
     const V3 v = to_voxel(p, a.voxelSize, half_extent(a.n));
@@ -542,28 +520,43 @@ __device__ __forceinline__ PixelTerms pixel_terms_batched(const PixelPass& a, bo
     const bool in2 = zpos && !outside(v, 2.f, a.n);  // computePoseGradients' (TSDF.cu:617-624)
     const Cell c = cell_of(in1 ? v : v3(0.f, 0.f, 0.f), a.n);
     const size_t sy = static_cast<size_t>(a.n.x), sz = sy * a.n.y;
-    const size_t x2 = in2 ? 2 : 0, y2 = in2 ? 2 * sy : 0, z2 = in2 ? 2 * sz : 0;
     const float* q = a.tsdf + c.base;
-    // the cell's corners (z, y, x) ...
+    // the cell's corners (z, y, x)
     const float c000 = q[0], c001 = q[1], c010 = q[sy], c011 = q[sy + 1];
     const float c100 = q[sz], c101 = q[sz + 1], c110 = q[sz + sy], c111 = q[sz + sy + 1];
-    // ... and the voxels one further along each axis
-    const float x00 = q[x2], x01 = q[sy + x2], x10 = q[sz + x2], x11 = q[sz + sy + x2];
-    const float y00 = q[y2], y01 = q[y2 + 1], y10 = q[sz + y2], y11 = q[sz + y2 + 1];
-    const float z00 = q[z2], z01 = q[z2 + 1], z10 = q[z2 + sy], z11 = q[z2 + sy + 1];
+    float gx, gy, gz;  // gradient_at: the blend of the eight corners' gradients
+    if (a.grads) {     // (uniform) ... from the materialised volume (TSDF.cu:429-464)
+        const float* pg = a.grads + 3 * c.base;
+        float gv[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t off = 3 * ((k & 1) + ((k >> 1) & 1) * sy + (k >> 2) * sz);
+            gv[k][0] = pg[off];
+            gv[k][1] = pg[off + 1];
+            gv[k][2] = pg[off + 2];
+        }
+        gx = blend8(gv[0][0], gv[1][0], gv[2][0], gv[3][0], gv[4][0], gv[5][0], gv[6][0], gv[7][0], c.fx, c.fy, c.fz);
+        gy = blend8(gv[0][1], gv[1][1], gv[2][1], gv[3][1], gv[4][1], gv[5][1], gv[6][1], gv[7][1], c.fx, c.fy, c.fz);
+        gz = blend8(gv[0][2], gv[1][2], gv[2][2], gv[3][2], gv[4][2], gv[5][2], gv[6][2], gv[7][2], c.fx, c.fy, c.fz);
+    } else {           // ... or forward differences taken here: the voxels one further along each axis
+        const size_t x2 = in2 ? 2 : 0, y2 = in2 ? 2 * sy : 0, z2 = in2 ? 2 * sz : 0;
+        const float x00 = q[x2], x01 = q[sy + x2], x10 = q[sz + x2], x11 = q[sz + sy + x2];
+        const float y00 = q[y2], y01 = q[y2 + 1], y10 = q[sz + y2], y11 = q[sz + y2 + 1];
+        const float z00 = q[z2], z01 = q[z2 + 1], z10 = q[z2 + sy], z11 = q[z2 + sy + 1];
+        gx = blend8(c001 - c000, x00 - c001, c011 - c010, x01 - c011, c101 - c100, x10 - c101, c111 - c110, x11 - c111,
+                    c.fx, c.fy, c.fz);
+        gy = blend8(c010 - c000, c011 - c001, y00 - c010, y01 - c011, c110 - c100, c111 - c101, y10 - c110, y11 - c111,
+                    c.fx, c.fy, c.fz);
+        gz = blend8(c100 - c000, c101 - c001, c110 - c010, c111 - c011, z00 - c100, z01 - c101, z10 - c110, z11 - c111,
+                    c.fx, c.fy, c.fz);
+    }
     const float* qw = a.weights + c.base;
     const float w000 = qw[0], w001 = qw[1], w010 = qw[sy], w011 = qw[sy + 1];
     const float w100 = qw[sz], w101 = qw[sz + 1], w110 = qw[sz + sy], w111 = qw[sz + sy + 1];
     const size_t pp = valid ? pix : 0;
     const float wCur = a.wCur[pp], iwCur = a.iwCur[pp], assoc = a.assoc[pp];
     PixelTerms o;
-    // forward differences at the eight corners, blended (gradient_at), / voxelSize (TSDF.cu:626-630)
-    const float gx = blend8(c001 - c000, x00 - c001, c011 - c010, x01 - c011, c101 - c100, x10 - c101, c111 - c110, x11 - c111,
-                            c.fx, c.fy, c.fz);
-    const float gy = blend8(c010 - c000, c011 - c001, y00 - c010, y01 - c011, c110 - c100, c111 - c101, y10 - c110, y11 - c111,
-                            c.fx, c.fy, c.fz);
-    const float gz = blend8(c100 - c000, c101 - c001, c110 - c010, c111 - c011, z00 - c100, z01 - c101, z10 - c110, z11 - c111,
-                            c.fx, c.fy, c.fz);
+    // / voxelSize, and the rotational part (TSDF.cu:626-637)
     const V3 gt = v3(gx, gy, gz) / a.voxelSize;
     const M33 S{{0.f, -p.z, p.y}, {p.z, 0.f, -p.x}, {-p.y, p.x, 0.f}};
     const V3 gr = mul(S, gt);
@@ -581,10 +574,7 @@ __device__ __forceinline__ PixelTerms pixel_terms_batched(const PixelPass& a, bo
     w = tw * w;
     w = w * assoc;
     o.w = w;
-    if (valid) {
-        if (a.trial) a.iwOut[pix] = o.iw;
-        a.wOut[pix] = w;
-    } else {
+    if (!valid) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) o.g[k] = 0.f;
         o.r = o.w = o.e = o.iw = 0.f;
@@ -601,15 +591,18 @@ __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_tra
     if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// kWide: the launch has at most one workgroup per CU (a single model: the camera stage): 128 registers instead of 64,
-// every load of a pixel in one batch (pixel_terms_batched), the two pixels of a wave that has two side by side.
-// Same values, same sums: which kernel runs is the host's choice and changes no bit of the state.
-template <bool kWide>
-__global__ __launch_bounds__(kTrackBlock, kWide ? 4 : 8) void k_track_step(const TrackFrame f) {  // waves per SIMD: one / two workgroups per CU
+// One workgroup per CU (4 waves per SIMD, 128 registers): the prologue is paid once per CU -- two workgroups sharing
+// a CU slow each other's scalar part by 40 % -- and the per-pixel pass has the registers to request all of a pixel's
+// voxels at once, for two pixels side by side.  A workgroup takes every gridDim.x-th row of kRowPixels pixels, up to
+// kMaxRows of them per pass: per wave a row is one slot (two for the first waves, which take a second pixel); the
+// points of all slots are tested first (one batch of loads), then the slots with a live pixel are worked off two at a
+// time.  An object covers a few of its rows: its stage used to walk them one after the other, a barrier each.
+constexpr int kMaxRows = 4;
+__global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame f) {
     constexpr int kWaves = kTrackBlock / 64;
     __shared__ double sums[kCols];
     __shared__ emf_track_state_t st;
-    __shared__ float red[kWaves][32], redMax[kWaves];
+    __shared__ float red[kMaxRows][kWaves][32], redMax[kMaxRows][kWaves];
     const int m = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef EMF_TRACK_TRACE  // timing probe: 10 ns stamps of workgroup (EMF_TRACK_TRACE) of model 0, per launch
     long long* stamps = reinterpret_cast<long long*>(state_buf(f, 0, 1) + 1) + 8 * f.launch;
@@ -638,9 +631,24 @@ __global__ __launch_bounds__(kTrackBlock, kWide ? 4 : 8) void k_track_step(const
     state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
     const emf_model_t& md = f.models[m];
     const I3 n{md.res[0], md.res[1], md.res[2]};
-    size_t pix;
-    V3 pc;
-    bool valid = load_point(f, pix, pc, blockIdx.x, kRowPixels, 0);  // (the first row's points: fetched under the prologue)
+    // the points of the workgroup's first row: fetched under the prologue
+    const size_t npx = static_cast<size_t>(f.w) * f.h;
+    const bool second = wave < kRowExtra / 64;  // (uniform per wave: this wave has a second pixel in every row)
+    // the point of a slot's pixel; loaded whether the pixel exists or not (pixel 0 instead), so that the loads of
+    // several slots go out together
+    const auto slot_point = [&](unsigned row, int sec, size_t& pix, V3& pc) {
+        pix = static_cast<size_t>(row) * kRowPixels + (sec ? kTrackBlock : 0) + threadIdx.x;
+        const bool ok = pix < npx;
+        const size_t pp = ok ? pix : 0;
+        const int y = static_cast<int>(pp / f.w), x = static_cast<int>(pp - static_cast<size_t>(y) * f.w);
+        const float* p = f.points.row(y) + 3 * x;
+        pc = v3(p[0], p[1], p[2]);
+        return ok;
+    };
+    size_t pixA, pixB = 0;
+    V3 pcA, pcB = v3(0.f, 0.f, 0.f);
+    const bool okA = slot_point(blockIdx.x, 0, pixA, pcA);
+    const bool okB = second && slot_point(blockIdx.x, 1, pixB, pcB);
     // ---- prologue ----
     if (in->pending != 0) {  // (uniform: read from global memory, not from the copy in flight)
         // lane-strided partial sums in double, then a fixed xor tree -- the same order on every run.
@@ -737,107 +745,145 @@ __global__ __launch_bounds__(kTrackBlock, kWide ? 4 : 8) void k_track_step(const
     a.iwCur = scratch_iw(f, m, iwSel);
     a.iwOut = scratch_iw(f, m, 1 - iwSel);
     float* const mine = scratch_partials(f, m, f.launch & 1);
-    const bool batched = kWide && a.grads == nullptr;  // (uniform)
     // A pixel's 28 products As = (g_j * g_k) * w, bs = (r * g_j) * w, r^2 w (computeAb / multSingletonCol; column
     // order: the upper triangle of A row by row (21), b (6), err) and the trial step's error, summed over the wave
-    // into the wave's line of red[] (`first`: stored, else added to what the wave's first pixels left there)
-    const auto accumulate = [&](const PixelTerms& o, bool first) {
+    // into the wave's line of its row in red[] (`first`: stored, else added to what the row's first pixels left there)
+    const auto accumulate = [&](const PixelTerms& o, int j, bool first) {
+        float* const line = red[j][wave];
         {
             float s[16];
             int q = 0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int jj = 0; jj < 6; ++jj)
 #pragma unroll
-                for (int k = j; k < 6; ++k)
-                    if (6 * j - j * (j - 1) / 2 + (k - j) < 16) s[q++] = (o.g[j] * o.g[k]) * o.w;
+                for (int k = jj; k < 6; ++k)
+                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) < 16) s[q++] = (o.g[jj] * o.g[k]) * o.w;
             wave_sum16(s, lane);
-            if (!(lane & 3)) red[wave][lane >> 2] = first ? s[0] : red[wave][lane >> 2] + s[0];
+            if (!(lane & 3)) line[lane >> 2] = first ? s[0] : line[lane >> 2] + s[0];
         }
         {
             float s[16];
             int q = 0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int jj = 0; jj < 6; ++jj)
 #pragma unroll
-                for (int k = j; k < 6; ++k)
-                    if (6 * j - j * (j - 1) / 2 + (k - j) >= 16) s[q++] = (o.g[j] * o.g[k]) * o.w;
+                for (int k = jj; k < 6; ++k)
+                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) >= 16) s[q++] = (o.g[jj] * o.g[k]) * o.w;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) s[q++] = (o.r * o.g[j]) * o.w;
+            for (int jj = 0; jj < 6; ++jj) s[q++] = (o.r * o.g[jj]) * o.w;
             s[q++] = (o.r * o.r) * o.w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
             s[q++] = o.e;
             s[13] = s[14] = s[15] = 0.f;
             wave_sum16(s, lane);
-            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1)
-                red[wave][16 + (lane >> 2)] = first ? s[0] : red[wave][16 + (lane >> 2)] + s[0];
+            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) line[16 + (lane >> 2)] = first ? s[0] : line[16 + (lane >> 2)] + s[0];
         }
         const float wmx = wave_max(fabsf(o.iw));
-        if (lane == 0) redMax[wave] = first ? wmx : fmaxf(redMax[wave], wmx);
+        if (lane == 0) redMax[j][wave] = first ? wmx : fmaxf(redMax[j][wave], wmx);
     };
-    // A pixel whose point is invalid or falls outside the volume's interpolation range contributes
-    // exact zeros to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such
-    // pixels -- most of the image, for an object -- stores its zeros and skips the arithmetic.
-    const auto alive_at = [&](bool valid_, const V3& pc_) {
-        return valid_ && pc_.z > 0 && !outside(to_voxel(mul(a.R, pc_) + a.t, a.voxelSize, half_extent(n)), 1.f, n);
+    const auto terms = [&](bool ok, size_t pix, const V3& pc) { return pixel_terms(a, ok, pix, pc); };
+    const auto alive_at = [&](bool ok, const V3& pc) {
+        return ok && pc.z > 0 && !outside(to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(n)), 1.f, n);
     };
-    const auto dead_wave = [&](bool valid_, size_t pix_, bool first) {
-        if (valid_) {
-            if (trial) a.iwOut[pix_] = 0.f;
-            a.wOut[pix_] = 0.f;
-        }
-        if (first) {
-            if (lane < kCols - 1) red[wave][lane] = 0.f;
-            if (lane == 0) redMax[wave] = 0.f;
-        }
+    const auto dead_slot = [&](bool ok, size_t pix) {  // a wave without a live pixel: zeros to the images
+        if (!ok) return;
+        if (trial) a.iwOut[pix] = 0.f;
+        a.wOut[pix] = 0.f;
     };
-    // The image in rows of kRowPixels pixels, one row of partial sums each -- however many of them a workgroup
-    // takes (the launch sizes the grid so that all workgroups are resident at once and the prologue is paid once
-    // per workgroup): the sums do not depend on the grid, nor on which of the two kernels runs.  A row is the
-    // workgroup's lanes once plus a second pixel for its first waves.
-    const bool second = wave < kRowExtra / 64;  // (uniform per wave)
-    for (unsigned blk = blockIdx.x; blk < static_cast<unsigned>(f.nblocks); blk += gridDim.x) {
-        if (blk != blockIdx.x) {
-            __syncthreads();  // red[] of the previous row has been read
-            valid = load_point(f, pix, pc, blk, kRowPixels, 0);
-        }
-        size_t pix2 = 0;
-        V3 pc2 = v3(0.f, 0.f, 0.f);
-        const bool valid2 = second && load_point(f, pix2, pc2, blk, kRowPixels, kTrackBlock);
-        const bool live1 = __ballot(alive_at(valid, pc)) != 0ull;
-        const bool live2 = second && __ballot(alive_at(valid2, pc2)) != 0ull;
-        if (kWide && live1 && live2) {
-            // both pixels' loads in flight together
-            const PixelTerms o1 = batched ? pixel_terms_batched(a, valid, pix, pc) : pixel_terms(a, valid, pix, pc);
-            const PixelTerms o2 = batched ? pixel_terms_batched(a, valid2, pix2, pc2) : pixel_terms(a, valid2, pix2, pc2);
-            STAMP(5);
-            accumulate(o1, true);
-            accumulate(o2, false);
-        } else {
-            if (live1) {
-                const PixelTerms o1 = batched ? pixel_terms_batched(a, valid, pix, pc) : pixel_terms(a, valid, pix, pc);
-                STAMP(5);
-                accumulate(o1, true);
-            } else {
-                dead_wave(valid, pix, true);
-            }
+    // The image in rows of kRowPixels pixels, one row of partial sums each: the sums depend neither on the grid nor
+    // on how the rows are grouped into passes.
+    for (unsigned base = blockIdx.x; base < static_cast<unsigned>(f.nblocks); base += gridDim.x * kMaxRows) {
+        if (base != blockIdx.x) __syncthreads();  // red[] of the previous pass has been read
+        // A pixel whose point is invalid or falls outside the volume's interpolation range contributes exact zeros
+        // to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such pixels -- most of the
+        // image, for an object -- stores its zeros and skips the arithmetic.
+        unsigned live = 0u;  // bit 2 j + sec: the wave has a live pixel in slot sec of the pass's j-th row
+        int nrows = 1;
+        const bool single = static_cast<unsigned>(f.nblocks) <= gridDim.x;  // a row per workgroup: its points are here already
+        if (single) {
+            if (__ballot(alive_at(okA, pcA)) != 0ull) live |= 1u;
+            else dead_slot(okA, pixA);
             if (second) {
-                if (live2) {
-                    const PixelTerms o2 = batched ? pixel_terms_batched(a, valid2, pix2, pc2) : pixel_terms(a, valid2, pix2, pc2);
-                    accumulate(o2, false);
-                } else {
-                    dead_wave(valid2, pix2, false);
+                if (__ballot(alive_at(okB, pcB)) != 0ull) live |= 2u;
+                else dead_slot(okB, pixB);
+            }
+        } else {
+            // every slot's point first (one batch of loads), then the tests and the dead slots' zeros
+            V3 pcs[2 * kMaxRows];
+#pragma unroll
+            for (int j = 0; j < kMaxRows; ++j)
+#pragma unroll
+                for (int sec = 0; sec < 2; ++sec) {
+                    size_t pix;
+                    pcs[2 * j + sec] = v3(0.f, 0.f, 0.f);
+                    if (base + j * gridDim.x < static_cast<unsigned>(f.nblocks) && (sec == 0 || second))
+                        slot_point(base + j * gridDim.x, sec, pix, pcs[2 * j + sec]);
+                }
+#pragma unroll
+            for (int j = 0; j < kMaxRows; ++j) {
+                const unsigned row = base + j * gridDim.x;
+                if (row < static_cast<unsigned>(f.nblocks)) {
+                    nrows = j + 1;
+#pragma unroll
+                    for (int sec = 0; sec < 2; ++sec)
+                        if (sec == 0 || second) {
+                            const size_t pix = static_cast<size_t>(row) * kRowPixels + (sec ? kTrackBlock : 0) + threadIdx.x;
+                            const bool ok = pix < npx;
+                            if (__ballot(alive_at(ok, pcs[2 * j + sec])) != 0ull) live |= 1u << (2 * j + sec);
+                            else dead_slot(ok, pix);
+                        }
                 }
             }
         }
+        live = __builtin_amdgcn_readfirstlane(live);
+        unsigned touched = 0u;  // rows this wave has a sum for
+        while (live != 0u) {  // the live slots, two at a time: two pixels' loads in flight together
+            const int s1 = __builtin_ctz(live);
+            live &= live - 1u;
+            const int s2 = live != 0u ? __builtin_ctz(live) : -1;
+            if (s2 >= 0) live &= live - 1u;
+            size_t pix1 = s1 ? pixB : pixA, pix2 = pixB;
+            V3 pc1 = s1 ? pcB : pcA, pc2 = pcB;
+            bool ok1 = s1 ? okB : okA, ok2 = okB;
+            if (!single) {  // (from L1: pass 1 has just read them)
+                ok1 = slot_point(base + (s1 >> 1) * gridDim.x, s1 & 1, pix1, pc1);
+                if (s2 >= 0) ok2 = slot_point(base + (s2 >> 1) * gridDim.x, s2 & 1, pix2, pc2);
+            }
+            const PixelTerms o1 = terms(ok1, pix1, pc1);
+            if (s2 >= 0) {
+                const PixelTerms o2 = terms(ok2, pix2, pc2);
+                store_terms(a, ok1, pix1, o1);
+                store_terms(a, ok2, pix2, o2);
+                STAMP(5);
+                accumulate(o1, s1 >> 1, !((touched >> (s1 >> 1)) & 1u));
+                touched |= 1u << (s1 >> 1);
+                accumulate(o2, s2 >> 1, !((touched >> (s2 >> 1)) & 1u));
+                touched |= 1u << (s2 >> 1);
+            } else {
+                store_terms(a, ok1, pix1, o1);
+                STAMP(5);
+                accumulate(o1, s1 >> 1, !((touched >> (s1 >> 1)) & 1u));
+                touched |= 1u << (s1 >> 1);
+            }
+        }
+        for (int j = 0; j < nrows; ++j)
+            if (!((touched >> j) & 1u)) {
+                if (lane < kCols - 1) red[j][wave][lane] = 0.f;
+                if (lane == 0) redMax[j][wave] = 0.f;
+            }
         __syncthreads();
-        if (threadIdx.x < kCols - 1) {
-            float v = red[0][threadIdx.x];
-            for (int i = 1; i < kWaves; ++i) v += red[i][threadIdx.x];
-            // component-major: the next prologue reads each component contiguously
-            mine[static_cast<size_t>(threadIdx.x) * f.nblocks + blk] = v;
-        } else if (threadIdx.x == kCols - 1) {
-            float v = redMax[0];
-            for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[i]);
-            mine[static_cast<size_t>(kCols - 1) * f.nblocks + blk] = v;
+        if (threadIdx.x < static_cast<unsigned>(nrows) * 32u) {
+            const int j = threadIdx.x >> 5, col = threadIdx.x & 31;
+            const unsigned row = base + j * gridDim.x;
+            if (col < kCols - 1) {
+                float v = red[j][0][col];
+                for (int i = 1; i < kWaves; ++i) v += red[j][i][col];
+                // component-major: the next prologue reads each component contiguously
+                mine[static_cast<size_t>(col) * f.nblocks + row] = v;
+            } else if (col == kCols - 1) {
+                float v = redMax[j][0];
+                for (int i = 1; i < kWaves; ++i) v = fmaxf(v, redMax[j][i]);
+                mine[static_cast<size_t>(kCols - 1) * f.nblocks + row] = v;
+            }
         }
     }
     STAMP(6);
@@ -1009,18 +1055,10 @@ void enqueue_step(TrackFrame& f, int nmodels, int launch, hipStream_t s) {
     if (launch == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
     // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
     f.launch = launch;
-    // a single model whose rows fit the CUs one each (the camera stage at 640 x 480: 253 rows): the kernel with the
-    // registers of a workgroup per CU; else two workgroups per CU, each taking its share of the rows
-    static const int wideMode = std::getenv("EMF_TRACK_WIDE") ? std::atoi(std::getenv("EMF_TRACK_WIDE")) : 1;  // (A/B)
-    if ((nmodels == 1 && wideMode == 1) || wideMode == 2) {
-        const int wgs = std::max(1, std::min(f.nblocks, compute_units() / nmodels));
-        hipLaunchKernelGGL(k_track_step<true>, dim3(static_cast<unsigned>(wgs), static_cast<unsigned>(nmodels)),
-                           dim3(kTrackBlock), 0, s, f);
-    } else {
-        const int perModel = std::max(1, std::min(f.nblocks, 2 * compute_units() / nmodels));
-        hipLaunchKernelGGL(k_track_step<false>, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
-                           dim3(kTrackBlock), 0, s, f);
-    }
+    // a workgroup per CU, shared out among the models; each takes its share of a model's rows
+    const int perModel = std::max(1, std::min(f.nblocks, compute_units() / nmodels));
+    hipLaunchKernelGGL(k_track_step, dim3(static_cast<unsigned>(perModel), static_cast<unsigned>(nmodels)),
+                       dim3(kTrackBlock), 0, s, f);
 }
 }  // namespace
 
