@@ -53,7 +53,7 @@ constexpr int kTrackBlock = EMF_TRACK_BLOCK;   // threads per workgroup
 #ifndef EMF_TRACK_ROW_EXTRA
 #define EMF_TRACK_ROW_EXTRA 192  // 640 x 480 pixels in rows of 1024 are 300 rows for 256 CUs: 44 CUs carry two workgroups and the
                                  // launch ends with them (20.4 us against 16.3).  Rows of 1024 + 192 pixels are 253: a workgroup
-                                 // per CU, the first three waves take a second pixel
+                                 // per CU, three waves take a second pixel
 #endif
 constexpr int kRowExtra = EMF_TRACK_ROW_EXTRA;          // pixels of a row beyond the workgroup's lanes (whole waves)
 constexpr int kRowPixels = kTrackBlock + kRowExtra;     // pixels per row of partial sums
@@ -594,7 +594,7 @@ __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_tra
 // One workgroup per CU (4 waves per SIMD, 128 registers): the prologue is paid once per CU -- two workgroups sharing
 // a CU slow each other's scalar part by 40 % -- and the per-pixel pass has the registers to request all of a pixel's
 // voxels at once, for two pixels side by side.  A workgroup takes every gridDim.x-th row of kRowPixels pixels, up to
-// kMaxRows of them per pass: per wave a row is one slot (two for the first waves, which take a second pixel); the
+// kMaxRows of them per pass: per wave a row is one slot (two for the three waves that take a second pixel of it); the
 // points of all slots are tested first (one batch of loads), then the slots with a live pixel are worked off two at a
 // time.  An object covers a few of its rows: its stage used to walk them one after the other, a barrier each.
 constexpr int kMaxRows = 4;
@@ -633,18 +633,34 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     const I3 n{md.res[0], md.res[1], md.res[2]};
     // the points of the workgroup's first row: fetched under the prologue
     const size_t npx = static_cast<size_t>(f.w) * f.h;
-    const bool second = wave < kRowExtra / 64;  // (uniform per wave: this wave has a second pixel in every row)
-    // the point of a slot's pixel; loaded whether the pixel exists or not (pixel 0 instead), so that the loads of
-    // several slots go out together
+    // A row's kRowExtra pixels beyond the workgroup's lanes are the second pixels of its first kRowExtra / 64 waves.
+    // (Measured and dropped: other waves for every row of a workgroup, so that not the same three carry all second slots --
+    // 18.1 instead of 17.3 us per launch, for the camera's single row as for four objects' four.)
+    const auto extra_of = [&](unsigned) { return wave < kRowExtra / 64 ? wave : -1; };
+    // the pixel of slot (row, sec) and its point; the point is loaded whether the pixel exists or not (pixel 0 instead),
+    // so that the loads of several slots go out together
+    const bool dense = f.points.pitch == static_cast<size_t>(f.w) * 12;  // (no row padding: the pixel index is the address)
+    const auto slot_pixel = [&](unsigned row, int sec) {
+        return static_cast<size_t>(row) * kRowPixels + (sec ? kTrackBlock + 64 * extra_of(row) + lane : threadIdx.x);
+    };
     const auto slot_point = [&](unsigned row, int sec, size_t& pix, V3& pc) {
-        pix = static_cast<size_t>(row) * kRowPixels + (sec ? kTrackBlock : 0) + threadIdx.x;
+        pix = slot_pixel(row, sec);
         const bool ok = pix < npx;
-        const size_t pp = ok ? pix : 0;
-        const int y = static_cast<int>(pp / f.w), x = static_cast<int>(pp - static_cast<size_t>(y) * f.w);
-        const float* p = f.points.row(y) + 3 * x;
+        // (32-bit: a 64-bit quotient by a run-time divisor is ~150 instructions, and a wave takes up to eight of these
+        // per launch; fill_frame admits fewer than 2^31 pixels)
+        const unsigned pp = ok ? static_cast<unsigned>(pix) : 0u;
+        const float* p;
+        if (dense) {
+            p = f.points.data + 3 * static_cast<size_t>(pp);
+        } else {
+            const unsigned uw = static_cast<unsigned>(f.w);
+            const int y = static_cast<int>(pp / uw), x = static_cast<int>(pp - static_cast<unsigned>(y) * uw);
+            p = f.points.row(y) + 3 * x;
+        }
         pc = v3(p[0], p[1], p[2]);
         return ok;
     };
+    const bool second = extra_of(blockIdx.x) >= 0;  // (of the workgroup's first row)
     size_t pixA, pixB = 0;
     V3 pcA, pcB = v3(0.f, 0.f, 0.f);
     const bool okA = slot_point(blockIdx.x, 0, pixA, pcA);
@@ -781,8 +797,18 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
         if (lane == 0) redMax[j][wave] = first ? wmx : fmaxf(redMax[j][wave], wmx);
     };
     const auto terms = [&](bool ok, size_t pix, const V3& pc) { return pixel_terms(a, ok, pix, pc); };
+    // May the pixel lie in the volume's interpolation range?  The wave-skip below only needs "certainly not": the
+    // voxel coordinate through a reciprocal instead of the three divisions of to_voxel (a third of a slot's test), with a
+    // margin a hundred times the two forms' difference (< 2.4e-7 relative: 5e-4 voxels in the largest volume).  A wave
+    // that passes with no pixel inside after all takes the arithmetic and gets the same zeros out of it.
+    const float rcpVoxel = 1.f / a.voxelSize;
+    const V3 halfExt = half_extent(n);
+    const float hiX = static_cast<float>(n.x) + 0.05f, hiY = static_cast<float>(n.y) + 0.05f, hiZ = static_cast<float>(n.z) + 0.05f;
     const auto alive_at = [&](bool ok, const V3& pc) {
-        return ok && pc.z > 0 && !outside(to_voxel(mul(a.R, pc) + a.t, a.voxelSize, half_extent(n)), 1.f, n);
+        const V3 p = mul(a.R, pc) + a.t;
+        const float vx = p.x * rcpVoxel + halfExt.x, vy = p.y * rcpVoxel + halfExt.y, vz = p.z * rcpVoxel + halfExt.z;
+        const bool out = vx < -0.05f || vx + 1.f >= hiX || vy < -0.05f || vy + 1.f >= hiY || vz < -0.05f || vz + 1.f >= hiZ;
+        return ok && pc.z > 0 && !out;
     };
     const auto dead_slot = [&](bool ok, size_t pix) {  // a wave without a live pixel: zeros to the images
         if (!ok) return;
@@ -815,7 +841,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
                 for (int sec = 0; sec < 2; ++sec) {
                     size_t pix;
                     pcs[2 * j + sec] = v3(0.f, 0.f, 0.f);
-                    if (base + j * gridDim.x < static_cast<unsigned>(f.nblocks) && (sec == 0 || second))
+                    if (base + j * gridDim.x < static_cast<unsigned>(f.nblocks) && (sec == 0 || extra_of(base + j * gridDim.x) >= 0))
                         slot_point(base + j * gridDim.x, sec, pix, pcs[2 * j + sec]);
                 }
 #pragma unroll
@@ -825,8 +851,8 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
                     nrows = j + 1;
 #pragma unroll
                     for (int sec = 0; sec < 2; ++sec)
-                        if (sec == 0 || second) {
-                            const size_t pix = static_cast<size_t>(row) * kRowPixels + (sec ? kTrackBlock : 0) + threadIdx.x;
+                        if (sec == 0 || extra_of(row) >= 0) {
+                            const size_t pix = slot_pixel(row, sec);
                             const bool ok = pix < npx;
                             if (__ballot(alive_at(ok, pcs[2 * j + sec])) != 0ull) live |= 1u << (2 * j + sec);
                             else dead_slot(ok, pix);
@@ -835,6 +861,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             }
         }
         live = __builtin_amdgcn_readfirstlane(live);
+        STAMP(7);
         unsigned touched = 0u;  // rows this wave has a sum for
         while (live != 0u) {  // the live slots, two at a time: two pixels' loads in flight together
             const int s1 = __builtin_ctz(live);
@@ -871,6 +898,9 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
                 if (lane == 0) redMax[j][wave] = 0.f;
             }
         __syncthreads();
+#ifdef EMF_TRACK_TRACE
+        STAMP(4);  // (probe builds: the stamp behind the state's store is overwritten by the pass's barrier)
+#endif
         if (threadIdx.x < static_cast<unsigned>(nrows) * 32u) {
             const int j = threadIdx.x >> 5, col = threadIdx.x & 31;
             const unsigned row = base + j * gridDim.x;
@@ -1005,6 +1035,8 @@ int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* 
     f.points = img<const float>(points);
     f.w = points->width;
     f.h = points->height;
+    if (static_cast<size_t>(f.w) * f.h >= (static_cast<size_t>(1) << 31))  // (the step kernel indexes pixels in 32 bits)
+        return fail(EMF_E_LIMIT, "%s: %d x %d pixels, expected fewer than 2^31", fn, f.w, f.h);
     f.nblocks = static_cast<int>(ceil_div(static_cast<size_t>(f.w) * f.h, kRowPixels));
     f.prm = *prm;
     f.scratch = static_cast<char*>(scratch_dev);

@@ -1,7 +1,7 @@
 """Where a k_track_step launch spends its time (build with EXTRA=-DEMF_TRACK_TRACE=<workgroup>): stamps of one
 workgroup of model 0 for the first launches of a 20-iteration call on tests/test_gpu_tracking.py's world
-scaled to 640x480.  Columns: us from kernel entry to [reduce done, barrier, lm_advance done, state stored,
-per-pixel loads done, end]."""
+scaled to 640x480.  Columns: us from kernel entry to [reduce done, barrier, lm_advance done, the pass's barrier (probe
+builds overwrite "state stored" with it), first pixel terms done, end, slots tested (pass 1)]."""
 import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -29,4 +29,4 @@ if wg[:, 0].any():
     print("  first to end:", [(int(i), round(float(s0[i]), 2), round(float(e0[i]), 2)) for i in order[:4]])
 for i, r in enumerate(st):
     if r[0] == 0: continue
-    print(i, " ".join("%6.2f" % ((x - r[0]) / 100.0) if x else "   -  " for x in r[1:7]))
+    print(i, " ".join("%6.2f" % ((x - r[0]) / 100.0) if x else "   -  " for x in r[1:8]))
