@@ -763,8 +763,10 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     float* const mine = scratch_partials(f, m, f.launch & 1);
     // A pixel's 28 products As = (g_j * g_k) * w, bs = (r * g_j) * w, r^2 w (computeAb / multSingletonCol; column
     // order: the upper triangle of A row by row (21), b (6), err) and the trial step's error, summed over the wave
-    // into the wave's line of its row in red[] (`first`: stored, else added to what the row's first pixels left there)
-    const auto accumulate = [&](const PixelTerms& o, int j, bool first) {
+    // into the wave's line of its row in red[].  A wave with two pixels in the row adds the second one's products to the
+    // first one's lane by lane and sums once (a dead partner would add exact zeros: the sums do not depend on which
+    // slots were skipped).
+    const auto accumulate = [&](const PixelTerms& o, const PixelTerms* o2, int j) {
         float* const line = red[j][wave];
         {
             float s[16];
@@ -773,9 +775,13 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             for (int jj = 0; jj < 6; ++jj)
 #pragma unroll
                 for (int k = jj; k < 6; ++k)
-                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) < 16) s[q++] = (o.g[jj] * o.g[k]) * o.w;
+                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) < 16) {
+                        s[q] = (o.g[jj] * o.g[k]) * o.w;
+                        if (o2) s[q] += (o2->g[jj] * o2->g[k]) * o2->w;
+                        ++q;
+                    }
             wave_sum16(s, lane);
-            if (!(lane & 3)) line[lane >> 2] = first ? s[0] : line[lane >> 2] + s[0];
+            if (!(lane & 3)) line[lane >> 2] = s[0];
         }
         {
             float s[16];
@@ -784,17 +790,29 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             for (int jj = 0; jj < 6; ++jj)
 #pragma unroll
                 for (int k = jj; k < 6; ++k)
-                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) >= 16) s[q++] = (o.g[jj] * o.g[k]) * o.w;
+                    if (6 * jj - jj * (jj - 1) / 2 + (k - jj) >= 16) {
+                        s[q] = (o.g[jj] * o.g[k]) * o.w;
+                        if (o2) s[q] += (o2->g[jj] * o2->g[k]) * o2->w;
+                        ++q;
+                    }
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) s[q++] = (o.r * o.g[jj]) * o.w;
-            s[q++] = (o.r * o.r) * o.w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
-            s[q++] = o.e;
+            for (int jj = 0; jj < 6; ++jj) {
+                s[q] = (o.r * o.g[jj]) * o.w;
+                if (o2) s[q] += (o2->r * o2->g[jj]) * o2->w;
+                ++q;
+            }
+            s[q] = (o.r * o.r) * o.w;  // computeError: sqr, multiply, sum (TSDF.cpp:390-394)
+            if (o2) s[q] += (o2->r * o2->r) * o2->w;
+            ++q;
+            s[q] = o.e;
+            if (o2) s[q] += o2->e;
+            ++q;
             s[13] = s[14] = s[15] = 0.f;
             wave_sum16(s, lane);
-            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) line[16 + (lane >> 2)] = first ? s[0] : line[16 + (lane >> 2)] + s[0];
+            if (!(lane & 3) && 16 + (lane >> 2) < kCols - 1) line[16 + (lane >> 2)] = s[0];
         }
-        const float wmx = wave_max(fabsf(o.iw));
-        if (lane == 0) redMax[j][wave] = first ? wmx : fmaxf(redMax[j][wave], wmx);
+        const float wmx = wave_max(o2 ? fmaxf(fabsf(o.iw), fabsf(o2->iw)) : fabsf(o.iw));
+        if (lane == 0) redMax[j][wave] = wmx;
     };
     const auto terms = [&](bool ok, size_t pix, const V3& pc) { return pixel_terms(a, ok, pix, pc); };
     // May the pixel lie in the volume's interpolation range?  The wave-skip below only needs "certainly not": the
@@ -818,7 +836,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     // The image in rows of kRowPixels pixels, one row of partial sums each: the sums depend neither on the grid nor
     // on how the rows are grouped into passes.
     for (unsigned base = blockIdx.x; base < static_cast<unsigned>(f.nblocks); base += gridDim.x * kMaxRows) {
-        if (base != blockIdx.x) __syncthreads();  // red[] of the previous pass has been read
+        if (base != blockIdx.x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // red[] of the previous pass has been read
         // A pixel whose point is invalid or falls outside the volume's interpolation range contributes exact zeros
         // to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such pixels -- most of the
         // image, for an object -- stores its zeros and skips the arithmetic.
@@ -863,33 +881,32 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
         live = __builtin_amdgcn_readfirstlane(live);
         STAMP(7);
         unsigned touched = 0u;  // rows this wave has a sum for
-        while (live != 0u) {  // the live slots, two at a time: two pixels' loads in flight together
-            const int s1 = __builtin_ctz(live);
-            live &= live - 1u;
-            const int s2 = live != 0u ? __builtin_ctz(live) : -1;
-            if (s2 >= 0) live &= live - 1u;
-            size_t pix1 = s1 ? pixB : pixA, pix2 = pixB;
-            V3 pc1 = s1 ? pcB : pcA, pc2 = pcB;
-            bool ok1 = s1 ? okB : okA, ok2 = okB;
+        while (live != 0u) {  // row by row; a wave's two pixels of a row side by side: their loads in flight together
+            const int j = __builtin_ctz(live) >> 1;
+            const unsigned both = (live >> (2 * j)) & 3u;
+            live &= ~(3u << (2 * j));
+            touched |= 1u << j;
+            const unsigned row = base + j * gridDim.x;
+            size_t pix1 = pixA, pix2 = pixB;
+            V3 pc1 = pcA, pc2 = pcB;
+            bool ok1 = okA, ok2 = okB;
             if (!single) {  // (from L1: pass 1 has just read them)
-                ok1 = slot_point(base + (s1 >> 1) * gridDim.x, s1 & 1, pix1, pc1);
-                if (s2 >= 0) ok2 = slot_point(base + (s2 >> 1) * gridDim.x, s2 & 1, pix2, pc2);
+                if (both & 1u) ok1 = slot_point(row, 0, pix1, pc1);
+                if (both & 2u) ok2 = slot_point(row, 1, pix2, pc2);
             }
-            const PixelTerms o1 = terms(ok1, pix1, pc1);
-            if (s2 >= 0) {
+            if (both == 3u) {
+                const PixelTerms o1 = terms(ok1, pix1, pc1);
                 const PixelTerms o2 = terms(ok2, pix2, pc2);
                 store_terms(a, ok1, pix1, o1);
                 store_terms(a, ok2, pix2, o2);
                 STAMP(5);
-                accumulate(o1, s1 >> 1, !((touched >> (s1 >> 1)) & 1u));
-                touched |= 1u << (s1 >> 1);
-                accumulate(o2, s2 >> 1, !((touched >> (s2 >> 1)) & 1u));
-                touched |= 1u << (s2 >> 1);
+                accumulate(o1, &o2, j);
             } else {
-                store_terms(a, ok1, pix1, o1);
+                const bool sec = both == 2u;
+                const PixelTerms o1 = sec ? terms(ok2, pix2, pc2) : terms(ok1, pix1, pc1);
+                store_terms(a, sec ? ok2 : ok1, sec ? pix2 : pix1, o1);
                 STAMP(5);
-                accumulate(o1, s1 >> 1, !((touched >> (s1 >> 1)) & 1u));
-                touched |= 1u << (s1 >> 1);
+                accumulate(o1, nullptr, j);
             }
         }
         for (int j = 0; j < nrows; ++j)
@@ -897,7 +914,9 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
                 if (lane < kCols - 1) red[j][wave][lane] = 0.f;
                 if (lane == 0) redMax[j][wave] = 0.f;
             }
-        __syncthreads();
+        // (a barrier for red[] alone: __syncthreads() also waits for the wave's global stores -- up to sixteen zeros per
+        // lane of a wave with dead slots -- to be acknowledged, 3 us that nothing here needs)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef EMF_TRACK_TRACE
         STAMP(4);  // (probe builds: the stamp behind the state's store is overwritten by the pass's barrier)
 #endif
