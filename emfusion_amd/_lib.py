@@ -190,7 +190,7 @@ class EmfTrackState(C.Structure):
                 ("wSel", C.c_int32), ("needAccum", C.c_int32), ("haveSpec", C.c_int32),
                 ("spec", C.c_float * 28), ("checkB", C.c_int32),
                 ("pending", C.c_int32), ("body", C.c_int32), ("iterTarget", C.c_int32),
-                ("logCur", C.c_float), ("logTrial", C.c_float)]
+                ("logCur", C.c_float), ("logTrial", C.c_float), ("wFac", C.c_float)]
 
 _lib = None
 

@@ -73,6 +73,7 @@ struct TrackFrame {
     size_t scratchStride;   // bytes per model
     int launch;             // index of the launch within the trackIterate call (parity of the double buffers)
     int iterations;         // LM iterations the call asks for
+    int rescale;            // an accepted step whose weight maximum moved rescales its sums (0: makes them anew, one launch more)
     uint32_t* watch;        // host memory (or null): [0] <- seq, [1 + m] <- model m is done (emf_hip_trackStep)
     uint32_t seq;
 };
@@ -380,6 +381,7 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
         for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
         st.needAccum = 0;
         st.haveSpec = 1;
+        st.wFac = 1.f;  // (the pass has written the current pose's weight image with that pose's maximum)
     } else if (st.pending == kBodyTrial) {
         // ---- computePoseUpdate, second half (TSDF.cpp:315-337) ----
         const float errNew = static_cast<float>(sums[28]);
@@ -403,10 +405,24 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
             st.evaluateGradient = 1;
             st.accepted += 1;
             st.iwSel ^= 1;  // the trial pose's integration weights become the current ones
+            const float mxCur = __uint_as_float(st.maxIwBits), mxNew = __uint_as_float(st.maxIwTrialBits);
             if (st.maxIwTrialBits == st.maxIwBits) {  // the body's weights were normalised correctly
                 for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
                 st.haveSpec = 1;
                 st.wSel ^= 1;
+                st.wFac = 1.f;
+            } else if (f.rescale && static_cast<double>(mxCur) > 2.220446049250313e-16) {
+                // ... by the previous pose's maximum: every weight, hence every sum, carries the factor mxNew / mxCur too
+                // many.  The weights are products iw * (1 / max) * huber * assoc: taking the factor out afterwards differs
+                // from making them anew by the rounding of two multiplications (2e-7 relative; the sums are compared with
+                // the oracle's at 2e-5) and saves the launch that would make them anew -- one per accepted step for as
+                // long as a model's integration weights have not reached their cap (its first maxTSDFWeight frames).
+                const float k = static_cast<double>(mxNew) > 2.220446049250313e-16
+                                    ? static_cast<float>(static_cast<double>(mxCur) / static_cast<double>(mxNew)) : 0.f;
+                for (int q = 0; q < 28; ++q) st.spec[q] = static_cast<float>(sums[q]) * k;
+                st.haveSpec = 1;
+                st.wSel ^= 1;
+                st.wFac = k;
             } else {
                 st.needAccum = 1;
             }
@@ -494,6 +510,7 @@ struct PixelPass {  // (wave-uniform)
     V3 t;
     bool trial;
     float scale, huberThresh, maxWeight;
+    float wFac;          // factor on wCur (emf_track_state_t::wFac)
     const float* wCur;   // the weight image of the current pose (trial: read for the step's error)
     float* wOut;         // the weight image this pass fills
     const float* iwCur;  // clamped integration weights at the current pose (read when the pass is at that pose)
@@ -565,7 +582,7 @@ __device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid
     const float rIn = blend8(c000, c001, c010, c011, c100, c101, c110, c111, c.fx, c.fy, c.fz);
     o.r = in1 ? rIn : 0.f;
     const float iwIn = blend8(w000, w001, w010, w011, w100, w101, w110, w111, c.fx, c.fy, c.fz);
-    o.e = a.trial ? (o.r * o.r) * wCur : 0.f;
+    o.e = a.trial ? (o.r * o.r) * (wCur * a.wFac) : 0.f;  // (wFac = 1 leaves the weight as it is)
     o.iw = a.trial ? fminf(in1 ? iwIn : 0.f, a.maxWeight) : iwCur;
     const float ab = fabsf(o.r);
     float tw = ab != 0.f ? a.huberThresh / ab : 0.f;
@@ -753,6 +770,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     // the next prologue)
     const float mx = __uint_as_float(__builtin_amdgcn_readfirstlane(st.maxIwBits));
     a.scale = uni(static_cast<double>(mx) > 2.220446049250313e-16 ? static_cast<float>(1.0 / static_cast<double>(mx)) : 0.f);
+    a.wFac = uni(st.wFac);
     a.huberThresh = f.prm.huberThresh;
     a.maxWeight = f.prm.maxWeight;
     const int iwSel = __builtin_amdgcn_readfirstlane(st.iwSel), wSel = __builtin_amdgcn_readfirstlane(st.wSel);
@@ -1000,6 +1018,7 @@ __global__ void k_track_prepare(const PrepareArgs a) {
     st.pending = st.body = 0;
     st.iterTarget = 0;
     st.logCur = st.logTrial = se3_log_norm(state_R(st.R), v3(st.t[0], st.t[1], st.t[2]));
+    st.wFac = 1.f;
     a.states[m] = st;
 }
 
@@ -1060,6 +1079,8 @@ int fill_frame(TrackFrame& f, const emf_model_t* models_dev, emf_track_state_t* 
     f.prm = *prm;
     f.scratch = static_cast<char*>(scratch_dev);
     f.scratchStride = scratchBytesPerModel;
+    const char* const rs = std::getenv("EMF_TRACK_RESCALE");  // (A/B and the test of the launch it saves; read per call)
+    f.rescale = rs ? std::atoi(rs) != 0 : 1;
     if (scratchBytesPerModel < emf_hip_trackScratchBytes(f.w, f.h) || scratchBytesPerModel % 16)
         return fail(EMF_E_ARG, "%s: scratch of %zu bytes per model, need %zu (multiple of 16)", fn,
                     scratchBytesPerModel, emf_hip_trackScratchBytes(f.w, f.h));
@@ -1193,5 +1214,5 @@ int emf_hip_computePoseGradients(const float* tsdf, const float* grads, const em
 
 }  // extern "C"
 
-static_assert(sizeof(emf_track_state_t) == 492, "emf_track_state_t layout is mirrored in _lib.py");
+static_assert(sizeof(emf_track_state_t) == 496, "emf_track_state_t layout is mirrored in _lib.py");
 static_assert(sizeof(emf_model_t) == 168, "emf_model_t layout is mirrored in _lib.py");

@@ -773,6 +773,10 @@ typedef struct emf_track_state {
     /* |log| of the two poses (the step-size test of TSDF.cpp:292-296 needs the current pose's): kept with
      * the poses, so that no launch has to make them in front of its solve */
     float logCur, logTrial;
+    /* factor on the current pose's per-pixel weight image: 1, or -- when a step was accepted whose weights had been
+     * normalised by the previous pose's maximum although the accepted pose's is another -- the ratio of the two
+     * maxima (see emf_hip_trackIterate) */
+    float wFac;
 } emf_track_state_t;
 
 /* bytes of scratch per model for emf_hip_trackIterate on a width x height image */

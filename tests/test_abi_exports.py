@@ -58,8 +58,8 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_struct_mirrors_have_the_sizes_the_library_asserts():
     """emf_model_t / emf_track_state_t are mirrored by ctypes structures; csrc/tracking.hip holds the
-    matching static_asserts (168 and 492 bytes)."""
+    matching static_asserts (168 and 496 bytes)."""
     import ctypes as C
     assert C.sizeof(_lib.EmfModel) == 168
-    assert C.sizeof(_lib.EmfTrackState) == 492
+    assert C.sizeof(_lib.EmfTrackState) == 496
     assert C.sizeof(_lib.EmfVolumeOut) == 32
