@@ -12,22 +12,22 @@
 // reads the final pose once:
 //   k_track_maxw   first launch of a stage only: the clamped integration-weight lookup per pixel and
 //                  its image maximum (the NORM_INF of cv::cuda::normalize)
-//   k_track_step   [prologue | per-pixel body] -- see the comment above the kernel.  Prologue, in every
-//                  workgroup: the previous launch's partial sums added in a fixed order, the gain
-//                  ratio and accept / reject of the pending trial step, damping, convergence tests,
-//                  (A + mu I) x = b, the next trial pose exp(-x) * pose.  Body: residual of the trial
-//                  pose under the current weights, the integration weights and their maximum there,
-//                  and the pose gradient (6), Huber x normalised weight x association weight and the
-//                  21 + 6 + 1 sums A = sum w g g^T, b = sum w r g, sum r^2 w the NEXT iteration needs
-//                  if the step is accepted -- reduced in registers (v_permlane swaps), through LDS, to
-//                  one row of partials per 1024 pixels; `As` is never materialised.
-// The four launches this replaced (sums | solve | trial error | verdict; round 1) cost 46 us per
-// iteration, of which 20 were the 168 ds_bpermute shuffles of the 28 wave sums; now 15-23 us.
-// Measured and dropped: finishing the scalar part in the LAST workgroup of the per-pixel kernel
-// (ticket counter, __threadfence) -- on this multi-XCD part a device-scope release writes the XCD's L2
-// back, 1200 times per kernel: 51 -> 325 us per iteration; fetching value, gradient and weight of a
-// pixel in one batch of 28 loads instead of three dependent ones (the 64 registers that let two
-// workgroups share a CU spill: -7 %).
+//   k_track_step   [prologue | per-pixel body] -- see the comment above the kernel.  One workgroup per CU.  Prologue,
+//                  in every workgroup: the previous launch's partial sums added in a fixed order, the gain ratio and
+//                  accept / reject of the pending trial step, damping, convergence tests, (A + mu I) x = b, the next
+//                  trial pose exp(-x) * pose.  Body: residual of the trial pose under the current weights, the
+//                  integration weights and their maximum there, and the pose gradient (6), Huber x normalised weight x
+//                  association weight and the 21 + 6 + 1 sums A = sum w g g^T, b = sum w r g, sum r^2 w the NEXT
+//                  iteration needs if the step is accepted -- all of a pixel's loads in one batch, reduced in
+//                  registers (v_permlane swaps), through LDS, to one row of partials per 1216 pixels; `As` is never
+//                  materialised.
+// The four launches this replaced (sums | solve | trial error | verdict; round 1) cost 46 us per iteration, of which
+// 20 were the 168 ds_bpermute shuffles of the 28 wave sums; rounds 2-3: 15-23 us in a 64-register kernel with two
+// workgroups per CU; round 4: 14-15 us in-kernel (DESIGN.md section 10 has the table of what each change removed).
+// Measured and dropped: finishing the scalar part in the LAST workgroup of the per-pixel kernel (ticket counter,
+// __threadfence) -- on this multi-XCD part a device-scope release writes the XCD's L2 back, 1200 times per kernel:
+// 51 -> 325 us per iteration; a persistent kernel with a grid barrier of relaxed agent-scope atomics: 8 us per
+// exchange against 5 for a kernel boundary; look-ahead past rejected steps, slot masks, LDS-held points (round 4).
 //
 // Parity: per-pixel quantities follow the reference's operations one by one (the pose gradient
 // is bit-identical to the oracle; tests/test_gpu_tracking.py).  Sums are formed in a different --

@@ -794,12 +794,15 @@ int emf_hip_trackPrepare(emf_track_state_t* states_dev, const emf_pose_t* poseCO
  * partial sums in a fixed order, judges the pending trial step, solves for the next one -- the same
  * arithmetic in every workgroup, workgroup 0 stores the state), then evaluates the new trial pose per
  * pixel: its error under the current weights AND, speculatively, the Hessian sums the next iteration
- * needs if the step is accepted.  That speculation assumes the maximum integration weight seen from
- * the trial pose equals the current one (it is the weight cap after a few frames); when it does not,
- * the sums are re-made at the accepted pose by one extra launch.  The call enqueues iterations + 3
- * launches (rounded up to even): one spare for such a miss -- read `iterations` / `haveTrial` from the
- * state to see how far a model got; launches with nothing left to do return at once, as do converged
- * models.  Each model's `assoc` map supplies the association weights.
+ * needs if the step is accepted.  That speculation normalises the weights by the maximum integration
+ * weight of the CURRENT pose (the trial pose's is known after the pass; it is the weight cap after a few
+ * frames); when the two differ, the sums -- linear in the normaliser -- are multiplied by the ratio of the
+ * maxima, and the accepted pose's weight image by the same factor where it is read (`wFac`): 2e-7 relative
+ * from weights made anew.  (EMF_TRACK_RESCALE=0 in the environment: the sums are re-made at the accepted
+ * pose by one extra launch, rounds 1-3.)  The call enqueues iterations + 3 launches (rounded up to even):
+ * one spare for such an extra launch -- read `iterations` / `haveTrial` from the state to see how far a
+ * model got; launches with nothing left to do return at once, as do converged models.  Each model's
+ * `assoc` map supplies the association weights.
  * scratch_dev: nmodels * scratchBytesPerModel bytes (>= emf_hip_trackScratchBytes). */
 int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                          const emf_image_t* points, const emf_track_params_t* params,
