@@ -120,7 +120,7 @@ SIGNATURES = {
     "emf_hip_trackIterate": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
                              C.c_int, _STREAM],
     "emf_hip_trackStep": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t,
-                          C.c_int, C.c_int, C.c_void_p, C.c_uint32, _STREAM],
+                          C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, _STREAM],
     "emf_hip_trackWeightImages": [_FP, _FP, C.c_int, _IMG, C.c_void_p, _FP, C.c_size_t, _FP, _FP, _STREAM],
     "emf_hip_computePoseGradients": [_FP, _FP, _IMG, _F9, _F9, _I3, C.c_float, _FP, _STREAM],
     "emf_hip_integrateBatched": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_int, _FP,

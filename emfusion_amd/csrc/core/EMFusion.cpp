@@ -17,6 +17,7 @@
 #include "Output.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <exception>
 #include <fstream>
 #include <chrono>
@@ -24,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace emf {
 
@@ -1073,6 +1075,13 @@ Matx33f orthonormalised(const Matx33f& M) {
 }
 }  // namespace
 
+namespace {
+// the pinned block the step kernel reports to: progress and done words, then (from this byte on) the states of models
+// that are done
+constexpr size_t kTrackFinalOffset = 256;
+static_assert(kTrackFinalOffset >= sizeof(uint32_t) * (1 + EMF_MAX_BATCH), "room for the words");
+}  // namespace
+
 void EMFusion::trackModels(int first, int count) {
     if (count <= 0) return;
     if (!batched)
@@ -1088,7 +1097,7 @@ void EMFusion::trackModels(int first, int count) {
                  "hipHostMalloc");
         // progress words the step kernel writes while the stream runs (emf_hip_trackStep)
         if (trackWindow > 0 &&
-            (hipHostMalloc(reinterpret_cast<void**>(&trackWatch), sizeof(uint32_t) * (1 + EMF_MAX_BATCH),
+            (hipHostMalloc(reinterpret_cast<void**>(&trackWatch), kTrackFinalOffset + sizeof(emf_track_state_t) * EMF_MAX_BATCH,
                            hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
              hipHostGetDevicePointer(reinterpret_cast<void**>(&trackWatchDev), trackWatch, 0) != hipSuccess)) {
             (void)hipGetLastError();  // no device-visible host memory here: poll in chunks instead
@@ -1126,30 +1135,50 @@ void EMFusion::trackModels(int first, int count) {
             // last model finishes return at once (~2 us each); the states are read back once.
             volatile uint32_t* watch = trackWatch;
             for (int i = 0; i <= count; ++i) watch[i] = 0u;
+            const emf_track_state_t* const finalHost =
+                reinterpret_cast<const emf_track_state_t*>(reinterpret_cast<const char*>(trackWatch) + kTrackFinalOffset);
+            emf_track_state_t* const finalDev =
+                reinterpret_cast<emf_track_state_t*>(reinterpret_cast<char*>(trackWatchDev) + kTrackFinalOffset);
             const int maxLaunches = 2 * params.maxTrackingIter + 4;  // (every step a speculation miss)
             const auto t0 = std::chrono::steady_clock::now();
             int launch = 0;
+            // the stage's tag in the upper half of every sequence number and done word: the previous stage's last launches
+            // may still be queued (nobody waits for them) and write their words after the reset above
+            trackStageTag = (trackStageTag + 1u) & 0xffffu;
+            if (trackStageTag == 0u) trackStageTag = 1u;
+            const uint32_t tag = trackStageTag << 16;
+            const auto progress = [&]() { const uint32_t w = watch[0]; return (w & 0xffff0000u) == tag ? static_cast<int>(w & 0xffffu) : 0; };
+            const auto done = [&](int m) { const uint32_t w = watch[1 + m]; return (w & 0xffff0000u) == tag && (w & 3u) != 0u; };
             for (; launch < maxLaunches; ++launch) {
-                for (unsigned spins = 0; launch - static_cast<int>(watch[0]) >= trackWindow; ++spins)
+                for (unsigned spins = 0; launch - progress() >= trackWindow; ++spins)
                     if ((spins & 0xffffu) == 0xffffu &&
                         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
                         throw HipError("EMFusion: the tracking launches make no progress", EMF_E_ARG);
                 bool all = launch > 0;
-                for (int m = 0; m < count && all; ++m) all = watch[1 + m] != 0u;
+                for (int m = 0; m < count && all; ++m) all = done(m);
                 if (all) break;
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, trackWatchDev, static_cast<uint32_t>(launch + 1),
-                                           main.abi()),
+                                           params.maxTrackingIter, trackWatchDev, tag | static_cast<uint32_t>(launch + 1),
+                                           finalDev, main.abi()),
                          "trackStep");
             }
             if (launch & 1)  // an even number of launches leaves the state in `states`
                 emfCheck(emf_hip_trackStep(currentTable() + first, states, count, &pv, &tp, scratch, per, launch,
-                                           params.maxTrackingIter, nullptr, 0u, main.abi()),
+                                           params.maxTrackingIter, nullptr, 0u, nullptr, main.abi()),
                          "trackStep");
-            hipCheck(hipMemcpyAsync(trackStatesHost + first, states, sizeof(emf_track_state_t) * count,
-                                    hipMemcpyDeviceToHost, main.get()),
-                     "hipMemcpyAsync");
-            main.waitForCompletion();
+            bool all = true;
+            for (int m = 0; m < count && all; ++m) all = done(m);
+            if (all) {
+                // every model's state arrived in front of its word: no copy command, no wait for the stream (the launches
+                // still queued pass the states on and return)
+                std::atomic_thread_fence(std::memory_order_acquire);
+                std::memcpy(trackStatesHost + first, finalHost, sizeof(emf_track_state_t) * count);
+            } else {  // (the launch budget ran out first)
+                hipCheck(hipMemcpyAsync(trackStatesHost + first, states, sizeof(emf_track_state_t) * count,
+                                        hipMemcpyDeviceToHost, main.get()),
+                         "hipMemcpyAsync");
+                main.waitForCompletion();
+            }
             if (std::getenv("EMF_TRACK_LOG")) {  // diagnosis: launches against judged steps
                 int it = 0, acc = 0;
                 for (int m = first; m < first + count; ++m) {

@@ -413,6 +413,7 @@ private:
     int trackWindow = 6;                       // launches kept ahead of the device's progress report (0: poll in chunks)
     uint32_t* trackWatch = nullptr;            // pinned host words the step kernel reports to
     uint32_t* trackWatchDev = nullptr;         // ... as the device addresses them
+    uint32_t trackStageTag = 0;                // upper half of the words of the stage in flight (trackModels)
     DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_BATCH]
     DeviceBuffer trackScratch;                 // EMF_MAX_BATCH x emf_hip_trackScratchBytes
     emf_track_state_t* trackStatesHost = nullptr;  // pinned mirror

@@ -75,6 +75,7 @@ struct TrackFrame {
     int iterations;         // LM iterations the call asks for
     int rescale;            // an accepted step whose weight maximum moved rescales its sums (0: makes them anew, one launch more)
     uint32_t* watch;        // host memory (or null): [0] <- seq, [1 + m] <- model m is done (emf_hip_trackStep)
+    emf_track_state_t* finalStates;  // host memory (or null): [m] <- model m's state, in front of watch[1 + m]
     uint32_t seq;
 };
 
@@ -601,11 +602,23 @@ __device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid
 
 // progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
 // go to the host's memory while the kernel runs
-__device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st) {
+// (one wave: a model that is done also sends its state, before the word that says so -- the host needs no copy command
+// and no wait for the stream to read a stage's result)
+__device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st, int lane) {
     if (!f.watch) return;
     const uint32_t done = st.converged ? 1u : (st.pending == 0 && st.iterations >= st.iterTarget ? 2u : 0u);
-    __hip_atomic_store(f.watch + 1 + m, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (done != 0u && f.finalStates) {
+        const unsigned* const src = reinterpret_cast<const unsigned*>(&st);
+        unsigned* const dst = reinterpret_cast<unsigned*>(f.finalStates + m);
+        for (int i = lane; i < kStateWords; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: the state is out before the word)
+    }
+    if (lane == 0) {
+        // (the upper half of seq travels with the word: a host that does not wait for a stage's last launches tells their
+        // words from the next stage's by it)
+        __hip_atomic_store(f.watch + 1 + m, (f.seq & 0xffff0000u) | done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (m == 0) __hip_atomic_store(f.watch, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // One workgroup per CU (4 waves per SIMD, 128 registers): the prologue is paid once per CU -- two workgroups sharing
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
         if (blockIdx.x == 0) {
             state_copy(reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1)),
                        reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
-            if (threadIdx.x == 0) report(f, m, *in);
+            if (wave == 0) report(f, m, *in, lane);
         }
         return;
     }
@@ -731,10 +744,10 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     STAMP(2);
     if (threadIdx.x == 0) {
         lm_advance(st, sums, f);
-        if (blockIdx.x == 0) report(f, m, st);
     }
     STAMP(3);
     __syncthreads();
+    if (blockIdx.x == 0 && wave == 0) report(f, m, st, lane);
     const int body = __builtin_amdgcn_readfirstlane(st.body);
     if (blockIdx.x == 0) {
         emf_track_state_t* const out = state_buf(f, m, (f.launch + 1) & 1);
@@ -1148,6 +1161,7 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
     const int launches = (iterations + 3 + 1) & ~1;
     f.iterations = iterations;
     f.watch = nullptr;
+    f.finalStates = nullptr;
     f.seq = 0;
     for (int i = 0; i < launches; ++i) enqueue_step(f, nmodels, i, as_stream(stream));
     return launch_status("trackIterate");
@@ -1156,13 +1170,14 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
 int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                       const emf_image_t* points, const emf_track_params_t* params,
                       void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
-                      uint32_t* watch, uint32_t seq, emf_stream_t stream) {
+                      uint32_t* watch, uint32_t seq, emf_track_state_t* finalStates, emf_stream_t stream) {
     TrackFrame f;
     EMF_TRY(fill_frame(f, models_dev, states_dev, nmodels, points, params, scratch_dev,
                        scratchBytesPerModel, "trackStep"));
     if (launch < 0 || iterations < 0) return fail(EMF_E_ARG, "trackStep: launch = %d, iterations = %d", launch, iterations);
     f.iterations = iterations;
     f.watch = watch;
+    f.finalStates = finalStates;
     f.seq = seq;
     enqueue_step(f, nmodels, launch, as_stream(stream));
     return launch_status("trackStep");
@@ -1178,6 +1193,7 @@ int emf_hip_trackWeightImages(const emf_model_t* models_dev, const emf_track_sta
     if (!huber_dev && !track_dev) return EMF_OK;
     f.launch = f.iterations = 0;
     f.watch = nullptr;
+    f.finalStates = nullptr;
     f.seq = 0;
     const size_t px = static_cast<size_t>(f.w) * f.h;
     hipLaunchKernelGGL(k_track_weight_images, dim3(static_cast<unsigned>(ceil_div(px, 256)), static_cast<unsigned>(nmodels)),

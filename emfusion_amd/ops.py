@@ -528,12 +528,13 @@ def track_iterate(models_dev, states_dev, nmodels, points, params, scratch, scra
 
 
 def track_step(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model, launch,
-               iterations, watch=None, seq=0, stream=None):
-    """One launch of the LM step kernel (emf_hip_trackStep); watch: address of host-pinned uint32s or None."""
+               iterations, watch=None, seq=0, stream=None, final_states=None):
+    """One launch of the LM step kernel (emf_hip_trackStep); watch: address of host-pinned uint32s or None;
+    final_states: address of nmodels EmfTrackState the device can write (a done model's state, ahead of its word) or None."""
     check("emf_hip_trackStep",
           _L.emf_hip_trackStep(_ptr(models_dev), _ptr(states_dev), nmodels, C.byref(image_view(points)),
                                C.byref(params), _ptr(scratch), scratch_per_model, launch, iterations,
-                               watch, seq, _stream(stream)))
+                               watch, seq, final_states, _stream(stream)))
 
 
 def track_weight_images(models_dev, states_dev, nmodels, points, params, scratch, scratch_per_model,

@@ -815,16 +815,21 @@ int emf_hip_trackIterate(const emf_model_t* models_dev, emf_track_state_t* state
  * maximum pass and lets every model do `iterations` more iterations) and has the device report to
  * `watch`, which must be host memory the device can write (hipHostMalloc, coherent):
  *   watch[0]      <- seq when the launch has begun (any nonzero number the caller increases per launch),
- *   watch[1 + m]  <- 1 when model m has converged, 2 when it has done its iterations, else 0.
+ *   watch[1 + m]  <- 1 when model m has converged, 2 when it has done its iterations, else 0 -- in the lower half;
+ *                    the upper half is seq's (a stage tag, if the caller puts one there: launches of the previous stage
+ *                    that are still queued write too).
  * These are hints to stop enqueuing (written with system-scope stores while the stream runs: keep a
  * few launches ahead of watch[0], stop when every watch[1 + m] != 0); the states are read as usual.
  * The number of launches of a stage must be even (the state alternates between the caller's array
  * and a shadow in the scratch): end with one more launch if it is not -- a launch with nothing to
- * do returns at once.  watch may be NULL. */
+ * do returns at once.  watch may be NULL.
+ * finalStates (host memory the device can write, nmodels entries, or NULL): the launch that finds model m done
+ * stores its state to finalStates[m] IN FRONT OF watch[1 + m] (system scope, release): a host that has seen the
+ * word (and an acquire fence) reads the stage's result there -- no copy command, no wait for the stream. */
 int emf_hip_trackStep(const emf_model_t* models_dev, emf_track_state_t* states_dev, int nmodels,
                       const emf_image_t* points, const emf_track_params_t* params,
                       void* scratch_dev, size_t scratchBytesPerModel, int launch, int iterations,
-                      uint32_t* watch, uint32_t seq, emf_stream_t stream);
+                      uint32_t* watch, uint32_t seq, emf_track_state_t* finalStates, emf_stream_t stream);
 
 /* The two weight images a stage leaves behind, as the reference's debug output reads them at the end of a frame
  * (TSDF::getHuberWeights / getTrackingWeights, TSDF.cpp:346-354: `trackWeights` = min(huberThresh / |tsdf value|, 1)

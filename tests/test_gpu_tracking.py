@@ -250,8 +250,9 @@ def test_speculation_miss_stays_in_parity(oracle, ops, dev, world, monkeypatch, 
 
 
 def test_large_image_many_blocks(oracle, ops, dev, monkeypatch):
-    """1280 x 960: 1200 blocks of 1024 pixels -- more than a launch has workgroups (each takes several
-    blocks) and more rows of partial sums than one batch of the prologue's loads (3 batches)."""
+    """1280 x 960: 1011 rows of 1216 pixels -- more than a launch has workgroups (two models: eight rows per workgroup,
+    two passes of four; one model: one pass of four) and more rows of partial sums than one batch of the prologue's
+    loads (2 batches)."""
     import sys
     mod = sys.modules[__name__]
     monkeypatch.setattr(mod, "W", 1280)
@@ -281,12 +282,14 @@ def test_launch_by_launch_with_progress_words(ops, dev, world):
     memory and reads them while the stream runs)."""
     ref = DeviceTracker(ops, world, [0, 1]).iterate(100)
     dt = DeviceTracker(ops, world, [0, 1])
+    from emfusion_amd import _lib
     watch = dev_full((3,), 0, np.uint32)
+    final = dev_full((2 * C.sizeof(_lib.EmfTrackState),), 0, np.uint8)  # where a done model's state is sent ahead of its word
     launch = 0
     while True:
         for _ in range(8):
             ops.track_step(dt.table, dt.states, dt.n, dt.points, dt.params, dt.scratch, dt.per_model, launch, 100,
-                           watch.ptr, launch + 1)
+                           watch.ptr, launch + 1, final_states=final.ptr)
             launch += 1
         w = to_np(watch)
         assert w[0] == launch
@@ -294,8 +297,10 @@ def test_launch_by_launch_with_progress_words(ops, dev, world):
             break
         assert launch < 220
     sts = ops.read_track_states(dt.states, 2)  # (an even number of launches: the state is in the caller's array)
+    sent = ops.read_track_states(final, 2)
     for k in (0, 1):
         assert _fields(sts[k]) == _fields(ref[k])
+        assert _fields(sent[k]) == _fields(ref[k])
         assert w[1 + k] == (1 if sts[k].converged else 2)
     assert launch < 100  # both converge long before the iteration budget
 
