@@ -649,6 +649,18 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     // column is the maximum)
     constexpr int kColsPerWave = (kCols + kWaves - 1) / kWaves;
     const float* const prev = scratch_partials(f, m, (f.launch + 1) & 1);
+    // The first batch of this wave's partial sums is requested BEFORE the state says whether they are wanted: the state and
+    // the sums, both written on other XCDs by the previous launch, are two misses all the way to memory -- side by side
+    // instead of in a row.  (The compiler sinks a load behind the branch that alone uses it: the other side "uses" the
+    // values too.  Volatile loads are waited for one by one: 4.8 instead of 3.2 us.)
+    float v0[kColsPerWave][8];
+#pragma unroll
+    for (int q = 0; q < kColsPerWave; ++q) {
+        const int c = wave + q * kWaves;
+        const float* const col = prev + static_cast<size_t>(c < kCols ? c : 0) * f.nblocks;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v0[q][j] = col[min(lane + 64 * j, f.nblocks - 1)];
+    }
     // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
         if (blockIdx.x == 0) {
@@ -656,6 +668,10 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
                        reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
             if (wave == 0) report(f, m, *in, lane);
         }
+#pragma unroll
+        for (int q = 0; q < kColsPerWave; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(v0[q][j]));  // (see above)
         return;
     }
     state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
@@ -714,7 +730,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = i0 + 64 * j;
-                    v[q][j] = i < f.nblocks ? col[i] : 0.f;
+                    v[q][j] = i >= f.nblocks ? 0.f : (i0 == lane ? v0[q][j] : col[i]);
                 }
             }
 #pragma unroll
