@@ -602,6 +602,10 @@ __device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid
 
 // progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
 // go to the host's memory while the kernel runs
+// A workgroup barrier for LDS contents alone: __syncthreads() also waits for every global load and store the wave has
+// in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // (one wave: a model that is done also sends its state, before the word that says so -- the host needs no copy command
 // and no wait for the stream to read a stage's result)
 __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st, int lane) {
@@ -661,20 +665,23 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v0[q][j] = col[min(lane + 64 * j, f.nblocks - 1)];
     }
+    // (likewise the state's own words: one per lane, in flight with the flags the branch below reads)
+    static_assert(kStateWords <= kTrackBlock, "a word per lane");
+    const unsigned stWord = threadIdx.x < kStateWords ? reinterpret_cast<const unsigned*>(in)[threadIdx.x] : 0u;
     // nothing left to do for this model in this call (lm_advance would find the same): pass the state on
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
         if (blockIdx.x == 0) {
-            state_copy(reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1)),
-                       reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
+            if (threadIdx.x < kStateWords) reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1))[threadIdx.x] = stWord;
             if (wave == 0) report(f, m, *in, lane);
         }
+        asm volatile("" ::"v"(stWord));
 #pragma unroll
         for (int q = 0; q < kColsPerWave; ++q)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(v0[q][j]));  // (see above)
         return;
     }
-    state_copy(reinterpret_cast<unsigned*>(&st), reinterpret_cast<const unsigned*>(in), threadIdx.x, kTrackBlock);
+    if (threadIdx.x < kStateWords) reinterpret_cast<unsigned*>(&st)[threadIdx.x] = stWord;
     const emf_model_t& md = f.models[m];
     const I3 n{md.res[0], md.res[1], md.res[2]};
     // the points of the workgroup's first row: fetched under the prologue
@@ -756,13 +763,13 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
         }
     }
     STAMP(1);
-    __syncthreads();
+    lds_barrier();  // (not __syncthreads(): that would also wait for the points requested above -- a miss to memory, 1 us)
     STAMP(2);
     if (threadIdx.x == 0) {
         lm_advance(st, sums, f);
     }
     STAMP(3);
-    __syncthreads();
+    lds_barrier();
     if (blockIdx.x == 0 && wave == 0) report(f, m, st, lane);
     const int body = __builtin_amdgcn_readfirstlane(st.body);
     if (blockIdx.x == 0) {
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     // The image in rows of kRowPixels pixels, one row of partial sums each: the sums depend neither on the grid nor
     // on how the rows are grouped into passes.
     for (unsigned base = blockIdx.x; base < static_cast<unsigned>(f.nblocks); base += gridDim.x * kMaxRows) {
-        if (base != blockIdx.x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // red[] of the previous pass has been read
+        if (base != blockIdx.x) lds_barrier();  // red[] of the previous pass has been read
         // A pixel whose point is invalid or falls outside the volume's interpolation range contributes exact zeros
         // to everything (value, gradient, weights: TSDF.cu:617-624, 676-683): a wave of such pixels -- most of the
         // image, for an object -- stores its zeros and skips the arithmetic.
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             }
         // (a barrier for red[] alone: __syncthreads() also waits for the wave's global stores -- up to sixteen zeros per
         // lane of a wave with dead slots -- to be acknowledged, 3 us that nothing here needs)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        lds_barrier();
 #ifdef EMF_TRACK_TRACE
         STAMP(4);  // (probe builds: the stamp behind the state's store is overwritten by the pass's barrier)
 #endif
