@@ -663,7 +663,10 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
         const int c = wave + q * kWaves;
         const float* const col = prev + static_cast<size_t>(c < kCols ? c : 0) * f.nblocks;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v0[q][j] = col[min(lane + 64 * j, f.nblocks - 1)];
+        for (int j = 0; j < 8; ++j) {
+            v0[q][j] = 0.f;
+            if (64 * j < f.nblocks) v0[q][j] = col[min(lane + 64 * j, f.nblocks - 1)];  // (uniform: 253 rows are 4 of the 8)
+        }
     }
     // (likewise the state's own words: one per lane, in flight with the flags the branch below reads)
     static_assert(kStateWords <= kTrackBlock, "a word per lane");
@@ -742,10 +745,12 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
+                if (i0 - lane + 64 * j < f.nblocks) {  // (uniform; the rows beyond the last would add +0.0: the same bits)
 #pragma unroll
-                for (int q = 0; q < kColsPerWave; ++q) {
-                    acc[q] += static_cast<double>(v[q][j]);
-                    if (wave + q * kWaves == kCols - 1) mx = fmaxf(mx, v[q][j]);
+                    for (int q = 0; q < kColsPerWave; ++q) {
+                        acc[q] += static_cast<double>(v[q][j]);
+                        if (wave + q * kWaves == kCols - 1) mx = fmaxf(mx, v[q][j]);
+                    }
                 }
         }
 #pragma unroll
@@ -762,6 +767,10 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
             }
         }
     }
+#ifdef EMF_TRACK_TRACE  // every wave of the traced workgroup, launch 6: arrival at the barrier behind the column sums
+    if (blockIdx.x == EMF_TRACK_TRACE && m == 0 && lane == 0 && f.launch == 6)
+        (reinterpret_cast<long long*>(state_buf(f, 0, 1) + 1) + 8 * 24 + 2 * f.nblocks)[wave] = wall_clock64();
+#endif
     STAMP(1);
     lds_barrier();  // (not __syncthreads(): that would also wait for the points requested above -- a miss to memory, 1 us)
     STAMP(2);
@@ -1135,7 +1144,7 @@ size_t emf_hip_trackScratchBytes(int width, int height) {
     const size_t nblocks = ceil_div(px, kRowPixels);
     size_t bytes = (4 * px + 2 * nblocks * kCols) * sizeof(float) + sizeof(emf_track_state_t);
 #ifdef EMF_TRACK_TRACE
-    bytes += (24 * 8 + 2 * nblocks) * sizeof(long long);
+    bytes += (24 * 8 + 2 * nblocks + 2 * 16) * sizeof(long long);
 #endif
     return (bytes + 255) / 256 * 256;
 }

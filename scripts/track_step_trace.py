@@ -30,3 +30,7 @@ if wg[:, 0].any():
 for i, r in enumerate(st):
     if r[0] == 0: continue
     print(i, " ".join("%6.2f" % ((x - r[0]) / 100.0) if x else "   -  " for x in r[1:8]))
+wv = raw[off + 24 * 64 + 16 * nb:off + 24 * 64 + 16 * nb + 16 * 8].view(np.int64)
+if wv.any() and st[6][0]:
+    print("launch 6, waves' arrival at the barrier behind the column sums (us from kernel entry):",
+          " ".join("%.2f" % ((x - st[6][0]) / 100.0) for x in wv))
