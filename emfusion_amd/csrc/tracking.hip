@@ -379,10 +379,21 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
         return;
     }
     if (st.pending == kBodyAccum) {
-        for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
+        // (the pass has written the current pose's weight image with that pose's maximum -- or, the first pass of a stage
+        // that looks the integration weights up itself, with the weight cap for the maximum it could not know yet: the
+        // factor goes the way of an accepted step's, below)
+        float k = 1.f;
+        const uint32_t mxBits = __float_as_uint(static_cast<float>(sums[kCols - 1]));
+        if (f.rescale && mxBits != st.maxIwBits) {
+            const float mxGuess = __uint_as_float(st.maxIwBits), mxTrue = __uint_as_float(mxBits);
+            k = static_cast<double>(mxTrue) > 2.220446049250313e-16
+                    ? static_cast<float>(static_cast<double>(mxGuess) / static_cast<double>(mxTrue)) : 0.f;
+            st.maxIwBits = mxBits;
+        }
+        for (int q = 0; q < 28; ++q) st.spec[q] = k == 1.f ? static_cast<float>(sums[q]) : static_cast<float>(sums[q]) * k;
         st.needAccum = 0;
         st.haveSpec = 1;
-        st.wFac = 1.f;  // (the pass has written the current pose's weight image with that pose's maximum)
+        st.wFac = k;
     } else if (st.pending == kBodyTrial) {
         // ---- computePoseUpdate, second half (TSDF.cpp:315-337) ----
         const float errNew = static_cast<float>(sums[28]);
@@ -438,6 +449,9 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
     st.pending = 0;
     if (st.iterations >= st.iterTarget) return;
     if (st.needAccum) {
+        // a stage's first pass looks the integration weights up itself (no k_track_maxw in front of it) and normalises by
+        // the weight cap, which is their maximum once a volume has been seen maxTSDFWeight times
+        if (st.firstIteration && f.rescale) st.maxIwBits = __float_as_uint(f.prm.maxWeight);
         st.body = st.pending = kBodyAccum;
         return;
     }
@@ -510,6 +524,7 @@ struct PixelPass {  // (wave-uniform)
     M33 R;
     V3 t;
     bool trial;
+    bool lookupIw;       // the pass looks the clamped integration weights up (a trial pose; a stage's first pass) or reads iwCur
     float scale, huberThresh, maxWeight;
     float wFac;          // factor on wCur (emf_track_state_t::wFac)
     const float* wCur;   // the weight image of the current pose (trial: read for the step's error)
@@ -521,7 +536,7 @@ struct PixelPass {  // (wave-uniform)
 // what a pass leaves per pixel: the combined weight, and at a trial pose the clamped integration weight
 __device__ __forceinline__ void store_terms(const PixelPass& a, bool valid, size_t pix, const PixelTerms& o) {
     if (!valid) return;
-    if (a.trial) a.iwOut[pix] = o.iw;
+    if (a.lookupIw) a.iwOut[pix] = o.iw;
     a.wOut[pix] = o.w;
 }
 
@@ -584,7 +599,7 @@ __device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid
     o.r = in1 ? rIn : 0.f;
     const float iwIn = blend8(w000, w001, w010, w011, w100, w101, w110, w111, c.fx, c.fy, c.fz);
     o.e = a.trial ? (o.r * o.r) * (wCur * a.wFac) : 0.f;  // (wFac = 1 leaves the weight as it is)
-    o.iw = a.trial ? fminf(in1 ? iwIn : 0.f, a.maxWeight) : iwCur;
+    o.iw = a.lookupIw ? fminf(in1 ? iwIn : 0.f, a.maxWeight) : iwCur;
     const float ab = fabsf(o.r);
     float tw = ab != 0.f ? a.huberThresh / ab : 0.f;
     tw = fminf(tw, 1.0f);
@@ -810,6 +825,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     a.R = M33{{uni(Rp[0]), uni(Rp[1]), uni(Rp[2])}, {uni(Rp[3]), uni(Rp[4]), uni(Rp[5])}, {uni(Rp[6]), uni(Rp[7]), uni(Rp[8])}};
     a.t = v3(uni(tp[0]), uni(tp[1]), uni(tp[2]));
     a.trial = trial;
+    a.lookupIw = trial || (f.rescale != 0 && __builtin_amdgcn_readfirstlane(st.firstIteration) != 0);
     // cv::cuda::normalize(NORM_INF, alpha = 1): scale = norm > DBL_EPSILON ? 1 / norm : 0
     // (trial: the current pose's maximum, assumed to hold at the trial pose as well -- checked by
     // the next prologue)
@@ -822,7 +838,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     a.wCur = scratch_w(f, m, wSel);
     a.wOut = scratch_w(f, m, trial ? 1 - wSel : wSel);
     a.iwCur = scratch_iw(f, m, iwSel);
-    a.iwOut = scratch_iw(f, m, 1 - iwSel);
+    a.iwOut = scratch_iw(f, m, trial ? 1 - iwSel : iwSel);
     float* const mine = scratch_partials(f, m, f.launch & 1);
     // A pixel's 28 products As = (g_j * g_k) * w, bs = (r * g_j) * w, r^2 w (computeAb / multSingletonCol; column
     // order: the upper triangle of A row by row (21), b (6), err) and the trial step's error, summed over the wave
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     };
     const auto dead_slot = [&](bool ok, size_t pix) {  // a wave without a live pixel: zeros to the images
         if (!ok) return;
-        if (trial) a.iwOut[pix] = 0.f;
+        if (a.lookupIw) a.iwOut[pix] = 0.f;
         a.wOut[pix] = 0.f;
     };
     // The image in rows of kRowPixels pixels, one row of partial sums each: the sums depend neither on the grid nor
@@ -1169,7 +1185,8 @@ void enqueue_step(TrackFrame& f, int nmodels, int launch, hipStream_t s) {
     const dim3 px(ceil_div(static_cast<size_t>(f.w) * f.h, kTrackBlock), static_cast<unsigned>(nmodels));
     // the weight maximum is looked up at the first pose of a stage only (device flag); in a later
     // call of the stage the kernel returns at once
-    if (launch == 0) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
+    // (only where the first pass cannot fold it in: EMF_TRACK_RESCALE=0)
+    if (launch == 0 && !f.rescale) hipLaunchKernelGGL(k_track_maxw, px, dim3(kTrackBlock), 0, s, f);
     // all workgroups of a launch resident at once (two per CU), each taking its share of the blocks
     f.launch = launch;
     // a workgroup per CU, shared out among the models; each takes its share of a model's rows
