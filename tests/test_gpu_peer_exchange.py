@@ -29,7 +29,9 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 pytestmark = pytest.mark.gpu
-ENV = dict(GPU_MAX_HW_QUEUES="24", HSA_ENABLE_IPC_MODE_LEGACY="0")
+# EMF_PEER_TIMEOUT_MS: a rank's wait is bounded (5 s by default); on a box that has just started, one rank thread's first
+# launches can lag the other's by more than that (first run on a fresh box: the 5 s bound hit, the next four runs 2 s each)
+ENV = dict(GPU_MAX_HW_QUEUES="24", HSA_ENABLE_IPC_MODE_LEGACY="0", EMF_PEER_TIMEOUT_MS="60000")
 
 
 def _exchanges_scenario(world):

@@ -32,6 +32,7 @@ def run_job(world, nobj, depth_broadcast, track=False):
     synth.close()
     comms = pipeline.Communicator.local_group(world) if world > 1 else [None]
     out, errors = [None] * world, []
+    ready = threading.Barrier(world)  # the ranks enter their first frame together (a bounded wait sits in the peer transport)
 
     def rank_main(r):
         try:
@@ -41,6 +42,7 @@ def run_job(world, nobj, depth_broadcast, track=False):
             ids = [fus.add_object(c, vs) for c, _, vs in first]
             mine = [i for i in ids if fus.owns_object(i)]
             keep = []
+            ready.wait(timeout=120)
             for f, (depth, sid, R, t) in enumerate(frames):
                 # with the broadcast on, only rank 0 holds the real depth: the others start from zeros
                 d = to_dev(depth if (r == 0 or not depth_broadcast) else np.zeros_like(depth))
