@@ -106,11 +106,9 @@ __device__ __forceinline__ M33 state_R(const float* R) {
     return M33{{R[0], R[1], R[2]}, {R[3], R[4], R[5]}, {R[6], R[7], R[8]}};
 }
 
-// pixel of this lane: the image in runs of `run` pixels (rows of partial sums: kRowPixels, the lanes' first pixel
-// at offset 0, the second one of the first waves at kTrackBlock), blockIdx.y = model
-__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc, unsigned block = blockIdx.x,
-                                           int run = kTrackBlock, int offset = 0) {
-    pix = static_cast<size_t>(block) * run + offset + threadIdx.x;
+// pixel of this lane of k_track_maxw: the image in runs of kTrackBlock pixels, blockIdx.y = model
+__device__ __forceinline__ bool load_point(const TrackFrame& f, size_t& pix, V3& pc) {
+    pix = static_cast<size_t>(blockIdx.x) * kTrackBlock + threadIdx.x;
     pc = v3(0.f, 0.f, 0.f);
     if (pix >= static_cast<size_t>(f.w) * f.h) return false;
     const int y = static_cast<int>(pix / f.w), x = static_cast<int>(pix - static_cast<size_t>(y) * f.w);
@@ -615,12 +613,12 @@ __device__ __forceinline__ PixelTerms pixel_terms(const PixelPass& a, bool valid
     return o;
 }
 
-// progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
-// go to the host's memory while the kernel runs
 // A workgroup barrier for LDS contents alone: __syncthreads() also waits for every global load and store the wave has
 // in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// progress report to the host (hints only: see emf_hip_trackStep); system scope, so that the stores
+// go to the host's memory while the kernel runs
 // (one wave: a model that is done also sends its state, before the word that says so -- the host needs no copy command
 // and no wait for the stream to read a stage's result)
 __device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st, int lane) {
