@@ -350,26 +350,24 @@ __device__ __forceinline__ void state_copy(unsigned* dst, const unsigned* src, i
         if (!kSkipLogTrial || i != kLogTrialWord) dst[i] = src[i];
 }
 
-// TSDF::reduceHessians' results (TSDF.cpp:264-279) from the 28 sums
-__device__ __forceinline__ void adopt_sums(emf_track_state_t& st, const float* sums) {
-    int q = 0;
-    for (int j = 0; j < 6; ++j)
-        for (int k = j; k < 6; ++k) {
-            const float v = sums[q++];
-            st.A[6 * j + k] = v;
-            st.A[6 * k + j] = v;
-        }
-    for (int j = 0; j < 6; ++j) st.b[j] = sums[21 + j];
+// TSDF::reduceHessians' results (TSDF.cpp:264-279) from the 28 sums; the wave's lanes take an element each
+__device__ __forceinline__ void adopt_sums(emf_track_state_t& st, const float* sums, int lane) {
+    if (lane < 36) {
+        const int j = lane / 6, k = lane - 6 * j, a = min(j, k), b = max(j, k);
+        st.A[lane] = sums[6 * a - a * (a - 1) / 2 + (b - a)];  // (the upper triangle row by row)
+    }
+    if (lane < 6) st.b[lane] = sums[21 + lane];
     st.err = sums[27];
     st.needAccum = st.haveSpec = 0;
     st.checkB = 1;
 }
 
-// One lane: everything between two per-pixel passes.  Sets st.body (what this launch does per
-// pixel) and st.pending (what the next launch will find in the partial sums).
+// One wave: everything between two per-pixel passes.  Sets st.body (what this launch does per pixel) and st.pending
+// (what the next launch will find in the partial sums).  Every lane runs the scalar logic on the same LDS values -- the
+// instructions of one lane -- and the copies of arrays take a lane per element.
 // st.logCur / st.logTrial: |log| of the current and of the trial pose (the step-size test needs the one of the
 // pose the verdict leaves current); the trial's is made beside the per-pixel pass of the launch that made the pose.
-__device__ void lm_advance(emf_track_state_t& st, const double* sums, const TrackFrame& f) {
+__device__ void lm_advance(emf_track_state_t& st, const double* sums, const TrackFrame& f, int lane) {
     if (f.launch == 0) st.iterTarget = st.iterations + f.iterations;
     st.body = kBodyNone;
     if (st.converged) {
@@ -388,7 +386,7 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
                     ? static_cast<float>(static_cast<double>(mxGuess) / static_cast<double>(mxTrue)) : 0.f;
             st.maxIwBits = mxBits;
         }
-        for (int q = 0; q < 28; ++q) st.spec[q] = k == 1.f ? static_cast<float>(sums[q]) : static_cast<float>(sums[q]) * k;
+        if (lane < 28) st.spec[lane] = k == 1.f ? static_cast<float>(sums[lane]) : static_cast<float>(sums[lane]) * k;
         st.needAccum = 0;
         st.haveSpec = 1;
         st.wFac = k;
@@ -405,8 +403,8 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
         st.rho = rho;
         st.iterations += 1;
         if (rho > 0) {  // accept (TSDF.cpp:322-327)
-            for (int k = 0; k < 9; ++k) st.R[k] = st.Rtrial[k];
-            for (int k = 0; k < 3; ++k) st.t[k] = st.ttrial[k];
+            if (lane < 9) st.R[lane] = st.Rtrial[lane];
+            if (lane < 3) st.t[lane] = st.ttrial[lane];
             st.logCur = st.logTrial;
             const float c = 2.f * rho - 1.f;
             const float rhoFac = 1.f - c * c * c;
@@ -417,7 +415,7 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
             st.iwSel ^= 1;  // the trial pose's integration weights become the current ones
             const float mxCur = __uint_as_float(st.maxIwBits), mxNew = __uint_as_float(st.maxIwTrialBits);
             if (st.maxIwTrialBits == st.maxIwBits) {  // the body's weights were normalised correctly
-                for (int k = 0; k < 28; ++k) st.spec[k] = static_cast<float>(sums[k]);
+                if (lane < 28) st.spec[lane] = static_cast<float>(sums[lane]);
                 st.haveSpec = 1;
                 st.wSel ^= 1;
                 st.wFac = 1.f;
@@ -429,7 +427,7 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
                 // long as a model's integration weights have not reached their cap (its first maxTSDFWeight frames).
                 const float k = static_cast<double>(mxNew) > 2.220446049250313e-16
                                     ? static_cast<float>(static_cast<double>(mxCur) / static_cast<double>(mxNew)) : 0.f;
-                for (int q = 0; q < 28; ++q) st.spec[q] = static_cast<float>(sums[q]) * k;
+                if (lane < 28) st.spec[lane] = static_cast<float>(sums[lane]) * k;
                 st.haveSpec = 1;
                 st.wSel ^= 1;
                 st.wFac = k;
@@ -454,7 +452,7 @@ __device__ void lm_advance(emf_track_state_t& st, const double* sums, const Trac
         return;
     }
     // the iteration proper starts here: its A, b, err (TSDF.cpp:264-275) are the sums made ahead of it
-    if (st.haveSpec) adopt_sums(st, st.spec);
+    if (st.haveSpec) adopt_sums(st, st.spec, lane);
     if (st.checkB) {  // TSDF.cpp:276-278, on freshly reduced sums only
         st.checkB = 0;
         float maxB = 0.f;
@@ -787,9 +785,7 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     STAMP(1);
     lds_barrier();  // (not __syncthreads(): that would also wait for the points requested above -- a miss to memory, 1 us)
     STAMP(2);
-    if (threadIdx.x == 0) {
-        lm_advance(st, sums, f);
-    }
+    if (wave == 0) lm_advance(st, sums, f, lane);
     STAMP(3);
     lds_barrier();
     if (blockIdx.x == 0 && wave == 0) report(f, m, st, lane);
