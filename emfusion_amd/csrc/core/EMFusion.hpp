@@ -410,7 +410,7 @@ private:
     void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)
     int trackChunk = 8;                        // iterations per convergence poll (0: never poll)
     int trackPredicted[2] = {0, 0};            // iterations the camera / object stage took last frame
-    int trackWindow = 6;                       // launches kept ahead of the device's progress report (0: poll in chunks)
+    int trackWindow = 4;                       // launches kept ahead of the device's progress report (0: poll in chunks); 2 ... 6 measured: 4 leaves a stage 3 idle launches instead of 5
     uint32_t* trackWatch = nullptr;            // pinned host words the step kernel reports to
     uint32_t* trackWatchDev = nullptr;         // ... as the device addresses them
     uint32_t trackStageTag = 0;                // upper half of the words of the stage in flight (trackModels)
