@@ -201,7 +201,7 @@ public:
     void check() override {
         if (*own_->error)
             throw HipError("peer exchange " + std::to_string(*own_->error) + ": a peer's flag did not arrive within " +
-                           std::to_string(timeoutMs_) + " ms (ranks disagree about the sequence of exchanges?); the "
+                           std::to_string(*own_->error == 1u ? std::max(timeoutMs_, 60000u) : timeoutMs_) + " ms (ranks disagree about the sequence of exchanges?); the "
                            "exchange's consumer left its outputs untouched", EMF_E_PEER_TIMEOUT);
     }
 
@@ -216,6 +216,9 @@ private:
                            std::to_string(g_.slotBytes), EMF_E_LIMIT);
         if (bytes % 16)
             throw HipError("peer exchange: message of " + std::to_string(bytes) + " bytes is not a multiple of 16", EMF_E_ARG);
+        // the FIRST exchange also absorbs the ranks' start-up skew (a rank whose first launches load code objects, or
+        // whose process came up later): a minute for it, the configured bound from then on
+        g_.timeoutMs = seq_ == 0 ? std::max(timeoutMs_, 60000u) : timeoutMs_;
         return ++seq_;
     }
     int rank_, world_;
