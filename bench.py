@@ -277,6 +277,8 @@ def main():
     visible = fus.visible_objects()
 
 
+    track_steps = []
+
     def replay_with_counters():
         """March samples and hits of exactly the timed launches, counted in an UNTIMED replay (the byte model of
         the raycast needs them; the per-wave counters cost the raycast and the sweep beside it ~13 % when they
@@ -299,6 +301,9 @@ def main():
                 if args.track:
                     fus.set_tracking(camera=True, objects=True)
             step(f)
+            if args.track and f >= args.warmup:  # LM steps of the replayed (= the timed) stages: what frames/s is made of
+                res = [fus.track_result(i) for i in [0] + list(mine)]
+                track_steps.append((res[0]["iterations"], res[0]["accepted"], max(r["iterations"] for r in res[1:]) if mine else 0))
         fus.synchronize()
         return fus.raycast_stats()
 
@@ -355,6 +360,16 @@ def main():
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
         }
+        if args.track and track_steps:
+            n = len(track_steps)
+            result["tracking_steps"] = {
+                "note": "LM steps of the timed frames' stages, counted in the untimed replay: one launch per step, +1 for the sums "
+                        "at the stage's first pose, +1 for the last verdict, + the launches the host had queued when the stage ended",
+                "camera_per_frame": round(sum(t[0] for t in track_steps) / n, 1),
+                "camera_accepted_per_frame": round(sum(t[1] for t in track_steps) / n, 1),
+                "objects_longest_per_frame": round(sum(t[2] for t in track_steps) / n, 1),
+                "frames_in_which_an_object_used_the_whole_budget": sum(1 for t in track_steps if t[2] >= prm.max_tracking_iter),
+            }
         # priced by the newest committed PMC summary of THIS workload (profiles/*_counters.json carry a workload key)
         key = workload_key(W, H, args.bg_res, args.obj_res, nobj_total, args.track) if world == 1 else None
         result["config"]["workload_key"] = key
