@@ -619,10 +619,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // go to the host's memory while the kernel runs
 // (one wave: a model that is done also sends its state, before the word that says so -- the host needs no copy command
 // and no wait for the stream to read a stage's result)
-__device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st, int lane) {
+__device__ __forceinline__ void report(const TrackFrame& f, int m, const emf_track_state_t& st, int lane, bool sendState = true) {
     if (!f.watch) return;
     const uint32_t done = st.converged ? 1u : (st.pending == 0 && st.iterations >= st.iterTarget ? 2u : 0u);
-    if (done != 0u && f.finalStates) {
+    if (done != 0u && f.finalStates && sendState) {
         const unsigned* const src = reinterpret_cast<const unsigned*>(&st);
         unsigned* const dst = reinterpret_cast<unsigned*>(f.finalStates + m);
         for (int i = lane; i < kStateWords; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -686,7 +686,8 @@ __global__ __launch_bounds__(kTrackBlock, 4) void k_track_step(const TrackFrame 
     if (in->converged || (f.launch > 0 && in->pending == 0 && in->iterations >= in->iterTarget)) {
         if (blockIdx.x == 0) {
             if (threadIdx.x < kStateWords) reinterpret_cast<unsigned*>(state_buf(f, m, (f.launch + 1) & 1))[threadIdx.x] = stWord;
-            if (wave == 0) report(f, m, *in, lane);
+            // (the state went out when the model became done; a call that FINDS it done sends it with its first launch)
+            if (wave == 0) report(f, m, *in, lane, f.launch == 0);
         }
         asm volatile("" ::"v"(stWord));
 #pragma unroll
