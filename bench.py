@@ -65,8 +65,9 @@ def parse_args():
                          "metric of BASELINE.json is measured WITHOUT this flag")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target", action="store_true",
-                    help="skip the second measurement (north_star's target configuration, bg 512^3 + 8 x 128^3) that the "
-                         "default N = 1 run appends as `target_config`")
+                    help="skip the two further measurements the default N = 1 run appends: `target_config` (north_star's "
+                         "target configuration, bg 512^3 + 8 x 128^3) and `steady_state` (the headline's workload over "
+                         "frames 25..124, a window that holds four mask frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time for the oracle baseline sample")
     ap.add_argument("--all-kernel-events", action="store_true",
@@ -356,6 +357,7 @@ def main():
                 "tracking": "camera + objects, weighted LM-ICP, <= 100 iterations" if args.track
                             else "none (poses supplied, SURVEY 8d)",
                 "mask_frames_every": mask_every,
+                "mask_frames_in_timed_window": [f for f in range(args.warmup, nframes) if f % mask_every == 0],
                 "visible_objects_last_frame": len(visible),
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
@@ -390,6 +392,7 @@ def main():
     if rank == 0 and is_headline and not args.no_target:
         # north_star's own target (>= 30 frames/s with 8 object volumes), same protocol, same process, behind the headline
         result["target_config"] = measure_target(args, pipeline, ops, DeviceArray, fus_params=prm)
+        result["steady_state"] = measure_steady_state(args, pipeline, ops, DeviceArray, prm, nobj_total)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
 
@@ -407,19 +410,18 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
-    """north_star: ">= 30 frames/sec integrate+raycast+EM-update at 640x480 with 1 background (512^3) + 8 object (128^3)
-    volumes on 1 MI355X".  The headline's protocol (W warm-up frames, K timed ones between synchronisations, inputs
-    resident in HBM, the interpreter's collector kept out) on that scene, in a second emf::EMFusion of this process."""
+def measure_window(args, pipeline, ops, DeviceArray, prm, nobj, first, count):
+    """Frames [first, first + count) of the synthetic stream with `nobj` objects, timed between two device
+    synchronisations after frames [0, first) have run untimed, in a fresh emf::EMFusion of this process: the headline's
+    protocol (inputs resident in HBM, the interpreter's collector kept out) on another scene or another window."""
     import gc
     W, H = args.width, args.height
-    prm = fus_params
     K = np.array(prm.K, np.float32)
     synth = pipeline.SyntheticStream(W, H, K, nobj, seed=0xE3F5)
     fus = pipeline.Fusion(prm, None)
     ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(nobj)]
     frames, keep = [], []
-    for f in range(args.warmup + args.steps):
+    for f in range(first + count):
         depth, sid = synth.render(f)
         R, t = synth.camera_pose(f)
         poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
@@ -428,13 +430,13 @@ def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
         d = DeviceArray.from_numpy(depth)
         keep.append((d, masks))
         frames.append((ops.image_view(d), R, t, poses, {i: ops.image_view(m) for i, m in masks.items()}, rm))
-    for f in range(args.warmup):
+    for f in range(first):
         fus.process_frame(*frames[f])
     fus.synchronize()
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    for f in range(args.warmup, args.warmup + args.steps):
+    for f in range(first, first + count):
         fus.process_frame(*frames[f])
     fus.synchronize()
     elapsed = time.perf_counter() - t0
@@ -442,6 +444,14 @@ def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
     visible = len(fus.visible_objects())
     fus.close()
     synth.close()
+    return elapsed, visible, [f for f in range(first, first + count) if f % prm.mask_frames == 0]
+
+
+def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
+    """north_star: ">= 30 frames/sec integrate+raycast+EM-update at 640x480 with 1 background (512^3) + 8 object (128^3)
+    volumes on 1 MI355X".  The headline's protocol (W warm-up frames, K timed ones) on that scene."""
+    W, H = args.width, args.height
+    elapsed, visible, _ = measure_window(args, pipeline, ops, DeviceArray, fus_params, nobj, args.warmup, args.steps)
     return {"workload": f"bg {args.bg_res}^3 @ {args.bg_voxel * 100:g} cm + {nobj} obj {args.obj_res}^3, {W}x{H}, full EM "
                         "association + weighted fusion (north_star's single-GPU target; also one GPU's share of "
                         "BASELINE.json configs[3])",
@@ -449,6 +459,20 @@ def measure_target(args, pipeline, ops, DeviceArray, fus_params, nobj=8):
             "value": round(args.steps / elapsed, 3), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "steps": args.steps, "warmup": args.warmup, "target": 30.0, "visible_objects_last_frame": visible,
             "note": "no HIP-event pairs in this second run (the headline's run has them around every 4th long launch)"}
+
+
+STEADY_FIRST, STEADY_COUNT = 25, 100
+
+
+def measure_steady_state(args, pipeline, ops, DeviceArray, fus_params, nobj):
+    """The headline's workload over frames 25..124 of the same stream: volumes populated, weights saturating, and
+    four mask frames (30, 60, 90, 120: `integrateMasks`, EMFusion.cpp:891-906, every 30th frame) inside the window --
+    the driver's `--steps 20 --warmup 5` window (frames 5..24) holds none and is still filling the volumes."""
+    elapsed, visible, mask_frames = measure_window(args, pipeline, ops, DeviceArray, fus_params, nobj, STEADY_FIRST, STEADY_COUNT)
+    return {"frames": [STEADY_FIRST, STEADY_FIRST + STEADY_COUNT - 1], "value": round(STEADY_COUNT / elapsed, 3), "unit": "frames/s",
+            "ms_per_step": round(1e3 * elapsed / STEADY_COUNT, 4), "mask_frames_in_window": mask_frames,
+            "visible_objects_last_frame": visible,
+            "note": "same workload and protocol as the headline line, later and longer window; no HIP-event pairs"}
 
 
 # kernel kind -> (HIP kernel symbol for the rocprof cross-check, per-unit algorithmic bytes note)
@@ -739,6 +763,8 @@ def roofline(kern, stats, P, copy_gbs=None, profiled=True, steps=None, l1_probe=
                 for k in res if k in ires}
     if dom["kind"] == "raycast" and stats is not None:
         roof["march_samples_per_launch"] = round(stats[0] / max(steps or dom["launches"], 1), 1)
+        # samples gathered incl. the speculative ones of the lanes-per-ray march that were dropped (= samples with one lane per ray)
+        roof["march_gathered_per_launch"] = round(stats[2] / max(steps or dom["launches"], 1), 1)
     return roof, rows
 
 

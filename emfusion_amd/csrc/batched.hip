@@ -53,6 +53,7 @@ struct EstepArgs {
     // maps is this rank's contribution to the E-step's exchange and goes straight into its slot on every peer
     char* peerSlots[EMF_MAX_PEERS];
     int peerWorld;    // 0: objSum is an ordinary image
+    int peerFences;   // emf_peer_t::systemFences (ranks on distinct devices): the stores are followed by a system-scope fence
     size_t peerOff;   // byte offset of this rank's slot (parity included) in a peer's receive buffer
 };
 
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
             if (a.peerWorld) {  // (uniform) write-through: the value must be in the peer's memory, not in my L2
                 for (int p = 0; p < a.peerWorld; ++p)
                     __builtin_nontemporal_store(s, reinterpret_cast<float*>(a.peerSlots[p] + a.peerOff) + pix);
+                if (a.peerFences) __threadfence_system();
             } else {
                 a.objSum.row(y)[x] = s;
             }
@@ -139,6 +141,7 @@ struct RaycastBatchArgs {
     const float* farBounds;    // [model][2 tilesY][2 tilesX] per 8x8-pixel cell, or nullptr (see k_far_bounds)
     // objects (slots 1..): the tiles their volume box can project to (host-computed from the pose); only
     // those get a marching workgroup, the rest of the object's images is zero-filled 16 tiles per workgroup
+    const float* bgYPairs;             // y-pair copy of the background's tsdf (emf_hip_buildYPairs) or nullptr
     short rect[EMF_MAX_BATCH][4];      // tx0, ty0, width, height in tiles (slot 0 unused)
     int objStart[EMF_MAX_BATCH + 1];   // prefix sum of width * height over slots 1..; [m] = first block of slot m
 };
@@ -196,104 +199,86 @@ __device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned sampl
 __device__ __forceinline__ void trace_wave(unsigned long long, unsigned, int, int, int, int) {}
 #endif
 
-template <bool WAVE>
-__global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
-#ifdef EMF_RAY_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-#else
-    const unsigned long long trace_t0 = 0;
-#endif
-    // grid = nmodels x (8 * chunk) blocks, model-major: the background's (longest) rays start first.
-    // Block b runs on XCD b % 8 (observed dispatch order; used for L2 locality only): give each XCD
-    // a contiguous run of `chunk` tiles in raster order, i.e. a horizontal band of the image, so
-    // the voxels its rays walk stay in that XCD's 4 MiB L2.
+// Which tile of which model does workgroup `b` of the batched raycast grid serve?  Order: the background's BORDER
+// tiles first (their rays graze seen / unseen space at half-voxel steps all the way: the longest marches of the
+// image), then the objects' footprints, then the background's interior -- XCD-banded: block b runs on XCD b % 8
+// (observed dispatch order; used for L2 locality only) and each XCD gets a contiguous run of tiles in raster
+// order, i.e. a horizontal band of the image, so the voxels its rays walk stay in that XCD's 4 MiB L2 -- then the
+// zero-fill of the objects' images outside their footprints.  (Measured, frames/s of the bench: background first
+// 1227, objects first 1340, this order 1385.)
+// Returns 1: march (m, tile); 2: zero-fill workgroup `tile` (index over all objects); 0: nothing to do.
+__device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int b, int& m, int& tile) {
     const int perModel = 8 * a.chunk;
-#ifndef EMF_RAY_ORDER
-#define EMF_RAY_ORDER 2  // measured (frames/s of the bench): 0 = background first 1227, 1 = objects first 1340, 2 = 1385
-#endif
-#if EMF_RAY_ORDER == 2
-    // the background's BORDER tiles first (their rays graze seen / unseen space at half-voxel steps all
-    // the way: the longest marches of the image), then the objects, then the background's interior
-    int m, tile;
-    {
-        const int ring = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
-        const int b = blockIdx.x;
-        const int objBlocks = a.objStart[a.nmodels];
-        if (b < ring) {
-            m = 0;
-            if (b < a.tilesX) tile = b;                                              // top row
-            else if (b < 2 * a.tilesX) tile = (a.tilesY - 1) * a.tilesX + (b - a.tilesX);  // bottom row
-            else {
-                const int k = b - 2 * a.tilesX;                                       // left / right columns
-                tile = (1 + (k >> 1)) * a.tilesX + ((k & 1) ? a.tilesX - 1 : 0);
-            }
-        } else if (b < ring + objBlocks) {  // a tile of an object's footprint
-            const int o = b - ring;
-            m = 1;
-            while (m + 1 < a.nmodels && o >= a.objStart[m + 1]) ++m;
-            const int i = o - a.objStart[m], rw = a.rect[m][2];
-            tile = (a.rect[m][1] + i / rw) * a.tilesX + a.rect[m][0] + i % rw;
+    const int ring = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
+    const int objBlocks = a.objStart[a.nmodels];
+    if (b < ring) {
+        m = 0;
+        if (b < a.tilesX) tile = b;                                              // top row
+        else if (b < 2 * a.tilesX) tile = (a.tilesY - 1) * a.tilesX + (b - a.tilesX);  // bottom row
+        else {
+            const int k = b - 2 * a.tilesX;                                       // left / right columns
+            tile = (1 + (k >> 1)) * a.tilesX + ((k & 1) ? a.tilesX - 1 : 0);
+        }
+    } else if (b < ring + objBlocks) {  // a tile of an object's footprint
+        const int o = b - ring;
+        m = 1;
+        while (m + 1 < a.nmodels && o >= a.objStart[m + 1]) ++m;
+        const int i = o - a.objStart[m], rw = a.rect[m][2];
+        tile = (a.rect[m][1] + i / rw) * a.tilesX + a.rect[m][0] + i % rw;
+    } else {
+        m = 0;
+        int i = b - ring - objBlocks;
+        const int bgBlocks = ring ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : perModel;
+        if (i >= bgBlocks) {
+            tile = i - bgBlocks;
+            return 2;
+        }
+        if (ring) {  // interior tiles, XCD-banded like the full image
+            const int inX = a.tilesX - 2, inY = a.tilesY - 2, chunkIn = (inX * inY + 7) / 8;
+            const int t = (i & 7) * chunkIn + (i >> 3);
+            if (t >= inX * inY) return 0;
+            tile = (1 + t / inX) * a.tilesX + 1 + t % inX;
         } else {
-            m = 0;
-            int i = b - ring - objBlocks;
-            const int bgBlocks = ring ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : perModel;
-            if (i >= bgBlocks) {
-                // zero-fill of the objects' images outside their footprints: kZeroTiles tiles per workgroup
-                i -= bgBlocks;
-                const int perObj = (a.tilesX * a.tilesY + kZeroTiles - 1) / kZeroTiles;
-                const int mz = 1 + i / perObj;
-                if (mz >= a.nmodels) return;
-                const emf_model_t& mo = a.models[mz];
-                const int tx0 = a.rect[mz][0], ty0 = a.rect[mz][1], tx1 = tx0 + a.rect[mz][2], ty1 = ty0 + a.rect[mz][3];
-                const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
-                for (int t = (i % perObj) * kZeroTiles; t < min((i % perObj + 1) * kZeroTiles, a.tilesX * a.tilesY); ++t) {
-                    const int tyz = t / a.tilesX, txz = t - tyz * a.tilesX;
-                    if (txz >= tx0 && txz < tx1 && tyz >= ty0 && tyz < ty1) continue;  // marched above
-                    const int x = txz * kRbTile + px, y = tyz * kRbTile + py;
-                    if (x < a.w && y < a.h) {
-                        const size_t pix = static_cast<size_t>(y) * a.w + x;
-                        mo.raylengths[pix] = 0.f;
-                        float* pv = mo.vertices + 3 * pix;
-                        float* pn = mo.normals + 3 * pix;
-                        pv[0] = pv[1] = pv[2] = 0.f;
-                        pn[0] = pn[1] = pn[2] = 0.f;
-                        mo.hitMask[pix] = 0;
-                    }
-                }
-                return;
-            }
-            if (ring) {  // interior tiles, XCD-banded like the full image
-                const int inX = a.tilesX - 2, inY = a.tilesY - 2, chunkIn = (inX * inY + 7) / 8;
-                const int t = (i & 7) * chunkIn + (i >> 3);
-                if (t >= inX * inY) return;
-                tile = (1 + t / inX) * a.tilesX + 1 + t % inX;
-            } else {
-                tile = (i & 7) * a.chunk + (i >> 3);
-            }
+            tile = (i & 7) * a.chunk + (i >> 3);
         }
     }
-#else
-    if (static_cast<int>(blockIdx.x) >= a.nmodels * perModel) return;
-#if EMF_RAY_ORDER == 1  // objects first, background last
-    const int mm = blockIdx.x / perModel;
-    const int m = mm == a.nmodels - 1 ? 0 : mm + 1;
-    const int i = blockIdx.x - mm * perModel;
-#else
-    const int m = blockIdx.x / perModel;  // (objects-first order was measured: 1 % slower)
-    const int i = blockIdx.x - m * perModel;
-#endif
-    const int tile = (i & 7) * a.chunk + (i >> 3);
-#endif
-    if (tile >= a.tilesX * a.tilesY) return;  // block-uniform
-    const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
+    if (tile >= a.tilesX * a.tilesY) return 0;
     // multi-GPU: the replicated background is marched in row bands, one per rank; the rows of the
     // other bands are neither marched nor written here (they arrive by all-gather)
-    if (m == 0 && a.bandTiles > 0 && (tyy < a.bandTile0 || tyy >= a.bandTile0 + a.bandTiles)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = txx * kRbTile + (wave & 1) * 8 + (lane & 7);
-    const int y = tyy * kRbTile + (wave >> 1) * 8 + (lane >> 3);
+    if (m == 0 && a.bandTiles > 0) {
+        const int tyy = tile / a.tilesX;
+        if (tyy < a.bandTile0 || tyy >= a.bandTile0 + a.bandTiles) return 0;
+    }
+    return 1;
+}
+
+// zero-fill of the objects' images outside their footprints: kZeroTiles tiles per index i; a workgroup of 256
+// threads writes one 16x16 tile per round, `part` of `parts` workgroups sharing the index take every parts-th tile
+__device__ __forceinline__ void raycast_zero_fill(const RaycastBatchArgs& a, int i, int part, int parts) {
+    const int perObj = (a.tilesX * a.tilesY + kZeroTiles - 1) / kZeroTiles;
+    const int mz = 1 + i / perObj;
+    if (mz >= a.nmodels) return;
+    const emf_model_t& mo = a.models[mz];
+    const int tx0 = a.rect[mz][0], ty0 = a.rect[mz][1], tx1 = tx0 + a.rect[mz][2], ty1 = ty0 + a.rect[mz][3];
+    const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+    for (int t = (i % perObj) * kZeroTiles + part; t < min((i % perObj + 1) * kZeroTiles, a.tilesX * a.tilesY); t += parts) {
+        const int tyz = t / a.tilesX, txz = t - tyz * a.tilesX;
+        if (txz >= tx0 && txz < tx1 && tyz >= ty0 && tyz < ty1) continue;  // marched
+        const int x = txz * kRbTile + px, y = tyz * kRbTile + py;
+        if (x < a.w && y < a.h) {
+            const size_t pix = static_cast<size_t>(y) * a.w + x;
+            mo.raylengths[pix] = 0.f;
+            float* pv = mo.vertices + 3 * pix;
+            float* pn = mo.normals + 3 * pix;
+            pv[0] = pv[1] = pv[2] = 0.f;
+            pn[0] = pn[1] = pn[2] = 0.f;
+            mo.hitMask[pix] = 0;
+        }
+    }
+}
+
+__device__ __forceinline__ RayVolume ray_volume_of(const RaycastBatchArgs& a, int m, bool flags) {
     const emf_model_t& md = a.models[m];
-    const bool valid = x < a.w && y < a.h;
     RayVolume v;
     v.tsdf = md.tsdf;
     v.grads = md.grads;
@@ -303,14 +288,63 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     v.cam = pose_t(a.poses.p[m]);
     v.n = I3{md.res[0], md.res[1], md.res[2]};
     // reserved bit 1: answer uniform lookups from the flags without gathering
-    v.bricks = (!WAVE && md.brickFlags) ? md.brickFlags + brick_count(v.n) : nullptr;
+    v.bricks = (flags && md.brickFlags) ? md.brickFlags + brick_count(v.n) : nullptr;
     v.blendFromFlags = (md.reserved & 2) != 0;
     v.voxelSize = md.voxelSize;
     v.truncdist = md.truncdist;
     v.rcpVoxel = ((a.divideMask >> m) & 1u) ? 0.f : md.rcpVoxel;
+    return v;
+}
+
+// MODE 0: one lane per ray, flag-aware per-lane march (march_ray: brick flags, 64-bit offsets);
+// MODE 1: one lane per ray, march_lane (march_wave.hpp), a workgroup = a 16x16-pixel tile, a wave = an 8x8 cell;
+// MODE 4: FOUR lanes per ray, march_quad<4>: a workgroup = ONE 8x8 cell (4 waves of 4x4 pixels x 4 rows), four
+//         workgroups per tile -- consecutive on the same XCD (grid index b: XCD = b % 8, the tile's block index
+//         = 8 (b / 32) + b % 8, cell = (b / 8) % 4);
+// MODE 2: TWO lanes per ray, march_quad<2>: a workgroup = a 16x8 half tile (4 waves of 8x4 pixels x 2 rows), two per tile.
+template <int MODE>
+__global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
+#ifdef EMF_RAY_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#else
+    const unsigned long long trace_t0 = 0;
+#endif
+    int m, tile, sub = 0, vb = blockIdx.x;
+    if (MODE >= 2) {
+        const int s = blockIdx.x >> 3;
+        vb = ((s / MODE) << 3) | (blockIdx.x & 7);
+        sub = s % MODE;
+    }
+    const int role = raycast_block_role(a, vb, m, tile);
+    if (role == 0) return;
+    if (role == 2) {
+        raycast_zero_fill(a, tile, sub, MODE >= 2 ? MODE : 1);
+        return;
+    }
+    const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const emf_model_t& md = a.models[m];
+    const RayVolume v = ray_volume_of(a, m, MODE == 0);
     // incoming raylength is zero by construction (the reference zeroes it first, Q5)
-    RayHit r;
-    if constexpr (WAVE) {
+    if constexpr (MODE != 0) {
+        int x, y, cellX, cellY;
+        if (MODE == 4) {
+            cellX = 2 * txx + (sub & 1);
+            cellY = 2 * tyy + (sub >> 1);
+            x = cellX * 8 + (wave & 1) * 4 + (lane & 3);
+            y = cellY * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
+        } else if (MODE == 2) {
+            cellX = 2 * txx + (wave & 1);
+            cellY = 2 * tyy + sub;
+            x = cellX * 8 + (lane & 7);
+            y = cellY * 8 + (wave >> 1) * 4 + ((lane >> 3) & 3);
+        } else {
+            cellX = 2 * txx + (wave & 1);
+            cellY = 2 * tyy + (wave >> 1);
+            x = cellX * 8 + (lane & 7);
+            y = cellY * 8 + (lane >> 3);
+        }
+        const bool valid = x < a.w && y < a.h;
         const size_t pix = static_cast<size_t>(y) * a.w + x;
         auto sink = [&](float raylength, const V3& vertex, const V3& normal) {
             md.raylengths[pix] = raylength;
@@ -324,16 +358,19 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
             pn[2] = normal.z;
             md.hitMask[pix] = 1;
         };
-        // far bound of this wave's 8x8-pixel cell: beyond it no sample of any of its rays can complete
+        // far bound of this 8x8-pixel cell: beyond it no sample of any of its rays can complete
         // a hit (k_far_bounds); 0 = none of its rays can hit at all
         float cut = __builtin_inff();
-        if (a.farBounds)
-            cut = a.farBounds[(static_cast<size_t>(m) * (2 * a.tilesY) + 2 * tyy + (wave >> 1)) * (2 * a.tilesX) +
-                              2 * txx + (wave & 1)];
+        if (a.farBounds) cut = a.farBounds[(static_cast<size_t>(m) * (2 * a.tilesY) + cellY) * (2 * a.tilesX) + cellX];
         // (a cell with cut == 0 still sets its rays up: one whose first sample lies in the volume's outer shell is
         // exempt from the bound -- ray_setup -- and must be marched like in the reference)
-        const MarchCount c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
-        if (valid && !c.hit) {  // zeros where there is no hit
+        MarchCount c;
+        if constexpr (MODE >= 2)
+            c = march_wave_quad<MODE>(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, lane);
+        else
+            c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, m == 0 ? a.bgYPairs : nullptr);
+        const bool counts = MODE < 2 || lane < 64 / (MODE >= 2 ? MODE : 1);  // one lane per ray reports
+        if (valid && !c.hit && counts) {  // zeros where there is no hit
             md.raylengths[pix] = 0.f;
             float* pv = md.vertices + 3 * pix;
             float* pn = md.normals + 3 * pix;
@@ -341,7 +378,7 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
             pn[0] = pn[1] = pn[2] = 0.f;
             md.hitMask[pix] = 0;
         }
-        add_ray_stats(a.stats, c.samples, c.hit ? 1u : 0u, c.samples, 0u, lane);
+        add_ray_stats(a.stats, c.samples, (c.hit && counts) ? 1u : 0u, c.gathered, 0u, lane);
 #ifdef EMF_MARCH_STAMP
         {   // the stamps are the wave's, but only lanes that entered the march hold them: take the maximum over lanes
             MarchCount cs = c;
@@ -355,29 +392,32 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
 #else
         trace_wave(trace_t0, c.samples, m, tile, wave, lane);
 #endif
-        return;
     } else {
+        const int x = txx * kRbTile + (wave & 1) * 8 + (lane & 7);
+        const int y = tyy * kRbTile + (wave >> 1) * 8 + (lane >> 3);
+        const bool valid = x < a.w && y < a.h;
+        RayHit r;
         r.hit = false;
         r.samples = r.gathered = r.skipped = 0;
         r.raylength = 0.f;
         r.vertex = r.normal = v3(0.f, 0.f, 0.f);
         if (valid) r = march_ray(v, x, y, a.fx, a.fy, a.cx, a.cy, 0.f);
+        if (valid) {
+            const size_t pix = static_cast<size_t>(y) * a.w + x;
+            md.raylengths[pix] = r.raylength;  // zeros where there is no hit
+            float* pv = md.vertices + 3 * pix;
+            float* pn = md.normals + 3 * pix;
+            pv[0] = r.vertex.x;
+            pv[1] = r.vertex.y;
+            pv[2] = r.vertex.z;
+            pn[0] = r.normal.x;
+            pn[1] = r.normal.y;
+            pn[2] = r.normal.z;
+            md.hitMask[pix] = r.hit ? 1 : 0;
+        }
+        add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
+        trace_wave(trace_t0, r.samples, m, tile, wave, lane);
     }
-    if (valid) {
-        const size_t pix = static_cast<size_t>(y) * a.w + x;
-        md.raylengths[pix] = r.raylength;  // zeros where there is no hit
-        float* pv = md.vertices + 3 * pix;
-        float* pn = md.normals + 3 * pix;
-        pv[0] = r.vertex.x;
-        pv[1] = r.vertex.y;
-        pv[2] = r.vertex.z;
-        pn[0] = r.normal.x;
-        pn[1] = r.normal.y;
-        pn[2] = r.normal.z;
-        md.hitMask[pix] = r.hit ? 1 : 0;
-    }
-    add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
-    trace_wave(trace_t0, r.samples, m, tile, wave, lane);
 }
 
 // ---- ray far bounds ----------------------------------------------------------------------------------
@@ -405,6 +445,15 @@ struct FarBoundArgs {
     float fx, fy, cx, cy;
     float* bounds;  // [model][cellsY][cellsX]
 };
+
+__global__ __launch_bounds__(256) void k_build_ypairs(const float* __restrict__ tsdf, I3 n, float* __restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    const size_t total = static_cast<size_t>(n.x) * n.y * n.z;
+    if (i >= total) return;
+    const int y = static_cast<int>((i / n.x) % n.y);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    reinterpret_cast<f2*>(out)[i] = f2{tsdf[i], y + 1 < n.y ? tsdf[i + n.x] : 0.f};
+}
 
 __global__ __launch_bounds__(256) void k_far_init(const FarBoundArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x, cells = a.cellsX * a.cellsY;
@@ -1003,6 +1052,7 @@ int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, i
         a.norm = img<float>(norm);
     }
     a.peerWorld = 0;
+    a.peerFences = 0;
     a.peerOff = 0;
     for (int p = 0; p < EMF_MAX_PEERS; ++p) a.peerSlots[p] = nullptr;
     if (group) {
@@ -1011,6 +1061,7 @@ int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, i
         if (static_cast<size_t>(a.w) * a.h * sizeof(float) > pa.slotBytes)
             return fail(EMF_E_ARG, "%s: %d x %d floats exceed the %zu-byte slot", fn, a.w, a.h, pa.slotBytes);
         a.peerWorld = pa.world;
+        a.peerFences = pa.fences;
         a.peerOff = (static_cast<size_t>(seq & 1u) * pa.world + pa.rank) * pa.slotBytes;
         for (int p = 0; p < pa.world; ++p) a.peerSlots[p] = pa.slots[p];
     } else if (!normalize) {
@@ -1147,6 +1198,26 @@ int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* re
     return launch_status("updateRelevantTiles");
 }
 
+// ---- y-pair copy of a tsdf volume (round 5 probe): Q(z, y, x) = {T(z, y, x), T(z, y + 1, x)} (0 beyond the last row)
+static const float* g_pairProbe = nullptr;  // picked up (for the background) by the next emf_hip_raycastBatched
+static float* g_pairBuf = nullptr;
+static size_t g_pairBytes = 0;
+
+int emf_hip_debugPairProbe(const float* tsdf_dev, const int32_t res[3], emf_stream_t stream) {
+    EMF_REQUIRE_PTR(tsdf_dev);
+    EMF_TRY(check_res(res));
+    const size_t voxels = static_cast<size_t>(res[0]) * res[1] * res[2];
+    if (g_pairBytes < voxels * 8) {
+        if (g_pairBuf) (void)hipFree(g_pairBuf);
+        if (hipMalloc(reinterpret_cast<void**>(&g_pairBuf), voxels * 8) != hipSuccess) return fail(EMF_E_LIMIT, "debugPairProbe: hipMalloc");
+        g_pairBytes = voxels * 8;
+    }
+    hipLaunchKernelGGL(k_build_ypairs, dim3(static_cast<unsigned>(ceil_div(voxels, size_t(256)))), dim3(256), 0, as_stream(stream),
+                       tsdf_dev, I3{res[0], res[1], res[2]}, g_pairBuf);
+    g_pairProbe = g_pairBuf;
+    return launch_status("debugPairProbe");
+}
+
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
@@ -1182,6 +1253,8 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
     a.farBounds = farBounds_dev;
+    a.bgYPairs = (offsets32 && static_cast<unsigned long long>(res_host[0]) * res_host[1] * res_host[2] <= (1ull << 29)) ? g_pairProbe : nullptr;
+    g_pairProbe = nullptr;
     a.bandTile0 = bgBandRow0 / kRbTile;
     a.bandTiles = bgBandRows / kRbTile;
     // footprints of the objects: the tiles the (slightly enlarged) volume box projects to
@@ -1227,22 +1300,23 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
         a.objStart[m + 1] = a.objStart[m] + a.rect[m][2] * a.rect[m][3];
     }
     a.rect[0][0] = a.rect[0][1] = a.rect[0][2] = a.rect[0][3] = 0;
-#if EMF_RAY_ORDER == 2
     // background: border ring + interior rounded up to whole XCD chunks (or all of it when banded);
     // objects: footprint tiles, and ceil(tiles / kZeroTiles) zero-fill workgroups each
     const int ringTiles = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
     const int bgBlocks = ringTiles ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : 8 * a.chunk;
     const int zeroBlocks = (nmodels - 1) * static_cast<int>(ceil_div(a.tilesX * a.tilesY, kZeroTiles));
-    const dim3 grid(static_cast<unsigned>(ringTiles + a.objStart[nmodels] + bgBlocks + zeroBlocks));
-#else
-    const dim3 grid(static_cast<unsigned>(nmodels) * 8u * a.chunk);
-#endif
-    if (useBrickFlags || !offsets32)  // the wave march addresses with 32-bit byte offsets
-        hipLaunchKernelGGL(k_raycast_batched<false>, grid, dim3(64 * kRbWaves), 0,
-                           as_stream(stream), a);
+    const unsigned blocks = static_cast<unsigned>(ringTiles + a.objStart[nmodels] + bgBlocks + zeroBlocks);
+    // EMF_MARCH_ROWS = 1 / 2 / 4 lanes per ray (march_lane / march_quad<2> / march_quad<4>); same images (A/B, read per call)
+    const char* mr = std::getenv("EMF_MARCH_ROWS");
+    const int rows = mr ? std::atoi(mr) : 1;
+    if (useBrickFlags || !offsets32)  // the wave marches address with 32-bit byte offsets
+        hipLaunchKernelGGL(k_raycast_batched<0>, dim3(blocks), dim3(64 * kRbWaves), 0, as_stream(stream), a);
+    else if (rows == 4)  // four workgroups (8x8 cells) per tile, tiles in whole groups of 8 (one per XCD)
+        hipLaunchKernelGGL(k_raycast_batched<4>, dim3(32u * ((blocks + 7u) / 8u)), dim3(64 * kRbWaves), 0, as_stream(stream), a);
+    else if (rows == 2)
+        hipLaunchKernelGGL(k_raycast_batched<2>, dim3(16u * ((blocks + 7u) / 8u)), dim3(64 * kRbWaves), 0, as_stream(stream), a);
     else
-        hipLaunchKernelGGL(k_raycast_batched<true>, grid, dim3(64 * kRbWaves), 0,
-                           as_stream(stream), a);
+        hipLaunchKernelGGL(k_raycast_batched<1>, dim3(blocks), dim3(64 * kRbWaves), 0, as_stream(stream), a);
     return launch_status("raycastBatched");
 }
 

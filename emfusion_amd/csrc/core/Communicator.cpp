@@ -121,7 +121,9 @@ public:
         // that poll, include/emf_hip.h emf_peer_t::waitInFront); EMF_PEER_WAIT_IN_FRONT=0 lets the consumers poll
         // themselves where every rank has a GPU of its own (A/B on a node; never when ranks share a device).
         g_.waitInFront = 1u;
-        if (const char* f = std::getenv("EMF_PEER_FENCES")) g_.systemFences = f[0] == '1' ? 1u : 0u;
+        // ranks on distinct devices: system-scope release / acquire around every flag (peer_core.hpp "Memory ordering":
+        // the fence-free protocol has only been validated with the ranks on one device)
+        g_.systemFences = (!waitInFront && world > 1) ? 1u : 0u;
         if (const char* w = std::getenv("EMF_PEER_WAIT_IN_FRONT")) g_.waitInFront = (w[0] == '0' && !waitInFront) ? 0u : 1u;
         g_.rank = rank;
         g_.world = world;

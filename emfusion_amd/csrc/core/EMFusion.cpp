@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <cstring>
 
+extern "C" int emf_hip_debugPairProbe(const float*, const int32_t*, emf_stream_t);  // round-5 probe (batched.hip)
+
 namespace emf {
 
 namespace {
@@ -1472,6 +1474,10 @@ void EMFusion::raycastBatched() {
     const int n = static_cast<int>(co.size());
     uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
     {
+        static const bool pairProbe = std::getenv("EMF_PAIR_PROBE") != nullptr;  // round-5 probe (timing of the raycast only)
+        if (pairProbe) {
+            emfCheck(emf_hip_debugPairProbe(background.tsdfPtr(), resHost.data(), main.abi()), "debugPairProbe");
+        }
         auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
         const emf_model_t* table = currentTable();
         const int w = params.frameSize.width, h = params.frameSize.height;

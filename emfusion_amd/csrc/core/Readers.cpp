@@ -218,10 +218,10 @@ Size readExr(const std::string& path, std::vector<float>& pixels, const std::str
     while (pos < raw.size() && raw[pos] != '\0') {
         const std::string name = cstr(pos);
         cstr(pos);  // type name
-        if (pos + 4 > raw.size()) throw std::runtime_error(path + ": truncated EXR header");
+        if (pos > raw.size() || raw.size() - pos < 4) throw std::runtime_error(path + ": truncated EXR header");
         const uint32_t size = le32(r + pos);
         pos += 4;
-        if (pos + size > raw.size()) throw std::runtime_error(path + ": truncated EXR header");
+        if (size > raw.size() - pos) throw std::runtime_error(path + ": truncated EXR header");
         attrs[name] = raw.substr(pos, size);
         pos += size;
     }
@@ -277,14 +277,21 @@ Size readExr(const std::string& path, std::vector<float>& pixels, const std::str
     }
     const int perBlock = comp == 3 ? 16 : 1;
     const int nblocks = (h + perBlock - 1) / perBlock;
-    if (pos + 8 * static_cast<size_t>(nblocks) > raw.size()) throw std::runtime_error(path + ": truncated EXR offset table");
+    if (pos > raw.size() || 8 * static_cast<size_t>(nblocks) > raw.size() - pos)
+        throw std::runtime_error(path + ": truncated EXR offset table");
+    // the image is sized from a 16-byte header field: before allocating, hold it against what the file can carry.  A stored
+    // block never shrinks below 1 / 1032 of its lines (zlib's and the RLE's best ratios are ~1 : 1030 and 1 : 64),
+    // so w * h pixels need at least lineBytes * h / 1032 bytes of blocks behind the offset table
+    if (lineBytes == 0 || lineBytes * static_cast<size_t>(h) / 1032 > raw.size())
+        throw std::runtime_error(path + ": EXR data window is larger than the file can hold");
     pixels.assign(static_cast<size_t>(w) * h, 0.f);
     for (int b = 0; b < nblocks; ++b) {
         const uint64_t off = le64(r + pos + 8 * static_cast<size_t>(b));
-        if (off + 8 > raw.size()) throw std::runtime_error(path + ": EXR block offset beyond the file");
+        // (wrap-free: `off` is an untrusted 64-bit value)
+        if (raw.size() < 8 || off > raw.size() - 8) throw std::runtime_error(path + ": EXR block offset beyond the file");
         const int y = static_cast<int>(le32(r + off));
         const uint32_t size = le32(r + off + 4);
-        if (off + 8 + size > raw.size() || y < ymin || y > ymax) throw std::runtime_error(path + ": bad EXR block");
+        if (size > raw.size() - 8 - off || y < ymin || y > ymax) throw std::runtime_error(path + ": bad EXR block");
         const int lines = std::min(perBlock, ymax - y + 1);
         const size_t want = static_cast<size_t>(lines) * lineBytes;
         std::string data(raw, off + 8, size);

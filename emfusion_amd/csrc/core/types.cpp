@@ -216,26 +216,35 @@ void register_stream(hipStream_t s) {
 // behind it); that completes every fence recorded on it, and those are destroyed before the stream goes.
 void unregister_stream(hipStream_t s) {
     Registry& r = reg();
-    std::lock_guard<std::mutex> lock(r.m);
-    uint64_t owner = 0;
-    for (const LiveStream& ls : r.streams)
-        if (ls.s == s) owner = ls.owner;
     bool drain = false;
-    for (const Pooled& b : r.pool) {
-        drain = drain || (b.parked && b.home == owner);
-        for (const Fence& f : b.fences) drain = drain || f.stream == s;
-    }
-    if (drain) {
-        (void)hipStreamSynchronize(s);
-        for (Pooled& b : r.pool) {
-            for (Fence& f : b.fences)
-                if (f.stream == s) (void)hipEventDestroy(f.event);
-            b.fences.erase(std::remove_if(b.fences.begin(), b.fences.end(), [s](const Fence& f) { return f.stream == s; }),
-                           b.fences.end());
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        uint64_t owner = 0;
+        for (const LiveStream& ls : r.streams)
+            if (ls.s == s) owner = ls.owner;
+        for (const Pooled& b : r.pool) {
+            drain = drain || (b.parked && b.home == owner);
+            for (const Fence& f : b.fences) drain = drain || f.stream == s;
         }
     }
-    r.streams.erase(std::remove_if(r.streams.begin(), r.streams.end(), [s](const LiveStream& ls) { return ls.s == s; }),
-                    r.streams.end());
+    // The wait happens OUTSIDE the registry lock: work queued on `s` may be spinning on a peer's flag (the
+    // rehearsal runs several ranks as threads of one process), and the rank that would raise the flag needs
+    // pool_acquire / pool_release -- the same mutex -- to enqueue the exchange that does.
+    if (drain) (void)hipStreamSynchronize(s);
+    std::vector<hipEvent_t> dead;
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        if (drain)
+            for (Pooled& b : r.pool) {
+                for (Fence& f : b.fences)
+                    if (f.stream == s) dead.push_back(f.event);
+                b.fences.erase(std::remove_if(b.fences.begin(), b.fences.end(), [s](const Fence& f) { return f.stream == s; }),
+                               b.fences.end());
+            }
+        r.streams.erase(std::remove_if(r.streams.begin(), r.streams.end(), [s](const LiveStream& ls) { return ls.s == s; }),
+                        r.streams.end());
+    }
+    for (hipEvent_t e : dead) (void)hipEventDestroy(e);
 }
 }  // namespace
 

@@ -50,6 +50,17 @@ __device__ __forceinline__ pair_f gload2(const float* base, unsigned byteOff) {
     return *(gpair_p)((gchar_p)base + byteOff);
 }
 
+// A wave-uniform pointer pinned into scalar registers.  The volume pointers come out of the device model table; the
+// compiler knows they are uniform but keeps them in VGPRs and re-reads them with v_readfirstlane (+ s_nop 4) in front of
+// every gather of every iteration -- and, with one SGPR pair recycled for all four row bases, splits the four gathers
+// of a sample around an s_waitcnt: two memory round trips per iteration instead of one (round 5, ISA of march_quad).
+__device__ __forceinline__ const float* scalar_ptr(const float* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+    return reinterpret_cast<const float*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // x / voxelSize: IEEE division, or its checked 3-instruction equal (rcp != 0, see the header)
 __device__ __forceinline__ float div_voxel(float x, float d, float rcp) {
     if (rcp != 0.f) {  // wave-uniform
@@ -128,6 +139,7 @@ __device__ __forceinline__ float trilinear_weights_g(const RayVolume& v, const C
 struct MarchCount {
     bool hit;
     unsigned samples;  // main-loop samples taken (byte-model statistic)
+    unsigned gathered; // march_quad: samples gathered incl. the speculative ones that were dropped (= samples otherwise)
 #ifdef EMF_MARCH_STAMP
     // attribution build only (scripts/raycast_attribution.py): shader clocks of the wave's loop iterations, split
     // at the moment the four corner gathers have been issued and at the moment they have all returned
@@ -192,49 +204,7 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, const V3& half, co
     if (!outside_flat(p, 2.f, nf)) r.maxRay = fminf(r.maxRay, cut);
 }
 
-// One iteration of `while ((raylength += raystep) <= maxRaylength)` (TSDF.cu:523-572) for the
-// calling lane.  Clears r.active when the march ends (range exhausted, back-side crossing, hit).
-// A hit is handed to `sink(raylength, vertex, normal)` at once instead of being carried through
-// the loop in registers (7 loop-carried values cost ~25 register moves per iteration).
-template <class Sink>
-__device__ __forceinline__ void ray_step(const RayVolume& v, const V3& half, const V3& nf,
-                                         RayState& r, MarchCount& out, Sink& sink) {
-    r.raylength += r.raystep;
-    if (!(r.raylength <= r.maxRay)) {
-        r.active = false;
-        return;
-    }
-    const V3 p = to_voxel(v.cam + r.dir * r.raylength, v, half);
-    if (outside_flat(p, 2.f, nf)) return;
-    ++out.samples;
-    const Cell32 c = cell32_of(p, v.n);
-    const float next = trilinear1_g(v.tsdf, c, v.n);
-    // zero crossing from behind: leave the volume's surface shell
-    if (r.tsdf < 0 && next > 0 && trilinear_weights_g(v, c) > 0.f) {
-        r.active = false;
-        return;
-    }
-    if (fabsf(next) < 1.f) r.raystep = v.voxelSize;
-    if (fabsf(next) < .8f) r.raystep = 0.5f * v.voxelSize;
-    if (r.tsdf > 0 && next < 0) {
-        // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:542-543)
-        const float tstar = r.raylength - r.raystep * r.tsdf / (next - r.tsdf);
-        const V3 ps = to_voxel(v.cam + r.dir * tstar, v, half);
-        if (outside_flat(ps, 2.f, nf)) return;  // reference `continue`: tsdf is NOT advanced
-        const Cell32 cs = cell32_of(ps, v.n);
-        if (trilinear_weights_g(v, cs) > 0.f) {
-            const V3 g = gradient_at(v, widen(cs));
-            const M33 Rt = transpose(v.R);
-            out.hit = true;
-            sink(tstar, mul(Rt, r.dir * tstar), mul(Rt, g / norm(g)));  // 0/0 -> NaN like the reference
-            r.active = false;
-            return;
-        }
-    }
-    r.tsdf = next;
-}
-
-// ---- the march, second form: one divergent loop per lane ---------------------------------------------
+// ---- the march: one divergent loop per lane ---------------------------------------------
 // scripts/probes/march_probe.hip: a wave that is alone on its SIMD issues ONE instruction every 8
 // clocks, whatever the instruction (VALU, SALU, branch, s_nop, s_waitcnt) and however independent --
 // gfx950 needs four waves per SIMD to fill the VALU.  The march is 4800 waves of ~250..600 strictly
@@ -249,7 +219,7 @@ __device__ __forceinline__ void ray_step(const RayVolume& v, const V3& half, con
 //   * fraction = v_fract_f32 (x - floor(x): the bits of x - float(int(x)) for x >= 0);
 //   * the two crossing tests (TSDF.cu:533, 541) hide behind one integer test "the sign bits of the
 //     previous and the new sample differ"; only then the exact tests, the weights and a possible hit run.
-// Arithmetic and its order are those of ray_step above (the reference's): same bits.
+// Arithmetic and its order are the reference's (TSDF.cu:523-572): same bits.
 // Measured and dropped: touching the line the ray will want 8 / 16 half-voxel steps ahead with a fifth
 // load per step (a lone wave on cold lines: 1302 -> 1224 clk / step; the full image: +19 %, the bench
 // -5 %: loads return in order, so the march waits for the prefetch of the step before anyway).
@@ -262,14 +232,26 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { 
 //     comparison per axis) means 0 <= x and x + 2 < Nx whatever the rounding of x + 2; only a sample
 //     in the outermost cells takes the six float comparisons;
 //   * x / voxelSize by multiplication or by division is decided once per wave, not once per sample.
-template <bool RCP, class Sink>
+//   PAIRS (round 5): the four corner gathers of a sample as TWO 16-byte gathers from the y-pair copy of the volume
+// (`ypairs`, emf_hip_buildYPairs: element (z, y, x) = {T(z, y, x), T(z, y + 1, x)}, so 16 bytes at (z, y, x) hold the
+// four (x, y) corners of one z plane).  The crowd regime of this kernel is bound by the CU's gather path at ~20
+// clocks per 64-lane gather INSTRUCTION whatever it loads; this halves the instructions.
+typedef float quad_f __attribute__((ext_vector_type(4), aligned(8)));
+typedef const __attribute__((address_space(1))) quad_f* gquad_p;
+__device__ __forceinline__ quad_f gload4(const float* base, unsigned byteOff) {
+    return *(gquad_p)((gchar_p)base + byteOff);
+}
+
+template <bool RCP, class Sink, bool PAIRS = false>
 __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, const V3& nf, RayState& r,
-                                           MarchCount& out, Sink& sink) {
+                                           MarchCount& out, Sink& sink, const float* ypairs = nullptr) {
     const unsigned sy = 4u * static_cast<unsigned>(v.n.x), sz = sy * static_cast<unsigned>(v.n.y);
-    const float* const row00 = v.tsdf;
-    const float* const row01 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sy);
-    const float* const row10 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz);
-    const float* const row11 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz + sy);
+    const float* const prow0 = ypairs;
+    const float* const prow1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ypairs) + 2u * sz);
+    const float* const row00 = scalar_ptr(v.tsdf);
+    const float* const row01 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sy));
+    const float* const row10 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz));
+    const float* const row11 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz + sy));
     const float vs = v.voxelSize, hvs = 0.5f * v.voxelSize, rcp = v.rcpVoxel;
     // cells [0, lim) are inside whatever the rounding (lim may be <= 0 for tiny volumes: nothing is)
     const unsigned limx = static_cast<unsigned>(max(v.n.x - 3, 0)), limy = static_cast<unsigned>(max(v.n.y - 3, 0)),
@@ -304,8 +286,13 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
                         fz = __builtin_amdgcn_fractf(p.z);
             const unsigned off = mad24(static_cast<unsigned>(lz), sz,
                                        mad24(static_cast<unsigned>(ly), sy, static_cast<unsigned>(lx) << 2));
-            const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off),
-                         e = gload2(row11, off);
+            pair_f a, b, d, e;
+            if (PAIRS) {
+                const quad_f lo = gload4(prow0, 2u * off), hi = gload4(prow1, 2u * off);
+                a = pair_f{lo.x, lo.z}; b = pair_f{lo.y, lo.w}; d = pair_f{hi.x, hi.z}; e = pair_f{hi.y, hi.w};
+            } else {
+                a = gload2(row00, off); b = gload2(row01, off); d = gload2(row10, off); e = gload2(row11, off);
+            }
 #ifdef EMF_MARCH_STAMP
             const unsigned long long ckSent = march_clock();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -362,7 +349,7 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
 #endif
         }
     }
-    out.samples = samples;
+    out.samples = out.gathered = samples;
 #ifdef EMF_MARCH_STAMP
     out.ckIssue = ckIssue; out.ckWait = ckWait; out.ckRest = ckRest; out.iters = iters;
     out.lateIssue = lateIssue; out.lateWait = lateWait; out.lateRest = lateRest;
@@ -370,9 +357,147 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
 #endif
 }
 
-#ifndef EMF_MARCH_LANE
-#define EMF_MARCH_LANE 1  // 0: the wave-voted loop over ray_step (A/B builds)
-#endif
+// ---- the march, third form: FOUR LANES PER RAY (round 5) ----------------------------------------------
+// march_lane's duration is the serial chain of its longest rays: 250-650 iterations at ~0.6 us each
+// (58-65 % in-order issue at one instruction per 8-10 clocks, 35-42 % queued L1 / L2 service for the four
+// corner gathers), with two waves per SIMD and the VALU 80 % idle.  Nothing that hides
+// latency INSIDE a lane shortens that chain; this form trades chain length for width instead.
+//
+// A wave serves 16 rays.  Lane 16 j + r (row j = 0..3) holds ray r's state (t, step, tsdf, tmax) --
+// replicated, every row computes it from the same inputs -- and evaluates the reference's iteration j + 1
+// counted from the current state UNDER THE ASSUMPTION that iterations 1..j change nothing but the
+// raylength: t_1 = t + step, t_2 = t_1 + step, ... by sequential float adds, i.e. exactly the values of
+// `raylength += raystep` (TSDF.cu:523) while raystep holds.  Iteration j is TRANSPARENT iff it is skipped
+// (TSDF.cu:525-528: the sample is outside, `continue`) or the step after the 0.8 / 1.0 tests
+// (TSDF.cu:537-540) is the step before them and the signs of the previous and the new blend are equal (so
+// neither crossing test, TSDF.cu:533 / 541, can fire); `raylength > max` is never transparent.  The first
+// non-transparent row j* runs the reference's full iteration body for its sample with the blend of the last
+// accepted sample before it as `tsdf`; rows behind it hold speculation on a state that did not
+// materialise and are dropped.  The ray's new state -- (t_j*, step and tsdf after that body), or (t_4, step, last
+// blend) when all four rows were transparent -- goes back to the four rows through two ds_bpermute.
+//   Exact by construction: every accepted sample is taken at the raylength, with the step and against the
+// previous blend the reference's loop would have had, in the reference's order; what differs is only that
+// up to three samples per wave iteration are taken for nothing.
+//   "sign of the previous blend": row j tests against the sign of the STATE's tsdf, not of row j - 1's
+// blend.  The first row for which (step changes | sign differs from the state's) is the first
+// non-transparent one either way: all accepted samples before it have the state's sign.
+//   Rows are 16 lanes apart, not adjacent, so that the four lanes the vector L1 looks up together (one
+// tag look-up per aligned group of four lanes) are four x-adjacent pixels at the SAME sample, as in
+// march_lane -- a quad of consecutive samples of one ray would touch four z planes = four lines.
+//   ROWS = 2 (lanes r and r + 32, 32 rays per wave) is the same scheme with two rows: half the chain for ~5 % more
+// gathers, against a third of the chain for 20-60 % more with four.
+template <int ROWS, bool RCP, class Sink>
+__device__ __forceinline__ void march_quad(const RayVolume& v, const V3& half, const V3& nf, RayState& r,
+                                           MarchCount& out, Sink& sink, int lane) {
+    const unsigned sy = 4u * static_cast<unsigned>(v.n.x), sz = sy * static_cast<unsigned>(v.n.y);
+    const float* const row00 = scalar_ptr(v.tsdf);
+    const float* const row01 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sy));
+    const float* const row10 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz));
+    const float* const row11 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz + sy));
+    const float vs = v.voxelSize, hvs = 0.5f * v.voxelSize, rcp = v.rcpVoxel;
+    const unsigned limx = static_cast<unsigned>(max(v.n.x - 3, 0)), limy = static_cast<unsigned>(max(v.n.y - 3, 0)),
+                   limz = static_cast<unsigned>(max(v.n.z - 3, 0));
+    static_assert(ROWS == 2 || ROWS == 4, "two or four lanes per ray");
+    constexpr unsigned RAYS = 64u / ROWS, SHIFT = ROWS == 4 ? 4u : 5u;
+    const unsigned ray = static_cast<unsigned>(lane) & (RAYS - 1u), row = static_cast<unsigned>(lane) >> SHIFT;
+    const unsigned myBit = 1u << (8u * row);  // this row's bit in the per-ray byte masks below
+    const V3 dir = r.dir;
+    const float tmax = r.maxRay;
+    float t = r.raylength, step = r.raystep, tsdf = r.tsdf;
+    unsigned samples = 0, gathered = 0;
+    for (;;) {
+        const float t1 = t + step, t2 = t1 + step, t3 = ROWS == 4 ? t2 + step : t2, t4 = ROWS == 4 ? t3 + step : t2;
+        if (!(t1 <= tmax)) break;  // (per ray: its rows leave together)
+        const float tj = ROWS == 4 ? (row == 0u ? t1 : row == 1u ? t2 : row == 2u ? t3 : t4) : (row == 0u ? t1 : t2);
+        const bool over = !(tj <= tmax);
+        const V3 pm = v.cam + dir * tj;
+        V3 p;
+        if (RCP) {
+            p = v3(div_voxel(pm.x, vs, rcp), div_voxel(pm.y, vs, rcp), div_voxel(pm.z, vs, rcp)) + half;
+        } else {
+            p = pm / vs + half;
+        }
+        const int lx = static_cast<int>(floorf(p.x)), ly = static_cast<int>(floorf(p.y)),
+                  lz = static_cast<int>(floorf(p.z));
+        bool inside = (static_cast<unsigned>(lx) < limx) & (static_cast<unsigned>(ly) < limy) &
+                      (static_cast<unsigned>(lz) < limz);
+        if (!inside) inside = !outside_flat(p, 2.f, nf);
+        inside = inside && !over;
+        float next = 0.f, nstep = step, fx = 0.f, fy = 0.f, fz = 0.f;
+        unsigned off = 0u;
+        bool q = over, signs = false;
+        if (inside) {
+            fx = __builtin_amdgcn_fractf(p.x);
+            fy = __builtin_amdgcn_fractf(p.y);
+            fz = __builtin_amdgcn_fractf(p.z);
+            off = mad24(static_cast<unsigned>(lz), sz, mad24(static_cast<unsigned>(ly), sy, static_cast<unsigned>(lx) << 2));
+            const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off),
+                         e = gload2(row11, off);
+            next = blend8(a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, fx, fy, fz);
+            if (fabsf(next) < 1.f) nstep = vs;
+            if (fabsf(next) < .8f) nstep = hvs;
+            signs = (__float_as_int(tsdf) ^ __float_as_int(next)) < 0;
+            q = (nstep != step) | signs;
+        }
+        // per ray: byte k of `x` / `ia` = row k's flag
+        const unsigned long long qb = __builtin_amdgcn_ballot_w64(q), ib = __builtin_amdgcn_ballot_w64(inside);
+        unsigned x, iall;
+        if (ROWS == 4) {  // bits ray, ray + 16, ray + 32, ray + 48 -> bytes 0..3
+            const unsigned long long qm = qb >> ray, im = ib >> ray;
+            x = __builtin_amdgcn_perm(static_cast<unsigned>(qm >> 32), static_cast<unsigned>(qm), 0x06040200u) & 0x01010101u;
+            iall = __builtin_amdgcn_perm(static_cast<unsigned>(im >> 32), static_cast<unsigned>(im), 0x06040200u) & 0x01010101u;
+        } else {  // bits ray, ray + 32 -> bytes 0, 1
+            x = ((static_cast<unsigned>(qb) >> ray) & 1u) | (((static_cast<unsigned>(qb >> 32) >> ray) & 1u) << 8);
+            iall = ((static_cast<unsigned>(ib) >> ray) & 1u) | (((static_cast<unsigned>(ib >> 32) >> ray) & 1u) << 8);
+        }
+        const unsigned acc = x ^ (x - 1u);  // rows up to and including the first non-transparent one (all: none is)
+        const unsigned ia = iall & acc;     // accepted samples
+        samples += __popc(ia);
+        gathered += __popc(iall);
+        const bool body = (x & acc & myBit) != 0u && !over;  // this lane runs the full iteration
+        float outT = next, outS = over ? -1.f : nstep;       // step < 0: the ray is done
+        if (__builtin_amdgcn_ballot_w64(body && signs) != 0ull) {  // (wave-uniform) somebody's crossing tests need the previous blend
+            const unsigned ibf = ia & (myBit - 1u);  // accepted samples before this row
+            const int src = ibf ? static_cast<int>((((31u - __clz(ibf)) >> 3) << SHIFT) | ray) : lane;
+            const float got = __shfl(next, src);
+            const float prev = ibf ? got : tsdf;
+            if (body && signs) {
+                const Cell32 c{off, fx, fy, fz};
+                if (prev < 0 && next > 0 && trilinear_weights_g(v, c) > 0.f) {
+                    outS = -1.f;  // crossing from behind: `break`
+                } else if (prev > 0 && next < 0) {
+                    // interpolated crossing; uses the UPDATED raystep (Q1, TSDF.cu:537-543)
+                    const float tstar = tj - nstep * prev / (next - prev);
+                    const V3 ps = to_voxel(v.cam + dir * tstar, v, half);
+                    if (outside_flat(ps, 2.f, nf)) {
+                        outT = prev;  // reference `continue`: the step is updated, tsdf is NOT
+                    } else {
+                        const Cell32 cs = cell32_of(ps, v.n);
+                        if (trilinear_weights_g(v, cs) > 0.f) {
+                            const V3 g = gradient_at(v, widen(cs));
+                            const M33 Rt = transpose(v.R);
+                            out.hit = true;
+                            sink(tstar, mul(Rt, dir * tstar), mul(Rt, g / norm(g)));  // 0/0 -> NaN like the reference
+                            outS = -1.f;  // `break`
+                        }
+                    }
+                }
+            }
+        }
+        // the ray's new state: from row j*, or from the last sampled row when all four were transparent
+        const unsigned sb = x ? (x & acc) : ia;
+        const int src = sb ? static_cast<int>((((31u - __clz(sb)) >> 3) << SHIFT) | ray) : lane;
+        const float nt = __shfl(outT, src), ns = __shfl(outS, src);
+        if (sb) {
+            tsdf = nt;
+            step = ns;
+        }
+        t = ROWS == 4 ? ((x & 1u) ? t1 : (x & 0x100u) ? t2 : (x & 0x10000u) ? t3 : t4) : ((x & 1u) ? t1 : t2);
+        if (step < 0.f) break;
+    }
+    out.samples = row == 0u ? samples : 0u;
+    out.gathered = row == 0u ? gathered : 0u;
+}
 
 // March the ray of pixel (x, y); `valid` = the pixel exists.  All 64 lanes of the wave call this.
 // The volume must fit 32-bit byte offsets (Nx Ny Nz <= 2^30): the caller checks.
@@ -380,10 +505,10 @@ template <class Sink>
 __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid, int x, int y,
                                                  float fx, float fy, float cx, float cy,
                                                  float oldRaylength, Sink& sink,
-                                                 float cut = __builtin_inff()) {
+                                                 float cut = __builtin_inff(), const float* ypairs = nullptr) {
     MarchCount out;
     out.hit = false;
-    out.samples = 0;
+    out.samples = out.gathered = 0;
 #ifdef EMF_MARCH_STAMP
     out.ckIssue = out.ckWait = out.ckRest = out.lateIssue = out.lateWait = out.lateRest = 0;
     out.iters = 0;
@@ -396,18 +521,47 @@ __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid,
     r.raylength = r.maxRay = r.raystep = r.tsdf = 0.f;
     r.active = false;
     if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, cut, r);
-#if EMF_MARCH_LANE
     if (r.active) {
-        if (v.rcpVoxel != 0.f)  // wave-uniform
+        if (ypairs && v.rcpVoxel != 0.f)  // wave-uniform
+            march_lane<true, Sink, true>(v, half, nf, r, out, sink, ypairs);
+        else if (v.rcpVoxel != 0.f)
             march_lane<true>(v, half, nf, r, out, sink);
         else
             march_lane<false>(v, half, nf, r, out, sink);
     }
-#else
-    while (__ballot(r.active) != 0) {
-        if (r.active) ray_step(v, half, nf, r, out, sink);
-    }
+    return out;
+}
+
+// The ROWS-lanes-per-ray march for the ray of pixel (x, y): lanes r, r + 64 / ROWS, ... of the wave pass the SAME
+// pixel (and the same `valid`).  All 64 lanes call this.  On return `hit` is the ray's (equal in its four lanes), `samples`
+// is the ray's count in row 0 and zero in the other rows.  `sink` is called by whichever row found the hit.
+template <int ROWS, class Sink>
+__device__ __forceinline__ MarchCount march_wave_quad(const RayVolume& v, bool valid, int x, int y, float fx, float fy,
+                                                      float cx, float cy, float oldRaylength, Sink& sink, float cut,
+                                                      int lane) {
+    MarchCount out;
+    out.hit = false;
+    out.samples = out.gathered = 0;
+#ifdef EMF_MARCH_STAMP
+    out.ckIssue = out.ckWait = out.ckRest = out.lateIssue = out.lateWait = out.lateRest = 0;
+    out.iters = 0;
+    for (int k = 0; k < 6; ++k) out.hist[k] = 0;
 #endif
+    const V3 half = half_extent(v.n);
+    const V3 nf = v3(static_cast<float>(v.n.x), static_cast<float>(v.n.y), static_cast<float>(v.n.z));
+    RayState r;
+    r.dir = v3(0.f, 0.f, 1.f);
+    r.raylength = r.maxRay = r.raystep = r.tsdf = 0.f;
+    r.active = false;
+    if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, cut, r);  // (four times the same result)
+    if (r.active) {
+        if (v.rcpVoxel != 0.f)  // wave-uniform
+            march_quad<ROWS, true>(v, half, nf, r, out, sink, lane);
+        else
+            march_quad<ROWS, false>(v, half, nf, r, out, sink, lane);
+    }
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(out.hit) >> (static_cast<unsigned>(lane) & (64u / ROWS - 1u));
+    out.hit = (hm & (ROWS == 4 ? 0x0001000100010001ull : 0x0000000100000001ull)) != 0ull;
     return out;
 }
 

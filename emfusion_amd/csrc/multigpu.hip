@@ -161,6 +161,7 @@ __global__ void k_vis_flags_indexed(const int32_t* __restrict__ counts, int nmod
 struct PackPeer {
     char* slots[EMF_MAX_PEERS];
     int world;
+    int fences;  // emf_peer_t::systemFences (ranks on distinct devices): the stores are followed by a system-scope fence
     size_t off;  // this rank's slot (parity included) in a peer's receive buffer
     size_t pixels;
     int band0, bandRows;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void k_pack_keys_peer(const KeyPackTable t, co
             __builtin_nontemporal_store(m, reinterpret_cast<uint8_t*>(pp.slots[p] + pp.off + 12 * pp.pixels) + pix);
         }
     }
+    if (pp.fences) __threadfence_system();
 }
 
 struct FromKeysPeerArgs {
@@ -505,6 +507,7 @@ int emf_hip_packHitKeysPeer(int nlocal, const int32_t* listPos_host, const emf_i
     PackPeer pp;
     for (int p = 0; p < EMF_MAX_PEERS; ++p) pp.slots[p] = p < pa.world ? pa.slots[p] : nullptr;
     pp.world = pa.world;
+    pp.fences = pa.fences;
     pp.off = (static_cast<size_t>(seq & 1u) * pa.world + pa.rank) * pa.slotBytes;
     pp.pixels = static_cast<size_t>(w) * h;
     pp.band0 = bandRow0;

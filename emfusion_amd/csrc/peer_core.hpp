@@ -18,6 +18,7 @@ struct PeerArgs {
     uint32_t* error;
     unsigned long long timeoutTicks;  // of wall_clock64()
     int waitInConsumer;               // 0: the host entry has enqueued k_peer_signal_wait in front (emf_peer_t::waitInFront)
+    int fences;                       // emf_peer_t::systemFences: system-scope release before the flags, acquire behind the poll
 };
 
 // word of a rank's OWN flag page that mirrors its error word on the device: consumers that did not wait
@@ -52,6 +53,11 @@ __device__ __forceinline__ uint8_t load_slot1(const char* p) {
 // RELAXED system-scope atomic store (it bypasses the caches itself), the poll a relaxed system-scope load, and one
 // agent-scope acquire (an L1 invalidate) separates the poll from the slot reads, which are nontemporal loads of
 // fine-grained lines nothing on this device has written.
+//   That argument has only ever been tested with the ranks on ONE device (hipIpc rehearsals): no xGMI node was
+// available.  So it is the protocol only where ranks share a device.  Ranks on DISTINCT devices get
+// emf_peer_t::systemFences = 1 from the communicator: a system-scope release in front of every flag store and a
+// system-scope acquire behind every poll, in the wait launch and in the in-consumer wait alike (6.6 us per exchange,
+// measured on one device) -- until a multi-device run shows the slots never stale without them.
 
 // Signal + wait FUSED INTO THE CONSUMING KERNEL (round 4): called by every thread of every workgroup at the
 // kernel's start (it contains barriers).  The kernel's first workgroup raises this rank's flag on every peer and
@@ -64,7 +70,13 @@ __device__ __forceinline__ bool peer_signal_wait(const PeerArgs& a, uint32_t seq
     if (tid == 0) s_ok = 1;
     __syncthreads();
     if (tid < a.world) {
-        if (firstGroup) __hip_atomic_store(a.flags[tid] + a.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (firstGroup) {
+            if (a.fences) {  // (wave-uniform)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_store(a.flags[tid] + a.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const uint32_t* mine = a.flags[a.rank] + tid;
         const unsigned long long t0 = wall_clock64();
         for (;;) {
@@ -79,7 +91,10 @@ __device__ __forceinline__ bool peer_signal_wait(const PeerArgs& a, uint32_t seq
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (a.fences)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return s_ok != 0;
 }
 

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_peer_scatter(PeerArgs a, const char* __
         for (int p = 0; p < a.world; ++p)  // write-through: the data must be in the peer's memory, not in my L2
             __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(a.slots[p] + off + 16 * i));
     }
+    if (a.fences) __threadfence_system();  // (ranks on distinct devices: peer_core.hpp "Memory ordering")
 }
 
 // one wave: lane p signals peer p, then waits for peer p's signal
@@ -50,8 +51,8 @@ __global__ void k_peer_signal_wait(PeerArgs a, uint32_t seq, unsigned long long 
     if (p >= a.world) return;
     // emf_peer_t::systemFences (wave-uniform): the belt to the braces of peer_core.hpp's "Memory ordering of an exchange"
     // -- a system-scope release in front of the flags and an acquire behind the wait.  One wave per exchange, and still
-    // 6.6 us each while the background's sweep keeps the L2 dirty (0.654 -> 0.688 ms per one-rank sharded frame): off
-    // unless a node shows stale slots (EMF_PEER_FENCES=1).
+    // 6.6 us each while the background's sweep keeps the L2 dirty (0.654 -> 0.688 ms per one-rank sharded frame): on
+    // for ranks on distinct devices (never validated without), off where they share one.
     if (fences) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -221,6 +222,7 @@ int peer_args(const emf_peer_t* g, PeerArgs& a, const char* who) {
     a.error = g->error;
     a.timeoutTicks = timeout_ticks(g->timeoutMs);
     a.waitInConsumer = g->waitInFront ? 0 : 1;
+    a.fences = g->systemFences ? 1 : 0;
     return EMF_OK;
 }
 

@@ -211,9 +211,12 @@ typedef struct emf_peer {
                                         launch (k_peer_normalize at 640 x 480, one rank: 5.4 + 5.9 us against 40 us with
                                         1200 polling workgroups, 20 us with 256), and when ranks share a GPU (rehearsals)
                                         grids of spinning workgroups can keep a lagging rank's producer from starting */
-    uint32_t systemFences;           /* != 0: the wait launch brackets its flags with a system-scope release / acquire
-                                        (6.6 us per exchange beside the background's sweep, measured; off by default:
-                                        slots and flags are fine-grained memory, peer_core.hpp "Memory ordering") */
+    uint32_t systemFences;           /* != 0: every flag store follows a system-scope release and every poll is followed by a
+                                        system-scope acquire, in the wait launch and in consumers that wait themselves;
+                                        peerScatter ends with one (6.6 us per exchange beside the background's sweep,
+                                        measured).  The communicator sets it for ranks on DISTINCT devices; ranks sharing a
+                                        device run without (slots and flags are fine-grained memory, peer_core.hpp
+                                        "Memory ordering") */
 } emf_peer_t;
 size_t emf_hip_peerBufferBytes(int world, size_t slotBytes);
 int emf_hip_peerScatter(const emf_peer_t* group, const void* src, size_t bytes, size_t dstOffset, uint32_t seq,

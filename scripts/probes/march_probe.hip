@@ -97,11 +97,42 @@ __global__ __launch_bounds__(1024) void k_march(RayVolume v, int w, int h, float
     }
 }
 
+// the same image with FOUR lanes per ray (march_quad): a wave = a 4x4-pixel block, four waves = the 8x8 tile `tile`
+__global__ __launch_bounds__(1024) void k_march_quad(RayVolume v, int w, int h, float fx, float fy, float cx,
+                                                     float cy, int tile0, int tilesX, float* sinkBuf, Rec* rec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wavesPerBlock = blockDim.x >> 6;
+    const int gw = blockIdx.x * wavesPerBlock + wave;
+    const int tile = tile0 + (gw >> 2), sub = gw & 3;
+    const int ty = tile / tilesX, tx = tile - ty * tilesX;
+    const int x = tx * 8 + (sub & 1) * 4 + (lane & 3), y = ty * 8 + (sub >> 1) * 4 + ((lane >> 2) & 3);
+    const bool valid = x < w && y < h;
+    float acc = 0.f;
+    auto sink = [&](float raylength, const V3& vertex, const V3& normal) { acc += raylength + vertex.x + normal.x; };
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    const MarchCount c = march_wave_quad<4>(v, valid, x, y, fx, fy, cx, cy, 0.f, sink, __builtin_inff(), lane);
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    unsigned s = c.samples;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s = max(s, (unsigned)__shfl_xor((int)s, o));
+    if (acc == 12345.f) sinkBuf[0] = acc;
+    if (lane == 0) {
+        Rec r;
+        r.c0 = c0; r.c1 = c1; r.w0 = w0; r.w1 = w1;
+        r.samples = s;
+        r.hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        rec[gw] = r;
+    }
+}
+
 __global__ void k_fill(float* p, size_t n, float a, float b) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         // a / b alternate along x + y + z so that blends vary around their mean
         const size_t x = i & 511, y = (i >> 9) & 511, z = i >> 18;
         p[i] = ((x + y + z) & 1) ? a : b;
+        // scene 2 (a < 0): free space in front of a wall at z = 400: +1 up to the truncation band, a ramp through
+        // zero, the product's common case (one voxel per step, nothing happens until the surface)
+        if (a < 0.f) p[i] = z < 390 ? 1.f : z < 410 ? (400.f - (float)z) * 0.1f : -1.f;
     }
 }
 
@@ -136,7 +167,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&tsdf, vox * 4)); CK(hipMalloc(&wts, vox * 4)); CK(hipMalloc(&sinkBuf, 64));
     const size_t flushBytes = 3ull << 30;
     CK(hipMalloc(&flush, flushBytes));
-    CK(hipMalloc(&rec, sizeof(Rec) * 8192));
+    CK(hipMalloc(&rec, sizeof(Rec) * 32768));
     const int W = 640, H = 480;
     const float K[4] = {525.f, 525.f, 319.5f, 239.5f};
     RayVolume v{};
@@ -145,13 +176,14 @@ int main(int argc, char** argv) {
     v.cam = V3{0.013f, -0.021f, -2.5f};
     v.n = I3{N, N, N};
     v.voxelSize = 0.01f; v.truncdist = 0.1f;
-    for (int scene = 0; scene < 2; ++scene) {
+    for (int scene = 0; scene < 3; ++scene) {
         // scene 0: tsdf == 0.5 (half-voxel steps, never a crossing); scene 1: 0.7 / 0.9 checkerboard (blends
         // wander around 0.8: the step size flips between voxel and half voxel like on the frustum boundary)
-        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, tsdf, vox, scene == 0 ? 0.5f : 0.7f, scene == 0 ? 0.5f : 0.9f);
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, tsdf, vox, scene == 2 ? -1.f : scene == 0 ? 0.5f : 0.7f, scene == 0 ? 0.5f : 0.9f);
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, wts, vox, 1.f, 1.f);
         CK(hipDeviceSynchronize());
-        for (int rcp = 0; rcp < 2; ++rcp) {
+        for (int mode = 0; mode < 3; ++mode) {  // 0: lane march, division; 1: lane march, reciprocal; 2: quad march, reciprocal
+            const int rcp = mode > 0, quad = mode == 2;
             v.rcpVoxel = rcp ? 1.0f / v.voxelSize : 0.f;
             struct Case { const char* name; int blocks, threads, tile0; };
             const int tilesX = W / 8;
@@ -163,10 +195,16 @@ int main(int argc, char** argv) {
             for (const Case& cs : cases)
                 for (int warm = 0; warm < 2; ++warm) {
                     if (!warm) { CK(hipMemset(flush, warm, flushBytes)); CK(hipDeviceSynchronize()); }
-                    hipLaunchKernelGGL(k_march, dim3(cs.blocks), dim3(cs.threads), 0, 0, v, W, H, K[0], K[1], K[2], K[3], cs.tile0,
-                                       tilesX, sinkBuf, rec);
+                    // quad: the same pixels with four times the waves (lone wave: a 4x4 block of the tile)
+                    const int qblocks = cs.threads == 64 ? 1 : cs.blocks * 4;
+                    if (quad)
+                        hipLaunchKernelGGL(k_march_quad, dim3(qblocks), dim3(cs.threads), 0, 0, v, W, H, K[0], K[1], K[2], K[3],
+                                           cs.tile0, tilesX, sinkBuf, rec);
+                    else
+                        hipLaunchKernelGGL(k_march, dim3(cs.blocks), dim3(cs.threads), 0, 0, v, W, H, K[0], K[1], K[2], K[3], cs.tile0,
+                                           tilesX, sinkBuf, rec);
                     CK(hipDeviceSynchronize());
-                    const int nw = cs.blocks * cs.threads / 64;
+                    const int nw = (quad ? qblocks : cs.blocks) * cs.threads / 64;
                     std::vector<Rec> hrec(nw);
                     CK(hipMemcpy(hrec.data(), rec, sizeof(Rec) * nw, hipMemcpyDeviceToHost));
                     double clkPerStep = 0, nsPerStep = 0; unsigned long long wmin = ~0ull, wmax = 0; unsigned smax = 0, smin = ~0u;
@@ -177,7 +215,7 @@ int main(int argc, char** argv) {
                         smax = std::max(smax, r.samples); smin = std::min(smin, r.samples);
                     }
                     std::printf("scene %d %s %-30s %s: samples/ray %u..%u, %.0f shader clk/step, %.0f ns/step, span %.1f us\n", scene,
-                                rcp ? "rcp" : "div", cs.name, warm ? "warm" : "cold", smin, smax, clkPerStep / nw, nsPerStep / nw,
+                                quad ? "quad" : rcp ? "rcp" : "div", cs.name, warm ? "warm" : "cold", smin, smax, clkPerStep / nw, nsPerStep / nw,
                                 double(wmax - wmin) * 0.01);
                 }
         }
