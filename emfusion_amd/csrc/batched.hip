@@ -199,19 +199,43 @@ __device__ __forceinline__ void trace_wave(unsigned long long t0, unsigned sampl
 __device__ __forceinline__ void trace_wave(unsigned long long, unsigned, int, int, int, int) {}
 #endif
 
-// Which tile of which model does workgroup `b` of the batched raycast grid serve?  Order: the background's BORDER
+// Which tile of which model does workgroup `bx` of the batched raycast grid serve?  Order: the background's BORDER
 // tiles first (their rays graze seen / unseen space at half-voxel steps all the way: the longest marches of the
 // image), then the objects' footprints, then the background's interior -- XCD-banded: block b runs on XCD b % 8
 // (observed dispatch order; used for L2 locality only) and each XCD gets a contiguous run of tiles in raster
 // order, i.e. a horizontal band of the image, so the voxels its rays walk stay in that XCD's 4 MiB L2 -- then the
 // zero-fill of the objects' images outside their footprints.  (Measured, frames/s of the bench: background first
 // 1227, objects first 1340, this order 1385.)
-// Returns 1: march (m, tile); 2: zero-fill workgroup `tile` (index over all objects); 0: nothing to do.
-__device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int b, int& m, int& tile) {
-    const int perModel = 8 * a.chunk;
-    const int ring = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
-    const int objBlocks = a.objStart[a.nmodels];
-    if (b < ring) {
+// PARTS > 1 (lanes-per-ray march): a BACKGROUND tile is served by PARTS workgroups (`sub` = which part), consecutive
+// on one XCD; object tiles and zero-fill keep one workgroup each (their rays are short: median 12 samples -- and the
+// launch is paced by the workgroup dispatcher as soon as waves live only microseconds: with PARTS workgroups per
+// object tile the background's interior started at 210 us instead of 23, round 5).  Every region starts at a multiple
+// of 8 blocks.
+// Returns 1: march (m, tile, sub); 2: zero-fill workgroup `tile` (index over all objects); 0: nothing to do.
+struct RaycastGrid {
+    int ring, ringBlocks, objBlocks, objPad, bgTileBlocks, bgBlocks, zeroBlocks;
+};
+__host__ __device__ __forceinline__ RaycastGrid raycast_grid(int tilesX, int tilesY, int bandTiles, int chunk, int objBlocks,
+                                                           int nmodels, int parts) {
+    RaycastGrid g;
+    g.ring = (tilesX > 2 && tilesY > 2 && bandTiles == 0) ? 2 * tilesX + 2 * (tilesY - 2) : 0;
+    g.ringBlocks = (g.ring * parts + 7) / 8 * 8;
+    g.objBlocks = objBlocks;
+    g.objPad = (objBlocks + 7) / 8 * 8;
+    g.bgTileBlocks = g.ring ? 8 * (((tilesX - 2) * (tilesY - 2) + 7) / 8) : 8 * chunk;
+    g.bgBlocks = g.bgTileBlocks * parts;
+    g.zeroBlocks = (nmodels - 1) * ((tilesX * tilesY + kZeroTiles - 1) / kZeroTiles);
+    return g;
+}
+
+template <int PARTS>
+__device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int bx, int& m, int& tile, int& sub) {
+    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[a.nmodels], a.nmodels, PARTS);
+    sub = 0;
+    if (bx < g.ringBlocks) {
+        const int b = bx / PARTS;
+        sub = bx - b * PARTS;
+        if (b >= g.ring) return 0;
         m = 0;
         if (b < a.tilesX) tile = b;                                              // top row
         else if (b < 2 * a.tilesX) tile = (a.tilesY - 1) * a.tilesX + (b - a.tilesX);  // bottom row
@@ -219,21 +243,23 @@ __device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int
             const int k = b - 2 * a.tilesX;                                       // left / right columns
             tile = (1 + (k >> 1)) * a.tilesX + ((k & 1) ? a.tilesX - 1 : 0);
         }
-    } else if (b < ring + objBlocks) {  // a tile of an object's footprint
-        const int o = b - ring;
+    } else if (bx < g.ringBlocks + g.objPad) {  // a tile of an object's footprint
+        const int o = bx - g.ringBlocks;
+        if (o >= g.objBlocks) return 0;
         m = 1;
         while (m + 1 < a.nmodels && o >= a.objStart[m + 1]) ++m;
         const int i = o - a.objStart[m], rw = a.rect[m][2];
         tile = (a.rect[m][1] + i / rw) * a.tilesX + a.rect[m][0] + i % rw;
     } else {
         m = 0;
-        int i = b - ring - objBlocks;
-        const int bgBlocks = ring ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : perModel;
-        if (i >= bgBlocks) {
-            tile = i - bgBlocks;
+        const int j = bx - g.ringBlocks - g.objPad;
+        if (j >= g.bgBlocks) {
+            tile = j - g.bgBlocks;
             return 2;
         }
-        if (ring) {  // interior tiles, XCD-banded like the full image
+        const int s = j >> 3, i = ((s / PARTS) << 3) | (j & 7);  // i: the tile's block index, on XCD j % 8 like its parts
+        sub = s % PARTS;
+        if (g.ring) {  // interior tiles, XCD-banded like the full image
             const int inX = a.tilesX - 2, inY = a.tilesY - 2, chunkIn = (inX * inY + 7) / 8;
             const int t = (i & 7) * chunkIn + (i >> 3);
             if (t >= inX * inY) return 0;
@@ -298,10 +324,10 @@ __device__ __forceinline__ RayVolume ray_volume_of(const RaycastBatchArgs& a, in
 
 // MODE 0: one lane per ray, flag-aware per-lane march (march_ray: brick flags, 64-bit offsets);
 // MODE 1: one lane per ray, march_lane (march_wave.hpp), a workgroup = a 16x16-pixel tile, a wave = an 8x8 cell;
-// MODE 4: FOUR lanes per ray, march_quad<4>: a workgroup = ONE 8x8 cell (4 waves of 4x4 pixels x 4 rows), four
-//         workgroups per tile -- consecutive on the same XCD (grid index b: XCD = b % 8, the tile's block index
-//         = 8 (b / 32) + b % 8, cell = (b / 8) % 4);
-// MODE 2: TWO lanes per ray, march_quad<2>: a workgroup = a 16x8 half tile (4 waves of 8x4 pixels x 2 rows), two per tile.
+// MODE 4: the BACKGROUND with FOUR lanes per ray, march_quad<4>: a workgroup = ONE 8x8 cell (4 waves of 4x4 pixels x 4
+//         rows), four workgroups per tile; objects as in MODE 1;
+// MODE 2: the background with TWO lanes per ray, march_quad<2>: a workgroup = a 16x8 half tile (4 waves of 8x4 pixels x
+//         2 rows), two per tile; objects as in MODE 1.
 template <int MODE>
 __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
 #ifdef EMF_RAY_TRACE
@@ -309,16 +335,11 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
 #else
     const unsigned long long trace_t0 = 0;
 #endif
-    int m, tile, sub = 0, vb = blockIdx.x;
-    if (MODE >= 2) {
-        const int s = blockIdx.x >> 3;
-        vb = ((s / MODE) << 3) | (blockIdx.x & 7);
-        sub = s % MODE;
-    }
-    const int role = raycast_block_role(a, vb, m, tile);
+    int m, tile, sub;
+    const int role = raycast_block_role<(MODE >= 2 ? MODE : 1)>(a, blockIdx.x, m, tile, sub);
     if (role == 0) return;
     if (role == 2) {
-        raycast_zero_fill(a, tile, sub, MODE >= 2 ? MODE : 1);
+        raycast_zero_fill(a, tile, 0, 1);
         return;
     }
     const int tyy = tile / a.tilesX, txx = tile - tyy * a.tilesX;
@@ -328,12 +349,13 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     // incoming raylength is zero by construction (the reference zeroes it first, Q5)
     if constexpr (MODE != 0) {
         int x, y, cellX, cellY;
-        if (MODE == 4) {
+        const bool rows = MODE >= 2 && m == 0;  // (block-uniform) this tile's rays get MODE lanes each
+        if (MODE == 4 && rows) {
             cellX = 2 * txx + (sub & 1);
             cellY = 2 * tyy + (sub >> 1);
             x = cellX * 8 + (wave & 1) * 4 + (lane & 3);
             y = cellY * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
-        } else if (MODE == 2) {
+        } else if (MODE == 2 && rows) {
             cellX = 2 * txx + (wave & 1);
             cellY = 2 * tyy + sub;
             x = cellX * 8 + (lane & 7);
@@ -365,11 +387,17 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
         // (a cell with cut == 0 still sets its rays up: one whose first sample lies in the volume's outer shell is
         // exempt from the bound -- ray_setup -- and must be marched like in the reference)
         MarchCount c;
-        if constexpr (MODE >= 2)
-            c = march_wave_quad<MODE>(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, lane);
-        else
+        bool counts = true;  // one lane per ray reports
+        if constexpr (MODE >= 2) {
+            if (rows) {
+                c = march_wave_quad<MODE>(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, lane);
+                counts = lane < 64 / MODE;
+            } else {
+                c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
+            }
+        } else {
             c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, m == 0 ? a.bgYPairs : nullptr);
-        const bool counts = MODE < 2 || lane < 64 / (MODE >= 2 ? MODE : 1);  // one lane per ray reports
+        }
         if (valid && !c.hit && counts) {  // zeros where there is no hit
             md.raylengths[pix] = 0.f;
             float* pv = md.vertices + 3 * pix;
@@ -1300,23 +1328,22 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
         a.objStart[m + 1] = a.objStart[m] + a.rect[m][2] * a.rect[m][3];
     }
     a.rect[0][0] = a.rect[0][1] = a.rect[0][2] = a.rect[0][3] = 0;
-    // background: border ring + interior rounded up to whole XCD chunks (or all of it when banded);
-    // objects: footprint tiles, and ceil(tiles / kZeroTiles) zero-fill workgroups each
-    const int ringTiles = (a.tilesX > 2 && a.tilesY > 2 && a.bandTiles == 0) ? 2 * a.tilesX + 2 * (a.tilesY - 2) : 0;
-    const int bgBlocks = ringTiles ? 8 * (((a.tilesX - 2) * (a.tilesY - 2) + 7) / 8) : 8 * a.chunk;
-    const int zeroBlocks = (nmodels - 1) * static_cast<int>(ceil_div(a.tilesX * a.tilesY, kZeroTiles));
-    const unsigned blocks = static_cast<unsigned>(ringTiles + a.objStart[nmodels] + bgBlocks + zeroBlocks);
-    // EMF_MARCH_ROWS = 1 / 2 / 4 lanes per ray (march_lane / march_quad<2> / march_quad<4>); same images (A/B, read per call)
+    // EMF_MARCH_ROWS = 1 / 2 / 4 lanes per BACKGROUND ray (march_lane / march_quad<2> / march_quad<4>); same images (A/B, read per call)
     const char* mr = std::getenv("EMF_MARCH_ROWS");
-    const int rows = mr ? std::atoi(mr) : 1;
+    const int rows = (useBrickFlags || !offsets32) ? 1 : (mr ? std::atoi(mr) : 1);
+    const int parts = rows == 4 ? 4 : rows == 2 ? 2 : 1;
+    // background: border ring + interior rounded up to whole XCD chunks (or all of it when banded), `parts` workgroups per
+    // tile; objects: footprint tiles, and ceil(tiles / kZeroTiles) zero-fill workgroups each (raycast_grid)
+    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[nmodels], nmodels, parts);
+    const dim3 grid(static_cast<unsigned>(g.ringBlocks + g.objPad + g.bgBlocks + g.zeroBlocks));
     if (useBrickFlags || !offsets32)  // the wave marches address with 32-bit byte offsets
-        hipLaunchKernelGGL(k_raycast_batched<0>, dim3(blocks), dim3(64 * kRbWaves), 0, as_stream(stream), a);
-    else if (rows == 4)  // four workgroups (8x8 cells) per tile, tiles in whole groups of 8 (one per XCD)
-        hipLaunchKernelGGL(k_raycast_batched<4>, dim3(32u * ((blocks + 7u) / 8u)), dim3(64 * kRbWaves), 0, as_stream(stream), a);
-    else if (rows == 2)
-        hipLaunchKernelGGL(k_raycast_batched<2>, dim3(16u * ((blocks + 7u) / 8u)), dim3(64 * kRbWaves), 0, as_stream(stream), a);
+        hipLaunchKernelGGL(k_raycast_batched<0>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
+    else if (parts == 4)
+        hipLaunchKernelGGL(k_raycast_batched<4>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
+    else if (parts == 2)
+        hipLaunchKernelGGL(k_raycast_batched<2>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
     else
-        hipLaunchKernelGGL(k_raycast_batched<1>, dim3(blocks), dim3(64 * kRbWaves), 0, as_stream(stream), a);
+        hipLaunchKernelGGL(k_raycast_batched<1>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
     return launch_status("raycastBatched");
 }
 

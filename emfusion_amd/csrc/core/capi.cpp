@@ -123,6 +123,27 @@ int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion
     });
 }
 
+int emf_fusion_create_from_config(const char* path, const char* calibration, int materialize_gradients, emf_comm_t* comm,
+                                  emf_fusion_params_t* params_out, emf_fusion_t** out) {
+    REQ(out);
+    return guarded([&] {
+        // every field of the reference's Params, as apps/emfusion_synth --configfile builds them (apps/EM-Fusion.cpp:268-371):
+        // emf_fusion_params_t carries a subset only (no ignore_person, LM / Huber / bilateral / lifecycle thresholds)
+        Params q;
+        if (path && path[0]) loadConfigFile(q, path);
+        if (calibration && calibration[0]) loadCalibrationFile(q, calibration);
+        auto h = std::make_unique<emf_fusion>();
+        h->impl = std::make_unique<EMFusion>(q, materialize_gradients ? TSDF::Gradients::Materialized : TSDF::Gradients::OnTheFly,
+                                             comm ? comm->impl : nullptr);
+        if (params_out) {
+            const int rc = emf_io_load_config(path, calibration, params_out, nullptr, 0);
+            if (rc != 0) throw HipError("create_from_config: the configuration could not be re-read", rc);
+            params_out->materialize_gradients = materialize_gradients;
+        }
+        *out = h.release();
+    });
+}
+
 void emf_fusion_destroy(emf_fusion_t* h) { delete h; }
 
 int emf_fusion_trim_pool(uint64_t* bytes_freed) {
@@ -370,6 +391,19 @@ int emf_fusion_object_class(emf_fusion_t* h, int id, int32_t* class_id) {
         const ObjTSDF* o = h->impl->getObject(id);
         if (!o) throw HipError("object_class: no object " + std::to_string(id), EMF_E_ARG);
         *class_id = o->getClassID();
+    });
+}
+
+int emf_fusion_object_info(emf_fusion_t* h, int id, int32_t res[3], float* voxel_size, float* truncdist, float* existence) {
+    REQ(h);
+    return guarded([&] {
+        const ObjTSDF* o = h->impl->getObject(id);
+        if (!o) throw HipError("object_info: no object " + std::to_string(id), EMF_E_ARG);
+        const Vec3i r = o->getVolumeRes();
+        if (res) { res[0] = r[0]; res[1] = r[1]; res[2] = r[2]; }
+        if (voxel_size) *voxel_size = o->getVoxelSize();
+        if (truncdist) *truncdist = o->getTruncDist();
+        if (existence) *existence = o->getExProb();
     });
 }
 

@@ -103,6 +103,7 @@ def load() -> C.CDLL:
         "emf_io_tum_associations": [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), ip],
         "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_size_t, ip],
+        "emf_fusion_create_from_config": [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_void_p, C.POINTER(vp)],
         "emf_fusion_add_object": [vp, fp, C.c_float, ip],
         "emf_fusion_process_frame": [vp, img, fp, fp, C.c_int, ip, fp, fp, C.c_int, ip, img,
                                      C.c_int],
@@ -123,6 +124,7 @@ def load() -> C.CDLL:
         "emf_fusion_queue_instance_scores": [vp, C.c_int, C.c_int, C.c_void_p],
         "emf_fusion_object_class": [vp, C.c_int, ip],
         "emf_fusion_set_ignore_person": [vp, C.c_int],
+        "emf_fusion_object_info": [vp, C.c_int, ip, fp, fp, fp],
         "emf_fusion_render": [vp, C.c_void_p, C.c_void_p],
         "emf_fusion_extract_mesh": [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "emf_fusion_copy_mesh": [vp, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -407,6 +409,21 @@ class Fusion:
                load().emf_fusion_create(C.byref(params), comm._h if comm else None,
                                         C.byref(self._h)))
 
+    @classmethod
+    def from_config(cls, path=None, calibration=None, comm: Optional[Communicator] = None, materialize_gradients=False):
+        """The instance `apps/emfusion_synth --configfile` builds: every key of one of the reference's configuration
+        files (ignore_person, LM / Huber / bilateral / lifecycle thresholds included -- FusionParams holds a subset)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.params = FusionParams()
+        self._comm = comm
+        _check("emf_fusion_create_from_config",
+               load().emf_fusion_create_from_config(os.fspath(path).encode() if path else None,
+                                                    os.fspath(calibration).encode() if calibration else None,
+                                                    int(materialize_gradients), comm._h if comm else None,
+                                                    C.byref(self.params), C.byref(self._h)))
+        return self
+
     def close(self):
         if self._h:
             load().emf_fusion_destroy(self._h)
@@ -518,6 +535,14 @@ class Fusion:
         c = C.c_int32()
         _check("emf_fusion_object_class", load().emf_fusion_object_class(self._h, int(obj_id), C.byref(c)))
         return c.value
+
+    def object_info(self, obj_id: int) -> Dict[str, float]:
+        """resolution, voxel size, truncation distance and existence probability of an object volume as it is now."""
+        res = (C.c_int32 * 3)()
+        vox, trunc, ex = C.c_float(), C.c_float(), C.c_float()
+        _check("emf_fusion_object_info",
+               load().emf_fusion_object_info(self._h, int(obj_id), res, C.byref(vox), C.byref(trunc), C.byref(ex)))
+        return dict(res=tuple(res), voxel_size=vox.value, truncdist=trunc.value, existence=ex.value)
 
     def set_ignore_person(self, on=True):
         """Params.ignore_person: objects classified as person stay out of renderings and mesh files."""

@@ -71,6 +71,13 @@ const char* emf_fusion_last_error_string(void);
 void emf_fusion_default_params(emf_fusion_params_t* p);
 /* comm may be NULL (single GPU).  The handle shares ownership of comm. */
 int emf_fusion_create(const emf_fusion_params_t* p, emf_comm_t* comm, emf_fusion_t** out);
+/* The instance apps/emfusion_synth --configfile builds: EVERY key of one of the reference's configuration files (config/default.cfg, tum.cfg ...;
+ * apps/EM-Fusion.cpp:268-371) and, optionally, a Co-Fusion calibration.txt -- including the ones emf_fusion_params_t has no
+ * field for (ignore_person, FILTER_CLASSES, STATIC_OBJECTS, huberThresh, tau, eps1, eps2, nu_init, bilateral_*, volPad,
+ * existenceThresh, volIOUThresh, matchIOUThresh, distanceThresh, assocThresh).  path NULL or "": the defaults of data.h.
+ * params_out (may be NULL) receives the subset the struct does carry. */
+int emf_fusion_create_from_config(const char* path, const char* calibration, int materialize_gradients, emf_comm_t* comm,
+                                  emf_fusion_params_t* params_out, emf_fusion_t** out);
 void emf_fusion_destroy(emf_fusion_t* h);
 int emf_fusion_reset(emf_fusion_t* h);
 /* Device buffers released by destroyed / resized volumes wait in a process-wide pool instead of going through
@@ -123,6 +130,9 @@ int emf_fusion_queue_instance_masks(emf_fusion_t* h, int n, const emf_image_t* m
 int emf_fusion_queue_instance_scores(emf_fusion_t* h, int n, int num_classes, const double* scores);
 int emf_fusion_object_class(emf_fusion_t* h, int id, int32_t* class_id);
 int emf_fusion_set_ignore_person(emf_fusion_t* h, int on);
+/* geometry of an object volume as it is now (objects are created and resized inside frames): resolution, voxel size,
+ * truncation distance [m], existence probability (ObjTSDF::getExProb); any output pointer may be NULL */
+int emf_fusion_object_info(emf_fusion_t* h, int id, int32_t res[3], float* voxel_size, float* truncdist, float* existence);
 int emf_fusion_last_mask_assignment(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_last_created(emf_fusion_t* h, int32_t* ids, int capacity, int32_t* count);
 int emf_fusion_match_mask(emf_fusion_t* h, const emf_image_t* mask, int32_t* id, float* iou);

@@ -1,0 +1,238 @@
+"""BASELINE.json configs[2] -- "TUM fr3/walking_xyz preprocessed masks (config/tum.cfg), dynamic object count,
+pose-accuracy parity check" -- at full size, on a staged stand-in for the dataset (tests/tum_scene.py: 640 x 480,
+60 frames, three non-parallel planes + furniture, a walking `person` capsule, masks every 30 frames, ground truth).
+
+What the reference does with that configuration (run_exps.sh:31-33, eval_tum.sh:30-35): EM-Fusion -t <sequence>
+-c config/tum.cfg --background -e <out>, then ATE and RPE of poses-cam.txt against groundtruth.txt.  Here:
+  * `apps/emfusion_synth --sequence ... --masks ... --configfile tests/golden/tum_fullsize.cfg --out ...` is that run on the
+    native classes (TUM reader, bilateral pre-filter, objects spawned / matched / resized from the masks, camera and
+    object LM-ICP, result files), and the same frames go through the Python handle API (same C++ classes) so that
+    object ids, classes and per-stage track results can be read;
+  * the frame-level oracle (tests/oracle_pipeline.py + tests/oracle_tracking.py: the reference's schedule and LM driver
+    over the CPU restatement) tracks the same frames in closed loop.  Its object volume is created -- and, on mask frames,
+    re-seeded -- from the HIP run's object (centre, size, volumes): the mask-driven life cycle has its own parity tests
+    (tests/test_gpu_lifecycle.py), every per-frame stage (E-steps, camera and object LM, raycast, integration) is the
+    oracle's own;
+  * at a few check frames a second oracle instance starts from the HIP run's exact state of the frame before (volumes
+    downloaded, poses copied) and runs ONE frame: same inputs, one tracking stage each -- the per-stage agreement
+    without the closed loop's feedback.
+Asserted: (a) ATE (Horn-aligned RMSE) and RPE (1 s = 30 frames, as evaluate_rpe.py --fixed_delta) of the HIP trajectory
+against the truth are within 10 % + 0.2 mm of the oracle's against the truth and under an absolute bound; (b) the
+per-stage poses agree with the oracle's; (c) the person object exists, carries the class `person`, is tracked along the
+person's walk, and is absent from pose files and meshes (ignore_person, EMFusion.cpp:121, 139-150, 274).
+"""
+import json
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import tum_scene as S
+from tests.oracle_pipeline import Affine32, OraclePipeline
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+CFG = ROOT / "tests" / "golden" / "tum_fullsize.cfg"
+FRAMES = 60
+CHECK_FRAMES = (7, 24, 43, 58)  # per-stage comparisons from the HIP state of the frame before (none is a mask frame)
+# absolute bounds: a 1 cm voxel grid and 0.2 % depth noise (5 mm at 2.5 m); KinectFusion-class trackers sit well below
+# one voxel on such input
+ATE_BOUND, RPE_T_BOUND, RPE_R_BOUND = 0.010, 0.010, np.deg2rad(0.4)
+
+
+def _read_poses(path):
+    rows = [ln.split() for ln in Path(path).read_text().strip().splitlines()]
+    out = {}
+    for r in rows:
+        q = np.array([float(v) for v in r[4:8]])  # qx qy qz qw
+        x, y, z, w = q / np.linalg.norm(q)
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        out[int(r[0])] = (R, np.array([float(v) for v in r[1:4]]))
+    return out
+
+
+@pytest.fixture(scope="module")
+def staged(tmp_path_factory):
+    return S.stage(tmp_path_factory.mktemp("tum_fullsize"), frames=FRAMES)
+
+
+@pytest.fixture(scope="module")
+def app_run(staged, dev, tmp_path_factory):
+    out = tmp_path_factory.mktemp("tum_fullsize_out")
+    exe = ROOT / "apps" / "emfusion_synth"
+    assert exe.exists(), "apps/emfusion_synth is built by __graft_entry__.build()"
+    r = subprocess.run([str(exe), "--sequence", staged["seq"], "--masks", staged["masks"], "--configfile", str(CFG),
+                        "--out", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return dict(out=out, stdout=r.stdout, poses=_read_poses(out / "poses-cam.txt"))
+
+
+def _errors(est, truth):
+    """est / truth: lists of (R, t) camera -> world.  The estimate's world frame is its first camera = the truth's."""
+    ate = S.ate_rmse([e[1] for e in est], [t[1] for t in truth])
+    rt, rr = S.rpe(est, truth, 30)
+    rt1, rr1 = S.rpe(est, truth, 1)
+    return dict(ate=ate, rpe_t=rt, rpe_r=rr, rpe_t_1frame=rt1, rpe_r_1frame=rr1,
+                final_t_err=float(np.linalg.norm(est[-1][1] - truth[-1][1])))
+
+
+def _seed_object(orc, v, fus, oid):
+    """oracle object <- the HIP run's object as it is now (geometry, pose, volumes)."""
+    info = fus.object_info(oid)
+    R, t = fus.pose(oid)
+    v["n"] = tuple(info["res"])
+    v["vox"], v["trunc"] = np.float32(info["voxel_size"]), np.float32(info["truncdist"])
+    v["pose"] = Affine32(np.asarray(R, np.float32).reshape(3, 3), t)
+    v["tsdf"], v["wts"] = fus.volume("tsdf", oid).copy(), fus.volume("weights", oid).copy()
+    v["probs"], v["vmask"] = fus.volume("fgprobs", oid).copy(), fus.volume("fgmask", oid).copy()
+
+
+@pytest.fixture(scope="module")
+def runs(staged, oracle, dev):
+    from emfusion_amd import pipeline
+    oracle.set_threads(oracle.host_threads())
+    fus = pipeline.Fusion.from_config(CFG)
+    prm = fus.params
+    assert (prm.width, prm.height, tuple(prm.bg_res), tuple(prm.obj_res)) == (640, 480, (512, 512, 512), (64, 64, 64))
+    fus.use_preproc_masks(staged["masks"])
+    fus.set_cleanup(True)
+    K = np.array(prm.K, np.float32)
+
+    def new_oracle():
+        return OraclePipeline(oracle, prm.width, prm.height, K, 512, prm.bg_voxel_size, list(prm.volume_pose_t), 64,
+                              visibility_thresh=prm.visibility_thresh, boundary=prm.boundary)
+    orc = new_oracle()
+    hip, ora, objs, ora_objs, stage_cmp, created_at = [], [], {}, {}, [], {}
+    snapshot = None
+    for f in range(FRAMES):
+        raw = pipeline.read_depth_png(Path(staged["seq"]) / "depth" / f"{f:04d}.png")  # TUMRGBDReader's floats (raw * 1/5000)
+        fus.set_tracking(camera=f > 0, objects=f > 0)
+        fus.process_rgbd(raw)
+        fus.synchronize()
+        ids = fus.object_ids()
+        for i in ids:
+            created_at.setdefault(i, f)
+        hip.append(fus.pose(0))
+        objs[f] = {i: dict(pose=fus.pose(i), cls=fus.object_class(i), info=fus.object_info(i),
+                           track=fus.track_result(i) if f > created_at[i] else None) for i in ids}
+        cam_track = fus.track_result(0) if f > 0 else None
+
+        # ---- per-stage comparison: a scratch oracle starts from the HIP state of frame f - 1 and runs frame f
+        depth = oracle.preprocess_depth(raw)
+        if snapshot is not None and f in CHECK_FRAMES:
+            ob = new_oracle()
+            ob.frame = f
+            ob.bg["tsdf"], ob.bg["wts"] = snapshot["tsdf"], snapshot["wts"]
+            ob.pose = Affine32(np.asarray(snapshot["cam"][0], np.float32).reshape(3, 3), snapshot["cam"][1])
+            for i, o in snapshot["objects"].items():
+                vid = ob.add_object(np.zeros(3, np.float32), 1.0)
+                v = ob.objects[-1]
+                v.update(o)
+                v["id"] = i
+                v["assoc"] = np.ones((prm.height, prm.width), np.float32)
+                assert vid == len(ob.objects)
+            ob.vis = set(snapshot["visible"])
+            ob.process_frame(depth, None, track_camera=True, track_objects=True, track_iters=prm.max_tracking_iter)
+            row = dict(frame=f, cam_R=float(np.abs(np.asarray(hip[-1][0]).reshape(3, 3) - ob.pose.R).max()),
+                       cam_t=float(np.abs(np.asarray(hip[-1][1]) - ob.pose.t).max()),
+                       cam_steps_hip=cam_track["iterations"], cam_steps_oracle=ob.track[0].iterations, objects={})
+            for v in ob.objects:
+                Rh, th = objs[f][v["id"]]["pose"]
+                row["objects"][v["id"]] = dict(t=float(np.abs(np.asarray(th) - v["pose"].t).max()),
+                                               R=float(np.abs(np.asarray(Rh).reshape(3, 3) - v["pose"].R).max()))
+            stage_cmp.append(row)
+            del ob
+        snapshot = None
+        if f + 1 in CHECK_FRAMES:
+            snap_objs = {}
+            for i in ids:
+                v = {}
+                _seed_object(None, v, fus, i)
+                snap_objs[i] = v
+            snapshot = dict(tsdf=fus.volume("tsdf", 0).copy(), wts=fus.volume("weights", 0).copy(), cam=fus.pose(0),
+                            objects=snap_objs, visible=list(fus.visible_objects()))
+
+        # ---- closed-loop oracle: its own camera and object tracking; the object's life cycle follows the HIP run
+        known = {v["id"] for v in orc.objects}
+        if f == 0:
+            for i in ids:  # spawned from the masks inside HIP's frame 0, before its integration (EMFusion.cpp:100, 103)
+                info = fus.object_info(i)
+                vid = orc.add_object(np.asarray(fus.pose(i)[1], np.float32), np.float32(info["voxel_size"] * info["res"][0]))
+                assert vid == i
+        orc.process_frame(depth, Affine32(), track_camera=f > 0, track_objects=f > 0, track_iters=prm.max_tracking_iter)
+        if f % prm.mask_frames == 0:  # mask frame: fg probabilities (integrateMasks) and a possible resize came from the masks
+            for v in orc.objects:
+                if v["id"] in ids:
+                    _seed_object(orc, v, fus, v["id"])
+        ora.append((orc.pose.R.copy(), orc.pose.t.copy()))
+        ora_objs[f] = {v["id"]: (v["pose"].R.copy(), v["pose"].t.copy()) for v in orc.objects}
+        del known
+    result = dict(fus=fus, hip=[(np.asarray(R, np.float64).reshape(3, 3), np.asarray(t, np.float64)) for R, t in hip],
+                  oracle=[(R.astype(np.float64), t.astype(np.float64)) for R, t in ora], objects=objs, oracle_objects=ora_objs,
+                  stage_cmp=stage_cmp,
+                  truth=staged["truth"])
+    yield result
+    fus.close()
+
+
+def test_app_and_handle_api_track_the_same_trajectory(app_run, runs):
+    """apps/emfusion_synth --sequence --configfile and the Python handle API drive the same classes with the same inputs."""
+    assert sorted(app_run["poses"]) == list(range(FRAMES))
+    for f in range(FRAMES):
+        Ra, ta = app_run["poses"][f]
+        Rh, th = runs["hip"][f]
+        assert np.abs(ta - th).max() < 1e-6 and np.abs(Ra - Rh).max() < 3e-6, f  # (the pose file holds 6 significant digits)
+
+
+def test_trajectory_errors_match_the_oracles(app_run, runs):
+    truth = runs["truth"]
+    app = [app_run["poses"][f] for f in range(FRAMES)]
+    e_app, e_hip, e_orc = _errors(app, truth), _errors(runs["hip"], truth), _errors(runs["oracle"], truth)
+    sep = max(float(np.linalg.norm(h[1] - o[1])) for h, o in zip(runs["hip"], runs["oracle"]))
+    report = dict(frames=FRAMES, app_vs_truth=e_app, hip_vs_truth=e_hip, oracle_vs_truth=e_orc,
+                  max_hip_oracle_separation_m=sep, per_stage=runs["stage_cmp"])
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "tum_fullsize_report.json").write_text(json.dumps(report, indent=1))
+    print(json.dumps(report))
+    for k, bound in (("ate", ATE_BOUND), ("rpe_t", RPE_T_BOUND), ("rpe_r", RPE_R_BOUND)):
+        assert e_app[k] < bound and e_orc[k] < bound, (k, e_app[k], e_orc[k])
+        slack = 2e-4 if k != "rpe_r" else np.deg2rad(0.01)
+        assert e_app[k] <= 1.1 * e_orc[k] + slack, (k, e_app[k], e_orc[k])
+
+
+def test_per_stage_poses_agree_with_the_oracle_from_identical_state(runs):
+    assert [r["frame"] for r in runs["stage_cmp"]] == list(CHECK_FRAMES)
+    # one tracking stage (<= 100 LM iterations of up to 307 200 residuals, 20-30 taken here) from the same volumes, pose and
+    # depth: measured 1e-8 ... 1.3e-6 (the two sides sum the normal equations in different orders, and an accept /
+    # reject verdict that flips changes the iteration count by a few steps: 26 vs 23, 24 vs 21 in two of four frames)
+    for r in runs["stage_cmp"]:
+        assert r["cam_R"] < 1e-5 and r["cam_t"] < 1e-5, r
+        for o in r["objects"].values():
+            assert o["t"] < 1e-5 and o["R"] < 1e-5, r
+
+
+def test_the_person_exists_is_tracked_and_stays_out_of_the_result_files(app_run, runs):
+    objs = runs["objects"]
+    ids = sorted(objs[FRAMES - 1])
+    assert ids == [1], ids  # one person in the masks, spawned at frame 0, alive at the end
+    assert all(objs[f][1]["cls"] == S.PERSON_CLASS for f in range(FRAMES))
+    steps = [objs[f][1]["track"]["iterations"] for f in range(1, FRAMES)]
+    assert min(steps) >= 1
+    # the object's pose follows the walk: displacement of the volume in the world between frames 1 and 59
+    # (a capsule seen from one side under a changing aspect: the ICP follows the walk with a lag and slides along the
+    # axis -- 0.69 of 0.87 m in x, 0.12 m down; the reference's tracker on the same model, which is what the oracle's
+    # closed loop shows too -- so the truth is only a loose bound and the oracle's object pose the tight one)
+    d_est = np.asarray(objs[FRAMES - 1][1]["pose"][1], np.float64) - np.asarray(objs[1][1]["pose"][1], np.float64)
+    d_true = S.person_position(FRAMES - 1) - S.person_position(1)
+    assert d_est[0] > 0.6 * d_true[0] and np.linalg.norm(d_est - d_true) < 0.35, (d_est, d_true)
+    sep = [float(np.linalg.norm(np.asarray(objs[f][1]["pose"][1], np.float64) - runs["oracle_objects"][f][1][1])) for f in range(FRAMES)]
+    print("person volume, HIP vs closed-loop oracle [m]: max %.2e, last %.2e" % (max(sep), sep[-1]))
+    assert max(sep) < 0.02, sep
+    files = sorted(os.listdir(app_run["out"]))
+    assert "poses-cam.txt" in files and "mesh_bg.ply" in files, files
+    assert not [n for n in files if n.startswith("poses-1") or n.startswith("mesh_1")], files
