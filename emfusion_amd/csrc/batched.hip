@@ -141,7 +141,6 @@ struct RaycastBatchArgs {
     const float* farBounds;    // [model][2 tilesY][2 tilesX] per 8x8-pixel cell, or nullptr (see k_far_bounds)
     // objects (slots 1..): the tiles their volume box can project to (host-computed from the pose); only
     // those get a marching workgroup, the rest of the object's images is zero-filled 16 tiles per workgroup
-    const float* bgYPairs;             // y-pair copy of the background's tsdf (emf_hip_buildYPairs) or nullptr
     short rect[EMF_MAX_BATCH][4];      // tx0, ty0, width, height in tiles (slot 0 unused)
     int objStart[EMF_MAX_BATCH + 1];   // prefix sum of width * height over slots 1..; [m] = first block of slot m
 };
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
                 c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
             }
         } else {
-            c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut, m == 0 ? a.bgYPairs : nullptr);
+            c = march_wave(v, valid, x, y, a.fx, a.fy, a.cx, a.cy, 0.f, sink, cut);
         }
         if (valid && !c.hit && counts) {  // zeros where there is no hit
             md.raylengths[pix] = 0.f;
@@ -473,15 +472,6 @@ struct FarBoundArgs {
     float fx, fy, cx, cy;
     float* bounds;  // [model][cellsY][cellsX]
 };
-
-__global__ __launch_bounds__(256) void k_build_ypairs(const float* __restrict__ tsdf, I3 n, float* __restrict__ out) {
-    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
-    const size_t total = static_cast<size_t>(n.x) * n.y * n.z;
-    if (i >= total) return;
-    const int y = static_cast<int>((i / n.x) % n.y);
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    reinterpret_cast<f2*>(out)[i] = f2{tsdf[i], y + 1 < n.y ? tsdf[i + n.x] : 0.f};
-}
 
 __global__ __launch_bounds__(256) void k_far_init(const FarBoundArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x, cells = a.cellsX * a.cellsY;
@@ -737,6 +727,9 @@ struct IntegrateBatchArgs {
 };
 
 // 6 waves per SIMD (<= 80 VGPRs): measured best; 5 and below hide less, 8 spills
+// (Round 5, measured and dropped: 2 / 4 / 8 consecutive tiles per workgroup, on the suspicion that 4096 workgroups of a
+// microsecond or two are paced by the dispatcher -- 50 -> 63 / 70 / 103 us for the four 128^3 objects of configs[1]: the
+// launch is bound by the latency of a tile's dependent loads, and fewer, longer workgroups hide less of it.)
 __attribute__((amdgpu_waves_per_eu(EMF_INT_WPE, EMF_INT_WPE)))
 __global__ __launch_bounds__(256) void k_integrate_batched(const IntegrateBatchArgs a) {
     __shared__ unsigned lds[32];
@@ -943,9 +936,9 @@ __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs 
 }
 
 // tile `sub` (0..7) of list entry e
-template <bool OUT>
+template <bool OUT, bool WIN = false>
 __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a, unsigned e, unsigned sub,
-                                                      unsigned* lds) {
+                                                      unsigned* lds, float* win = nullptr) {
     const unsigned entry = a.list[e];
     const int m = static_cast<int>(entry >> 24), box = static_cast<int>(entry & 0xffffffu);
     IntegrateGeom g = geom_of(a.b, m);
@@ -963,13 +956,13 @@ __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a
         if constexpr (OUT) {
             const uint8_t* dp = a.out.dirtyPrev[m];
             const int force = (dp[t] ? 1 : 0) | (dp[nt + t] ? 2 : 0);
-            integrate_tile<true>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
-                                 a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
-                                 a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr,
-                                 md.unseenTiles ? md.unseenTiles + t : nullptr);
+            integrate_tile<true, WIN>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
+                                      a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
+                                      a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr,
+                                      md.unseenTiles ? md.unseenTiles + t : nullptr, win);
         } else {
-            integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, nullptr, nullptr, 0, nullptr, nullptr,
-                           false, sp, sp ? sp + nt : nullptr, md.unseenTiles ? md.unseenTiles + t : nullptr);
+            integrate_tile<false, WIN>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, nullptr, nullptr, 0, nullptr, nullptr,
+                                       false, sp, sp ? sp + nt : nullptr, md.unseenTiles ? md.unseenTiles + t : nullptr, win);
         }
     }
 }
@@ -982,6 +975,17 @@ __global__ __launch_bounds__(256) void k_integrate_listed(const IntegrateCullArg
     const unsigned e = blockIdx.x / kBoxTiles;
     if (e >= *a.count) return;
     integrate_listed_tile<OUT>(a, e, blockIdx.x % kBoxTiles, lds);
+}
+
+// the same with the tile's pixel window staged in LDS (integrate_tile<OUT, WIN = true>): the tag-bound regime
+template <bool OUT>
+__attribute__((amdgpu_waves_per_eu(EMF_INT_WPE, EMF_INT_WPE)))
+__global__ __launch_bounds__(256) void k_integrate_listed_win(const IntegrateCullArgs a) {
+    __shared__ unsigned lds[32];
+    __shared__ __attribute__((aligned(16))) float win[2 * kWinPixels];
+    const unsigned e = blockIdx.x / kBoxTiles;
+    if (e >= *a.count) return;
+    integrate_listed_tile<OUT, true>(a, e, blockIdx.x % kBoxTiles, lds, win);
 }
 
 // the entries a too-small grid left over: a few workgroups stride over [first, count)
@@ -1226,26 +1230,6 @@ int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* re
     return launch_status("updateRelevantTiles");
 }
 
-// ---- y-pair copy of a tsdf volume (round 5 probe): Q(z, y, x) = {T(z, y, x), T(z, y + 1, x)} (0 beyond the last row)
-static const float* g_pairProbe = nullptr;  // picked up (for the background) by the next emf_hip_raycastBatched
-static float* g_pairBuf = nullptr;
-static size_t g_pairBytes = 0;
-
-int emf_hip_debugPairProbe(const float* tsdf_dev, const int32_t res[3], emf_stream_t stream) {
-    EMF_REQUIRE_PTR(tsdf_dev);
-    EMF_TRY(check_res(res));
-    const size_t voxels = static_cast<size_t>(res[0]) * res[1] * res[2];
-    if (g_pairBytes < voxels * 8) {
-        if (g_pairBuf) (void)hipFree(g_pairBuf);
-        if (hipMalloc(reinterpret_cast<void**>(&g_pairBuf), voxels * 8) != hipSuccess) return fail(EMF_E_LIMIT, "debugPairProbe: hipMalloc");
-        g_pairBytes = voxels * 8;
-    }
-    hipLaunchKernelGGL(k_build_ypairs, dim3(static_cast<unsigned>(ceil_div(voxels, size_t(256)))), dim3(256), 0, as_stream(stream),
-                       tsdf_dev, I3{res[0], res[1], res[2]}, g_pairBuf);
-    g_pairProbe = g_pairBuf;
-    return launch_status("debugPairProbe");
-}
-
 int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
@@ -1281,8 +1265,6 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.cy = K[5];
     a.stats = reinterpret_cast<unsigned long long*>(stats);
     a.farBounds = farBounds_dev;
-    a.bgYPairs = (offsets32 && static_cast<unsigned long long>(res_host[0]) * res_host[1] * res_host[2] <= (1ull << 29)) ? g_pairProbe : nullptr;
-    g_pairProbe = nullptr;
     a.bandTile0 = bgBandRow0 / kRbTile;
     a.bandTiles = bgBandRows / kRbTile;
     // footprints of the objects: the tiles the (slightly enlarged) volume box projects to
@@ -1539,7 +1521,31 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
     }
     hipLaunchKernelGGL(k_integrate_cull, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), a);
     const unsigned boxes = launchBoxes == 0 || launchBoxes > total ? total : launchBoxes;
-    if (out_host) {
+    // Pixel windows in LDS (integrate_tile<OUT, WIN>) where the vector L1's tag rate binds the sweep and the raycast
+    // beside it: a volume of 2^29 voxels and more (1024^3 at 1280 x 960: tag rate 0.92 with both running); below that
+    // the gathers are cheaper than the fill and its barrier.  Same bits either way.
+    bool window = (depth->width & 3) == 0;
+    {
+        unsigned long long largest = 0;
+        for (int m = 0; m < nmodels; ++m)
+            largest = std::max(largest, static_cast<unsigned long long>(res_host[3 * m]) * res_host[3 * m + 1] * res_host[3 * m + 2]);
+        window = window && largest >= (1ull << 29);
+#ifdef EMF_DEBUG_SWITCHES
+        if (const char* w = std::getenv("EMF_INT_WINDOW")) window = (depth->width & 3) == 0 && w[0] != '0';
+#endif
+    }
+    if (window) {
+        if (out_host)
+            hipLaunchKernelGGL(k_integrate_listed_win<true>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
+        else
+            hipLaunchKernelGGL(k_integrate_listed_win<false>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
+        if (boxes < total) {
+            if (out_host)
+                hipLaunchKernelGGL(k_integrate_listed_rest<true>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+            else
+                hipLaunchKernelGGL(k_integrate_listed_rest<false>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
+        }
+    } else if (out_host) {
         hipLaunchKernelGGL(k_integrate_listed<true>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
         if (boxes < total)
             hipLaunchKernelGGL(k_integrate_listed_rest<true>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);

@@ -124,7 +124,7 @@ public:
         // ranks on distinct devices: system-scope release / acquire around every flag (peer_core.hpp "Memory ordering":
         // the fence-free protocol has only been validated with the ranks on one device)
         g_.systemFences = (!waitInFront && world > 1) ? 1u : 0u;
-        if (const char* w = std::getenv("EMF_PEER_WAIT_IN_FRONT")) g_.waitInFront = (w[0] == '0' && !waitInFront) ? 0u : 1u;
+        if (const char* w = debugEnv("EMF_PEER_WAIT_IN_FRONT")) g_.waitInFront = (w[0] == '0' && !waitInFront) ? 0u : 1u;
         g_.rank = rank;
         g_.world = world;
         g_.slotBytes = slotBytes;

@@ -27,8 +27,6 @@
 #include <cstdlib>
 #include <cstring>
 
-extern "C" int emf_hip_debugPairProbe(const float*, const int32_t*, emf_stream_t);  // round-5 probe (batched.hip)
-
 namespace emf {
 
 namespace {
@@ -88,15 +86,16 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_INT_CULL=0: one-level integration launch (every tile gets a workgroup and culls itself)
     const char* ic = std::getenv("EMF_INT_CULL");
     cullBoxes = !(ic && ic[0] == '0');
+    // Switches read through debugEnv() exist in builds with -DEMF_DEBUG_SWITCHES only: their A/B is on record as lost.
     // EMF_OBJ_CULL=1: the two-level launch also for the objects alone (A/B: measured slower for 4 and for 8 volumes of 128^3)
-    const char* oc = std::getenv("EMF_OBJ_CULL");
+    const char* oc = debugEnv("EMF_OBJ_CULL");
     objCull = oc && oc[0] == '1';
     // EMF_TRACK_CHUNK: LM iterations enqueued between two polls of the convergence flags
-    if (const char* tc = std::getenv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
-    if (const char* tw = std::getenv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
-    if (const char* fp = std::getenv("EMF_FUSE_POINTS")) fusePoints = fp[0] != '0';
-    if (const char* fv = std::getenv("EMF_FUSE_VISIBILITY")) fuseVisibility = fv[0] != '0';
-    if (const char* ef = std::getenv("EMF_EARLY_FAR_BOUNDS")) earlyFarBounds = ef[0] != '0';
+    if (const char* tc = debugEnv("EMF_TRACK_CHUNK")) trackChunk = std::atoi(tc);
+    if (const char* tw = debugEnv("EMF_TRACK_WINDOW")) trackWindow = std::atoi(tw);
+    if (const char* fp = debugEnv("EMF_FUSE_POINTS")) fusePoints = fp[0] != '0';
+    if (const char* fv = debugEnv("EMF_FUSE_VISIBILITY")) fuseVisibility = fv[0] != '0';
+    if (const char* ef = debugEnv("EMF_EARLY_FAR_BOUNDS")) earlyFarBounds = ef[0] != '0';
     // EMF_BG_OVERLAP=0: integrate the background in place after the raycast, as the reference does
     const char* bo = std::getenv("EMF_BG_OVERLAP");
     bgOverlap = !(bo && bo[0] == '0');
@@ -104,7 +103,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     const char* fb = std::getenv("EMF_FAR_BOUNDS");
     useFarBounds = !(fb && fb[0] == '0');
     // EMF_RAY_FOOTPRINTS=0: every object gets a marching workgroup for every tile of the image
-    const char* rf = std::getenv("EMF_RAY_FOOTPRINTS");
+    const char* rf = debugEnv("EMF_RAY_FOOTPRINTS");
     useFootprints = !(rf && rf[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
@@ -115,7 +114,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // Over a direct peer-write transport the sharded path's exchanges are fused into the kernels around them
     // (Communicator::peerGroup); EMF_PEER_FUSED=0 keeps the transport's own two-launch collectives (A/B; same bits)
     if (sharded) {
-        const char* pf = std::getenv("EMF_PEER_FUSED");
+        const char* pf = debugEnv("EMF_PEER_FUSED");
         const emf_peer_t* pg = comm->peerGroup();
         peerFused = pg && !(pf && pf[0] == '0') &&
                     pg->slotBytes >= emf_hip_peerRaycastSlotBytes(params.frameSize.width, params.frameSize.height);
@@ -301,7 +300,7 @@ void EMFusion::rebuildModelTable() {
         // for far bounds; its rays are short anyway and the scan (23 us beside the E-steps, which it slows from
         // 12 to 37 us) costs the frame more than the cut saves the raycast: 0.6095 vs 0.5956 ms.  EMF_FAR_SCAN=1
         // scans them.
-        const char* fsc = std::getenv("EMF_FAR_SCAN");
+        const char* fsc = debugEnv("EMF_FAR_SCAN");
         const bool scanSmall = fsc && fsc[0] == '1';
         if (md.signMaps && !md.relevantTiles && scanSmall) scanMask |= bit;
         if (md.signMaps && md.relevantTiles) listMask |= bit;
@@ -1181,7 +1180,7 @@ void EMFusion::trackModels(int first, int count) {
                          "hipMemcpyAsync");
                 main.waitForCompletion();
             }
-            if (std::getenv("EMF_TRACK_LOG")) {  // diagnosis: launches against judged steps
+            if (debugEnv("EMF_TRACK_LOG")) {  // diagnosis: launches against judged steps
                 int it = 0, acc = 0;
                 for (int m = first; m < first + count; ++m) {
                     it = std::max(it, trackStatesHost[m].iterations);
@@ -1203,7 +1202,7 @@ void EMFusion::trackModels(int first, int count) {
         int& predicted = trackPredicted[first == 0 ? 0 : 1];
         int taken = 0;
         // diagnosis (scripts/track_verdict_sequences.py): one line per poll and model, every chunk as long as asked
-        static const bool logVerdicts = std::getenv("EMF_TRACK_LOG") != nullptr;
+        static const bool logVerdicts = debugEnv("EMF_TRACK_LOG") != nullptr;
         for (int done = 0; done < params.maxTrackingIter;) {
             const int want = done == 0 && predicted > 0 && trackChunk > 0 && !logVerdicts ? std::max(chunk, predicted + 8) : chunk;
             const int n = std::min(want, params.maxTrackingIter - done);
@@ -1474,10 +1473,6 @@ void EMFusion::raycastBatched() {
     const int n = static_cast<int>(co.size());
     uint64_t* stats = statsOn ? raycastStatsDev.as<uint64_t>() : nullptr;
     {
-        static const bool pairProbe = std::getenv("EMF_PAIR_PROBE") != nullptr;  // round-5 probe (timing of the raycast only)
-        if (pairProbe) {
-            emfCheck(emf_hip_debugPairProbe(background.tsdfPtr(), resHost.data(), main.abi()), "debugPairProbe");
-        }
         auto kt = ktimers.scope(KernelTimers::Raycast, pixels() * n, main);
         const emf_model_t* table = currentTable();
         const int w = params.frameSize.width, h = params.frameSize.height;

@@ -289,7 +289,7 @@ void TSDF::computeAssociation(const emf_image_t& points, const Affine3f& cam_pos
 }
 
 int TSDF::brickFlagMode() {  // (read on every call: an instance picks the switch up when it is constructed)
-    const char* e = std::getenv("EMF_BRICK_FLAGS");
+    const char* e = debugEnv("EMF_BRICK_FLAGS");
     return e ? (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)) : 0;
 }
 

@@ -161,10 +161,21 @@ private:
     hipEvent_t ev_ = nullptr;  // lazily created by record()
 };
 
+/** Environment switches whose A/B is on record as lost ("switchboard"): read only by builds with
+ *  -DEMF_DEBUG_SWITCHES (make EXTRA_HOST=-DEMF_DEBUG_SWITCHES); the product build ignores them. */
+inline const char* debugEnv(const char* name) {
+#ifdef EMF_DEBUG_SWITCHES
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 /** Queue priority of one of the frame's streams: `dflt` unless the environment variable `env` says "high" / "+1",
  *  "normal" / "0" or "low" / "-1" (A/B measurements of the stream-to-queue mapping). */
 inline int streamPriority(const char* env, int dflt) {
-    const char* v = std::getenv(env);
+    const char* v = debugEnv(env);
     if (!v || !v[0]) return dflt;
     if (v[0] == 'h' || v[0] == '+' || v[0] == '1') return 1;
     if (v[0] == 'l' || v[0] == '-') return -1;

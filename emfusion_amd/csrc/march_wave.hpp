@@ -232,22 +232,10 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { 
 //     comparison per axis) means 0 <= x and x + 2 < Nx whatever the rounding of x + 2; only a sample
 //     in the outermost cells takes the six float comparisons;
 //   * x / voxelSize by multiplication or by division is decided once per wave, not once per sample.
-//   PAIRS (round 5): the four corner gathers of a sample as TWO 16-byte gathers from the y-pair copy of the volume
-// (`ypairs`, emf_hip_buildYPairs: element (z, y, x) = {T(z, y, x), T(z, y + 1, x)}, so 16 bytes at (z, y, x) hold the
-// four (x, y) corners of one z plane).  The crowd regime of this kernel is bound by the CU's gather path at ~20
-// clocks per 64-lane gather INSTRUCTION whatever it loads; this halves the instructions.
-typedef float quad_f __attribute__((ext_vector_type(4), aligned(8)));
-typedef const __attribute__((address_space(1))) quad_f* gquad_p;
-__device__ __forceinline__ quad_f gload4(const float* base, unsigned byteOff) {
-    return *(gquad_p)((gchar_p)base + byteOff);
-}
-
-template <bool RCP, class Sink, bool PAIRS = false>
+template <bool RCP, class Sink>
 __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, const V3& nf, RayState& r,
-                                           MarchCount& out, Sink& sink, const float* ypairs = nullptr) {
+                                           MarchCount& out, Sink& sink) {
     const unsigned sy = 4u * static_cast<unsigned>(v.n.x), sz = sy * static_cast<unsigned>(v.n.y);
-    const float* const prow0 = ypairs;
-    const float* const prow1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ypairs) + 2u * sz);
     const float* const row00 = scalar_ptr(v.tsdf);
     const float* const row01 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sy));
     const float* const row10 = scalar_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(v.tsdf) + sz));
@@ -286,13 +274,8 @@ __device__ __forceinline__ void march_lane(const RayVolume& v, const V3& half, c
                         fz = __builtin_amdgcn_fractf(p.z);
             const unsigned off = mad24(static_cast<unsigned>(lz), sz,
                                        mad24(static_cast<unsigned>(ly), sy, static_cast<unsigned>(lx) << 2));
-            pair_f a, b, d, e;
-            if (PAIRS) {
-                const quad_f lo = gload4(prow0, 2u * off), hi = gload4(prow1, 2u * off);
-                a = pair_f{lo.x, lo.z}; b = pair_f{lo.y, lo.w}; d = pair_f{hi.x, hi.z}; e = pair_f{hi.y, hi.w};
-            } else {
-                a = gload2(row00, off); b = gload2(row01, off); d = gload2(row10, off); e = gload2(row11, off);
-            }
+            const pair_f a = gload2(row00, off), b = gload2(row01, off), d = gload2(row10, off),
+                         e = gload2(row11, off);
 #ifdef EMF_MARCH_STAMP
             const unsigned long long ckSent = march_clock();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -505,7 +488,7 @@ template <class Sink>
 __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid, int x, int y,
                                                  float fx, float fy, float cx, float cy,
                                                  float oldRaylength, Sink& sink,
-                                                 float cut = __builtin_inff(), const float* ypairs = nullptr) {
+                                                 float cut = __builtin_inff()) {
     MarchCount out;
     out.hit = false;
     out.samples = out.gathered = 0;
@@ -522,9 +505,7 @@ __device__ __forceinline__ MarchCount march_wave(const RayVolume& v, bool valid,
     r.active = false;
     if (valid) ray_setup(v, half, nf, x, y, fx, fy, cx, cy, oldRaylength, cut, r);
     if (r.active) {
-        if (ypairs && v.rcpVoxel != 0.f)  // wave-uniform
-            march_lane<true, Sink, true>(v, half, nf, r, out, sink, ypairs);
-        else if (v.rcpVoxel != 0.f)
+        if (v.rcpVoxel != 0.f)  // wave-uniform
             march_lane<true>(v, half, nf, r, out, sink);
         else
             march_lane<false>(v, half, nf, r, out, sink);

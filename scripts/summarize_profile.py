@@ -20,6 +20,8 @@ SHORT = OrderedDict([("k_raycast_batched", "raycast"), ("k_stream_copy", "stream
                      ("k_far_bounds_listed", "far_bounds_listed"), ("k_far_bounds", "far_bounds_scan"), ("k_far_init", "far_init"), ("k_sign_maps", "sign_maps"),
                      ("k_relevant_tiles", "relevant_tiles"), ("k_relevant_reset", "relevant_reset"),
                      ("k_integrate_batched", "integrate"),
+                     ("k_track_step", "track_step"), ("k_track_prepare", "track_prepare"), ("k_track_maxw", "track_maxw"),
+                     ("k_track_weight_images", "track_weight_images"), ("k_pose_gradients", "pose_gradients"),
                      ("k_estep", "assoc"), ("k_composite", "composite"), ("k_vis_counts", "vis_counts"),
                      ("k_vis_flags", "vis_flags"), ("k_dilate_batched", "dilate_flags"),
                      ("k_compute_points", "points"), ("k_update_fgbg", "fgbg"), ("k_fg_probs", "fg_probs"),
@@ -120,6 +122,16 @@ if traffic:
                       f"{wr / 1e6:.1f} | {ws[0] * 1024 / (ws[1] or 1) / 1e6:.1f} | {hr:.2f} |")
         tj[k] = dict(read_bytes_per_launch=rd, write_bytes_per_launch=wr,
                      hbm_bytes_per_launch=rd + wr, l2_hit_rate=hr, launches=nd)
+    # the tracked workload: bench.py times whole tracking STAGES (one k_track_prepare + the LM launches that follow it), so
+    # the stage is the unit its roofline is priced in: per-stage bytes = sum over the tracking kernels / number of stages
+    TRACK_KINDS = ("track_step", "track_prepare", "track_maxw", "pose_gradients")
+    if "track_prepare" in tj and "track_step" in tj:
+        stages = tj["track_prepare"]["launches"]
+        agg = {f: sum(tj[k][f] * tj[k]["launches"] for k in TRACK_KINDS if k in tj) / stages
+               for f in ("read_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}
+        agg.update(l2_hit_rate=tj["track_step"]["l2_hit_rate"], launches=stages,
+                   note="per tracking STAGE: sum over " + ", ".join(k for k in TRACK_KINDS if k in tj) + " / stages")
+        tj["track"] = agg
     json.dump(dict(tag=tag, workload_key=workload_key, source="rocprofv3 --pmc TCC_EA0_* (scripts/profile_round.sh)",
                    kernels=tj, trace=stats), open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
     out_md.append("")
@@ -144,6 +156,21 @@ for pas in ("pmc_sq", "pmc_sq2", "pmc_tcp", "pmc_tcc", "pmc_rd", "pmc_wr"):
         timed = vals[-STEPS * per_frame:] if per_frame else vals
         counters[k][cn] = dict(per_launch=sum(v for v, _ in timed) / len(timed), instances=timed[0][1],
                                launches=len(timed), of=n)
+if "track_prepare" in counters and "track_step" in counters:
+    # per tracking stage (see the traffic table): counter totals of the tracking kernels over the number of stages
+    KINDS = ("track_step", "track_prepare", "track_maxw", "pose_gradients")
+    names = set()
+    for k in KINDS:
+        names |= set(counters.get(k, {}))
+    agg = {}
+    for cn in names:
+        stages = counters["track_prepare"].get(cn, {}).get("launches")
+        if not stages:
+            continue
+        tot = sum(counters[k][cn]["per_launch"] * counters[k][cn]["launches"] for k in KINDS if cn in counters.get(k, {}))
+        agg[cn] = dict(per_launch=tot / stages, instances=counters["track_step"].get(cn, {}).get("instances", 1), launches=stages,
+                       of=stages, launches_per_stage={k: counters[k][cn]["launches"] / stages for k in KINDS if cn in counters.get(k, {})})
+    counters["track"] = agg
 if counters:
     # durations of the same launches from the kernel trace of the PMC passes are perturbed by the counters; the
     # un-perturbed durations are those of the trace pass (`trace` in *_traffic.json) and of bench.py's HIP events

@@ -43,7 +43,8 @@ PATHS = (("per-volume launches", {"EMF_PER_VOLUME": "1"}),
          ("background integrated in place after the raycast", {"EMF_BG_OVERLAP": "0"}),
          ("every ray marched to the end of its range", {"EMF_FAR_BOUNDS": "0"}),
          ("every tile of the sweep loaded, one-level launch",
-          {"EMF_UNSEEN_TILES": "0", "EMF_DEEP_TILES": "0", "EMF_INT_CULL": "0"}))
+          {"EMF_UNSEEN_TILES": "0", "EMF_DEEP_TILES": "0", "EMF_INT_CULL": "0"}),
+         ("four lanes per background ray (march_quad)", {"EMF_MARCH_ROWS": "4"}))
 
 _REST = {1: ((-0.75, -0.10, 1.60), 0.22), 2: ((0.10, 0.00, 1.50), 0.25),
          3: ((0.65, 0.02, 2.00), 0.16), 4: ((0.70, 0.30, 1.80), 0.20)}

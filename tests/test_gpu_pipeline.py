@@ -25,7 +25,8 @@ def run(request, oracle, dev):
     composite from keys, indexed device-side visibility gate, per-frame depth broadcast; "peer": the same path
     over the direct peer-write transport with its exchanges fused into the path's kernels (E-step scattering its
     partial sum, wait + reduce + normalise; key packing scattering keys and the background band, wait + min +
-    composite + visibility), "peer_unfused": that transport's own two-launch collectives (EMF_PEER_FUSED=0)."""
+    composite + visibility), "peer_unfused": that transport's own two-launch collectives -- what the classes fall back
+    to when the group's slots are too small for the fused raycast exchange (13 bytes per pixel)."""
     import os
 
     from emfusion_amd import pipeline
@@ -39,8 +40,8 @@ def run(request, oracle, dev):
     if request.param.startswith("sharded"):
         os.environ["EMF_FORCE_SHARDED"] = "1"
         if "peer" in request.param:
-            os.environ["EMF_PEER_FUSED"] = "0" if request.param.endswith("unfused") else "1"
-            comm = pipeline.Communicator.local_group(1, transport="peer", max_bytes=W * H * 16)[0]
+            comm = pipeline.Communicator.local_group(1, transport="peer",
+                                                     max_bytes=W * H * (8 if request.param.endswith("unfused") else 16))[0]
         else:
             comm = pipeline.Communicator(pipeline.Communicator.unique_id(), 0, 1)
 
@@ -80,7 +81,6 @@ def run(request, oracle, dev):
     os.environ.pop("EMF_PER_VOLUME", None)
     os.environ.pop("EMF_BG_OVERLAP", None)
     os.environ.pop("EMF_FORCE_SHARDED", None)
-    os.environ.pop("EMF_PEER_FUSED", None)
     yield fus, orc, ids, history
     fus.close()
     if comm is not None:

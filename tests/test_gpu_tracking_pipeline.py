@@ -97,44 +97,3 @@ def test_volumes_stay_in_parity_under_tracking(run):
     # tolerance of the pipeline test with a slightly larger outlier budget
     assert_parity(fus.volume("weights", 0), orc.bg["wts"], "bg weights", rtol=1e-3, atol=1e-4, budget=1e-2)
     assert_parity(fus.volume("tsdf", 0), orc.bg["tsdf"], "bg tsdf", rtol=1e-3, atol=1e-3, budget=2e-2)
-
-
-def test_the_host_loops_agree(dev, monkeypatch):
-    """EMFusion::trackModels has three ways of feeding a stage's launches: launch by launch, a window ahead of the
-    device's progress words, the result read from the states the device sends with its done words (default); chunks of
-    EMF_TRACK_CHUNK iterations with a read-back per chunk (EMF_TRACK_WINDOW=0); the whole budget in one call.  Which
-    launches a model's steps fall into differs; its poses and counters do not."""
-    from emfusion_amd import pipeline
-    from emfusion_amd.ops import image_view
-
-    def tracked(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        prm = pipeline.make_params(W, H, BG_RES, BG_VOX, OBJ_RES, visibility_thresh=100, boundary=5, mask_frames=MASK_EVERY)
-        K = np.array(prm.K, np.float32)
-        synth = pipeline.SyntheticStream(W, H, K, NOBJ, seed=0xE3F5)
-        fus = pipeline.Fusion(prm, None)
-        ids = [fus.add_object(*[synth.sphere(k, 0)[i] for i in (0, 2)]) for k in range(NOBJ)]
-        fus.set_tracking(camera=True, objects=True)
-        out = []
-        for f in range(4):
-            depth, sid = synth.render(f)
-            R, t = synth.camera_pose(f)
-            poses = {i: (np.eye(3, dtype=np.float32).reshape(-1), synth.sphere(i - 1, f)[0]) for i in ids}
-            run_masks = f % MASK_EVERY == 0
-            d_depth = to_dev(depth)
-            d_masks = {i: to_dev((sid == i).astype(np.uint8)) for i in ids} if run_masks else {}
-            fus.process_frame(image_view(d_depth), R, t, poses, {i: image_view(m) for i, m in d_masks.items()}, run_masks)
-            fus.synchronize()
-            if f:
-                out.append([(np.asarray(fus.pose(i)[0]).tobytes(), np.asarray(fus.pose(i)[1]).tobytes(),
-                             fus.track_result(i)["iterations"], fus.track_result(i)["accepted"]) for i in [0] + ids])
-        fus.close()
-        synth.close()
-        for k in env:
-            monkeypatch.delenv(k)
-        return out
-    window = tracked({})
-    assert all(r[2] > 0 for row in window for r in row)
-    assert tracked({"EMF_TRACK_WINDOW": "0", "EMF_TRACK_CHUNK": "8"}) == window
-    assert tracked({"EMF_TRACK_WINDOW": "0"}) == window

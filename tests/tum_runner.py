@@ -1,0 +1,105 @@
+"""The closed-loop runner behind tests/test_gpu_tum_fullsize.py (640 x 480, the reference's configs[2] settings) and
+tests/test_gpu_tracking_divergence.py (160 x 120): a staged TUM-layout sequence (tests/tum_scene.py) goes, frame by
+frame, through the HIP classes (Python handle API: EMFusion::processFrame(RGBD) with preprocessed masks, camera and
+objects tracked from the second frame on) and through the frame-level oracle with its LM driver
+(tests/oracle_pipeline.py, tests/oracle_tracking.py), and at the check frames a scratch oracle runs ONE frame from the HIP
+run's exact state of the frame before.  Test infrastructure."""
+from pathlib import Path
+
+import numpy as np
+
+from tests.oracle_pipeline import Affine32, OraclePipeline
+
+
+def seed_object(v, fus, oid):
+    """oracle object <- the HIP run's object as it is now (geometry, pose, volumes)."""
+    info = fus.object_info(oid)
+    R, t = fus.pose(oid)
+    v["n"] = tuple(info["res"])
+    v["vox"], v["trunc"] = np.float32(info["voxel_size"]), np.float32(info["truncdist"])
+    v["pose"] = Affine32(np.asarray(R, np.float32).reshape(3, 3), t)
+    v["tsdf"], v["wts"] = fus.volume("tsdf", oid).copy(), fus.volume("weights", oid).copy()
+    v["probs"], v["vmask"] = fus.volume("fgprobs", oid).copy(), fus.volume("fgmask", oid).copy()
+
+
+def run_closed_loop(fus, oracle, staged, frames, check_frames):
+    """fus: a fresh pipeline.Fusion; staged: tum_scene.stage(...).  Returns dict(hip, oracle: [(R, t) float64 camera ->
+    world per frame], objects: {frame: {id: pose, cls, info, track}}, oracle_objects: {frame: {id: (R, t)}}, stage_cmp:
+    one row per check frame, cam_tracks: HIP's camera track result per frame)."""
+    from emfusion_amd import pipeline
+    prm = fus.params
+    fus.use_preproc_masks(staged["masks"])
+    fus.set_cleanup(True)
+    K = np.array(prm.K, np.float32)
+
+    def new_oracle():
+        return OraclePipeline(oracle, prm.width, prm.height, K, tuple(prm.bg_res), prm.bg_voxel_size, list(prm.volume_pose_t),
+                              prm.obj_res[0], rel_trunc=prm.bg_rel_truncdist, max_weight=prm.max_tsdf_weight,
+                              sigma=prm.assoc_sigma, alpha=prm.alpha, prior=prm.uni_prior,
+                              visibility_thresh=prm.visibility_thresh, boundary=prm.boundary)
+    orc = new_oracle()
+    hip, ora, objs, ora_objs, stage_cmp, created_at, cam_tracks = [], [], {}, {}, [], {}, []
+    snapshot = None
+    for f in range(frames):
+        raw = pipeline.read_depth_png(Path(staged["seq"]) / "depth" / f"{f:04d}.png")  # TUMRGBDReader's floats (raw * 1/5000)
+        fus.set_tracking(camera=f > 0, objects=f > 0)
+        fus.process_rgbd(raw)
+        fus.synchronize()
+        ids = fus.object_ids()
+        for i in ids:
+            created_at.setdefault(i, f)
+        hip.append(fus.pose(0))
+        objs[f] = {i: dict(pose=fus.pose(i), cls=fus.object_class(i), info=fus.object_info(i),
+                           track=fus.track_result(i) if f > created_at[i] else None) for i in ids}
+        cam_tracks.append(fus.track_result(0) if f > 0 else None)
+
+        # ---- per-stage comparison: a scratch oracle starts from the HIP state of frame f - 1 and runs frame f
+        depth = oracle.preprocess_depth(raw)
+        if snapshot is not None and f in check_frames:
+            ob = new_oracle()
+            ob.frame = f
+            ob.bg["tsdf"], ob.bg["wts"] = snapshot["tsdf"], snapshot["wts"]
+            ob.pose = Affine32(np.asarray(snapshot["cam"][0], np.float32).reshape(3, 3), snapshot["cam"][1])
+            for i, o in snapshot["objects"].items():
+                ob.add_object(np.zeros(3, np.float32), 1.0)
+                v = ob.objects[-1]
+                v.update(o)
+                v["id"] = i
+                v["assoc"] = np.ones((prm.height, prm.width), np.float32)
+            ob.vis = set(snapshot["visible"])
+            ob.process_frame(depth, None, track_camera=True, track_objects=True, track_iters=prm.max_tracking_iter)
+            row = dict(frame=f, cam_R=float(np.abs(np.asarray(hip[-1][0]).reshape(3, 3) - ob.pose.R).max()),
+                       cam_t=float(np.abs(np.asarray(hip[-1][1]) - ob.pose.t).max()),
+                       cam_steps_hip=cam_tracks[-1]["iterations"], cam_steps_oracle=ob.track[0].iterations, objects={})
+            for v in ob.objects:
+                Rh, th = objs[f][v["id"]]["pose"]
+                row["objects"][v["id"]] = dict(t=float(np.abs(np.asarray(th) - v["pose"].t).max()),
+                                               R=float(np.abs(np.asarray(Rh).reshape(3, 3) - v["pose"].R).max()))
+            stage_cmp.append(row)
+            del ob
+        snapshot = None
+        if f + 1 in check_frames:
+            snap_objs = {}
+            for i in ids:
+                v = {}
+                seed_object(v, fus, i)
+                snap_objs[i] = v
+            snapshot = dict(tsdf=fus.volume("tsdf", 0).copy(), wts=fus.volume("weights", 0).copy(), cam=fus.pose(0),
+                            objects=snap_objs, visible=list(fus.visible_objects()))
+
+        # ---- closed-loop oracle: its own camera and object tracking; the object's life cycle follows the HIP run
+        if f == 0:
+            for i in ids:  # spawned from the masks inside HIP's frame 0, before its integration (EMFusion.cpp:100, 103)
+                info = fus.object_info(i)
+                vid = orc.add_object(np.asarray(fus.pose(i)[1], np.float32), np.float32(info["voxel_size"] * info["res"][0]))
+                assert vid == i
+        orc.process_frame(depth, Affine32(), track_camera=f > 0, track_objects=f > 0, track_iters=prm.max_tracking_iter)
+        if f % prm.mask_frames == 0:  # mask frame: fg probabilities (integrateMasks) and a possible resize came from the masks
+            for v in orc.objects:
+                if v["id"] in ids:
+                    seed_object(v, fus, v["id"])
+        ora.append((orc.pose.R.copy(), orc.pose.t.copy()))
+        ora_objs[f] = {v["id"]: (v["pose"].R.copy(), v["pose"].t.copy()) for v in orc.objects}
+    return dict(hip=[(np.asarray(R, np.float64).reshape(3, 3), np.asarray(t, np.float64)) for R, t in hip],
+                oracle=[(R.astype(np.float64), t.astype(np.float64)) for R, t in ora], objects=objs, oracle_objects=ora_objs,
+                stage_cmp=stage_cmp, cam_tracks=cam_tracks, truth=staged["truth"][:frames])

@@ -112,11 +112,19 @@ SIDE_N = _rot([0, 1, 0], np.deg2rad(-8.0)) @ _rot([0, 0, 1], np.deg2rad(3.0)) @ 
 FLOOR_C, BACK_C, SIDE_C = 1.05, 3.1, 1.45  # n . X = c
 
 
-def render(f: int, rng: np.random.Generator | None = None, noise=0.002, dropout=0.01):
+def intrinsics(width=W, height=H):
+    """fx, fy, cx, cy of Params' default camera scaled to the image width (data.h:84-90)."""
+    s = width / 640.0
+    return FX * s, FY * s, width / 2 - 0.5, height / 2 - 0.5
+
+
+def render(f: int, rng: np.random.Generator | None = None, noise=0.002, dropout=0.01, size=(W, H)):
     """depth (H, W) float32 metres, instance ids (H, W) uint8: 0 static scene, 1 the person."""
     R, o = camera_pose(f)
-    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
-    d = np.stack([(u - CX) / FX, (v - CY) / FY, np.ones_like(u)], axis=-1)
+    w, h = size
+    fx, fy, cx, cy = intrinsics(w, h)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], axis=-1)
     D = d @ R.T
     layers = [
         _plane(o, D, FLOOR_N, FLOOR_C), _plane(o, D, BACK_N, BACK_C), _plane(o, D, SIDE_N, SIDE_C),
@@ -155,7 +163,7 @@ def quaternion(R):
     return q
 
 
-def stage(root, frames=60, seed=0x7A5C):
+def stage(root, frames=60, seed=0x7A5C, size=(W, H)):
     """Writes <root>/seq/{associations.txt, groundtruth.txt, depth/NNNN.png} and <root>/masks/MaskNNNN.plk.
     Returns dict(seq=..., masks=..., truth=[(R, t)], depth=[(H, W) f32 as the PNG holds it], ids=[...])."""
     from emfusion_amd import readers
@@ -166,9 +174,9 @@ def stage(root, frames=60, seed=0x7A5C):
     rng = np.random.default_rng(seed)
     lines, gt, truth, depths, idmaps = [], [], [], [], []
     for f in range(frames):
-        depth, ids = render(f, rng)
+        depth, ids = render(f, rng, size=size)
         q16 = np.round(depth * 5000.0).astype(np.uint16)
-        readers.write_png_gray16(seq / "depth" / f"{f:04d}.png", q16, filters=np.arange(H) % 5)
+        readers.write_png_gray16(seq / "depth" / f"{f:04d}.png", q16, filters=np.arange(size[1]) % 5)
         depths.append(q16.astype(np.float32) / np.float32(5000.0))
         idmaps.append(ids)
         ts = f / FPS
