@@ -936,9 +936,9 @@ __global__ __launch_bounds__(256) void k_integrate_cull(const IntegrateCullArgs 
 }
 
 // tile `sub` (0..7) of list entry e
-template <bool OUT, bool WIN = false>
+template <bool OUT>
 __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a, unsigned e, unsigned sub,
-                                                      unsigned* lds, float* win = nullptr) {
+                                                      unsigned* lds) {
     const unsigned entry = a.list[e];
     const int m = static_cast<int>(entry >> 24), box = static_cast<int>(entry & 0xffffffu);
     IntegrateGeom g = geom_of(a.b, m);
@@ -956,13 +956,13 @@ __device__ __forceinline__ void integrate_listed_tile(const IntegrateCullArgs& a
         if constexpr (OUT) {
             const uint8_t* dp = a.out.dirtyPrev[m];
             const int force = (dp[t] ? 1 : 0) | (dp[nt + t] ? 2 : 0);
-            integrate_tile<true, WIN>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
-                                      a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
-                                      a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr,
-                                      md.unseenTiles ? md.unseenTiles + t : nullptr, win);
+            integrate_tile<true>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.out.tsdf[m],
+                                 a.out.weights[m], force, a.out.dirtyNext[m] + t, a.out.dirtyNext[m] + nt + t,
+                                 a.b.visible && a.b.visible[m] == 0, sp, sp ? sp + nt : nullptr,
+                                 md.unseenTiles ? md.unseenTiles + t : nullptr);
         } else {
-            integrate_tile<false, WIN>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, nullptr, nullptr, 0, nullptr, nullptr,
-                                       false, sp, sp ? sp + nt : nullptr, md.unseenTiles ? md.unseenTiles + t : nullptr, win);
+            integrate_tile(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, nullptr, nullptr, 0, nullptr, nullptr,
+                           false, sp, sp ? sp + nt : nullptr, md.unseenTiles ? md.unseenTiles + t : nullptr);
         }
     }
 }
@@ -975,17 +975,6 @@ __global__ __launch_bounds__(256) void k_integrate_listed(const IntegrateCullArg
     const unsigned e = blockIdx.x / kBoxTiles;
     if (e >= *a.count) return;
     integrate_listed_tile<OUT>(a, e, blockIdx.x % kBoxTiles, lds);
-}
-
-// the same with the tile's pixel window staged in LDS (integrate_tile<OUT, WIN = true>): the tag-bound regime
-template <bool OUT>
-__attribute__((amdgpu_waves_per_eu(EMF_INT_WPE, EMF_INT_WPE)))
-__global__ __launch_bounds__(256) void k_integrate_listed_win(const IntegrateCullArgs a) {
-    __shared__ unsigned lds[32];
-    __shared__ __attribute__((aligned(16))) float win[2 * kWinPixels];
-    const unsigned e = blockIdx.x / kBoxTiles;
-    if (e >= *a.count) return;
-    integrate_listed_tile<OUT, true>(a, e, blockIdx.x % kBoxTiles, lds, win);
 }
 
 // the entries a too-small grid left over: a few workgroups stride over [first, count)
@@ -1521,31 +1510,7 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
     }
     hipLaunchKernelGGL(k_integrate_cull, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), a);
     const unsigned boxes = launchBoxes == 0 || launchBoxes > total ? total : launchBoxes;
-    // Pixel windows in LDS (integrate_tile<OUT, WIN>) where the vector L1's tag rate binds the sweep and the raycast
-    // beside it: a volume of 2^29 voxels and more (1024^3 at 1280 x 960: tag rate 0.92 with both running); below that
-    // the gathers are cheaper than the fill and its barrier.  Same bits either way.
-    bool window = (depth->width & 3) == 0;
-    {
-        unsigned long long largest = 0;
-        for (int m = 0; m < nmodels; ++m)
-            largest = std::max(largest, static_cast<unsigned long long>(res_host[3 * m]) * res_host[3 * m + 1] * res_host[3 * m + 2]);
-        window = window && largest >= (1ull << 29);
-#ifdef EMF_DEBUG_SWITCHES
-        if (const char* w = std::getenv("EMF_INT_WINDOW")) window = (depth->width & 3) == 0 && w[0] != '0';
-#endif
-    }
-    if (window) {
-        if (out_host)
-            hipLaunchKernelGGL(k_integrate_listed_win<true>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
-        else
-            hipLaunchKernelGGL(k_integrate_listed_win<false>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
-        if (boxes < total) {
-            if (out_host)
-                hipLaunchKernelGGL(k_integrate_listed_rest<true>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
-            else
-                hipLaunchKernelGGL(k_integrate_listed_rest<false>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);
-        }
-    } else if (out_host) {
+    if (out_host) {
         hipLaunchKernelGGL(k_integrate_listed<true>, dim3(kBoxTiles * boxes), dim3(256), 0, as_stream(stream), a);
         if (boxes < total)
             hipLaunchKernelGGL(k_integrate_listed_rest<true>, dim3(kBoxTiles * 64u), dim3(256), 0, as_stream(stream), a, boxes);

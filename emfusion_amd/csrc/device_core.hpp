@@ -399,7 +399,11 @@ __device__ __forceinline__ float4 load4(const float* p) {
 // instructions per voxel -- two IEEE divisions to project, a square root, up to two more divisions
 // to fuse -- put the VALU floor of the bench workload at ~0.30 ms; removing the load dependencies,
 // staging the pixel window in LDS, persistent tile scheduling were all measured and gave nothing
-// or lost, the 1 / lambda table and 6 waves per SIMD gave 9 %.
+// or lost, the 1 / lambda table and 6 waves per SIMD gave 9 %.  (The LDS window was built a second time in round 5
+// for the 1280 x 960 / 1024^3 share, where the L1 tag rate reads 0.92 with raycast and sweep overlapped: depth and
+// 1 / lambda over the bounding box of the tile's corner projections, 16-byte fills, ds_read in phase B, gather
+// fall-back per tile and per voxel; bit-identical over 150 tests -- and slower there too, 3.59 -> 3.76 ms
+// overlapped, 1.56 -> 1.74 ms alone, and 0.566 -> 0.587 ms per frame at 512^3: DESIGN.md 5.1d; in git history.)
 //
 // OUT = true is the out-of-place form behind emf_hip_integrateBatchedCulledOut: (tsdf, weights) are
 // only READ, the integrated state goes to (tsdfOut, weightsOut), a second copy of the volume that
@@ -410,20 +414,7 @@ __device__ __forceinline__ float4 load4(const float* p) {
 // tile, i.e. they are the next call's `force`.  (Free space below the weight cap changes its weight
 // every frame and its tsdf never: tracking the arrays apart halves what has to be stored there.)
 // Same arithmetic, same values: only where they are stored differs.
-//
-// WIN = true (round 5; `win`: 2 * kWinPixels floats of LDS): the tile's PIXEL WINDOW -- depth and 1 / lambda over the
-// bounding box of the projections of its eight corner voxels, +-1 pixel, x aligned to 4 pixels -- is staged in LDS
-// with coalesced 16-byte loads and the per-voxel lookups of phase B read it with ds_read instead of gathering from
-// global memory (24 gather instructions per wave and tile, 16+ tag look-ups each, whatever they touch).  For the
-// regime in which the vector L1's tag rate binds the sweep and the raycast beside it (1280 x 960 / 1024^3: 0.92
-// of the measured rate); where nothing is tag-bound (640 x 480 / 512^3) the fill, its barrier and the LDS cost
-// more than the gathers (round 1: 0.41-0.47 vs 0.387 ms), so the host selects the form per launch.  A tile whose
-// window does not fit (near the camera), or that touches the camera plane, gathers as before (block-uniform);
-// a voxel whose pixel falls outside the window it was sized for (cannot happen by construction; checked anyway)
-// gathers too.  Same loads of the same floats: same bits.
-constexpr int kWinPixels = 3072;  // per image: 12 KB; depth + 1 / lambda = 24 KB per workgroup
-
-template <bool OUT = false, bool WIN = false>
+template <bool OUT = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __restrict__ tsdf,
                                                float* __restrict__ weights,
                                                uint8_t* __restrict__ bricks, int x0, int y0,
@@ -433,7 +424,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                                                int force = 0, uint8_t* dirtyT = nullptr,
                                                uint8_t* dirtyW = nullptr, bool copyOnly = false,
                                                uint8_t* signPos = nullptr, uint8_t* signNeg = nullptr,
-                                               uint8_t* unseen = nullptr, float* win = nullptr) {
+                                               uint8_t* unseen = nullptr) {
     const V3 half = half_extent(a.n);
     // copyOnly (OUT, block-uniform): the model is not integrated this frame (visibility gate closed),
     // its second copy only has to catch up
@@ -483,46 +474,6 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
     }
     const int tid = threadIdx.x;
     const bool haveIl = a.invLambda.data != nullptr;
-    int wx0 = 0, wy0 = 0, ww = 0, wh = 0;  // pixel window of the tile (ww == 0: none, gather)
-    if (WIN) {
-        // projections of the tile's eight corner voxels: lane k & 7 takes corner k, three xor steps reduce
-        const int x1 = min(x0 + kTileX, a.n.x) - 1, y1 = min(y0 + kTileY, a.n.y) - 1, z1 = min(z0 + kTileZ, a.n.z) - 1;
-        const int k = tid & 7;
-        const V3 pc = voxel_in_camera(a, half, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, (k & 4) ? z1 : z0);
-        const V3 q = project(a, pc);
-        float umin = q.x / q.z, vmin = q.y / q.z, zmin = pc.z;
-        float umax = umin, vmax = vmin;
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
-            vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-            zmin = fminf(zmin, __shfl_xor(zmin, o));
-        }
-        // (every voxel centre of the tile lies in the box spanned by the corner voxels, all in front of the camera:
-        // its projection lies in the bounding box of theirs; +-1 pixel covers the rounding to the pixel grid)
-        if (zmin > 1e-3f && fabsf(umin) < 1e6f && fabsf(umax) < 1e6f && fabsf(vmin) < 1e6f && fabsf(vmax) < 1e6f &&
-            (a.w & 3) == 0) {
-            const int bx0 = max(static_cast<int>(floorf(umin)) - 1, 0) & ~3, bx1 = min((static_cast<int>(ceilf(umax)) + 2 + 3) & ~3, a.w);
-            const int by0 = max(static_cast<int>(floorf(vmin)) - 1, 0), by1 = min(static_cast<int>(ceilf(vmax)) + 2, a.h);
-            if (bx1 > bx0 && by1 > by0 && (bx1 - bx0) * (by1 - by0) <= kWinPixels) {
-                wx0 = bx0; wy0 = by0; ww = bx1 - bx0; wh = by1 - by0;
-            }
-        }
-        if (ww > 0) {  // block-uniform (the same eight corners in every wave)
-            const int per = ww >> 2, chunks = per * wh;
-            const bool fillIl = haveIl && !deep;
-            for (int c = tid; c < chunks; c += 256) {
-                const int ry = c / per, cx = (c - ry * per) << 2;
-                const float4 dv = *reinterpret_cast<const float4*>(a.depth.row(wy0 + ry) + wx0 + cx);
-                *reinterpret_cast<float4*>(win + ry * ww + cx) = dv;
-                if (fillIl) {
-                    const float4 iv = *reinterpret_cast<const float4*>(a.invLambda.row(wy0 + ry) + wx0 + cx);
-                    *reinterpret_cast<float4*>(win + kWinPixels + ry * ww + cx) = iv;
-                }
-            }
-            __syncthreads();
-        }
-    }
     bool gotWeight = false;  // a voxel of this lane has been fused into
     int anyChanged = 0;
     bool sawPos = false, sawNeg = false;  // signs among the tsdf values this lane holds at the end
@@ -566,14 +517,8 @@ __device__ __forceinline__ void integrate_tile(const IntegrateGeom& a, float* __
                 d[i][e] = il[i][e] = 0.f;
                 if (inMask & (1u << (4 * i + e))) {
                     const int px = pix[i][e] & 0xffffu, py = pix[i][e] >> 16;
-                    const unsigned rx = static_cast<unsigned>(px - wx0), ry = static_cast<unsigned>(py - wy0);
-                    if (WIN && rx < static_cast<unsigned>(ww) && ry < static_cast<unsigned>(wh)) {
-                        d[i][e] = win[ry * ww + rx];
-                        if (haveIl && !deep) il[i][e] = win[kWinPixels + ry * ww + rx];
-                    } else {
-                        d[i][e] = a.depth.row(py)[px];
-                        if (haveIl && !deep) il[i][e] = a.invLambda.row(py)[px];
-                    }
+                    d[i][e] = a.depth.row(py)[px];
+                    if (haveIl && !deep) il[i][e] = a.invLambda.row(py)[px];
                 }
             }
         float tv[2][4], wv[2][4];
