@@ -13,6 +13,7 @@ Three statements, in the order of how much feedback they contain:
     frame after starts from the other pose): bounded, and both stay the same distance from the truth;
   * neither is closer to the truth than the other: |HIP - truth| <= 1.1 |oracle - truth| + 0.5 mm in every frame."""
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -30,7 +31,11 @@ CHECK_FRAMES = (2, 5, 8, 11)
 def runs(oracle, dev, tmp_path_factory):
     from emfusion_amd import pipeline
     from tests.tum_runner import run_closed_loop
-    staged = S.stage(tmp_path_factory.mktemp("tum_small"), frames=FRAMES, size=(W, H))
+    S.TIME_SCALE = float(os.environ.get("EMF_TEST_TIME_SCALE", "1.0"))
+    try:
+        staged = S.stage(tmp_path_factory.mktemp("tum_small"), frames=FRAMES, size=(W, H))
+    finally:
+        S.TIME_SCALE = 1.0
     prm = pipeline.make_params(W, H, 256, 0.02, 64, visibility_thresh=400, boundary=10, mask_frames=30)
     fx, fy, cx, cy = S.intrinsics(W, H)
     assert np.allclose(np.array(prm.K, np.float32).reshape(3, 3), [[fx, 0, cx], [0, fy, cy], [0, 0, 1]])

@@ -40,9 +40,12 @@ def _rot(axis, angle):
     return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
 
 
+TIME_SCALE = 1.0  # seconds of scene time per second of frames (a test at a coarser resolution slows the scene down)
+
+
 def camera_pose(f: int):
     """camera -> world of frame f (float64); frame 0 is the identity."""
-    s = f / FPS
+    s = TIME_SCALE * f / FPS
     t = np.array([0.16 * np.sin(2 * np.pi * 0.45 * s), 0.10 * (1 - np.cos(2 * np.pi * 0.35 * s)),
                   0.14 * np.sin(2 * np.pi * 0.30 * s)])
     R = (_rot([0, 1, 0], np.deg2rad(3.0) * np.sin(2 * np.pi * 0.40 * s)) @
@@ -53,7 +56,7 @@ def camera_pose(f: int):
 
 def person_position(f: int):
     """foot point of the capsule's axis on the floor plane's level (world)."""
-    s = f / FPS
+    s = TIME_SCALE * f / FPS
     return np.array([-0.55 + 0.45 * s, 0.0, 2.05 + 0.12 * np.sin(2 * np.pi * 0.5 * s)])
 
 
