@@ -606,12 +606,18 @@ bool asArray(const P& v, NdArray& a, const std::string& file) {
     const std::string& fn = v->callable->s;
     auto shapeOf = [&](const P& t) {
         a.shape.clear();
-        for (const P& e : t->items) a.shape.push_back(e->i);
+        if (!t || (t->kind != PyVal::Tuple && t->kind != PyVal::List)) throw std::runtime_error(file + ": array shape is not a tuple");
+        for (const P& e : t->items) {
+            // (a negative extent would pass the size test below as a product of two negatives; 2^31 bounds the products)
+            if (!e || e->kind != PyVal::Int || e->i < 0 || e->i > 0x7fffffffLL) throw std::runtime_error(file + ": bad array shape");
+            a.shape.push_back(e->i);
+        }
     };
     if (endsWith(fn, "_reconstruct") && v->state && v->state->kind == PyVal::Tuple && v->state->items.size() >= 5) {
         const auto& s = v->state->items;
         shapeOf(s[1]);
         a.itemsize = dtypeItemsize(s[2], file, &a.kind);
+        if (!s[3]) throw std::runtime_error(file + ": malformed numpy array");
         a.fortran = s[3]->i != 0;
         a.data = bytesOf(s[4], file);
         return true;
@@ -621,6 +627,7 @@ bool asArray(const P& v, NdArray& a, const std::string& file) {
         a.data = bytesOf(s[0], file);
         a.itemsize = dtypeItemsize(s[1], file, &a.kind);
         shapeOf(s[2]);
+        if (!s[3]) throw std::runtime_error(file + ": malformed numpy array");
         a.fortran = s[3]->s == "F";
         return true;
     }
@@ -631,7 +638,10 @@ double asNumber(const P& v, const std::string& file) {
     if (v && v->kind == PyVal::Float) return v->f;
     if (v && v->kind == PyVal::Object && v->callable && v->callable->kind == PyVal::Global && endsWith(v->callable->s, "scalar") &&
         v->args && v->args->items.size() == 2) {  // numpy.core.multiarray.scalar(dtype, bytes)
-        const std::string& t = v->args->items[0]->args->items[0]->s;
+        const P& dt = v->args->items[0];  // numpy.dtype('f8', ...): an object whose first argument is the type string
+        if (!dt || !dt->args || dt->args->items.empty() || !dt->args->items[0] || !v->args->items[1])
+            throw std::runtime_error(file + ": malformed numpy scalar");
+        const std::string& t = dt->args->items[0]->s;
         const std::string& b = v->args->items[1]->s;
         if (t == "f8" && b.size() == 8) { double d; std::memcpy(&d, b.data(), 8); return d; }
         if (t == "f4" && b.size() == 4) { float f; std::memcpy(&f, b.data(), 4); return f; }

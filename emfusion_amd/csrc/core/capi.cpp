@@ -327,7 +327,8 @@ int emf_io_tum_associations(const char* file, int index, char* depth_name, int n
 }
 
 int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int32_t* height, uint8_t* masks,
-                              size_t mask_capacity, double* boxes, double* scores, size_t score_capacity, int32_t* nscores) {
+                              size_t mask_capacity, double* boxes, size_t box_capacity, double* scores, size_t score_capacity,
+                              int32_t* nscores) {
     REQ(path);
     return guarded([&] {
         PreprocMasks pm;
@@ -337,10 +338,12 @@ int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int3
         if (height) *height = pm.height;
         const size_t per = static_cast<size_t>(pm.width) * pm.height;
         const size_t ns = pm.scores.empty() ? 0 : pm.scores[0].size();
+        for (const auto& row : pm.scores)  // (a list of lists may be ragged; the flat output is not)
+            if (row.size() != ns) throw HipError("emf_io_load_preproc_masks: class-score rows of different lengths", EMF_E_ARG);
         if (nscores) *nscores = static_cast<int32_t>(ns);
         if (masks && mask_capacity >= per * k)
             for (int i = 0; i < k; ++i) std::memcpy(masks + per * i, pm.masks[i].data(), per);
-        if (boxes)
+        if (boxes && box_capacity >= 4 * static_cast<size_t>(k))
             for (int i = 0; i < k; ++i) std::memcpy(boxes + 4 * i, pm.boxes[i].data(), 4 * sizeof(double));
         if (scores && score_capacity >= ns * pm.scores.size())
             for (size_t i = 0; i < pm.scores.size(); ++i) std::memcpy(scores + ns * i, pm.scores[i].data(), ns * sizeof(double));

@@ -101,7 +101,7 @@ def load() -> C.CDLL:
         "emf_io_load_config": [C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t],
         "emf_io_image_reader": [C.c_char_p, C.c_char_p, C.c_char_p, ip, ip],
         "emf_io_tum_associations": [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), ip],
-        "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
+        "emf_io_load_preproc_masks": [C.c_char_p, ip, ip, ip, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_size_t,
                                       C.POINTER(C.c_double), C.c_size_t, ip],
         "emf_fusion_create_from_config": [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_void_p, C.POINTER(vp)],
         "emf_fusion_add_object": [vp, fp, C.c_float, ip],
@@ -783,12 +783,12 @@ def load_preproc_masks(path):
     """core/Readers.cpp loadPreprocessedMasks through the C API: (boxes (N, 4), masks (N, H, W) u8, scores (N, S))."""
     n, w, h, ns = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
     f = load().emf_io_load_preproc_masks
-    _check("emf_io_load_preproc_masks", f(os.fspath(path).encode(), C.byref(n), C.byref(w), C.byref(h), None, 0, None, None, 0, C.byref(ns)))
+    _check("emf_io_load_preproc_masks", f(os.fspath(path).encode(), C.byref(n), C.byref(w), C.byref(h), None, 0, None, 0, None, 0, C.byref(ns)))
     masks = np.zeros((n.value, h.value, w.value), np.uint8)
     boxes = np.zeros((n.value, 4), np.float64)
     scores = np.zeros((n.value, ns.value), np.float64)
     _check("emf_io_load_preproc_masks", f(os.fspath(path).encode(), C.byref(n), C.byref(w), C.byref(h), masks.ctypes.data, masks.nbytes,
-                                          boxes.ctypes.data_as(C.POINTER(C.c_double)), scores.ctypes.data_as(C.POINTER(C.c_double)),
+                                          boxes.ctypes.data_as(C.POINTER(C.c_double)), boxes.size, scores.ctypes.data_as(C.POINTER(C.c_double)),
                                           scores.size, C.byref(ns)))
     return boxes, masks, scores
 

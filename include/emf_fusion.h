@@ -201,8 +201,10 @@ int emf_io_load_config(const char* path, const char* calibration, emf_fusion_par
 int emf_io_read_exr(const char* path, const char* channel, float* out, size_t capacity, int32_t* width, int32_t* height);
 int emf_io_image_reader(const char* base, const char* colordir, const char* depthdir, int32_t* num_frames, int32_t* first);
 int emf_io_tum_associations(const char* file, int index, char* depth_name, int name_capacity, double* stamp, int32_t* count);
+/* capacities in elements (bytes of masks, doubles of boxes and scores); an output whose capacity is too small is not written */
 int emf_io_load_preproc_masks(const char* path, int32_t* n, int32_t* width, int32_t* height, uint8_t* masks,
-                              size_t mask_capacity, double* boxes, double* scores, size_t score_capacity, int32_t* nscores);
+                              size_t mask_capacity, double* boxes, size_t box_capacity, double* scores, size_t score_capacity,
+                              int32_t* nscores);
 /* from the next frame on, filter the incoming depth (EMFusion::preprocessDepth, SURVEY f-2) */
 int emf_fusion_set_preprocess(emf_fusion_t* h, int on);
 int emf_fusion_get_pose(emf_fusion_t* h, int id, float R[9], float t[3]);

@@ -74,6 +74,43 @@ def test_mask_pickles_in_other_shapes(tmp_path):
         pipeline.load_preproc_masks(tmp_path / "d.plk")
 
 
+def test_malformed_mask_pickles_are_rejected_not_read_out_of_bounds(tmp_path):
+    """ragged class-score rows used to be copied `len(row 0)` doubles each; a negative extent in an array's shape
+    passed the size test as a product of two negatives."""
+    m0 = np.zeros((8, 8), np.uint8)
+    with open(tmp_path / "ragged.plk", "wb") as f:
+        pickle.dump(([[0, 0, 1, 1]] * 2, [m0, m0], [[0.5] * 81, [0.5] * 3]), f, protocol=2)
+    with pytest.raises(pipeline.FusionError, match="different lengths"):
+        pipeline.load_preproc_masks(tmp_path / "ragged.plk")
+    with open(tmp_path / "ok.plk", "wb") as f:
+        pickle.dump(([[0, 0, 1, 1]], [m0], [[0.0] * 81]), f, protocol=2)
+    raw = bytearray((tmp_path / "ok.plk").read_bytes())
+    at = raw.index(b"K\x08K\x08")  # the shape tuple (8, 8) as two BININT1
+    # shape (-8, -8): BININT (4-byte signed) twice instead of BININT1 twice
+    raw[at:at + 4] = b""
+    raw[at:at] = b"J\xf8\xff\xff\xffJ\xf8\xff\xff\xff"
+    (tmp_path / "neg.plk").write_bytes(raw)
+    with pytest.raises(pipeline.FusionError, match="shape"):
+        pipeline.load_preproc_masks(tmp_path / "neg.plk")
+
+
+def test_exr_block_offsets_cannot_wrap(tmp_path):
+    """an offset-table entry near 2^64 passed `off + 8 > size` by wrapping and was then dereferenced."""
+    from tests.test_readers import write_exr
+    write_exr(tmp_path / "a.exr", {"Z": np.ones((4, 4), np.float32)}, 0, "f")
+    raw = bytearray((tmp_path / "a.exr").read_bytes())
+    # the offset table follows the header's terminating zero byte: find it as the first 8 bytes that point inside the file
+    import struct
+    for at in range(8, len(raw) - 8):
+        v = struct.unpack_from("<Q", raw, at)[0]
+        if at + 8 * 4 <= v < len(raw) and struct.unpack_from("<Q", raw, at + 8)[0] > v:
+            break
+    struct.pack_into("<Q", raw, at, 2 ** 64 - 4)
+    (tmp_path / "wrap.exr").write_bytes(raw)
+    with pytest.raises(pipeline.FusionError, match="offset beyond the file"):
+        pipeline.read_exr(tmp_path / "wrap.exr")
+
+
 # ---- OpenEXR depth files and the Co-Fusion directory layout in C++ (reference src/utils/ImageReader.cpp) --------------
 
 def test_cpp_exr_reader_on_a_real_file():
