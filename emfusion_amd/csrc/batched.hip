@@ -30,6 +30,10 @@ __device__ __forceinline__ V3 pose_t(const emf_pose_t& p) { return V3{p.t[0], p.
 
 // workgroup shape, measured on the 5-model bench frame (us per E-step): 64 x 4: 13.9, 128 x 4: 14.0,
 // 256 x 4: 15.0, 64 x 5: 14.9, 64 x 8: 16.8, 128 x 8: 17.6
+// (round 5, measured and dropped: an XCD-banded grid -- block b on XCD b % 8 takes a band of image rows, so that the voxel
+// lines neighbouring pixel rows share are fetched into one L2 instead of eight (33 MB from HBM per launch at an L2 hit rate
+// of 0.31) -- 18.0 -> 19.3 us per E-step: the launch is not bound by those fetches, and the bands concentrate each
+// XCD's gathers on fewer memory channels)
 #ifndef EMF_ESTEP_PIXELS
 #define EMF_ESTEP_PIXELS 64
 #define EMF_ESTEP_LANES 4
