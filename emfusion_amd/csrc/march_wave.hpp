@@ -220,6 +220,11 @@ __device__ __forceinline__ void ray_setup(const RayVolume& v, const V3& half, co
 //   * the two crossing tests (TSDF.cu:533, 541) hide behind one integer test "the sign bits of the
 //     previous and the new sample differ"; only then the exact tests, the weights and a possible hit run.
 // Arithmetic and its order are the reference's (TSDF.cu:523-572): same bits.
+// Measured and dropped (round 5): MORE waves per SIMD.  The hit's gradient (32 loads in flight, once per ray) sets the
+// kernel's register count: 86 VGPRs = 5 waves per SIMD with it, 71 = 7 with the three components taken one after the
+// other in a rolled loop, 64 = 8 under a cap (4 spilled VGPRs in the rare paths).  k_raycast: 0.383 / 0.419 / 0.420 ms
+// alone, 0.416 / 0.452 / 0.463 beside the sweep -- the waves a CU holds beyond 20 only take L1 and gather-path share from
+// each other (LDS-capped 4 / 3 / 2 waves lost too, round 1: five is the optimum from both sides).
 // Measured and dropped: touching the line the ray will want 8 / 16 half-voxel steps ahead with a fifth
 // load per step (a lone wave on cold lines: 1302 -> 1224 clk / step; the full image: +19 %, the bench
 // -5 %: loads return in order, so the march waits for the prefetch of the step before anyway).
