@@ -75,6 +75,15 @@ def run_closed_loop(fus, oracle, staged, frames, check_frames):
                 Rh, th = objs[f][v["id"]]["pose"]
                 row["objects"][v["id"]] = dict(t=float(np.abs(np.asarray(th) - v["pose"].t).max()),
                                                R=float(np.abs(np.asarray(Rh).reshape(3, 3) - v["pose"].R).max()))
+            # the whole TRACKED frame against the oracle's, from that identical state: what the two sides' poses (equal to
+            # ~1e-6) make of the same depth -- fraction of elements outside north_star's 1e-4 (+ an absolute floor)
+            from tests.parity_util import mismatch
+            row["frame_outputs_outside_1e-4"] = dict(
+                bg_tsdf=float(mismatch(fus.volume("tsdf", 0), ob.bg["tsdf"], 1e-4, 1e-6).mean()),
+                bg_weights=float(mismatch(fus.volume("weights", 0), ob.bg["wts"], 1e-4, 1e-6).mean()),
+                bg_raylengths=float(mismatch(fus.image("bg_raylengths"), ob.bg_ray, 1e-4, 1e-6).mean()),
+                bg_assoc=float(mismatch(fus.image("bg_assoc"), ob.bg_assoc, 1e-4, 1e-7).mean()),
+                segmentation=float((fus.image("segmentation") != ob.seg).mean()))
             stage_cmp.append(row)
             del ob
         snapshot = None
