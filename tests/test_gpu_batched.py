@@ -258,11 +258,14 @@ def test_estep_from_depth_equals_points_then_estep(ops, oracle, scene, dev, norm
         assert_parity(to_np(m.d_assoc), w, f"map {m.id}", exact=True)
 
 
-@pytest.mark.parametrize("use_flags,footprints", [(False, False), (True, False), (False, True)],
-                         ids=["plain", "brick_flags", "object_footprints"])
-def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, use_flags, footprints):
+@pytest.mark.parametrize("use_flags,footprints,rows", [(False, False, 1), (True, False, 1), (False, True, 1), (False, True, 2),
+                                                       (False, False, 4)],
+                         ids=["plain", "brick_flags", "object_footprints", "two_lanes_per_ray", "four_lanes_per_ray"])
+def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, scene, dev, monkeypatch, use_flags, footprints, rows):
     """footprints: with the voxel sizes on the host, objects get marching workgroups only where their box
-    projects to, and zero-fill workgroups elsewhere -- every pixel of every image is still written."""
+    projects to, and zero-fill workgroups elsewhere -- every pixel of every image is still written.
+    rows: the background's rays with 2 / 4 lanes each (march_quad, EMF_MARCH_ROWS): same pixels, same sample count."""
+    monkeypatch.setenv("EMF_MARCH_ROWS", str(rows))
     cam = camera_path(4)
     table = ops.upload_models([m.table_entry() for m in scene])
     poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
@@ -358,12 +361,16 @@ def test_raycast_far_bounds_cut_marches_without_changing_a_pixel(ops, oracle, sc
             m.d_sign = m.d_rel = None
 
 
+@pytest.mark.parametrize("rows", [1, 2, 4], ids=["one_lane", "two_lanes", "four_lanes"])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_far_bounds_are_conservative_on_adversarial_volumes(ops, oracle, dev, seed):
+def test_far_bounds_are_conservative_on_adversarial_volumes(ops, oracle, dev, monkeypatch, seed, rows):
     """Volumes no integration would produce -- isolated positive and negative blobs in unseen space, thin
     sheets, sign noise, a surface hugging the volume's outer shell -- seen from random poses (outside,
     inside, grazing): the batched raycast with far bounds, relevant-tile lists and object footprints equals
-    the oracle's full march bit for bit (a bound that is too tight anywhere would lose a hit)."""
+    the oracle's full march bit for bit (a bound that is too tight anywhere would lose a hit).  rows: the same with
+    two / four lanes per ray (march_quad) -- sign noise, thin sheets and shell surfaces are where its transparency
+    test, its dropped speculation and its `continue` / `break` cases get exercised."""
+    monkeypatch.setenv("EMF_MARCH_ROWS", str(rows))
     rng = np.random.default_rng(1000 + seed)
     res, vox = (96, 64, 80), 0.02
     nz, ny, nx = res[2], res[1], res[0]
