@@ -76,6 +76,7 @@ SIGNATURES = {
     "emf_hip_voxelReciprocalCached": [C.c_float, C.POINTER(C.c_float)],
     "emf_hip_voxelReciprocalBegin": [C.c_float, C.c_void_p, _STREAM],
     "emf_hip_voxelReciprocalEnd": [C.c_float, C.c_ulonglong, C.POINTER(C.c_float)],
+    "emf_hip_voxelReciprocalExhaustive": [C.c_float, C.POINTER(C.c_ulonglong)],
     "emf_hip_spinProbe": [C.c_void_p, C.c_uint32, _STREAM],
     "emf_hip_spinDelay": [C.c_uint32, _STREAM],
     "emf_hip_l1GatherProbe": [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, _STREAM],

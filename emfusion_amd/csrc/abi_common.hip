@@ -66,15 +66,53 @@ int launch_status(const char* what) {
     return EMF_OK;
 }
 
-// Exhaustive comparison of x / d with its reciprocal form (march_wave.hpp div_voxel) over all 2^32
-// float bit patterns; counts disagreements inside the range the march can produce.
+// Comparison of x / d with its reciprocal form (march_wave.hpp div_voxel); counts disagreements inside the range the
+// march can produce, 1e-30 <= |x| <= 1e30.
+//
+// FULL: all 2^32 float bit patterns (2.3 ms of the whole chip) -- the form rounds 1-5 ran per distinct voxel size; kept
+// as emf_hip_voxelReciprocalExhaustive for the test that the short form below gives the same verdict.
+//
+// Short form (default): every mantissa and both signs of THREE binades -- [1, 2), the one holding 1e-30 and the one
+// holding 1e30 -- 3 x 2^24 inputs.  Why that decides all binades of the guarded range: with r = fl(1 / d),
+//     q0 = fl(x r),  t = fma(-q0, d, x),  q = fma(t, r, q0),  D = fl(x / d),
+// and x' = 2^k x also inside the range,
+//   * q0' = 2^k q0 and D' = 2^k D: with 1e-6 <= d <= 1e3 (rcp_check_size) both stay in [1e-33, 1e36], normal floats, and
+//     round-to-nearest commutes with a power-of-two scaling of a normal result;
+//   * t is EXACT: x - q0 d is a multiple of ulp(q0) ulp(d) >= 2^(e_x - 47) of magnitude <= 2^(e_x - 22), i.e. it has at
+//     most 24 significant bits and, for e_x >= -100, a granularity >= 2^-147 > 2^-149 -- representable, as a subnormal
+//     below 2^-126.  So t' = 2^k t with no rounding at all, PROVIDED the fma keeps subnormal results and inputs (the
+//     premise k_check_reciprocal verifies on the device before it counts anything: a flushing mode fails the check);
+//   * q = fl(t r + q0) is normal again, so q' = 2^k q.
+// Hence q' == D' iff q == D: one binade decides, the two edge binades are swept as well (clipped by the guard exactly as
+// the full form clips them) so that the smallest residuals and the largest quotients of the range are exercised, not
+// argued.  tests/test_gpu_parity.py compares the two forms' verdicts over > 1000 voxel sizes.
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_check_reciprocal(float d, float rcp,
                                                           unsigned long long* mismatches) {
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+    const unsigned long long first = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     unsigned bad = 0;
-    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-         i < (1ull << 32); i += stride) {
-        const float x = __uint_as_float(static_cast<unsigned>(i));
+    if (!FULL && first == 0) {
+        // the premise: v_fma_f32 neither flushes a subnormal result nor a subnormal input (operands formed from
+        // blockDim so that nothing is folded at compile time)
+        const float one = static_cast<float>(blockDim.x) * (1.f / 256.f);
+        const float a = __uint_as_float(0x0d800001u) * one;   // 2^-100 (1 + 2^-23)
+        const float b = __uint_as_float(0x3f800001u) * one;   // 1 + 2^-23
+        const float c = __uint_as_float(0x0d800002u) * one;   // 2^-100 (1 + 2^-22)
+        const float t = __builtin_fmaf(-a, b, c);             // exactly -2^-146
+        bad += __float_as_uint(t) != 0x80000008u;
+        const float u = __builtin_fmaf(t, 1048576.f * one, 0.f * one);  // -2^-126
+        bad += __float_as_uint(u) != 0x80800000u;
+    }
+    const unsigned long long count = FULL ? (1ull << 32) : (3ull << 24);
+    for (unsigned long long i = first; i < count; i += stride) {
+        unsigned bits = static_cast<unsigned>(i);
+        if (!FULL) {
+            const unsigned region = static_cast<unsigned>(i >> 24);         // 0: [1, 2)   1: 2^-100 ..   2: 2^99 ..
+            const unsigned expo = region == 0 ? 127u : (region == 1 ? 27u : 226u);
+            bits = ((static_cast<unsigned>(i) & 0x800000u) << 8) | (expo << 23) | (static_cast<unsigned>(i) & 0x7fffffu);
+        }
+        const float x = __uint_as_float(bits);
         const float ax = fabsf(x);
         if (!(ax >= 1e-30f && ax <= 1e30f)) continue;  // also skips NaN
         const float q0 = x * rcp;
@@ -83,6 +121,7 @@ __global__ __launch_bounds__(256) void k_check_reciprocal(float d, float rcp,
     }
     if (bad) atomicAdd(mismatches, static_cast<unsigned long long>(bad));
 }
+constexpr unsigned kRcpShortBlocks = 2048;  // x 256 lanes: 96 inputs per lane
 
 __global__ void k_check_reciprocal_begin(unsigned long long* mismatches) {
     if (threadIdx.x == 0) *mismatches = 0ull;
@@ -218,7 +257,7 @@ int emf_hip_voxelReciprocal(float voxelSize, float* rcp) {
     if (e == hipSuccess) e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), st);
     if (e == hipSuccess) {
         const float r = 1.0f / voxelSize;
-        hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, r, counter);
+        hipLaunchKernelGGL(k_check_reciprocal<false>, dim3(kRcpShortBlocks), dim3(256), 0, st, voxelSize, r, counter);
         e = hipMemcpyAsync(&bad, counter, sizeof(bad), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e == hipSuccess) {
@@ -248,7 +287,7 @@ int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches
     if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalBegin")) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_check_reciprocal_begin, dim3(1), dim3(64), 0, st, mismatches);
-    hipLaunchKernelGGL(k_check_reciprocal, dim3(8192), dim3(256), 0, st, voxelSize, 1.0f / voxelSize, mismatches);
+    hipLaunchKernelGGL(k_check_reciprocal<false>, dim3(kRcpShortBlocks), dim3(256), 0, st, voxelSize, 1.0f / voxelSize, mismatches);
     return launch_status("voxelReciprocalBegin");
 }
 
@@ -259,6 +298,25 @@ int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, f
     if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalEnd")) return rc;
     *rcp = mismatches == 0 ? 1.0f / voxelSize : 0.f;
     rcp_remember(voxelSize, *rcp);
+    return EMF_OK;
+}
+
+int emf_hip_voxelReciprocalExhaustive(float voxelSize, unsigned long long* mismatches_host) {
+    using namespace emf_hip;
+    if (!mismatches_host) return fail(EMF_E_NULL, "voxelReciprocalExhaustive: mismatches_host is NULL");
+    if (const int rc = rcp_check_size(voxelSize, "voxelReciprocalExhaustive")) return rc;
+    unsigned long long* counter = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&counter), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(counter, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_check_reciprocal<true>, dim3(8192), dim3(256), 0, nullptr, voxelSize, 1.0f / voxelSize, counter);
+        e = hipMemcpy(mismatches_host, counter, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
+    if (counter) (void)hipFree(counter);
+    if (e != hipSuccess) {
+        set_error("voxelReciprocalExhaustive: %s", hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
     return EMF_OK;
 }
 

@@ -149,7 +149,7 @@ public:
     /**
      * Wait for the reciprocal checks of volumes created so far and adopt their verdicts.  Volumes created
      * inside frames are checked in the background and divide meanwhile; an application that adds its objects up front
-     * (emf_fusion_add_object does this) calls it once so that the checks -- 2.3 ms of device time per distinct voxel
+     * (emf_fusion_add_object does this) calls it once so that the checks -- some tens of microseconds per distinct voxel
      * size -- do not run beside its first frames.  Same results either way.
      */
     void settleReciprocals();

@@ -128,8 +128,8 @@ public:
     static int brickFlagMode();
 
     /**
-     * The checked reciprocal of the voxel size (emf_hip_voxelReciprocal) is a verdict over all 2^32
-     * inputs: ~2.3 ms of device time the first time a size is seen in the process.  With deferral on,
+     * The checked reciprocal of the voxel size (emf_hip_voxelReciprocal) is a device-side verdict
+     * (three binades of inputs, some tens of microseconds) the first time a size is seen in the process.  With deferral on,
      * a constructor that meets a new size does not wait for it: the check is enqueued on a stream of
      * its own, the march divides (same results) and pollReciprocal() adopts the verdict once it is in.
      * emf::EMFusion turns this on after its background exists, so objects created inside a frame
@@ -138,7 +138,7 @@ public:
     static void deferReciprocalChecks(bool on);
     /** True if the verdict arrived with this call (the owner refreshes its model table). */
     bool pollReciprocal();
-    /** Wait for a deferred check in flight (its 2.3 ms of device time end here); pollReciprocal() then adopts it. */
+    /** Wait for a deferred check in flight (it ends here); pollReciprocal() then adopts it. */
     void settleReciprocal();
     float reciprocal() const { return rcpVoxel; }
 

@@ -13,8 +13,9 @@
 //   * loop control per wave: one ballot per iteration instead of per-lane loop bookkeeping;
 //   * p / voxelSize: a constant divisor.  q = x * r, q' = fma(fma(-q, d, x), r, q) with
 //     r = 1 / d equals the IEEE quotient for every float x with 1e-30 <= |x| <= 1e30 -- not
-//     argued but CHECKED: emf_hip_voxelReciprocal runs all 2^32 inputs through both forms for the
-//     given d and hands out r only if none differs.  Outside that range: |x| < 1e-30 gives
+//     argued but CHECKED: emf_hip_voxelReciprocal runs every mantissa of three binades through both
+//     forms for the given d (which decides all binades of the range: both forms commute with 2^k
+//     scaling there, abi_common.hip) and hands out r only if none differs.  Outside that range: |x| < 1e-30 gives
 //     |q| < 1e-24 either way and the following "+ (N - 1) / 2" absorbs it (N = 1: the sample is
 //     outside the volume either way); |x| > 1e30 cannot occur because the host refuses r for poses
 //     with |t| > 1e15 and the march keeps |raylength| below that.  3 instructions instead of 11;

@@ -337,6 +337,14 @@ def voxel_reciprocal(voxel_size) -> float:
     return float(r.value)
 
 
+def voxel_reciprocal_exhaustive(voxel_size) -> int:
+    """Test aid: the number of floats x, 1e-30 <= |x| <= 1e30, on which the reciprocal form and the division differ,
+    counted over all 2^32 bit patterns (2.3 ms of the whole chip; nothing is cached)."""
+    n = C.c_ulonglong(0)
+    check("emf_hip_voxelReciprocalExhaustive", _L.emf_hip_voxelReciprocalExhaustive(float(voxel_size), C.byref(n)))
+    return int(n.value)
+
+
 def raycast_batched(models_dev, poses_co, res_list, width, height, K, stats=None,
                     use_brick_flags=False, stream=None, bg_band=(0, 0), far_bounds=None, voxel_sizes=None):
     """bg_band = (row0, rows): march only that row band of table slot 0 (multi-GPU background split).

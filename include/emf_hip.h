@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EMF_HIP_ABI_VERSION 7
+#define EMF_HIP_ABI_VERSION 8
 
 /* hipStream_t without dragging HIP headers into C callers */
 typedef struct ihipStream_t* emf_stream_t;
@@ -145,13 +145,17 @@ int emf_hip_raycastTSDF(const float* tsdf, const float* grads, const float* weig
 int emf_hip_streamCopy(void* dst, const void* src, size_t bytes, emf_stream_t stream);
 
 /* Reciprocal of a voxel size, CHECKED for use in place of the division x / voxelSize:
- * runs every one of the 2^32 float bit patterns x through  q = x * r; q = fma(fma(-q, d, x), r, q)
- * (r = 1 / d) and through the IEEE division on the device, and stores r in *rcp only if the two
- * agree bit for bit for all x with 1e-30 <= |x| <= 1e30 (0 otherwise; the march keeps its
- * arguments inside that range, see march_wave.hpp).  The verdict depends on the bit pattern of
- * voxelSize alone and is remembered for the life of the process: the first call for a size runs
- * the check on a stream of its own and waits for THAT (about 3 ms; no allocation, no device-wide
- * synchronisation), later calls for the same size return at once without touching the device. */
+ * runs float inputs x through  q = x * r; q = fma(fma(-q, d, x), r, q)  (r = 1 / d) and through the
+ * IEEE division on the device, and stores r in *rcp only if the two agree bit for bit for all x
+ * with 1e-30 <= |x| <= 1e30 (0 otherwise; the march keeps its arguments inside that range, see
+ * march_wave.hpp).  Swept: every mantissa and both signs of three binades -- [1, 2) and the two
+ * that hold the range's ends -- which decides every binade of the range because both forms
+ * commute with scaling by 2^k there (argument and its device-checked premise: abi_common.hip,
+ * k_check_reciprocal); some tens of microseconds instead of the 2.3 ms of all 2^32 inputs.
+ * The verdict depends on the bit pattern of voxelSize alone and is remembered for the life of
+ * the process: the first call for a size runs the check on a stream of its own and waits for THAT
+ * (no allocation, no device-wide synchronisation), later calls for the same size return at once
+ * without touching the device. */
 int emf_hip_voxelReciprocal(float voxelSize, float* rcp);
 
 /* The same check without any wait, for volumes created inside a frame (reference
@@ -168,6 +172,10 @@ int emf_hip_voxelReciprocal(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalCached(float voxelSize, float* rcp);
 int emf_hip_voxelReciprocalBegin(float voxelSize, unsigned long long* mismatches, emf_stream_t stream);
 int emf_hip_voxelReciprocalEnd(float voxelSize, unsigned long long mismatches, float* rcp);
+/* Test aid: the same comparison over ALL 2^32 bit patterns (2.3 ms of the whole chip, blocking, nothing cached):
+ * *mismatches_host = inputs of the guarded range on which the two forms differ.  The short form's verdict must be
+ * "usable" exactly when this is 0 (tests/test_gpu_parity.py). */
+int emf_hip_voxelReciprocalExhaustive(float voxelSize, unsigned long long* mismatches_host);
 
 /* Measurement aid (bench.py): `iterations` independent 8-byte gather loads per lane from a footprint that stays in every
  * CU's vector L1, `workgroups` x 256 lanes; linesPerInstruction = distinct 128-byte lines one 64-lane instruction touches

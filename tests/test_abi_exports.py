@@ -29,7 +29,7 @@ def test_dynamic_symbol_table_matches_header():
 def test_abi_version():
     import re
     declared = int(re.search(r"#define\s+EMF_HIP_ABI_VERSION\s+(\d+)", _lib.HEADER_PATH.read_text()).group(1))
-    assert declared == 7  # bump together with the struct mirrors in emfusion_amd/_lib.py
+    assert declared == 8  # bump together with the struct mirrors in emfusion_amd/_lib.py
     assert _lib.load().emf_hip_abi_version() == declared
 
 

@@ -155,7 +155,7 @@ _RCP = {}
 
 
 def checked_reciprocal(ops, vox):
-    """emf_hip_voxelReciprocal, once per voxel size (it sweeps all 2^32 floats on the device)."""
+    """emf_hip_voxelReciprocal, once per voxel size."""
     key = float(np.float32(vox))
     if key not in _RCP:
         _RCP[key] = ops.voxel_reciprocal(key)
@@ -169,6 +169,30 @@ def test_voxel_reciprocal_is_checked_and_exact(ops, dev):
     from emfusion_amd._lib import EmfHipError
     with pytest.raises(EmfHipError):
         ops.voxel_reciprocal(0.0)
+
+
+def test_short_reciprocal_check_gives_the_exhaustive_verdict(ops, dev):
+    """The product's check sweeps three binades (abi_common.hip, k_check_reciprocal); its verdict must be the one of
+    the sweep over all 2^32 bit patterns -- for the sizes the configurations use, the objects' 2 * extent / N, the
+    edges of the accepted range and a thousand random sizes, log-uniform over it.  Both verdicts occur."""
+    rng = np.random.default_rng(0x5EC1)
+    sizes = [0.01, 0.02, 0.04, 0.005, 1e-6, 1e3, 1.0, 0.5, 3.0, 0.0123456]
+    sizes += [2 * e / n for e in (0.15, 0.3, 0.45, 0.6, 1.2) for n in (64, 128, 256)]
+    sizes += list(2 * rng.uniform(0.05, 1.5, 200) / 128)          # spawned / resized objects
+    sizes += list(np.exp(rng.uniform(np.log(1e-6), np.log(1e3), 1000)))
+    accepted = rejected = 0
+    for v in sizes:
+        v = float(np.float32(v))
+        r = ops.voxel_reciprocal(v)
+        bad = ops.voxel_reciprocal_exhaustive(v)
+        assert (r != 0.0) == (bad == 0), (v, r, bad)
+        if r != 0.0:
+            assert r == float(np.float32(1) / np.float32(v))
+            accepted += 1
+        else:
+            rejected += 1
+    assert accepted > 100, (accepted, rejected)
+    print(f"reciprocal verdicts: {accepted} accepted, {rejected} rejected of {len(sizes)} sizes")
 
 
 def _raycast_dev(ops, dev, tsdf, grads, wts, fg, co, vox, ray0=None, stats=False, divide=False):
