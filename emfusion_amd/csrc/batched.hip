@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
                 for (int p = 0; p < a.peerWorld; ++p)
                     __builtin_nontemporal_store(s, reinterpret_cast<float*>(a.peerSlots[p] + a.peerOff) + pix);
                 if (a.peerFences) __threadfence_system();
-            } else {
+            } else if (a.objSum.data) {  // (uniform; a chunk of a longer model list hands out no sum)
                 a.objSum.row(y)[x] = s;
             }
         }
@@ -140,13 +140,14 @@ struct RaycastBatchArgs {
     int chunk;  // tiles per XCD = ceil(tilesX * tilesY / 8)
     float fx, fy, cx, cy;
     unsigned divideMask;  // bit m: model m must divide by voxelSize (pose out of the checked range)
+    int firstObj;    // 1: slot 0 is the background; 0: every slot is an object (a later chunk of a model list longer than EMF_MAX_BATCH)
     int bandTile0, bandTiles;  // slot 0 only: tile rows this rank marches (bandTiles == 0: all)
     unsigned long long* stats;
     const float* farBounds;    // [model][2 tilesY][2 tilesX] per 8x8-pixel cell, or nullptr (see k_far_bounds)
     // objects (slots 1..): the tiles their volume box can project to (host-computed from the pose); only
     // those get a marching workgroup, the rest of the object's images is zero-filled 16 tiles per workgroup
-    short rect[EMF_MAX_BATCH][4];      // tx0, ty0, width, height in tiles (slot 0 unused)
-    int objStart[EMF_MAX_BATCH + 1];   // prefix sum of width * height over slots 1..; [m] = first block of slot m
+    short rect[EMF_MAX_BATCH][4];      // tx0, ty0, width, height in tiles (the background's slot unused)
+    int objStart[EMF_MAX_BATCH + 1];   // prefix sum of width * height over the object slots; [m] = first block of slot m
 };
 constexpr int kZeroTiles = 16;  // tiles per zero-fill workgroup
 
@@ -219,21 +220,21 @@ struct RaycastGrid {
     int ring, ringBlocks, objBlocks, objPad, bgTileBlocks, bgBlocks, zeroBlocks;
 };
 __host__ __device__ __forceinline__ RaycastGrid raycast_grid(int tilesX, int tilesY, int bandTiles, int chunk, int objBlocks,
-                                                           int nmodels, int parts) {
+                                                           int nmodels, int parts, int firstObj) {
     RaycastGrid g;
-    g.ring = (tilesX > 2 && tilesY > 2 && bandTiles == 0) ? 2 * tilesX + 2 * (tilesY - 2) : 0;
+    g.ring = (firstObj && tilesX > 2 && tilesY > 2 && bandTiles == 0) ? 2 * tilesX + 2 * (tilesY - 2) : 0;
     g.ringBlocks = (g.ring * parts + 7) / 8 * 8;
     g.objBlocks = objBlocks;
     g.objPad = (objBlocks + 7) / 8 * 8;
-    g.bgTileBlocks = g.ring ? 8 * (((tilesX - 2) * (tilesY - 2) + 7) / 8) : 8 * chunk;
+    g.bgTileBlocks = !firstObj ? 0 : g.ring ? 8 * (((tilesX - 2) * (tilesY - 2) + 7) / 8) : 8 * chunk;
     g.bgBlocks = g.bgTileBlocks * parts;
-    g.zeroBlocks = (nmodels - 1) * ((tilesX * tilesY + kZeroTiles - 1) / kZeroTiles);
+    g.zeroBlocks = (nmodels - firstObj) * ((tilesX * tilesY + kZeroTiles - 1) / kZeroTiles);
     return g;
 }
 
 template <int PARTS>
 __device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int bx, int& m, int& tile, int& sub) {
-    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[a.nmodels], a.nmodels, PARTS);
+    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[a.nmodels], a.nmodels, PARTS, a.firstObj);
     sub = 0;
     if (bx < g.ringBlocks) {
         const int b = bx / PARTS;
@@ -249,7 +250,7 @@ __device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int
     } else if (bx < g.ringBlocks + g.objPad) {  // a tile of an object's footprint
         const int o = bx - g.ringBlocks;
         if (o >= g.objBlocks) return 0;
-        m = 1;
+        m = a.firstObj;
         while (m + 1 < a.nmodels && o >= a.objStart[m + 1]) ++m;
         const int i = o - a.objStart[m], rw = a.rect[m][2];
         tile = (a.rect[m][1] + i / rw) * a.tilesX + a.rect[m][0] + i % rw;
@@ -274,7 +275,7 @@ __device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int
     if (tile >= a.tilesX * a.tilesY) return 0;
     // multi-GPU: the replicated background is marched in row bands, one per rank; the rows of the
     // other bands are neither marched nor written here (they arrive by all-gather)
-    if (m == 0 && a.bandTiles > 0) {
+    if (m < a.firstObj && a.bandTiles > 0) {
         const int tyy = tile / a.tilesX;
         if (tyy < a.bandTile0 || tyy >= a.bandTile0 + a.bandTiles) return 0;
     }
@@ -285,7 +286,7 @@ __device__ __forceinline__ int raycast_block_role(const RaycastBatchArgs& a, int
 // threads writes one 16x16 tile per round, `part` of `parts` workgroups sharing the index take every parts-th tile
 __device__ __forceinline__ void raycast_zero_fill(const RaycastBatchArgs& a, int i, int part, int parts) {
     const int perObj = (a.tilesX * a.tilesY + kZeroTiles - 1) / kZeroTiles;
-    const int mz = 1 + i / perObj;
+    const int mz = a.firstObj + i / perObj;
     if (mz >= a.nmodels) return;
     const emf_model_t& mo = a.models[mz];
     const int tx0 = a.rect[mz][0], ty0 = a.rect[mz][1], tx1 = tx0 + a.rect[mz][2], ty1 = ty0 + a.rect[mz][3];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const Raycast
     // incoming raylength is zero by construction (the reference zeroes it first, Q5)
     if constexpr (MODE != 0) {
         int x, y, cellX, cellY;
-        const bool rows = MODE >= 2 && m == 0;  // (block-uniform) this tile's rays get MODE lanes each
+        const bool rows = MODE >= 2 && m < a.firstObj;  // (block-uniform) the background's rays get MODE lanes each
         if (MODE == 4 && rows) {
             cellX = 2 * txx + (sub & 1);
             cellY = 2 * tyy + (sub >> 1);
@@ -1089,8 +1090,7 @@ int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, i
         a.peerFences = pa.fences;
         a.peerOff = (static_cast<size_t>(seq & 1u) * pa.world + pa.rank) * pa.slotBytes;
         for (int p = 0; p < pa.world; ++p) a.peerSlots[p] = pa.slots[p];
-    } else if (!normalize) {
-        if (!objSum) return fail(EMF_E_NULL, "estepBatched: objSum is required when normalize == 0");
+    } else if (!normalize && objSum) {
         EMF_TRY(check_image(objSum, 4, "estepBatched: objSum"));
         EMF_TRY(check_same_size(objSum, points, "objSum", "points"));
         a.objSum = img<float>(objSum);
@@ -1223,11 +1223,12 @@ int emf_hip_updateRelevantTiles(const emf_model_t* models_dev, const int32_t* re
     return launch_status("updateRelevantTiles");
 }
 
-int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+namespace {
+int raycast_batched_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
                            const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
-                           emf_stream_t stream) {
+                           emf_stream_t stream, int firstObj, int rowsPerRay) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
     if (bgBandRows < 0 || bgBandRow0 < 0 || bgBandRow0 % kRbTile || bgBandRows % kRbTile)
         return fail(EMF_E_ARG, "raycastBatched: band [%d, +%d) must be non-negative multiples of %d rows",
@@ -1260,9 +1261,10 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     a.farBounds = farBounds_dev;
     a.bandTile0 = bgBandRow0 / kRbTile;
     a.bandTiles = bgBandRows / kRbTile;
+    a.firstObj = firstObj;
     // footprints of the objects: the tiles the (slightly enlarged) volume box projects to
     a.objStart[0] = a.objStart[1] = 0;
-    for (int m = 1; m < nmodels; ++m) {
+    for (int m = firstObj; m < nmodels; ++m) {
         const int32_t* r = res_host + 3 * m;
         const emf_pose_t& p = poseCO_host[m];
         // (the voxel size lives in the device table: without the host's copy the object keeps the whole image)
@@ -1302,14 +1304,14 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
         a.rect[m][3] = static_cast<short>(std::max(ty1 - ty0, 0));
         a.objStart[m + 1] = a.objStart[m] + a.rect[m][2] * a.rect[m][3];
     }
-    a.rect[0][0] = a.rect[0][1] = a.rect[0][2] = a.rect[0][3] = 0;
-    // EMF_MARCH_ROWS = 1 / 2 / 4 lanes per BACKGROUND ray (march_lane / march_quad<2> / march_quad<4>); same images (A/B, read per call)
-    const char* mr = std::getenv("EMF_MARCH_ROWS");
-    const int rows = (useBrickFlags || !offsets32) ? 1 : (mr ? std::atoi(mr) : 1);
+    if (firstObj) a.rect[0][0] = a.rect[0][1] = a.rect[0][2] = a.rect[0][3] = 0;
+    // rowsPerRay = 1 / 2 / 4 lanes per BACKGROUND ray (march_lane / march_quad<2> / march_quad<4>); same images
+    const int rows = (useBrickFlags || !offsets32 || !firstObj) ? 1 : rowsPerRay;
     const int parts = rows == 4 ? 4 : rows == 2 ? 2 : 1;
     // background: border ring + interior rounded up to whole XCD chunks (or all of it when banded), `parts` workgroups per
     // tile; objects: footprint tiles, and ceil(tiles / kZeroTiles) zero-fill workgroups each (raycast_grid)
-    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[nmodels], nmodels, parts);
+    const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[nmodels], nmodels, parts, firstObj);
+    if (g.ringBlocks + g.objPad + g.bgBlocks + g.zeroBlocks == 0) return EMF_OK;
     const dim3 grid(static_cast<unsigned>(g.ringBlocks + g.objPad + g.bgBlocks + g.zeroBlocks));
     if (useBrickFlags || !offsets32)  // the wave marches address with 32-bit byte offsets
         hipLaunchKernelGGL(k_raycast_batched<0>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
@@ -1320,6 +1322,36 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
     else
         hipLaunchKernelGGL(k_raycast_batched<1>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
     return launch_status("raycastBatched");
+}
+
+}  // namespace
+
+int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                           const int32_t* res_host, int nmodels, int width, int height,
+                           const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
+                           const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
+                           emf_stream_t stream) {
+    return raycast_batched_launch(models_dev, poseCO_host, res_host, nmodels, width, height, K, useBrickFlags, bgBandRow0,
+                                  bgBandRows, farBounds_dev, voxelSizes_host, stats, stream, 1, 1);
+}
+
+int emf_hip_raycastBatchedLanes(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                                const int32_t* res_host, int nmodels, int width, int height,
+                                const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
+                                const float* farBounds_dev, const float* voxelSizes_host, int lanesPerBgRay,
+                                uint64_t* stats, emf_stream_t stream) {
+    if (lanesPerBgRay != 1 && lanesPerBgRay != 2 && lanesPerBgRay != 4)
+        return fail(EMF_E_ARG, "raycastBatchedLanes: %d lanes per background ray (1, 2 or 4)", lanesPerBgRay);
+    return raycast_batched_launch(models_dev, poseCO_host, res_host, nmodels, width, height, K, useBrickFlags, bgBandRow0,
+                                  bgBandRows, farBounds_dev, voxelSizes_host, stats, stream, 1, lanesPerBgRay);
+}
+
+int emf_hip_raycastBatchedObjects(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                                  const int32_t* res_host, int nmodels, int width, int height,
+                                  const float K[9], int useBrickFlags, const float* farBounds_dev,
+                                  const float* voxelSizes_host, uint64_t* stats, emf_stream_t stream) {
+    return raycast_batched_launch(models_dev, poseCO_host, res_host, nmodels, width, height, K, useBrickFlags, 0, 0,
+                                  farBounds_dev, voxelSizes_host, stats, stream, 0, 1);
 }
 
 #ifdef EMF_RAY_TRACE

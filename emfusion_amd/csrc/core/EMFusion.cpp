@@ -58,7 +58,7 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
       occludedMask(_params.frameSize),
       visCounts(sizeof(int32_t) * EMF_MAX_MODELS),
       raycastStatsDev(4 * sizeof(uint64_t)),
-      modelTable(2 * sizeof(emf_model_t) * EMF_MAX_BATCH),
+      modelTable(2 * sizeof(emf_model_t) * EMF_MAX_MODELS),
       visibleDev(sizeof(int32_t) * EMF_MAX_MODELS),
       integrateStatsDev(sizeof(uint64_t)) {
     if (comm) {
@@ -95,6 +95,13 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
     // EMF_RAY_FOOTPRINTS=0: every object gets a marching workgroup for every tile of the image
     const char* rf = debugEnv("EMF_RAY_FOOTPRINTS");
     useFootprints = !(rf && rf[0] == '0');
+    // EMF_MARCH_ROWS = 1 (default) / 2 / 4 lanes per BACKGROUND ray (march_lane / march_quad<2> / march_quad<4>): same
+    // images (A/B measurements); read here, once -- anything else is refused, not silently marched with one lane
+    if (const char* mr = std::getenv("EMF_MARCH_ROWS")) {
+        marchLanes = std::atoi(mr);
+        if (marchLanes != 1 && marchLanes != 2 && marchLanes != 4)
+            throw HipError(std::string("EMFusion: EMF_MARCH_ROWS=") + mr + " (1, 2 or 4 lanes per background ray)", EMF_E_ARG);
+    }
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -282,30 +289,31 @@ void EMFusion::rebuildModelTable() {
     }
     bool tiled = true;
     voxelHost.clear();
-    scanMask = 0;
-    listMask = 0;
+    scanSlot.clear();
+    listSlot.clear();
+    anyScan = false;
     for (const auto& md : modelsHost) {
-        const unsigned bit = 1u << (voxelHost.size() & 31);
         // A volume too small for a relevant-tile list (an object: < 8192 tiles) could have its sign maps scanned
         // for far bounds; its rays are short anyway and the scan (23 us beside the E-steps, which it slows from
         // 12 to 37 us) costs the frame more than the cut saves the raycast: 0.6095 vs 0.5956 ms.  EMF_FAR_SCAN=1
         // scans them.
         const char* fsc = debugEnv("EMF_FAR_SCAN");
         const bool scanSmall = fsc && fsc[0] == '1';
-        if (md.signMaps && !md.relevantTiles && scanSmall) scanMask |= bit;
-        if (md.signMaps && md.relevantTiles) listMask |= bit;
+        scanSlot.push_back(md.signMaps && !md.relevantTiles && scanSmall);
+        listSlot.push_back(md.signMaps && md.relevantTiles);
+        anyScan = anyScan || scanSlot.back();
         voxelHost.push_back(md.voxelSize);
         resHost.insert(resHost.end(), md.res, md.res + 3);
         tiled &= md.res[0] % 4 == 0;
     }
-    // scratch of the two-level integration launch (every model on float4 tiles, no brick flags to keep)
+    // scratch of the two-level integration launch (every model on float4 tiles, no brick flags to keep): for the
+    // table chunk that holds the background -- the launch exists for the background's sake (integrateBatched)
     integrateCullScratch = DeviceBuffer();
-    if (cullBoxes && tiled && TSDF::brickFlagMode() == 0 &&
-        static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH)
+    if (cullBoxes && tiled && TSDF::brickFlagMode() == 0)
         integrateCullScratch = DeviceBuffer(emf_hip_integrateCullScratchBytes(
-            resHost.data(), static_cast<int>(modelsHost.size())));
-    batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly &&
-              static_cast<int>(modelsHost.size()) <= EMF_MAX_BATCH;
+            resHost.data(), std::min(static_cast<int>(modelsHost.size()), EMF_MAX_BATCH)));
+    // any number of models: stages are launched per chunk of EMF_MAX_BATCH table slots (forChunks)
+    batched = !forceLegacy && gradMode == TSDF::Gradients::OnTheFly;
     farBounds = DeviceBuffer();
     if (batched && useFarBounds)
         farBounds = DeviceBuffer(2 * emf_hip_raycastFarBoundBytes(static_cast<int>(modelsHost.size()),  // two halves, see computeFarBounds
@@ -325,7 +333,7 @@ void EMFusion::rebuildModelTable() {
             const emf_volume_out_t back = background.backBuffers();
             alt[0].tsdf = back.tsdf;
             alt[0].weights = back.weights;
-            hipCheck(hipMemcpy(modelTable.as<emf_model_t>() + EMF_MAX_BATCH, alt.data(),
+            hipCheck(hipMemcpy(modelTable.as<emf_model_t>() + EMF_MAX_MODELS, alt.data(),
                                alt.size() * sizeof(emf_model_t), hipMemcpyHostToDevice),
                      "model table upload");
         }
@@ -338,9 +346,11 @@ void EMFusion::rebuildModelTable() {
                            hipMemcpyHostToDevice),
                  "visibility upload");
         if (useFarBounds) {  // lists of new / rebuilt sign maps
-            emfCheck(emf_hip_updateRelevantTiles(modelTable.as<emf_model_t>(), resHost.data(),
-                                                 static_cast<int>(modelsHost.size()), Stream::Null().abi()),
-                     "updateRelevantTiles");
+            forChunks(0, static_cast<int>(modelsHost.size()), [&](int first, int count) {
+                emfCheck(emf_hip_updateRelevantTiles(modelTable.as<emf_model_t>() + first, resHost.data() + 3 * first,
+                                                     count, Stream::Null().abi()),
+                         "updateRelevantTiles");
+            });
             Stream::Null().waitForCompletion();
         }
     }
@@ -355,7 +365,7 @@ void EMFusion::adoptReciprocals() {
         modelsHost[slot].rcpVoxel = vol.reciprocal();
         for (int t = 0; t < 2; ++t) {
             if (t == 1 && !background.doubleBuffered()) break;
-            emf_model_t* row = modelTable.as<emf_model_t>() + t * EMF_MAX_BATCH + slot;
+            emf_model_t* row = modelTable.as<emf_model_t>() + t * EMF_MAX_MODELS + slot;
             hipCheck(hipMemcpyAsync(&row->rcpVoxel, &modelsHost[slot].rcpVoxel, sizeof(float),
                                     hipMemcpyHostToDevice, main.get()),
                      "reciprocal patch");
@@ -632,62 +642,47 @@ void EMFusion::integrateDepth() {
 
 // ---- batched path ----------------------------------------------------------------------------------
 
+// One E-step launch over the table slots [first, first + count) (<= EMF_MAX_BATCH of them).
+void EMFusion::launchEstep(const std::vector<emf_pose_t>& co, int first, int count, bool fromDepth, int normalize,
+                           const emf_image_t* norm, const emf_image_t* objSum) {
+    const emf_image_t pv = points.view();
+    const emf_model_t* table = currentTable() + first;
+    auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * count, main);
+    if (fromDepth)
+        emfCheck(emf_hip_estepBatchedFromDepth(table, co.data() + first, count, &depth, params.intr.val, &pv, normalize,
+                                               norm, objSum, main.abi()),
+                 "estepBatchedFromDepth");
+    else
+        emfCheck(emf_hip_estepBatched(table, co.data() + first, count, &pv, normalize, norm, objSum, main.abi()),
+                 "estepBatched");
+}
+
 void EMFusion::estepBatched() {
     std::vector<emf_pose_t> co;
     posesCO(co);
     const int n = static_cast<int>(co.size());
-    const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
-    const emf_model_t* table = currentTable();
     const bool fromDepth = pointsPending;  // the frame's first E-step also makes the points
     pointsPending = false;
-    auto launch = [&](int normalize, const emf_image_t* norm, const emf_image_t* objSum) {
-        auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
-        if (fromDepth)
-            emfCheck(emf_hip_estepBatchedFromDepth(table, co.data(), n, &depth, params.intr.val, &pv, normalize,
-                                                   norm, objSum, main.abi()),
-                     "estepBatchedFromDepth");
-        else
-            emfCheck(emf_hip_estepBatched(table, co.data(), n, &pv, normalize, norm, objSum, main.abi()),
-                     "estepBatched");
-    };
-    if (!sharded) {
-        launch(1, &nv, nullptr);
+    if (sharded) {
+        estepSharded(co, fromDepth);
         return;
     }
+    const emf_image_t nv = associationNorm.view();
+    if (n <= EMF_MAX_BATCH) {  // likelihoods, their sum and the normalised maps in ONE launch
+        launchEstep(co, 0, n, fromDepth, 1, &nv, nullptr);
+        return;
+    }
+    // More models than one launch takes: un-normalised likelihoods chunk by chunk (the first one forms the points on
+    // its way), then ONE normalisation over all maps -- the same add chain, background first, objects in ascending id
+    // (= table) order (EMFusion.cpp:654-657): the same bits as the fused launch and as the per-volume path.
+    forChunks(0, n, [&](int first, int count) { launchEstep(co, first, count, fromDepth && first == 0, 0, nullptr, nullptr); });
     std::vector<emf_image_t> maps;
     maps.push_back(bg_associationWeights.view());
-    for (auto& kv : objImages) maps.push_back(kv.second.associationWeights.view());
-    if (peerFused && maps.size() <= 16) {
-        // direct peer writes: the E-step's kernel stores its partial sum straight into the peers' slots, and ONE
-        // more launch waits for the peers, sums the slots in rank order and normalises -- two launches per E-step
-        // where the unsharded frame has one (round 3: five)
-        const uint32_t seq = comm->beginPeerExchange(main);
-        {
-            auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
-            emfCheck(emf_hip_estepBatchedPeer(table, co.data(), n, fromDepth ? &depth : nullptr, params.intr.val, &pv,
-                                              comm->peerGroup(), seq, main.abi()),
-                     "estepBatchedPeer");
-        }
-        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
-        emfCheck(emf_hip_peerNormalizeAssociation(comm->peerGroup(), seq, maps.data(), static_cast<int>(maps.size()), &sv,
-                                                  &nv, main.abi()),
-                 "peerNormalizeAssociation");
-        return;
-    }
-    // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
-    // xGMI, then every rank normalises its own maps
-    launch(0, nullptr, &sv);
-    // (Measured and dropped, round 3: the frame's LAST all-reduce + normalisation on a stream of their own beside
-    // the raycast -- they feed the integrations only.  With a 30 us latency model the frame got no shorter: the
-    // background's sweep needs the normalised weights and is as long as the raycast it runs beside.)
-    Stream& st = main;
-    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), st);
-    {
-        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), st);
-        emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv,
-                                              st.abi()),
-                 "normalizeAssociation");
-    }
+    for (auto& obj : objects) maps.push_back(objImages.at(obj.getID()).associationWeights.view());
+    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), static_cast<int>(maps.size()), nullptr,
+                                          &nv, main.abi()),
+             "normalizeAssociation");
 }
 
 void EMFusion::raycastBatched() {
@@ -710,10 +705,20 @@ void EMFusion::raycastBatched() {
         const int band = sharded && bgBands ? bgBandRows(h, world) : 0;
         const float* far = farBoundsReady && !flags ? farBoundsHalf() : nullptr;
         farBoundsReady = false;
-        emfCheck(emf_hip_raycastBatched(table, co.data(), resHost.data(), n, w, h, params.intr.val,
-                                        flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
-                                        band, far, useFootprints ? voxelHost.data() : nullptr, stats, main.abi()),
-                 "raycastBatched");
+        const size_t cells = emf_hip_raycastFarBoundBytes(1, w, h) / sizeof(float);  // bounds per model
+        forChunks(0, n, [&](int first, int count) {
+            const float* farChunk = far ? far + cells * first : nullptr;
+            const float* vox = useFootprints ? voxelHost.data() + first : nullptr;
+            if (first == 0)
+                emfCheck(emf_hip_raycastBatchedLanes(table, co.data(), resHost.data(), count, w, h, params.intr.val,
+                                                     flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
+                                                     band, farChunk, vox, marchLanes, stats, main.abi()),
+                         "raycastBatched");
+            else  // a chunk of objects only (more than EMF_MAX_BATCH models)
+                emfCheck(emf_hip_raycastBatchedObjects(table + first, co.data() + first, resHost.data() + 3 * first, count,
+                                                       w, h, params.intr.val, flags, farChunk, vox, stats, main.abi()),
+                         "raycastBatchedObjects");
+        });
         bandRowsPending = band;  // gathered together with the nearest-hit keys: one exchange (compositeAcrossRanks)
     }
     stamp(kRaycast);
@@ -737,14 +742,17 @@ void EMFusion::computeFarBounds(const std::vector<emf_pose_t>& co) {
     // integration (integrateBackgroundAsync: behind its last E-step).  No event of its own behind every raycast
     // any more (a record costs the critical stream ~8 us per frame).
     farSel ^= 1;
-    if (earlyFarBounds && scanMask == 0 && forkFrame == frameCount - 1 && overlapUsable() && !bgBackStale)
+    if (earlyFarBounds && !anyScan && forkFrame == frameCount - 1 && overlapUsable() && !bgBackStale)
         lists.waitOn(main);
     else
         lists.waitFor(main);  // the previous raycast has read the bounds (and in-place paths rebuilt lists on main)
-    emfCheck(emf_hip_raycastFarBounds(currentTable(), co.data(), resHost.data(), static_cast<int>(co.size()),
-                                      params.frameSize.width, params.frameSize.height, params.intr.val, scanMask,
-                                      farBoundsHalf(), lists.abi()),
-             "raycastFarBounds");
+    const size_t cells = emf_hip_raycastFarBoundBytes(1, params.frameSize.width, params.frameSize.height) / sizeof(float);
+    forChunks(0, static_cast<int>(co.size()), [&](int first, int count) {
+        emfCheck(emf_hip_raycastFarBounds(currentTable() + first, co.data() + first, resHost.data() + 3 * first, count,
+                                          params.frameSize.width, params.frameSize.height, params.intr.val,
+                                          chunkMask(scanSlot, first, count), farBoundsHalf() + cells * first, lists.abi()),
+                 "raycastFarBounds");
+    });
     farBoundsReady = true;
 }
 
@@ -833,23 +841,25 @@ void EMFusion::integrateBatched() {
         auto kt = ktimers.scope(KernelTimers::Integrate, vox, main);
         const emf_image_t il = invLambda.view();
         const emf_image_t* ilp = useLambdaTable ? &il : nullptr;
-        const emf_model_t* table = currentTable() + first;
-        const int32_t* vis = visibleDev.as<int32_t>() + first;
-        // two-level launch: the boxes of tiles outside the view cone never get a workgroup -- what the
-        // background needs; object volumes alone are small and mostly in view, and the list's counter
-        // reset + cull kernel cost them more (24 us of the frame) than the culled tiles would
-        if ((first == 0 || objCull) && cullBoxes && !integrateCullScratch.empty()) {
-            emfCheck(emf_hip_integrateBatchedCulled(table, oc.data() + first, resHost.data() + 3 * first, n - first,
-                                                    vis, &depth, ilp, params.intr.val,
-                                                    integrateCullScratch.data(), 0, nullptr,
-                                                    integrateStatsDev.as<uint64_t>(), main.abi()),
-                     "integrateBatchedCulled");
-        } else {
-            emfCheck(emf_hip_integrateBatched(table, oc.data() + first, resHost.data() + 3 * first, n - first, vis,
-                                              &depth, ilp, params.intr.val, TSDF::brickFlagMode() != 0,
-                                              integrateStatsDev.as<uint64_t>(), main.abi()),
-                     "integrateBatched");
-        }
+        forChunks(first, n, [&](int from, int count) {
+            const emf_model_t* table = currentTable() + from;
+            const int32_t* vis = visibleDev.as<int32_t>() + from;
+            // two-level launch: the boxes of tiles outside the view cone never get a workgroup -- what the
+            // background needs; object volumes alone are small and mostly in view, and the list's counter
+            // reset + cull kernel cost them more (24 us of the frame) than the culled tiles would
+            if ((from == 0 || (objCull && from < EMF_MAX_BATCH)) && cullBoxes && !integrateCullScratch.empty()) {
+                emfCheck(emf_hip_integrateBatchedCulled(table, oc.data() + from, resHost.data() + 3 * from, count,
+                                                        vis, &depth, ilp, params.intr.val,
+                                                        integrateCullScratch.data(), 0, nullptr,
+                                                        integrateStatsDev.as<uint64_t>(), main.abi()),
+                         "integrateBatchedCulled");
+            } else {
+                emfCheck(emf_hip_integrateBatched(table, oc.data() + from, resHost.data() + 3 * from, count, vis,
+                                                  &depth, ilp, params.intr.val, TSDF::brickFlagMode() != 0,
+                                                  integrateStatsDev.as<uint64_t>(), main.abi()),
+                         "integrateBatched");
+            }
+        });
     }
     const bool overlapped = bgInFlight;
     joinBackground();
@@ -857,12 +867,14 @@ void EMFusion::integrateBatched() {
         // The sign maps may have grown: rebuild the relevant-tile lists the NEXT frame's far bounds read.
         // Nothing of this frame needs them: with the streams in use they go to `lists`, behind the
         // integration above (the background's own list went there behind its integration already).
-        const int from = overlapped ? 1 : 0;
-        if (n > from && (listMask >> from) != 0) {
-            lists.waitFor(main);
-            emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, n - from, lists.abi()),
+        bool waited = false;
+        forChunks(overlapped ? 1 : 0, n, [&](int from, int count) {
+            if (chunkMask(listSlot, from, count) == 0) return;  // no model of this chunk keeps a list
+            if (!waited) lists.waitFor(main);
+            waited = true;
+            emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, count, lists.abi()),
                      "updateRelevantTiles");
-        }
+        });
     }
 }
 

@@ -12,6 +12,7 @@
 // (apps/EM-Fusion.cpp:152); it consumes poses / masks registered with setFrameInputs().
 #pragma once
 
+#include <algorithm>
 #include <list>
 #include <map>
 #include <string>
@@ -270,6 +271,8 @@ public:
     /** Voxels swept by the batched integration since the counter was last read (and reset). */
     uint64_t takeIntegratedVoxels();
     bool usesBatchedLaunches() const { return batched; }
+    /** Launches per stage on the batched path: 1 up to EMF_MAX_BATCH models, then one per chunk of the model table. */
+    int batchedChunks() const { return batched ? launchChunks() : 0; }
     /** The background is integrated out of place on a second stream, beside the raycast. */
     bool overlapsBackground() const { return overlapUsable(); }
     std::vector<int> objectIds() const { return allIds; }
@@ -312,6 +315,9 @@ private:
     void posesCO(std::vector<emf_pose_t>& out) const;
     void posesOC(std::vector<emf_pose_t>& out) const;
     void estepBatched();
+    void estepSharded(const std::vector<emf_pose_t>& co, bool fromDepth);
+    void launchEstep(const std::vector<emf_pose_t>& co, int first, int count, bool fromDepth, int normalize,
+                     const emf_image_t* norm, const emf_image_t* objSum);
     bool fusePoints = true;       // the frame's first E-step makes the points (EMF_FUSE_POINTS=0: own launch)
     bool pointsPending = false;   // ... and has not run yet
     bool visCountsClear = true;   // visCounts holds zeros (cleared at construction, left so by the fused pair)
@@ -414,8 +420,8 @@ private:
     uint32_t* trackWatch = nullptr;            // pinned host words the step kernel reports to
     uint32_t* trackWatchDev = nullptr;         // ... as the device addresses them
     uint32_t trackStageTag = 0;                // upper half of the words of the stage in flight (trackModels)
-    DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_BATCH]
-    DeviceBuffer trackScratch;                 // EMF_MAX_BATCH x emf_hip_trackScratchBytes
+    DeviceBuffer trackStates;                  // emf_track_state_t[EMF_MAX_MODELS]
+    DeviceBuffer trackScratch;                 // one emf_hip_trackScratchBytes block per table slot (grown on demand)
     emf_track_state_t* trackStatesHost = nullptr;  // pinned mirror
     std::map<int, TrackResult> trackResults;   // by model id
     DeviceImage<float, 3> points;
@@ -433,9 +439,27 @@ private:
     bool batched = true;            // false: per-volume launches (see EMFusion.cpp)
     bool forceLegacy = false;
     bool sharded = false;           // objects sharded over ranks: use the cross-rank exchanges
-    DeviceBuffer modelTable;        // 2 x emf_model_t[EMF_MAX_BATCH]: [1] has the background's two copies swapped
+    DeviceBuffer modelTable;        // 2 x emf_model_t[EMF_MAX_MODELS]: [1] has the background's two copies swapped
     int tableSel = 0;               // which of the two describes the background's current front copy
-    const emf_model_t* currentTable() const { return modelTable.as<emf_model_t>() + tableSel * EMF_MAX_BATCH; }
+    const emf_model_t* currentTable() const { return modelTable.as<emf_model_t>() + tableSel * EMF_MAX_MODELS; }
+    // A launch takes at most EMF_MAX_BATCH table slots (its poses travel by value in the kernel arguments); a longer
+    // model list -- the reference loops over any number of objects, EMFusion.cpp:635-670, 726-795, 865-889 -- is served
+    // in chunks of the table: f(first slot, count) for the slots [first, n), cut at multiples of EMF_MAX_BATCH, so
+    // that the chunk holding slot 0 is the only one with the background in it.
+    template <class F>
+    static void forChunks(int first, int n, F&& f) {
+        while (first < n) {
+            const int end = std::min(n, (first / EMF_MAX_BATCH + 1) * EMF_MAX_BATCH);
+            f(first, end - first);
+            first = end;
+        }
+    }
+    int launchChunks() const { return (static_cast<int>(modelsHost.size()) + EMF_MAX_BATCH - 1) / EMF_MAX_BATCH; }
+    uint32_t chunkMask(const std::vector<uint8_t>& flags, int first, int count) const {
+        uint32_t m = 0;
+        for (int k = 0; k < count; ++k) m |= flags[first + k] ? 1u << k : 0u;
+        return m;
+    }
     // Background kept twice (TSDF::enableDoubleBuffer): its integration runs out of place on `aux`,
     // concurrently with the raycast of the same frame, and the copies are flipped at the join.
     // EMF_BG_OVERLAP=0 keeps the reference's sequence raycast -> integrate (A/B measurements).
@@ -447,6 +471,7 @@ private:
     Stream aux{streamPriority("EMF_PRIO_AUX", -1)};
     // Raycast far bounds (emf_hip_raycastFarBounds): per model and 8x8-pixel cell, where a march may
     // stop because nothing can be hit any more.  EMF_FAR_BOUNDS=0 marches every ray to the end.
+    int marchLanes = 1;         // lanes per background ray (EMF_MARCH_ROWS, read by the constructor)
     bool useFootprints = true;  // objects are marched only where their volume box projects to
     bool useFarBounds = true;
     DeviceBuffer farBounds;       // two halves, written alternately (computeFarBounds)
@@ -470,7 +495,8 @@ private:
     std::vector<emf_model_t> modelsHost;
     std::vector<int32_t> resHost;   // 3 per model
     std::vector<float> voxelHost;   // voxel size per model (object footprints of the batched raycast)
-    uint32_t scanMask = 0, listMask = 0;  // far bounds: models whose sign maps are scanned / that keep a relevant-tile list
+    std::vector<uint8_t> scanSlot, listSlot;  // far bounds, per table slot: sign maps scanned / keeps a relevant-tile list
+    bool anyScan = false;
     DeviceBuffer visibleDev;        // int32 per model slot: integrate gate, written on the device
     DeviceBuffer integrateStatsDev; // u64: voxels swept by integrateBatched
     int32_t* visibleHost = nullptr; // pinned mirror of visCounts for visibleObjects()

@@ -9,6 +9,51 @@ namespace emf {
 
 using namespace detail;
 
+// The E-step of the sharded path: every rank computes the likelihood maps of ITS models, the per-pixel sum of the
+// object maps is exchanged (the ONE all-reduce SURVEY 8e / north_star name: reference EMFusion.cpp:653-665 sums all
+// maps), then every rank normalises its own maps with the joint sum.
+void EMFusion::estepSharded(const std::vector<emf_pose_t>& co, bool fromDepth) {
+    const int n = static_cast<int>(co.size());
+    const emf_image_t pv = points.view(), nv = associationNorm.view(), sv = objPartialSum.view();
+    std::vector<emf_image_t> maps;
+    maps.push_back(bg_associationWeights.view());
+    for (auto& obj : objects) maps.push_back(objImages.at(obj.getID()).associationWeights.view());
+    if (peerFused && maps.size() <= 16) {
+        // direct peer writes: the E-step's kernel stores its partial sum straight into the peers' slots, and ONE
+        // more launch waits for the peers, sums the slots in rank order and normalises -- two launches per E-step
+        // where the unsharded frame has one (round 3: five)
+        const uint32_t seq = comm->beginPeerExchange(main);
+        {
+            auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * n, main);
+            emfCheck(emf_hip_estepBatchedPeer(currentTable(), co.data(), n, fromDepth ? &depth : nullptr, params.intr.val, &pv,
+                                              comm->peerGroup(), seq, main.abi()),
+                     "estepBatchedPeer");
+        }
+        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+        emfCheck(emf_hip_peerNormalizeAssociation(comm->peerGroup(), seq, maps.data(), static_cast<int>(maps.size()), &sv,
+                                                  &nv, main.abi()),
+                 "peerNormalizeAssociation");
+        return;
+    }
+    // sharded objects: likelihoods + local object partial in one launch, ONE all-reduce over
+    // xGMI, then every rank normalises its own maps
+    if (n <= EMF_MAX_BATCH) {
+        launchEstep(co, 0, n, fromDepth, 0, nullptr, &sv);
+    } else {  // chunks of the table, then the local partial over all object maps in the same (table) order
+        forChunks(0, n, [&](int first, int count) { launchEstep(co, first, count, fromDepth && first == 0, 0, nullptr, nullptr); });
+        emfCheck(emf_hip_sumAssociation(maps.data() + 1, static_cast<int>(maps.size()) - 1, &sv, main.abi()), "sumAssociation");
+    }
+    // (Measured and dropped, round 3: the frame's LAST all-reduce + normalisation on a stream of their own beside
+    // the raycast -- they feed the integrations only.  With a 30 us latency model the frame got no shorter: the
+    // background's sweep needs the normalised weights and is as long as the raycast it runs beside.)
+    comm->allReduceSumF32(objPartialSum.ptr(), params.frameSize.area(), main);
+    {
+        auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+        emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), 1, &sv, &nv, main.abi()),
+                 "normalizeAssociation");
+    }
+}
+
 // Object volumes are sharded over ranks: merge the nearest hit of ALL objects with one
 // all-reduce(min) of packed (raylength, list position) keys, then finish the composite locally.
 // Every rank ends up with the same segmentation and the visibility counts of all objects.

@@ -48,15 +48,25 @@ static_assert(kTrackFinalOffset >= sizeof(uint32_t) * (1 + EMF_MAX_BATCH), "room
 void EMFusion::trackModels(int first, int count) {
     if (count <= 0) return;
     if (!batched)
-        throw HipError("EMFusion: tracking needs the batched path (<= 32 models, on-the-fly gradients)",
+        throw HipError("EMFusion: tracking needs the batched path (on-the-fly gradients, EMF_PER_VOLUME unset)",
                        EMF_E_LIMIT);
+    if (count > EMF_MAX_BATCH || first / EMF_MAX_BATCH != (first + count - 1) / EMF_MAX_BATCH) {
+        // more models than one launch takes: the stage runs chunk by chunk of the table (the models of a stage are
+        // independent of one another: reference EMFusion.cpp:689-723 tracks object after object)
+        forChunks(first, first + count, [&](int from, int cnt) { trackModels(from, cnt); });
+        return;
+    }
     const int w = params.frameSize.width, h = params.frameSize.height;
     const size_t per = emf_hip_trackScratchBytes(w, h);
+    const size_t slots = modelsHost.size();
+    if (trackScratch.bytes() < per * slots) {  // one block per table slot (storeTrackWeights reads them after the stage)
+        main.waitForCompletion();
+        trackScratch = DeviceBuffer(per * std::max(slots, std::min<size_t>(2 * slots, EMF_MAX_MODELS)));
+    }
     if (trackStates.empty()) {
-        trackStates = DeviceBuffer(sizeof(emf_track_state_t) * EMF_MAX_BATCH);
-        trackScratch = DeviceBuffer(per * EMF_MAX_BATCH);
+        trackStates = DeviceBuffer(sizeof(emf_track_state_t) * EMF_MAX_MODELS);
         hipCheck(hipHostMalloc(reinterpret_cast<void**>(&trackStatesHost),
-                               sizeof(emf_track_state_t) * EMF_MAX_BATCH, hipHostMallocDefault),
+                               sizeof(emf_track_state_t) * EMF_MAX_MODELS, hipHostMallocDefault),
                  "hipHostMalloc");
         // progress words the step kernel writes while the stream runs (emf_hip_trackStep)
         if (trackWindow > 0 &&

@@ -818,6 +818,7 @@ int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n) {
     return EMF_OK;
 }
 
+int emf_fusion_batched_chunks(emf_fusion_t* h) { return h ? h->impl->batchedChunks() : EMF_E_NULL; }
 int emf_fusion_background_overlap(emf_fusion_t* h) { return h ? (h->impl->overlapsBackground() ? 1 : 0) : EMF_E_NULL; }
 
 int emf_fusion_frame_index(emf_fusion_t* h) { return h ? h->impl->frameIndex() : EMF_E_NULL; }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_vis_counts_all(Img<const uint8_t> seg, 
 }
 
 struct GateTable {
-    int idx[EMF_MAX_BATCH];  // index into counts for each model slot (slot 0 unused)
+    int idx[EMF_MAX_BATCH + 1];  // index into counts for each model slot (slot 0 = the background, unused; then <= EMF_MAX_BATCH local objects)
 };
 __global__ void k_vis_flags_indexed(const int32_t* __restrict__ counts, int nmodels, int thresh,
                                     const GateTable g, int32_t* __restrict__ visible) {
@@ -446,10 +446,10 @@ int emf_hip_visibilityFlagsIndexed(const int32_t* visCounts, int nmodels,
                                    const int32_t* countIndex_host, int visibilityThresh,
                                    int32_t* visible_dev, emf_stream_t stream) {
     EMF_REQUIRE_PTR(visible_dev);
-    if (nmodels < 1 || nmodels > EMF_MAX_BATCH)
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH + 1)
         return fail(EMF_E_LIMIT, "visibilityFlagsIndexed: nmodels = %d", nmodels);
     GateTable g;
-    for (int s = 0; s < EMF_MAX_BATCH; ++s) g.idx[s] = 0;
+    for (int s = 0; s <= EMF_MAX_BATCH; ++s) g.idx[s] = 0;
     if (nmodels > 1) {
         EMF_REQUIRE_PTR(visCounts);
         EMF_REQUIRE_PTR(countIndex_host);
@@ -609,10 +609,10 @@ int emf_hip_visibilityFlagsMirror(int32_t* visCounts, int nall, int nmodels, con
                                   int visibilityThresh, int32_t* visible_dev, int32_t* countsMirror, emf_stream_t stream) {
     EMF_REQUIRE_PTR(visible_dev);
     EMF_REQUIRE_PTR(visCounts);
-    if (nmodels < 1 || nmodels > EMF_MAX_BATCH) return fail(EMF_E_LIMIT, "visibilityFlagsMirror: nmodels = %d", nmodels);
+    if (nmodels < 1 || nmodels > EMF_MAX_BATCH + 1) return fail(EMF_E_LIMIT, "visibilityFlagsMirror: nmodels = %d", nmodels);
     if (nall < 0 || nall > EMF_MAX_MODELS - 1) return fail(EMF_E_LIMIT, "visibilityFlagsMirror: nall = %d", nall);
     GateTable g;
-    for (int s = 0; s < EMF_MAX_BATCH; ++s) g.idx[s] = 0;
+    for (int s = 0; s <= EMF_MAX_BATCH; ++s) g.idx[s] = 0;
     if (nmodels > 1) {
         EMF_REQUIRE_PTR(countIndex_host);
         for (int s = 1; s < nmodels; ++s) {

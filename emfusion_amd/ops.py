@@ -346,16 +346,24 @@ def voxel_reciprocal_exhaustive(voxel_size) -> int:
 
 
 def raycast_batched(models_dev, poses_co, res_list, width, height, K, stats=None,
-                    use_brick_flags=False, stream=None, bg_band=(0, 0), far_bounds=None, voxel_sizes=None):
+                    use_brick_flags=False, stream=None, bg_band=(0, 0), far_bounds=None, voxel_sizes=None, lanes=1,
+                    objects_only=False):
     """bg_band = (row0, rows): march only that row band of table slot 0 (multi-GPU background split).
-    far_bounds: raycast_far_bounds()'s array for the same table, poses and image (same results, shorter marches)."""
+    far_bounds: raycast_far_bounds()'s array for the same table, poses and image (same results, shorter marches).
+    lanes: 1 / 2 / 4 lanes per background ray.  objects_only: the table (chunk) holds no background in slot 0."""
     res = (C.c_int32 * (3 * len(poses_co)))(*[int(v) for r in res_list for v in r])
-    check("emf_hip_raycastBatched",
-          _L.emf_hip_raycastBatched(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width,
-                                    height, _f(K, 9), int(use_brick_flags), int(bg_band[0]),
-                                    int(bg_band[1]), _ptr(far_bounds),
-                                    None if voxel_sizes is None else _f(voxel_sizes, len(poses_co)), _ptr(stats),
-                                    _stream(stream)))
+    vox = None if voxel_sizes is None else _f(voxel_sizes, len(poses_co))
+    if objects_only:
+        check("emf_hip_raycastBatchedObjects",
+              _L.emf_hip_raycastBatchedObjects(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width, height,
+                                               _f(K, 9), int(use_brick_flags), _ptr(far_bounds), vox, _ptr(stats),
+                                               _stream(stream)))
+        return
+    check("emf_hip_raycastBatchedLanes",
+          _L.emf_hip_raycastBatchedLanes(_ptr(models_dev), _poses(poses_co), res, len(poses_co), width,
+                                         height, _f(K, 9), int(use_brick_flags), int(bg_band[0]),
+                                         int(bg_band[1]), _ptr(far_bounds), vox, int(lanes), _ptr(stats),
+                                         _stream(stream)))
 
 
 def sign_map_bytes(res) -> int:

@@ -154,6 +154,7 @@ def load() -> C.CDLL:
         "emf_fusion_object_ids": [vp, ip, C.c_int, C.POINTER(C.c_int)],
         "emf_fusion_frame_index": [vp],
         "emf_fusion_background_overlap": [vp],
+        "emf_fusion_batched_chunks": [vp],
         "emf_fusion_owns_object": [vp, C.c_int],
         "emf_comm_unique_id": [vp],
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
@@ -697,6 +698,10 @@ class Fusion:
 
     def background_overlap(self) -> bool:
         return load().emf_fusion_background_overlap(self._h) == 1
+
+    def batched_chunks(self) -> int:
+        """0: per-volume path; k >= 1: batched path with k launches per stage (one per <= 32 table slots)."""
+        return int(load().emf_fusion_batched_chunks(self._h))
 
     def object_ids(self):
         """Live objects of the job in creation order."""

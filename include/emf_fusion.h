@@ -257,6 +257,9 @@ int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n);
 int emf_fusion_frame_index(emf_fusion_t* h);
 /* 1 if the background's integration runs out of place beside the raycast (double-buffered background) */
 int emf_fusion_background_overlap(emf_fusion_t* h);
+/* Which path the frames run on: 0 = per-volume (one stream per volume, host visibility gate: EMF_PER_VOLUME=1, materialised
+ * gradients), k >= 1 = batched with k launches per stage (1 up to EMF_MAX_BATCH models, then one per chunk of the table) */
+int emf_fusion_batched_chunks(emf_fusion_t* h);
 /* 1 if this rank holds object id's volume */
 int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);
 

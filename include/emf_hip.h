@@ -418,10 +418,12 @@ typedef struct emf_pose {
  *   poseCO_host[m]: camera -> volume m.  points: f32x3 W x H.
  *   normalize != 0: maps are written normalised, norm (f32 W x H, may be NULL) gets the
  *                   normaliser = sequential sum of all maps (+ nothing else): single-GPU form
- *   normalize == 0: maps are written UN-normalised and objSum (f32 W x H, required) receives the
- *                   sequential sum of the object maps (slots 1..): the partial a rank feeds to
+ *   normalize == 0: maps are written UN-normalised and objSum (f32 W x H, or NULL: no sum) receives
+ *                   the sequential sum of the object maps (slots 1..): the partial a rank feeds to
  *                   the all-reduce; finish with emf_hip_normalizeAssociation(nsum = 1, extraSum)
- * 1 <= nmodels <= EMF_MAX_BATCH. */
+ * 1 <= nmodels <= EMF_MAX_BATCH.  A model list longer than that is served in chunks of the table
+ * (models_dev + k, poseCO_host + k; normalize == 0, objSum NULL) followed by ONE
+ * emf_hip_normalizeAssociation over all maps (nsum = nmaps): the same sequential sum, the same bits. */
 int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
                          const emf_image_t* points, int normalize, const emf_image_t* norm,
                          const emf_image_t* objSum, emf_stream_t stream);
@@ -451,6 +453,23 @@ int emf_hip_raycastBatched(const emf_model_t* models_dev, const emf_pose_t* pose
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
                            const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
                            emf_stream_t stream);
+/* emf_hip_raycastBatched with the BACKGROUND's rays marched by lanesPerBgRay = 1, 2 or 4 lanes each (march_quad,
+ * march_wave.hpp: the lanes of a ray take consecutive samples speculatively; same images, same sample count; measured
+ * slower beside the background's integration, hence not the default).  Ignored (1) with brick flags or volumes above
+ * 4 GiB. */
+int emf_hip_raycastBatchedLanes(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                                const int32_t* res_host, int nmodels, int width, int height,
+                                const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
+                                const float* farBounds_dev, const float* voxelSizes_host, int lanesPerBgRay,
+                                uint64_t* stats, emf_stream_t stream);
+/* The same launch for a table chunk that holds OBJECTS ONLY (every slot, slot 0 included, is marched over its
+ * footprint and zero-filled outside it): the later chunks of a model list longer than EMF_MAX_BATCH
+ * (reference EMFusion.cpp:745-758 loops over any number of objects).  farBounds_dev: this chunk's part of the
+ * bounds (emf_hip_raycastFarBounds called with the same chunk). */
+int emf_hip_raycastBatchedObjects(const emf_model_t* models_dev, const emf_pose_t* poseCO_host,
+                                  const int32_t* res_host, int nmodels, int width, int height,
+                                  const float K[9], int useBrickFlags, const float* farBounds_dev,
+                                  const float* voxelSizes_host, uint64_t* stats, emf_stream_t stream);
 /* voxelSizes_host: NULL, or HOST float[nmodels], the voxel sizes stored in the table.  With them the
  * objects (slots 1..) get marching workgroups only for the 16x16-pixel tiles their volume box can project
  * to under poseCO_host; the rest of their images is zero-filled sixteen tiles per workgroup -- same
@@ -612,7 +631,7 @@ int emf_hip_compositeFromKeys(const uint64_t* keys, int nall, const int32_t* ids
 
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[countIndex_host[slot]] > visibilityThresh):
  * emf_hip_visibilityFlags for a rank whose model slots map to arbitrary entries of a global count
- * array.  1 <= nmodels <= EMF_MAX_BATCH. */
+ * array.  1 <= nmodels <= EMF_MAX_BATCH + 1 (the background + the objects one rank may own). */
 int emf_hip_visibilityFlagsIndexed(const int32_t* visCounts, int nmodels,
                                    const int32_t* countIndex_host, int visibilityThresh,
                                    int32_t* visible_dev, emf_stream_t stream);

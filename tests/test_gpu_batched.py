@@ -265,7 +265,6 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
     """footprints: with the voxel sizes on the host, objects get marching workgroups only where their box
     projects to, and zero-fill workgroups elsewhere -- every pixel of every image is still written.
     rows: the background's rays with 2 / 4 lanes each (march_quad, EMF_MARCH_ROWS): same pixels, same sample count."""
-    monkeypatch.setenv("EMF_MARCH_ROWS", str(rows))
     cam = camera_path(4)
     table = ops.upload_models([m.table_entry() for m in scene])
     poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in scene]
@@ -276,7 +275,7 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
         m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
     st = dev_full((4,), 0, np.uint64)
     ops.raycast_batched(table, poses, [m.res for m in scene], W, H, K, stats=st,
-                        use_brick_flags=use_flags, voxel_sizes=[m.vox for m in scene] if footprints else None)
+                        use_brick_flags=use_flags, voxel_sizes=[m.vox for m in scene] if footprints else None, lanes=rows)
     total = 0
     for m, (R, t) in zip(scene, poses):
         want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask if m.is_obj else None, W, H, R, t,
@@ -287,6 +286,33 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
                                  ["ray", "vert", "normal", "mask"]):
             assert_parity(to_np(got), w_, f"{name} model {m.id}", exact=True)
     assert int(to_np(st)[0]) == total
+
+
+def test_raycast_of_an_objects_only_table_chunk(ops, oracle, scene, dev):
+    """emf_hip_raycastBatchedObjects: a chunk of the model table without a background in slot 0 (what a model list longer
+    than EMF_MAX_BATCH is served with) -- every slot marched over its footprint, zero-filled elsewhere, every pixel
+    written, same bits as the per-model march."""
+    objs = [m for m in scene if m.is_obj]
+    assert len(objs) >= 2
+    cam = camera_path(4)
+    table = ops.upload_models([m.table_entry() for m in objs])
+    poses = [(rel_CO(cam, m.pose).R32, rel_CO(cam, m.pose).t32) for m in objs]
+    for footprints in (False, True):
+        for m in objs:
+            m.d_ray.copy_from(np.full((H, W), 5, np.float32))
+            m.d_vert.copy_from(np.full((H, W, 3), 5, np.float32))
+            m.d_nrm.copy_from(np.full((H, W, 3), 5, np.float32))
+            m.d_hit.copy_from(np.full((H, W), 5, np.uint8))
+        st = dev_full((4,), 0, np.uint64)
+        ops.raycast_batched(table, poses, [m.res for m in objs], W, H, K, stats=st, objects_only=True,
+                            voxel_sizes=[m.vox for m in objs] if footprints else None)
+        total = 0
+        for m, (R, t) in zip(objs, poses):
+            want = oracle.raycast_tsdf(m.tsdf, None, m.wts, m.vmask, W, H, R, t, K, m.vox, m.trunc, count_steps=True)
+            total += int(want[4].sum())
+            for got, w_, name in zip([m.d_ray, m.d_vert, m.d_nrm, m.d_hit], want, ["ray", "vert", "normal", "mask"]):
+                assert_parity(to_np(got), w_, f"{name} model {m.id} (footprints {footprints})", exact=True)
+        assert int(to_np(st)[0]) == total
 
 
 def tile_sign_maps(tsdf):
@@ -370,7 +396,6 @@ def test_far_bounds_are_conservative_on_adversarial_volumes(ops, oracle, dev, mo
     the oracle's full march bit for bit (a bound that is too tight anywhere would lose a hit).  rows: the same with
     two / four lanes per ray (march_quad) -- sign noise, thin sheets and shell surfaces are where its transparency
     test, its dropped speculation and its `continue` / `break` cases get exercised."""
-    monkeypatch.setenv("EMF_MARCH_ROWS", str(rows))
     rng = np.random.default_rng(1000 + seed)
     res, vox = (96, 64, 80), 0.02
     nz, ny, nx = res[2], res[1], res[0]
@@ -415,7 +440,7 @@ def test_far_bounds_are_conservative_on_adversarial_volumes(ops, oracle, dev, mo
         hits += int(want[3].sum())
         for mask in (0, 1):  # list walked / maps scanned
             bounds = ops.raycast_far_bounds(table, poses, [res], W, H, K, scan_mask=mask)
-            ops.raycast_batched(table, poses, [res], W, H, K, far_bounds=bounds, voxel_sizes=[m.vox])
+            ops.raycast_batched(table, poses, [res], W, H, K, far_bounds=bounds, voxel_sizes=[m.vox], lanes=rows)
             for got, w_, name in zip([m.d_ray, m.d_vert, m.d_nrm, m.d_hit], want, ["ray", "vert", "normal", "mask"]):
                 assert_parity(to_np(got), w_, f"seed {seed} pose {k} scan {mask}: {name}", exact=True)
     assert hits > 2000, hits
@@ -746,9 +771,9 @@ def test_batched_argument_checks(ops, dev):
     with pytest.raises(EmfHipError) as e:
         ops.estep_batched(table, [(np.eye(3), np.zeros(3))] * 33, pts)
     assert e.value.code == -5  # EMF_E_LIMIT
-    with pytest.raises(EmfHipError) as e:
-        ops.estep_batched(table, [(np.eye(3), np.zeros(3))], pts, normalize=False)
-    assert e.value.code == -1  # objSum required
+    with pytest.raises(EmfHipError) as e:  # (normalize=False without objSum is legal since ABI 8: a chunk of a longer list)
+        ops.raycast_batched(table, [(np.eye(3), np.zeros(3))], [(32, 32, 32)], W, H, K, lanes=3)
+    assert e.value.code == -4  # 1, 2 or 4 lanes per background ray
 
 
 def test_argument_checks_of_the_newer_entry_points(ops, dev):

@@ -174,12 +174,15 @@ def test_voxel_reciprocal_is_checked_and_exact(ops, dev):
 def test_short_reciprocal_check_gives_the_exhaustive_verdict(ops, dev):
     """The product's check sweeps three binades (abi_common.hip, k_check_reciprocal); its verdict must be the one of
     the sweep over all 2^32 bit patterns -- for the sizes the configurations use, the objects' 2 * extent / N, the
-    edges of the accepted range and a thousand random sizes, log-uniform over it.  Both verdicts occur."""
+    edges of the accepted range, a thousand random sizes, log-uniform over it, and the divisors whose mantissa is all ones
+    (the known exception of the Markstein correction this form is: its only candidates for a rejection)."""
     rng = np.random.default_rng(0x5EC1)
     sizes = [0.01, 0.02, 0.04, 0.005, 1e-6, 1e3, 1.0, 0.5, 3.0, 0.0123456]
     sizes += [2 * e / n for e in (0.15, 0.3, 0.45, 0.6, 1.2) for n in (64, 128, 256)]
     sizes += list(2 * rng.uniform(0.05, 1.5, 200) / 128)          # spawned / resized objects
     sizes += list(np.exp(rng.uniform(np.log(1e-6), np.log(1e3), 1000)))
+    ones = np.array([(e << 23) | m for e in range(108, 136) for m in (0x7fffff, 0x7ffffe, 0x7ffffd)], np.uint32).view(np.float32)
+    sizes += [float(v) for v in ones if 1e-6 <= v <= 1e3]
     accepted = rejected = 0
     for v in sizes:
         v = float(np.float32(v))
