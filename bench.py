@@ -20,6 +20,11 @@ The timed region holds the product path plus a HIP-event pair around every 4th l
 (raycast, background integration, tracking stage; --event-stride) and nothing else: the march-sample counters the byte model of `roofline` needs are
 collected afterwards, in an untimed replay of the same frames from a cleared state (--no-stats-replay skips it).
 
+Behind the headline, in the same line (bench_extras.py): `target_config`, `steady_state`, `entry_point` (the reference's
+processFrame(RGBD) on a staged TUM-layout scene), `strong_scaling` (configs[3]'s 64-object scene, fixed, split over the
+ranks) and -- N > 1 -- `rccl` (ranks / devices the transport saw), `sharded_parity` (replicas and joint images against a
+single-rank re-run) and `per_rank_roofline`.  An RCCL failure exits non-zero (--allow-fallback: gloo, labelled).
+
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
 torch is used for torch.distributed only (gloo rendezvous, barriers, max-reduce of the time); all
 device memory and streams belong to the product's own HIP runtime (emfusion_amd/devmem.py).
@@ -60,9 +65,27 @@ def parse_args():
                     help="skip the untimed replay that counts march samples (roofline.achieved of the raycast is "
                          "then null): for profiler passes that should see each launch once")
     ap.add_argument("--track", action="store_true",
-                    help="timed frames track the camera and the objects (LM-ICP, SURVEY f-1) instead "
-                         "of taking their poses as inputs; changes the metric name -- the headline "
-                         "metric of BASELINE.json is measured WITHOUT this flag")
+                    help="the tracked hot path on an OBSERVABLE scene: the staged TUM-layout sequence (tests/tum_scene.py, "
+                         "config/tum.cfg's values, BASELINE.json configs[2]) with depth maps and masks resident in HBM, camera "
+                         "and objects tracked (LM-ICP, SURVEY f-1); changes metric and workload -- the headline metric of "
+                         "BASELINE.json is measured WITHOUT this flag")
+    ap.add_argument("--entry", action="store_true",
+                    help="the reference's entry point, EMFusion::processFrame(const RGBD&), on the same staged sequence: host "
+                         "depth maps (double-buffered pinned upload), bilateral pre-filter, masks from Mask%%04d.plk, object "
+                         "life cycle, camera + object tracking, clean-up: configs[2]'s frames/s")
+    ap.add_argument("--track-spheres", action="store_true",
+                    help="rounds 2-5's tracked figure: configs[1]'s sphere scene with poses tracked instead of supplied "
+                         "(under-constrained: an object stage often burns its whole budget on unobservable motion; a footnote)")
+    ap.add_argument("--no-entry", action="store_true", help="skip the `entry_point` sub-line of the default N = 1 run")
+    ap.add_argument("--no-strong", action="store_true", help="skip the `strong_scaling` sub-run (configs[3]'s scene, fixed, "
+                                                             "split over the ranks)")
+    ap.add_argument("--strong-objects", type=int, default=64, help="objects of the strong-scaling scene (configs[3]: 64)")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip `sharded_parity` (replicas / joint images against a "
+                                                             "single-rank re-run on rank 0)")
+    ap.add_argument("--parity-frames", type=int, default=4)
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if RCCL cannot be brought up, fall back to host-staged collectives over gloo (loudly labelled) "
+                         "instead of exiting non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target", action="store_true",
                     help="skip the two further measurements the default N = 1 run appends: `target_config` (north_star's "
@@ -129,6 +152,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     devmem.set_device(local_rank % devmem.device_count())
     dev_name, arch, cus = ops.device_info()
+    if args.track or args.entry:
+        # the tracked hot path / the reference's entry point on the staged TUM-layout scene: a line of its own (bench_extras.py)
+        if world != 1:
+            raise SystemExit("--track / --entry measure one RGB-D stream on one GPU (--gpus 1)")
+        import bench_extras
+        result = bench_extras.tum_line(args, pipeline, ops, DeviceArray, roofline, workload_key,
+                                       f"{dev_name or 'MI355X'} {arch} {cus} CUs", "entry" if args.entry else "track")
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
+        return
+    args.track = args.track_spheres  # from here on: the sphere scene with free poses (footnote figure)
     if torch.cuda.is_available():
         # torch initialises its CUDA state lazily, on the first torch.cuda call: have that happen HERE and not in
         # the torch.cuda.synchronize() that brackets the timed region (measured, round 4: with the lazy
@@ -177,9 +212,18 @@ def main():
                 flags = [None] * world
                 dist.all_gather_object(flags, err)
                 bad = [f for f in flags if f]
+                if bad and not args.allow_fallback:
+                    # a multi-GPU line that silently measured something else is worse than none
+                    if comm is not None:
+                        comm.close()
+                    dist.barrier()
+                    dist.destroy_process_group()
+                    raise SystemExit(f"bench.py: RCCL communicator could NOT be created ({bad[0]}); refusing to measure "
+                                     "over another transport (--allow-fallback runs host-staged collectives over gloo, "
+                                     "--comm gloo / --comm peer select a rehearsal transport explicitly)")
                 if bad:
                     print(f"bench.py: RCCL communicator could NOT be created ({bad[0]}); falling back to "
-                          "host-staged collectives over gloo -- the multi-GPU numbers of this run are NOT "
+                          "host-staged collectives over gloo (--allow-fallback) -- the multi-GPU numbers of this run are NOT "
                           "those of the product's transport", file=sys.stderr, flush=True)
                     if comm is not None:
                         comm.close()
@@ -188,7 +232,9 @@ def main():
             elif err:
                 raise SystemExit("bench.py: RCCL communicator could not be created: " + err)
 
-    synth = pipeline.SyntheticStream(W, H, K, nobj_total, seed=0xE3F5)
+    def synth_factory(n):
+        return pipeline.SyntheticStream(W, H, K, n, seed=0xE3F5)
+    synth = synth_factory(nobj_total)
     fus = pipeline.Fusion(prm, comm)
     depth_broadcast = comm is not None and not args.no_depth_broadcast
     if depth_broadcast:
@@ -276,6 +322,7 @@ def main():
         print("PER_STEP_US " + " ".join("%.0f" % (1e6 * v) for v in per_step), file=sys.stderr, flush=True)
     kern = None if args.no_kernel_events else fus.kernel_timers_collect()
     visible = fus.visible_objects()
+    chunks = fus.batched_chunks()
 
 
     track_steps = []
@@ -310,11 +357,32 @@ def main():
 
     # the copy-bandwidth probe comes first: its kernel also marks, in a kernel trace of this command, where
     # the measured run ends and the replay begins (scripts/summarize_profile.py)
-    copy_gbs = copy_bandwidth(devmem, ops) if rank == 0 else None
-    l1p = l1_probe(devmem, ops) if rank == 0 else None
+    copy_gbs = copy_bandwidth(devmem, ops)  # every rank: its own device (the rehearsal's ranks share one)
+    l1p = l1_probe(devmem, ops)
     barrier()
     stats = replay_with_counters()
     barrier()
+
+    # ---- every rank prices ITS kernels with the committed profile of its share; rank 0 gathers the summaries ----
+    share_key = workload_key(W, H, args.bg_res, args.obj_res, len(mine), args.track)
+    my_roof = my_rows = None
+    if kern is not None:
+        my_roof, my_rows = roofline(kern, stats, P, copy_gbs, share_key, args.steps, l1p)
+    per_rank = None
+    if comm is not None:
+        ray = next((r for r in (my_rows or []) if r["kind"] == "raycast"), None)
+        integ = next((r for r in (my_rows or []) if r["kind"] in ("integrate_bg", "integrate")), None)
+        brief = {"rank": rank, "objects": len(mine), "workload_key": share_key,
+                 "dominant_kernel": my_roof["kernel"] if my_roof else None,
+                 "avg_launch_ms": my_roof["avg_launch_ms"] if my_roof else None,
+                 "bound": my_roof.get("bound") if my_roof else None, "frac": my_roof.get("frac") if my_roof else None,
+                 "hbm_frac": ((my_roof.get("resources") or {}).get("hbm") or {}).get("frac") if my_roof else None,
+                 "raycast_ms": ray["avg_ms"] if ray else None, "integrate_ms": integ["avg_ms"] if integ else None,
+                 "hbm_copy_GBs": copy_gbs, "counters_from": my_roof.get("counters_from") if my_roof else None}
+        per_rank = [brief]
+        if dist is not None:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, brief)
 
     result = None
     if rank == 0:
@@ -359,6 +427,8 @@ def main():
                 "mask_frames_every": mask_every,
                 "mask_frames_in_timed_window": [f for f in range(args.warmup, nframes) if f % mask_every == 0],
                 "visible_objects_last_frame": len(visible),
+                "path": "batched" if chunks else "per-volume",
+                "launches_per_stage": chunks,
                 "device": f"{dev_name or 'MI355X'} {arch} {cus} CUs",
             },
         }
@@ -372,13 +442,18 @@ def main():
                 "objects_longest_per_frame": round(sum(t[2] for t in track_steps) / n, 1),
                 "frames_in_which_an_object_used_the_whole_budget": sum(1 for t in track_steps if t[2] >= prm.max_tracking_iter),
             }
-        # priced by the newest committed PMC summary of THIS workload (profiles/*_counters.json carry a workload key)
-        key = workload_key(W, H, args.bg_res, args.obj_res, nobj_total, args.track) if world == 1 else None
-        result["config"]["workload_key"] = key
-        if kern is not None:
-            result["roofline"], result["kernels"] = roofline(kern, stats, P, copy_gbs, key or False, args.steps, l1p)
-        else:
-            result["roofline"] = None
+        # priced by the newest committed PMC summary of THIS workload (profiles/*_counters.json carry a workload key);
+        # with N > 1 every rank is priced with the profile of its SHARE (its objects + the background on one GPU)
+        result["config"]["workload_key"] = share_key
+        result["roofline"] = my_roof
+        if my_rows is not None:
+            result["kernels"] = my_rows
+        if world > 1 or comm is not None:
+            result["per_rank_roofline"] = per_rank
+            if my_roof is not None:
+                my_roof["share_note"] = ("counters of the committed profile of this rank's share run UNSHARDED on one GPU "
+                                         f"({share_key}); the sharded launch marches 1/{world} of the background's rows and adds "
+                                         "the exchanges, durations are this run's HIP events on this rank")
         result["hbm_copy_GBs"] = copy_gbs  # attainable D2D stream bandwidth of THIS box (read + write)
         # work aggregate for the scaling curves: every rank's volumes advance one frame per step
         result["volume_frames_per_s"] = round(fps * (world + nobj_total), 1)
@@ -388,11 +463,32 @@ def main():
                                   "= the N=1 value); volume_frames_per_s is the aggregate work rate, which "
                                   "grows with N")
     fus.close()
+    import bench_extras
+    if comm is not None:
+        # what the transport itself saw, and the line's own proof that the sharded frames are the single-GPU frames
+        rep = bench_extras.transport_report(comm, dist, world, args.comm)
+        par = None if args.no_parity else bench_extras.sharded_parity(pipeline, ops, DeviceArray, prm, comm, dist, rank, world,
+                                                                        nobj_total, synth_factory, depth_broadcast,
+                                                                        frames=args.parity_frames)
+        if rank == 0:
+            result["rccl"] = rep
+            result["sharded_parity"] = par
+            if par is not None and not par.get("ok"):
+                print("bench.py: sharded_parity FAILED -- the sharded frames differ from the single-rank frames: " + json.dumps(par),
+                      file=sys.stderr, flush=True)
+    if not args.no_strong and not args.track and args.strong_objects > 0:
+        strong = bench_extras.strong_scaling(args, pipeline, ops, DeviceArray, prm, comm, dist, rank, world, synth_factory,
+                                             depth_broadcast, args.strong_objects)
+        if rank == 0:
+            result["strong_scaling"] = strong
     is_headline = (world, nobj_total, args.bg_res, args.obj_res, W, H, args.track, comm) == (1, 4, 512, 128, 640, 480, False, None)
     if rank == 0 and is_headline and not args.no_target:
         # north_star's own target (>= 30 frames/s with 8 object volumes), same protocol, same process, behind the headline
         result["target_config"] = measure_target(args, pipeline, ops, DeviceArray, fus_params=prm)
         result["steady_state"] = measure_steady_state(args, pipeline, ops, DeviceArray, prm, nobj_total)
+    if rank == 0 and is_headline and not args.no_entry:
+        # the reference's own entry point, processFrame(RGBD), on the staged TUM-layout scene (configs[2]'s throughput)
+        result["entry_point"] = bench_extras.entry_point(pipeline, ops, DeviceArray)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, prm, K, synth, ids)
 

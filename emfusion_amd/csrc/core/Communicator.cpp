@@ -14,6 +14,20 @@
 #include <vector>
 
 namespace emf {
+
+std::string describeCurrentDevice() {
+    int dev = -1;
+    char bus[32] = {0};
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, static_cast<int>(sizeof(bus)) - 1, dev) != hipSuccess)
+        (void)hipGetLastError();
+    return "\"device\": " + std::to_string(dev) + ", \"pci_bus_id\": \"" + bus + "\"";
+}
+
+std::string Communicator::describe() const {
+    return "{\"transport\": \"host-staged / in-process (rehearsal)\", \"ranks\": " + std::to_string(size()) + ", \"rank\": " +
+           std::to_string(rank()) + ", " + describeCurrentDevice() + ", \"version\": null}";
+}
+
 namespace {
 
 void ncclCheck(ncclResult_t r, const char* what) {
@@ -61,6 +75,19 @@ public:
     }
     void groupStart() override { ncclCheck(ncclGroupStart(), "ncclGroupStart"); }
     void groupEnd() override { ncclCheck(ncclGroupEnd(), "ncclGroupEnd"); }
+    std::string describe() const override {
+        // asked of the communicator, not remembered from the constructor's arguments
+        int count = -1, user = -1, dev = -1, version = 0;
+        (void)ncclCommCount(comm_, &count);
+        (void)ncclCommUserRank(comm_, &user);
+        (void)ncclCommCuDevice(comm_, &dev);
+        (void)ncclGetVersion(&version);
+        char bus[32] = {0};
+        if (dev < 0 || hipDeviceGetPCIBusId(bus, static_cast<int>(sizeof(bus)) - 1, dev) != hipSuccess) (void)hipGetLastError();
+        return "{\"transport\": \"rccl\", \"ranks\": " + std::to_string(count) + ", \"rank\": " + std::to_string(user) +
+               ", \"device\": " + std::to_string(dev) + ", \"pci_bus_id\": \"" + bus + "\", \"version\": " +
+               std::to_string(version) + "}";
+    }
 
 private:
     ncclComm_t comm_ = nullptr;
@@ -115,7 +142,8 @@ public:
     // memories in the in-process form).  slots / flags of all ranks are already addressable from here.
     PeerCommunicator(int rank, int world, size_t slotBytes, std::shared_ptr<PeerMemory> own,
                      std::vector<std::shared_ptr<PeerMemory>> keep, const std::vector<void*>& slots,
-                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped, bool waitInFront /* ranks share a GPU */)
+                     const std::vector<uint32_t*>& flags, std::vector<void*> ipcMapped, bool waitInFront /* SOME ranks share a GPU */,
+                     bool oneDevice /* ALL ranks sit on one GPU */)
         : rank_(rank), world_(world), own_(std::move(own)), keep_(std::move(keep)), ipcMapped_(std::move(ipcMapped)) {
         // The exchange's signal + wait is a one-wave launch in front of its consumer (measured cheaper than consumers
         // that poll, include/emf_hip.h emf_peer_t::waitInFront); EMF_PEER_WAIT_IN_FRONT=0 lets the consumers poll
@@ -123,7 +151,9 @@ public:
         g_.waitInFront = 1u;
         // ranks on distinct devices: system-scope release / acquire around every flag (peer_core.hpp "Memory ordering":
         // the fence-free protocol has only been validated with the ranks on one device)
-        g_.systemFences = (!waitInFront && world > 1) ? 1u : 0u;
+        // -- decided by "every rank on ONE device", not by "some two ranks share one": in a mixed layout (4 ranks over 2
+        // GPUs) some pairs do sit on distinct devices
+        g_.systemFences = (world > 1 && !oneDevice) ? 1u : 0u;
         if (const char* w = debugEnv("EMF_PEER_WAIT_IN_FRONT")) g_.waitInFront = (w[0] == '0' && !waitInFront) ? 0u : 1u;
         g_.rank = rank;
         g_.world = world;
@@ -198,6 +228,11 @@ public:
                  "peerWaitCopyFromSlots");
     }
     uint64_t exchangesIssued() const override { return seq_; }
+    std::string describe() const override {
+        return "{\"transport\": \"peer-write (hipIpc-mapped receive buffers)\", \"ranks\": " + std::to_string(world_) +
+               ", \"rank\": " + std::to_string(rank_) + ", " + describeCurrentDevice() + ", \"version\": null, \"system_fences\": " +
+               std::to_string(g_.systemFences) + ", \"wait_in_front\": " + std::to_string(g_.waitInFront) + "}";
+    }
     const emf_peer_t* peerGroup() const override { return &g_; }
     uint32_t beginPeerExchange(Stream&) override { return begin(0); }
     void check() override {
@@ -263,6 +298,7 @@ public:
         inGroup_ = false;
     }
     uint64_t exchangesIssued() const override { return exchanges_; }
+    std::string describe() const override { return inner_->describe(); }
     const emf_peer_t* peerGroup() const override { return inner_->peerGroup(); }
     uint32_t beginPeerExchange(Stream& s) override {
         delay(s);
@@ -443,7 +479,7 @@ std::vector<std::shared_ptr<Communicator>> makePeerCommunicatorsLocal(int worldS
     std::vector<std::shared_ptr<Communicator>> out;
     for (int r = 0; r < worldSize; ++r)
         out.push_back(std::make_shared<PeerCommunicator>(r, worldSize, slotBytes, mem[r], mem, slots, flags,
-                                                         std::vector<void*>(), worldSize > 1));
+                                                         std::vector<void*>(), worldSize > 1, true));
     return out;
 }
 
@@ -471,9 +507,13 @@ std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, si
         throw HipError("makePeerCommunicator: the bootstrap all-gather failed", EMF_E_ARG);
     std::vector<void*> slots(boot.world), mapped;
     std::vector<uint32_t*> flags(boot.world);
-    bool shared = false;
+    bool shared = false, oneDevice = true;  // some pair of ranks on one GPU / all ranks on one GPU
     for (int p = 0; p < boot.world; ++p)
-        for (int q = p + 1; q < boot.world; ++q) shared = shared || std::strncmp(all[p].bus, all[q].bus, sizeof(mine.bus)) == 0;
+        for (int q = p + 1; q < boot.world; ++q) {
+            const bool same = std::strncmp(all[p].bus, all[q].bus, sizeof(mine.bus)) == 0;
+            shared = shared || same;
+            oneDevice = oneDevice && same;
+        }
     for (int p = 0; p < boot.world; ++p) {
         if (p == boot.rank) {
             slots[p] = own->rx;
@@ -489,7 +529,7 @@ std::shared_ptr<Communicator> makePeerCommunicator(const PeerBootstrap& boot, si
         mapped.push_back(b);
     }
     return std::make_shared<PeerCommunicator>(boot.rank, boot.world, slotBytes, own,
-                                              std::vector<std::shared_ptr<PeerMemory>>(), slots, flags, mapped, shared);
+                                              std::vector<std::shared_ptr<PeerMemory>>(), slots, flags, mapped, shared, oneDevice);
 }
 
 std::shared_ptr<Communicator> makeDelayedCommunicator(std::shared_ptr<Communicator> inner, int microseconds) {

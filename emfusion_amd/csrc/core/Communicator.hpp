@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "types.hpp"
@@ -57,7 +58,16 @@ public:
     /** Throws (EMF_E_PEER_TIMEOUT) if an exchange enqueued earlier has timed out on the device; call after a
      *  synchronisation.  Transports that report failures at the call itself do nothing. */
     virtual void check() {}
+    /**
+     * What the transport itself reports about this rank -- not what the launcher asked for: a JSON object
+     * {"transport", "ranks" (ncclCommCount for RCCL), "rank", "device" (ordinal the communicator is bound to),
+     * "pci_bus_id", "version"}.  bench.py gathers one per rank into the multi-GPU line (`rccl`), so that the first run
+     * on a real node shows whether N ranks really sat on N distinct devices.
+     */
+    virtual std::string describe() const;
 };
+/** {"device": current HIP device ordinal, "pci_bus_id": "..."} fields of describe(), shared by the transports. */
+std::string describeCurrentDevice();
 
 /** Rank that owns an object volume: round-robin by (1-based) object id. */
 inline int ownerOf(int objectId, int worldSize) { return (objectId - 1) % worldSize; }

@@ -21,6 +21,7 @@
 #include "Readers.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,7 +39,6 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
       background(_params.globalVolumeDims, _params.globalVoxelSize,
                  _params.globalRelTruncDist * _params.globalVoxelSize, _params.volumePose,
                  _params.tsdfParams, _params.frameSize, gradients),
-      depthUpload(_params.frameSize),
       depthFiltered(_params.frameSize),
       invLambda(_params.frameSize),
       points(_params.frameSize),
@@ -102,6 +102,8 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
         if (marchLanes != 1 && marchLanes != 2 && marchLanes != 4)
             throw HipError(std::string("EMFusion: EMF_MARCH_ROWS=") + mr + " (1, 2 or 4 lanes per background ray)", EMF_E_ARG);
     }
+    const char* au = std::getenv("EMF_ASYNC_UPLOAD");
+    asyncUpload = !(au && au[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
     useLambdaTable = !(lt && lt[0] == '0');
     // sharded mode: the two cross-rank exchanges are used.  EMF_FORCE_SHARDED=1 turns it on for a
@@ -155,6 +157,11 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
 EMFusion::~EMFusion() {
     (void)hipDeviceSynchronize();
     for (auto& e : stamps) (void)hipEventDestroy(e);
+    for (auto& u : uploadSlots) {
+        if (u.pinned) (void)hipHostFree(u.pinned);
+        if (u.copied) (void)hipEventDestroy(u.copied);
+        if (u.frameDone) (void)hipEventDestroy(u.frameDone);
+    }
     if (visCountsHost) (void)hipHostFree(visCountsHost);
     if (visibleHost) (void)hipHostFree(visibleHost);
     if (trackStatesHost) (void)hipHostFree(trackStatesHost);
@@ -461,11 +468,48 @@ void EMFusion::processFrame(const RGBD& frame) {
     if (frame.size.width != params.frameSize.width || frame.size.height != params.frameSize.height)
         throw HipError("EMFusion::processFrame: frame size differs from Params::frameSize",
                        EMF_E_SHAPE);
-    depthUpload.upload(frame.depth, main);  // reference EMFusion.cpp:72
+    const auto t0 = std::chrono::steady_clock::now();
+    int slot = 0;
+    const emf_image_t depthDev = stageDepth(frame.depth, slot);  // reference EMFusion.cpp:72
+    uploadHostSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ++uploads;
     FrameInputs in = pending;
     in.preprocessDepth = true;              // reference EMFusion.cpp:74
     if (!maskPath.empty() && frameCount % params.maskRCNNFrames == 0) loadPreprocMasks(in);  // EMFusion.cpp:99-101, 375-395
-    runSchedule(depthUpload.view(), in);
+    runSchedule(depthDev, in);
+    if (asyncUpload) {  // the slot's device image may be overwritten once this frame's kernels are through
+        UploadSlot& u = uploadSlots[slot];
+        hipCheck(hipEventRecord(u.frameDone, main.get()), "hipEventRecord(frame done)");
+        u.frameDoneValid = true;
+    }
+}
+
+// Hand the host depth map to the device; returns the view the frame's kernels read.
+emf_image_t EMFusion::stageDepth(const float* host, int& slot) {
+    slot = static_cast<int>(uploads & 1u);
+    UploadSlot& u = uploadSlots[slot];
+    const size_t bytes = static_cast<size_t>(params.frameSize.area()) * sizeof(float);
+    if (u.dev.empty()) {
+        u.dev = DeviceImage<float>(params.frameSize);
+        hipCheck(hipHostMalloc(reinterpret_cast<void**>(&u.pinned), bytes, hipHostMallocDefault), "hipHostMalloc(depth staging)");
+        hipCheck(hipEventCreateWithFlags(&u.copied, hipEventDisableTiming), "hipEventCreate");
+        hipCheck(hipEventCreateWithFlags(&u.frameDone, hipEventDisableTiming), "hipEventCreate");
+    }
+    const emf_image_t view = u.dev.view();
+    if (!asyncUpload) {  // pageable source on the frame's stream: the runtime stages it, this call blocks
+        hipCheck(hipMemcpyAsync(u.dev.ptr(), host, bytes, hipMemcpyHostToDevice, main.get()), "hipMemcpyAsync H2D");
+        return view;
+    }
+    // the staging buffer is free once the copy of two frames ago has left it (long ago: no wait in practice)
+    if (u.copiedValid) hipCheck(hipEventSynchronize(u.copied), "hipEventSynchronize(depth staging)");
+    std::memcpy(u.pinned, host, bytes);
+    // ... and the device image once the frame of two frames ago is through with it
+    if (u.frameDoneValid) hipCheck(hipStreamWaitEvent(copyStream.get(), u.frameDone, 0), "hipStreamWaitEvent(frame done)");
+    hipCheck(hipMemcpyAsync(u.dev.ptr(), u.pinned, bytes, hipMemcpyHostToDevice, copyStream.get()), "hipMemcpyAsync H2D (pinned)");
+    hipCheck(hipEventRecord(u.copied, copyStream.get()), "hipEventRecord(depth copied)");
+    u.copiedValid = true;
+    hipCheck(hipStreamWaitEvent(main.get(), u.copied, 0), "hipStreamWaitEvent(depth copied)");
+    return view;
 }
 
 void EMFusion::processFrame(const emf_image_t& depthDev, const FrameInputs& in) {

@@ -277,6 +277,9 @@ public:
     bool overlapsBackground() const { return overlapUsable(); }
     std::vector<int> objectIds() const { return allIds; }
     bool ownsObject(int id) const;
+    /** Host seconds processFrame(const RGBD&) has spent so far handing the depth maps to the device (staging memcpy +
+     *  enqueue with the double-buffered upload; the blocking copy with EMF_ASYNC_UPLOAD=0), and the number of frames. */
+    std::pair<double, uint64_t> uploadHostTime() const { return {uploadHostSeconds, uploads}; }
     const FrameTimings& lastTimings() const { return timings; }
     void enableTimings(bool on) { timingsOn = on; }
     /** Per-launch HIP-event timers (see KernelTimers.hpp); maxLaunches = 0 switches them off. */
@@ -362,7 +365,24 @@ private:
 
     // frame-sized device images (reference EMFusion.h:447-489)
     emf_image_t depth{};  // view of the current depth map
-    DeviceImage<float> depthUpload;
+    // processFrame(const RGBD&): the host depth map goes through one of TWO pinned staging buffers and, on a copy stream
+    // of its own, into one of TWO device images, so that the transfer of frame k + 1 runs while frame k's kernels do
+    // (what the reference's reader thread + upload amount to, RGBDReader.cpp:72-117, EMFusion.cpp:72); the frame's
+    // `main` stream waits for the copy's event.  EMF_ASYNC_UPLOAD=0: hipMemcpyAsync from the caller's pageable memory on
+    // `main` (rounds 1-5: the runtime stages it and the host blocks; A/B measurements).
+    struct UploadSlot {
+        DeviceImage<float> dev;
+        float* pinned = nullptr;
+        hipEvent_t copied = nullptr;     // the H2D copy out of `pinned` into `dev` is through
+        hipEvent_t frameDone = nullptr;  // the frame that read `dev` is through (recorded on `main` at its end)
+        bool copiedValid = false, frameDoneValid = false;
+    };
+    UploadSlot uploadSlots[2];
+    Stream copyStream{streamPriority("EMF_PRIO_COPY", 1)};
+    uint64_t uploads = 0;
+    bool asyncUpload = true;
+    double uploadHostSeconds = 0.0;  // host time processFrame(RGBD) spent getting the depth map on its way (sum)
+    emf_image_t stageDepth(const float* host, int& slotOut);
     std::string maskPath;                              // usePreprocMasks
     std::vector<DeviceImage<uint8_t>> preprocMaskDev;  // the instances of the last mask frame (device copies)
     std::vector<uint8_t> lastMaskVis;

@@ -818,6 +818,16 @@ int emf_fusion_object_ids(emf_fusion_t* h, int32_t* ids, int cap, int* n) {
     return EMF_OK;
 }
 
+int emf_fusion_upload_host_time(emf_fusion_t* h, double* seconds, uint64_t* frames) {
+    REQ(h);
+    REQ(seconds);
+    REQ(frames);
+    return guarded([&] {
+        const auto t = h->impl->uploadHostTime();
+        *seconds = t.first;
+        *frames = t.second;
+    });
+}
 int emf_fusion_batched_chunks(emf_fusion_t* h) { return h ? h->impl->batchedChunks() : EMF_E_NULL; }
 int emf_fusion_background_overlap(emf_fusion_t* h) { return h ? (h->impl->overlapsBackground() ? 1 : 0) : EMF_E_NULL; }
 
@@ -926,6 +936,16 @@ int emf_comm_create_delayed(emf_comm_t* inner, int microseconds, emf_comm_t** ou
         auto c = std::make_unique<emf_comm>();
         c->impl = makeDelayedCommunicator(inner->impl, microseconds);
         *out = c.release();
+    });
+}
+
+int emf_comm_describe(emf_comm_t* c, char* json, size_t cap) {
+    REQ(c);
+    REQ(json);
+    return guarded([&] {
+        const std::string s = c->impl->describe();
+        if (s.size() + 1 > cap) throw HipError("emf_comm_describe: buffer too small", EMF_E_ARG);
+        std::memcpy(json, s.c_str(), s.size() + 1);
     });
 }
 

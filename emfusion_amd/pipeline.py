@@ -155,7 +155,9 @@ def load() -> C.CDLL:
         "emf_fusion_frame_index": [vp],
         "emf_fusion_background_overlap": [vp],
         "emf_fusion_batched_chunks": [vp],
+        "emf_fusion_upload_host_time": [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "emf_fusion_owns_object": [vp, C.c_int],
+        "emf_comm_describe": [vp, C.c_char_p, C.c_size_t],
         "emf_comm_unique_id": [vp],
         "emf_comm_create": [vp, C.c_int, C.c_int, C.POINTER(vp)],
         "emf_comm_destroy": [vp],
@@ -343,6 +345,13 @@ class Communicator:
         _check("emf_comm_create_delayed", load().emf_comm_create_delayed(self._h, int(microseconds), C.byref(c._h)))
         c.rank, c.world, c._inner = self.rank, self.world, self
         return c
+
+    def describe(self) -> dict:
+        """What the transport itself reports about this rank: ranks it sees, device ordinal, PCI bus id, version."""
+        import json as _json
+        buf = C.create_string_buffer(1024)
+        _check("emf_comm_describe", load().emf_comm_describe(self._h, buf, len(buf)))
+        return _json.loads(buf.value.decode())
 
     def exchanges(self) -> int:
         """Exchanges issued so far through a delayed() communicator (0 for the others)."""
@@ -698,6 +707,12 @@ class Fusion:
 
     def background_overlap(self) -> bool:
         return load().emf_fusion_background_overlap(self._h) == 1
+
+    def upload_host_time(self):
+        """(seconds, frames): host time process_rgbd has spent handing depth maps to the device so far."""
+        s, n = C.c_double(0), C.c_uint64(0)
+        _check("emf_fusion_upload_host_time", load().emf_fusion_upload_host_time(self._h, C.byref(s), C.byref(n)))
+        return float(s.value), int(n.value)
 
     def batched_chunks(self) -> int:
         """0: per-volume path; k >= 1: batched path with k launches per stage (one per <= 32 table slots)."""

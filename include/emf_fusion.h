@@ -260,6 +260,9 @@ int emf_fusion_background_overlap(emf_fusion_t* h);
 /* Which path the frames run on: 0 = per-volume (one stream per volume, host visibility gate: EMF_PER_VOLUME=1, materialised
  * gradients), k >= 1 = batched with k launches per stage (1 up to EMF_MAX_BATCH models, then one per chunk of the table) */
 int emf_fusion_batched_chunks(emf_fusion_t* h);
+/* Host time emf_fusion_process_rgbd has spent so far handing depth maps to the device -- staging memcpy + enqueue with the
+ * double-buffered pinned upload (default), the blocking pageable copy with EMF_ASYNC_UPLOAD=0 -- and the frames it covers */
+int emf_fusion_upload_host_time(emf_fusion_t* h, double* seconds, uint64_t* frames);
 /* 1 if this rank holds object id's volume */
 int emf_fusion_owns_object(emf_fusion_t* h, int obj_id);
 
@@ -297,6 +300,10 @@ int emf_comm_gather_row_bands(emf_comm_t* c, void* dev, size_t bytes_per_row, in
  * through a delayed communicator (0 for the others). */
 int emf_comm_create_delayed(emf_comm_t* inner, int microseconds, emf_comm_t** out);
 int emf_comm_exchanges(emf_comm_t* c, uint64_t* out);
+/* What the transport reports about this rank (asked of RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice /
+ * ncclGetVersion, + the device's PCI bus id), as a JSON object in `json` (cap >= 512): {"transport", "ranks", "rank",
+ * "device", "pci_bus_id", "version"}.  bench.py --gpus N gathers one per rank into its line. */
+int emf_comm_describe(emf_comm_t* c, char* json, size_t cap);
 /* Rehearsal backend, one process per rank: collectives are staged through host memory and handed to
  * the caller's functions (0 = success), e.g. torch.distributed over gloo -- lets the N-rank job run on
  * a box with fewer than N GPUs (bench.py --comm gloo). */

@@ -12,8 +12,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # the driver's protocol (python bench.py --steps 20 --warmup 5): the summaries average over the TIMED launches only
 STEPS=${STEPS:-20}; WARMUP=${WARMUP:-5}
 export EMF_PROFILE_STEPS=$STEPS EMF_PROFILE_WARMUP=$WARMUP
-BENCH="python bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-target $ARGS"
-PMCBENCH="python bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-kernel-events --no-stats-replay --no-target $ARGS"
+BENCH="python bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-target --no-strong --no-entry $ARGS"
+PMCBENCH="python bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-kernel-events --no-stats-replay --no-target --no-strong --no-entry $ARGS"
 export EMF_PROFILE_ARGS="$ARGS"
 T=${PROFILE_TIMEOUT:-200}
 timeout $T rocprofv3 --kernel-trace --stats -d $out/trace -o t -- $BENCH > $out/trace.log 2>&1; echo "trace rc=$?"

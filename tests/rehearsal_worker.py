@@ -7,7 +7,8 @@ one process per rank, as on a node; the ranks' receive buffers are mapped into e
 exchanges are the direct peer-write ones (emf::makePeerCommunicator; waitInFront mode: a one-wave wait in front
 of every consumer).  Every rank writes DIR/rank<r>.npz: digests of its background replica and of the joint images,
 its visible set, and -- rank 0 only -- the joint images themselves.  `--world 1` runs the same 64-object scene in
-ONE process without a communicator (per-volume path: more than 32 models) as the reference of the comparison.
+ONE process without a communicator as the reference of the comparison: on the batched path, three chunks of the model
+table (round 6; the per-volume path, which this run fell back to through round 5, with EMF_PER_VOLUME=1).
 Test infrastructure (tests/test_gpu_config3_rehearsal.py); SURVEY.md 8(e)."""
 from __future__ import annotations
 
@@ -69,7 +70,7 @@ def main():
 
     def dg(a):
         return xxhash.xxh3_128(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).hexdigest()
-    out = dict(rank=rank, world=world, mine=np.array(mine), visible=np.array(vis[-1]),
+    out = dict(rank=rank, world=world, mine=np.array(mine), visible=np.array(vis[-1]), chunks=fus.batched_chunks(),
                visible_per_frame=np.array([",".join(map(str, v)) for v in vis]))
     joint = {k: fus.image(k) for k in ("segmentation", "raylengths", "bg_raylengths", "bg_assoc", "assoc_norm")}
     for k, a in joint.items():

@@ -7,7 +7,9 @@ two exchanges compute):
     rank order on every rank alike, so replicas cannot drift),
   * every rank owns its eight objects (round-robin by id) and all ranks agree on the visible set of every frame,
   * the joint segmentation / ray lengths / association normaliser equal those of ONE process running the same
-    64-object scene without any exchange (per-volume path), up to the re-ordered normaliser sum.
+    64-object scene without any exchange, up to the re-ordered normaliser sum;
+  * that ONE process runs configs[3]'s whole scene on the BATCHED path -- three chunks of the model table (round 6: more
+    than 32 models used to drop the frame to the per-volume path) -- and is byte-identical to the per-volume run.
 No scaling curve is measured here or anywhere in this repository: the ranks share one GPU."""
 import os
 import socket
@@ -39,17 +41,21 @@ def runs(dev, tmp_path_factory):
     single = subprocess.run([sys.executable, worker, "--world", "1", "--out", str(out / "single"), "--frames", str(FRAMES),
                              "--objects", str(OBJECTS)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert single.returncode == 0, single.stdout[-2000:] + single.stderr[-3000:]
+    legacy = subprocess.run([sys.executable, worker, "--world", "1", "--out", str(out / "legacy"), "--frames", str(FRAMES),
+                             "--objects", str(OBJECTS)], cwd=ROOT, env=dict(env, EMF_PER_VOLUME="1"), capture_output=True,
+                            text=True, timeout=900)
+    assert legacy.returncode == 0, legacy.stdout[-2000:] + legacy.stderr[-3000:]
     job = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={WORLD}",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, "--out",
                           str(out / "job"), "--frames", str(FRAMES), "--objects", str(OBJECTS)],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert job.returncode == 0, job.stdout[-2000:] + job.stderr[-3000:]
     ranks = [np.load(out / "job" / f"rank{r}.npz") for r in range(WORLD)]
-    return np.load(out / "single" / "rank0.npz"), ranks
+    return np.load(out / "single" / "rank0.npz"), ranks, np.load(out / "legacy" / "rank0.npz")
 
 
 def test_every_rank_owns_its_objects_and_replicas_are_bit_identical(runs):
-    _, ranks = runs
+    _, ranks, _ = runs
     for r, d in enumerate(ranks):
         assert int(d["rank"]) == r and int(d["world"]) == WORLD
         assert list(d["mine"]) == [i for i in range(1, OBJECTS + 1) if (i - 1) % WORLD == r]
@@ -65,7 +71,7 @@ def test_every_rank_owns_its_objects_and_replicas_are_bit_identical(runs):
 
 
 def test_joint_images_equal_the_single_process_run(runs):
-    single, ranks = runs
+    single, ranks, _ = runs
     r0 = ranks[0]
     assert list(single["visible_per_frame"]) == list(r0["visible_per_frame"]), "visible sets, frame by frame"
     seg, seg1 = r0["img_segmentation"], single["img_segmentation"]
@@ -79,3 +85,15 @@ def test_joint_images_equal_the_single_process_run(runs):
     assert_parity(r0["bg_tsdf_sample"], single["bg_tsdf_sample"], "background tsdf (every 8th voxel)", rtol=1e-4, atol=1e-6,
                   budget=1e-3)
     assert abs(float(r0["bg_weights_sum"]) - float(single["bg_weights_sum"])) < 1e-5 * float(single["bg_weights_sum"])
+
+
+def test_one_gpu_runs_the_whole_scene_batched_and_byte_identical_to_the_per_volume_path(runs):
+    """64 objects + background = 65 models: three launches per stage (reference EMFusion.cpp:635-670, 726-795, 865-889 loop
+    over any number of objects); same bytes as one launch per volume."""
+    single, _, legacy = runs
+    assert int(single["chunks"]) == 3 and int(legacy["chunks"]) == 0
+    assert list(single["visible_per_frame"]) == list(legacy["visible_per_frame"])
+    keys = [k for k in single.files if k.startswith("digest_")]
+    assert len(keys) >= 9
+    bad = [k for k in keys if str(single[k]) != str(legacy[k])]
+    assert not bad, bad
