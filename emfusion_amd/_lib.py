@@ -134,8 +134,6 @@ SIGNATURES = {
     "emf_hip_integrateBatchedCulled": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, _FP, C.c_uint32, _FP, _FP,
                                        _STREAM],
     "emf_hip_integrateDirtyMapBytes": [_I3],
-    "emf_hip_raycastSweepFused": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, _FP, _FP, C.c_int, _FP, _FP, _IMG, _IMG,
-                                  C.c_void_p, C.c_int, _FP, _FP, _STREAM],
     "emf_hip_integrateBatchedCulledOut": [_FP, _FP, _I3, C.c_int, _FP, _IMG, _IMG, _F9, C.c_void_p, C.c_int, _FP,
                                           C.c_uint32, _FP, _FP, _STREAM],
     "emf_hip_integratePrepareOut": [C.c_void_p, _I3, C.c_int, _FP, _STREAM],

@@ -333,14 +333,14 @@ __device__ __forceinline__ RayVolume ray_volume_of(const RaycastBatchArgs& a, in
 // MODE 2: the background with TWO lanes per ray, march_quad<2>: a workgroup = a 16x8 half tile (4 waves of 8x4 pixels x
 //         2 rows), two per tile; objects as in MODE 1.
 template <int MODE>
-__device__ __forceinline__ void raycast_block(const RaycastBatchArgs& a, int bx) {
+__global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
 #ifdef EMF_RAY_TRACE
     const unsigned long long trace_t0 = wall_clock64();
 #else
     const unsigned long long trace_t0 = 0;
 #endif
     int m, tile, sub;
-    const int role = raycast_block_role<(MODE >= 2 ? MODE : 1)>(a, bx, m, tile, sub);
+    const int role = raycast_block_role<(MODE >= 2 ? MODE : 1)>(a, blockIdx.x, m, tile, sub);
     if (role == 0) return;
     if (role == 2) {
         raycast_zero_fill(a, tile, 0, 1);
@@ -450,11 +450,6 @@ __device__ __forceinline__ void raycast_block(const RaycastBatchArgs& a, int bx)
         add_ray_stats(a.stats, r.samples, r.hit ? 1u : 0u, r.gathered, r.skipped, lane);
         trace_wave(trace_t0, r.samples, m, tile, wave, lane);
     }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(64 * kRbWaves) void k_raycast_batched(const RaycastBatchArgs a) {
-    raycast_block<MODE>(a, static_cast<int>(blockIdx.x));
 }
 
 // ---- ray far bounds ----------------------------------------------------------------------------------
@@ -998,77 +993,6 @@ __global__ __launch_bounds__(256) void k_integrate_listed_rest(const IntegrateCu
     }
 }
 
-// ---- raycast and the background's out-of-place sweep as ONE grid (round 6 experiment, EMF_FUSED_SWEEP=1) ---------------
-// Two queues give the dispatcher no order: "every slot a short march wave frees is as likely to go to a workgroup of the
-// background's integration" (round 5).  One launch whose block index selects the role does: blocks [0, rayBlocks) are the
-// raycast's (border ring, objects' footprints, interior, zero fill -- raycast_block_role's order), the blocks behind them
-// the listed sweep's, so every raycast workgroup is placed before any sweep workgroup and the sweep back-fills exactly the
-// slots the march's tail leaves.  Registers = the march's (86 VGPRs: 5 waves per SIMD for both bodies; the sweep alone is
-// compiled for 6).  The sweep is the background's only (table slot 0, out of place): what it needs travels in SweepOneArgs,
-// the two full argument blocks together exceed the 4 KiB of kernel arguments.
-struct SweepOneArgs {
-    emf_pose_t pose;  // volume -> camera
-    Img<const float> depth, invLambda;
-    int w, h;
-    M33 K;
-    bool pinhole;
-    const unsigned* list;   // entries of k_integrate_cull (slot 0 only: model bits are 0)
-    const unsigned* count;  // [0] survivors, [1] float bits of the frame's largest depth
-    float* outTsdf;
-    float* outWeights;
-    const uint8_t* dirtyPrev;
-    uint8_t* dirtyNext;
-    int deepTiles;
-};
-
-__device__ __forceinline__ void sweep_one_tile(const RaycastBatchArgs& r, const SweepOneArgs& a, unsigned e, unsigned sub,
-                                               unsigned* lds) {
-    const emf_model_t& md = r.models[0];
-    IntegrateGeom g;
-    g.depth = a.depth;
-    g.invLambda = a.invLambda;
-    g.assoc = Img<const float>{md.assoc, static_cast<size_t>(a.w) * sizeof(float)};
-    g.w = a.w;
-    g.h = a.h;
-    g.R = pose_R(a.pose);
-    g.t = pose_t(a.pose);
-    g.K = a.K;
-    g.pinhole = a.pinhole;
-    g.n = I3{md.res[0], md.res[1], md.res[2]};
-    g.voxelSize = md.voxelSize;
-    g.truncdist = md.truncdist;
-    g.maxWeight = md.maxWeight;
-    g.maxDepthBits = a.deepTiles ? a.count + 1 : nullptr;
-    const int box = static_cast<int>(a.list[e] & 0xffffffu);
-    const int nbx = (g.n.x + kBoxX - 1) / kBoxX, nby = (g.n.y + kBoxY - 1) / kBoxY;
-    const int bx = box % nbx, by = (box / nbx) % nby, bz = box / (nbx * nby);
-    const int dx = static_cast<int>(sub % EMF_INT_BOX_X), dy = static_cast<int>((sub / EMF_INT_BOX_X) % EMF_INT_BOX_Y),
-              dz = static_cast<int>(sub / (EMF_INT_BOX_X * EMF_INT_BOX_Y));
-    const int x0 = (EMF_INT_BOX_X * bx + dx) * kTileX, y0 = (EMF_INT_BOX_Y * by + dy) * kTileY,
-              z0 = (EMF_INT_BOX_Z * bz + dz) * kTileZ;
-    if (x0 < g.n.x && y0 < g.n.y && z0 < g.n.z) {  // block-uniform
-        const size_t t = tile_index(g.n, x0, y0, z0), nt = tile_count(g.n);
-        uint8_t* sp = md.signMaps ? md.signMaps + t : nullptr;
-        const int force = (a.dirtyPrev[t] ? 1 : 0) | (a.dirtyPrev[nt + t] ? 2 : 0);
-        integrate_tile<true>(g, md.tsdf, md.weights, nullptr, x0, y0, z0, lds, a.outTsdf, a.outWeights, force,
-                             a.dirtyNext + t, a.dirtyNext + nt + t, false, sp, sp ? sp + nt : nullptr,
-                             md.unseenTiles ? md.unseenTiles + t : nullptr);
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_raycast_sweep(const RaycastBatchArgs r, const SweepOneArgs s, int rayBlocks) {
-    __shared__ unsigned lds[32];
-    const int bx = static_cast<int>(blockIdx.x);
-    if (bx < rayBlocks) {
-        raycast_block<MODE>(r, bx);
-        return;
-    }
-    const unsigned j = static_cast<unsigned>(bx - rayBlocks), e = j / kBoxTiles;
-    if (e >= *s.count) return;
-    sweep_one_tile(r, s, e, j % kBoxTiles, lds);
-}
-
 // refresh the dilated flags of every model that has a flag buffer (one thread per brick)
 struct DilateBatchArgs {
     const emf_model_t* models;
@@ -1304,8 +1228,7 @@ int raycast_batched_launch(const emf_model_t* models_dev, const emf_pose_t* pose
                            const int32_t* res_host, int nmodels, int width, int height,
                            const float K[9], int useBrickFlags, int bgBandRow0, int bgBandRows,
                            const float* farBounds_dev, const float* voxelSizes_host, uint64_t* stats,
-                           emf_stream_t stream, int firstObj, int rowsPerRay, const SweepOneArgs* sweep = nullptr,
-                           unsigned sweepBlocks = 0) {
+                           emf_stream_t stream, int firstObj, int rowsPerRay) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastBatched"));
     if (bgBandRows < 0 || bgBandRow0 < 0 || bgBandRow0 % kRbTile || bgBandRows % kRbTile)
         return fail(EMF_E_ARG, "raycastBatched: band [%d, +%d) must be non-negative multiples of %d rows",
@@ -1390,17 +1313,6 @@ int raycast_batched_launch(const emf_model_t* models_dev, const emf_pose_t* pose
     const RaycastGrid g = raycast_grid(a.tilesX, a.tilesY, a.bandTiles, a.chunk, a.objStart[nmodels], nmodels, parts, firstObj);
     if (g.ringBlocks + g.objPad + g.bgBlocks + g.zeroBlocks == 0) return EMF_OK;
     const dim3 grid(static_cast<unsigned>(g.ringBlocks + g.objPad + g.bgBlocks + g.zeroBlocks));
-    if (sweep) {  // one grid: the raycast's blocks, then the background's listed sweep (k_raycast_sweep)
-        if (useBrickFlags || !offsets32) return fail(EMF_E_ARG, "raycastSweepFused: needs the wave march (no brick flags, volumes <= 4 GiB)");
-        const dim3 both(grid.x + sweepBlocks);
-        if (parts == 4)
-            hipLaunchKernelGGL(k_raycast_sweep<4>, both, dim3(256), 0, as_stream(stream), a, *sweep, static_cast<int>(grid.x));
-        else if (parts == 2)
-            hipLaunchKernelGGL(k_raycast_sweep<2>, both, dim3(256), 0, as_stream(stream), a, *sweep, static_cast<int>(grid.x));
-        else
-            hipLaunchKernelGGL(k_raycast_sweep<1>, both, dim3(256), 0, as_stream(stream), a, *sweep, static_cast<int>(grid.x));
-        return launch_status("raycastSweepFused");
-    }
     if (useBrickFlags || !offsets32)  // the wave marches address with 32-bit byte offsets
         hipLaunchKernelGGL(k_raycast_batched<0>, grid, dim3(64 * kRbWaves), 0, as_stream(stream), a);
     else if (parts == 4)
@@ -1652,87 +1564,6 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
         }
     }
     return launch_status("integrateBatchedCulled");
-}
-
-int emf_hip_raycastSweepFused(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, const int32_t* res_host,
-                              int nmodels, int width, int height, const float K[9], const float* farBounds_dev,
-                              const float* voxelSizes_host, int lanesPerBgRay, uint64_t* rayStats,
-                              const emf_pose_t* bgPoseOC_host, const emf_image_t* depth, const emf_image_t* invLambda,
-                              const emf_volume_out_t* bgOut_host, int prepared, void* scratch_dev, uint64_t* sweepStats,
-                              emf_stream_t stream) {
-    EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, "raycastSweepFused"));
-    EMF_REQUIRE_PTR(res_host);
-    EMF_REQUIRE_PTR(bgPoseOC_host);
-    EMF_REQUIRE_PTR(bgOut_host);
-    EMF_REQUIRE_PTR(scratch_dev);
-    EMF_REQUIRE_PTR(K);
-    EMF_TRY(check_image(depth, 4, "raycastSweepFused: depth"));
-    if (depth->width != width || depth->height != height) return fail(EMF_E_SHAPE, "raycastSweepFused: depth is not %d x %d", width, height);
-    if (invLambda) {
-        EMF_TRY(check_image(invLambda, 4, "raycastSweepFused: invLambda"));
-        EMF_TRY(check_same_size(depth, invLambda, "depth", "invLambda"));
-    }
-    if (lanesPerBgRay != 1 && lanesPerBgRay != 2 && lanesPerBgRay != 4)
-        return fail(EMF_E_ARG, "raycastSweepFused: %d lanes per background ray (1, 2 or 4)", lanesPerBgRay);
-    EMF_TRY(check_res(res_host));
-    if (res_host[0] % 4 != 0) return fail(EMF_E_SHAPE, "raycastSweepFused: the background's Nx = %d, needs Nx %% 4 == 0", res_host[0]);
-    if (!bgOut_host->tsdf || !bgOut_host->weights || !bgOut_host->dirtyPrev || !bgOut_host->dirtyNext)
-        return fail(EMF_E_NULL, "raycastSweepFused: tsdf / weights / dirtyPrev / dirtyNext of the second copy are all required");
-    // ---- the box list of the background (k_integrate_cull with the out-of-place rules), as emf_hip_integrateBatchedCulledOut
-    IntegrateCullArgs c;
-    c.b.models = models_dev;
-    c.b.nmodels = 1;
-    c.b.poses.p[0] = *bgPoseOC_host;
-    c.b.tileStart[0] = 0;
-    c.boxStart[0] = 0;
-    c.boxStart[1] = static_cast<int>(ceil_div(res_host[0], kBoxX)) * static_cast<int>(ceil_div(res_host[1], kBoxY)) *
-                    static_cast<int>(ceil_div(res_host[2], kBoxZ));
-    c.b.visible = nullptr;
-    c.b.stats = reinterpret_cast<unsigned long long*>(sweepStats);
-    c.b.depth = img<const float>(depth);
-    c.b.invLambda = invLambda ? img<const float>(invLambda) : Img<const float>{nullptr, 0};
-    c.b.w = width;
-    c.b.h = height;
-    c.b.K = m33_from(K);
-    c.b.pinhole = is_pinhole(c.b.K);
-    c.count = static_cast<unsigned*>(scratch_dev);
-    c.list = c.count + 4;
-    c.out = IntegrateOutTable{};
-    c.out.tsdf[0] = bgOut_host->tsdf;
-    c.out.weights[0] = bgOut_host->weights;
-    c.out.dirtyPrev[0] = bgOut_host->dirtyPrev;
-    c.out.dirtyNext[0] = bgOut_host->dirtyNext;
-    c.haveOut = 1;
-    const char* dt = std::getenv("EMF_DEEP_TILES");
-    c.deepTiles = !(dt && dt[0] == '0') ? 1 : 0;
-    if (!prepared) {
-        hipError_t e = hipMemsetAsync(c.count, 0, 2 * sizeof(unsigned), as_stream(stream));
-        if (e == hipSuccess)
-            e = hipMemsetAsync(bgOut_host->dirtyNext, 0, emf_hip_integrateDirtyMapBytes(res_host), as_stream(stream));
-        if (e != hipSuccess) {
-            set_error("raycastSweepFused: memset: %s", hipGetErrorString(e));
-            return static_cast<int>(e);
-        }
-    }
-    const unsigned total = static_cast<unsigned>(c.boxStart[1]);
-    hipLaunchKernelGGL(k_integrate_cull, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), c);
-    SweepOneArgs sw;
-    sw.pose = *bgPoseOC_host;
-    sw.depth = c.b.depth;
-    sw.invLambda = c.b.invLambda;
-    sw.w = width;
-    sw.h = height;
-    sw.K = c.b.K;
-    sw.pinhole = c.b.pinhole;
-    sw.list = c.list;
-    sw.count = c.count;
-    sw.outTsdf = bgOut_host->tsdf;
-    sw.outWeights = bgOut_host->weights;
-    sw.dirtyPrev = bgOut_host->dirtyPrev;
-    sw.dirtyNext = bgOut_host->dirtyNext;
-    sw.deepTiles = c.deepTiles;
-    return raycast_batched_launch(models_dev, poseCO_host, res_host, nmodels, width, height, K, 0, 0, 0, farBounds_dev,
-                                  voxelSizes_host, rayStats, stream, 1, lanesPerBgRay, &sw, kBoxTiles * total);
 }
 
 int emf_hip_visibilityFlags(const int32_t* visCounts, int nmodels, int visibilityThresh,

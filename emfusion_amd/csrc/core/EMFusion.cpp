@@ -102,8 +102,6 @@ EMFusion::EMFusion(const Params& _params, TSDF::Gradients gradients,
         if (marchLanes != 1 && marchLanes != 2 && marchLanes != 4)
             throw HipError(std::string("EMFusion: EMF_MARCH_ROWS=") + mr + " (1, 2 or 4 lanes per background ray)", EMF_E_ARG);
     }
-    const char* fsw = std::getenv("EMF_FUSED_SWEEP");
-    bgFused = fsw && fsw[0] == '1';
     const char* au = std::getenv("EMF_ASYNC_UPLOAD");
     asyncUpload = !(au && au[0] == '0');
     const char* lt = std::getenv("EMF_LAMBDA_TABLE");
@@ -594,12 +592,9 @@ void EMFusion::runSchedule(const emf_image_t& depthDev, const FrameInputs& in) {
             storeFgProbs();  // what obj.getFgProbVals returns at the frame's end (EMFusion.cpp:120): this E-step's look-ups
         }
         stamp(kEstep);
-        // EMF_FUSED_SWEEP=1: the background's sweep rides in the raycast's own grid instead of on `aux` beside it
-        fuseSweepNow = bgFused && overlapUsable() && !bgInFlight && !sharded && TSDF::brickFlagMode() == 0;
-        if (!fuseSweepNow) integrateBackgroundAsync();  // runs beside the raycast (see there)
+        integrateBackgroundAsync();  // runs beside the raycast (see there)
         joinFarBounds();
         raycast();
-        fuseSweepNow = false;
     } else {
         pose = in.cam_pose;
         applyObjectPoses();
@@ -758,26 +753,7 @@ void EMFusion::raycastBatched() {
         forChunks(0, n, [&](int first, int count) {
             const float* farChunk = far ? far + cells * first : nullptr;
             const float* vox = useFootprints ? voxelHost.data() + first : nullptr;
-            if (first == 0 && fuseSweepNow) {
-                if (bgBackStale) {  // an in-place integration (other path) in between: re-equalise the copies
-                    quiesce();
-                    background.resyncBack();
-                    bgBackStale = false;
-                    bgPrepared = false;
-                }
-                if (!useFarBounds || farBounds.empty()) main.waitFor(lists);  // (else joinFarBounds has: the preparation below ran there)
-                const emf_pose_t oc = toPose(pose.inv() * background.getPose());
-                const emf_image_t il = invLambda.view();
-                const emf_volume_out_t out = background.backBuffers();
-                emfCheck(emf_hip_raycastSweepFused(table, co.data(), resHost.data(), count, w, h, params.intr.val, farChunk, vox,
-                                                   marchLanes, stats, &oc, &depth, useLambdaTable ? &il : nullptr, &out,
-                                                   bgPrepared ? 1 : 0, bgCullScratch.data(), integrateStatsDev.as<uint64_t>(),
-                                                   main.abi()),
-                         "raycastSweepFused");
-                bgInFlight = true;
-                bgFusedThisFrame = true;
-                bgPrepared = false;
-            } else if (first == 0)
+            if (first == 0)
                 emfCheck(emf_hip_raycastBatchedLanes(table, co.data(), resHost.data(), count, w, h, params.intr.val,
                                                      flags, band ? std::min(rank * band, ((h + 15) / 16) * 16) : 0,
                                                      band, farChunk, vox, marchLanes, stats, main.abi()),
@@ -890,7 +866,7 @@ void EMFusion::integrateBackgroundAsync() {
 void EMFusion::joinBackground() {
     if (!bgInFlight) return;
     rebuildBackgroundList();  // (a frame without far bounds: frame 0)
-    if (!bgFusedThisFrame) main.waitOn(aux);  // the record() behind the integration kernels (fused: it ran on `main` itself)
+    main.waitOn(aux);  // the record() behind the integration kernels
     background.flip();
     tableSel ^= 1;
     bgInFlight = false;
@@ -930,29 +906,19 @@ void EMFusion::integrateBatched() {
         });
     }
     const bool overlapped = bgInFlight;
-    const bool fusedBg = bgFusedThisFrame;
-    const emf_volume_out_t fusedOut = fusedBg ? background.backBuffers() : emf_volume_out_t{};  // (before the flip)
     joinBackground();
-    bgFusedThisFrame = false;
     if (useFarBounds && !farBounds.empty()) {
         // The sign maps may have grown: rebuild the relevant-tile lists the NEXT frame's far bounds read.
         // Nothing of this frame needs them: with the streams in use they go to `lists`, behind the
         // integration above (the background's own list went there behind its integration already).
         bool waited = false;
-        forChunks(overlapped && !fusedBg ? 1 : 0, n, [&](int from, int count) {
+        forChunks(overlapped ? 1 : 0, n, [&](int from, int count) {
             if (chunkMask(listSlot, from, count) == 0) return;  // no model of this chunk keeps a list
             if (!waited) lists.waitFor(main);
             waited = true;
             emfCheck(emf_hip_updateRelevantTiles(currentTable() + from, resHost.data() + 3 * from, count, lists.abi()),
                      "updateRelevantTiles");
         });
-        if (fusedBg) {  // clear, off everybody's path, what the NEXT fused call wants clean (as integrateBackgroundAsync does on `aux`)
-            if (!waited) lists.waitFor(main);
-            emf_volume_out_t next = fusedOut;
-            next.dirtyNext = const_cast<uint8_t*>(fusedOut.dirtyPrev);
-            emfCheck(emf_hip_integratePrepareOut(&next, resHost.data(), 1, bgCullScratch.data(), lists.abi()), "integratePrepareOut");
-            bgPrepared = true;
-        }
     }
 }
 

@@ -485,11 +485,6 @@ private:
     // EMF_BG_OVERLAP=0 keeps the reference's sequence raycast -> integrate (A/B measurements).
     bool bgOverlap = true;
     bool bgInFlight = false;        // the out-of-place integration of this frame has been enqueued
-    // EMF_FUSED_SWEEP=1 (round 6 experiment): the background's out-of-place sweep rides in the raycast's grid
-    // (emf_hip_raycastSweepFused) instead of running on `aux` beside it
-    bool bgFused = false;
-    bool bgFusedThisFrame = false;  // ... and did so this frame: its list rebuild / next-call preparation are still owed
-    bool fuseSweepNow = false;      // runSchedule -> raycastBatched: this raycast carries the background's sweep
     bool bgBackStale = false;       // the background was integrated in place: the copies differ
     // the background's sweep yields to the raycast when both have workgroups to place (its long chains should
     // start as early as they can): lowest queue priority for the second stream (+1 % frames/s)

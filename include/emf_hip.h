@@ -588,19 +588,6 @@ int emf_hip_integrateBatchedCulledOut(const emf_model_t* models_dev, const emf_p
 int emf_hip_integratePrepareOut(const emf_volume_out_t* out_host, const int32_t* res_host, int nmodels,
                                 void* scratch_dev, emf_stream_t stream);
 
-/* The raycast of all models AND the background's out-of-place integration (emf_hip_integrateBatchedCulledOut for table slot 0)
- * as ONE grid: the raycast's workgroups come first in the grid, the listed sweep's behind them, so the dispatcher places
- * every march workgroup before any sweep workgroup and the sweep back-fills the slots the march's tail leaves (two streams
- * give it no order).  Same results as the two calls.  Round 6 experiment (EMF_FUSED_SWEEP=1 in emf::EMFusion; measured in
- * DESIGN.md 5.3).  bgPoseOC_host: volume -> camera of slot 0; bgOut_host / prepared / scratch_dev as in
- * emf_hip_integrateBatchedCulledOut with nmodels = 1. */
-int emf_hip_raycastSweepFused(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, const int32_t* res_host,
-                              int nmodels, int width, int height, const float K[9], const float* farBounds_dev,
-                              const float* voxelSizes_host, int lanesPerBgRay, uint64_t* rayStats,
-                              const emf_pose_t* bgPoseOC_host, const emf_image_t* depth, const emf_image_t* invLambda,
-                              const emf_volume_out_t* bgOut_host, int prepared, void* scratch_dev, uint64_t* sweepStats,
-                              emf_stream_t stream);
-
 /* visible_dev[slot] = (slot == 0) ? 1 : (visCounts[slot - 1] > visibilityThresh)  for
  * slot < nmodels (EMFusion.cpp:778-791): turns compositeRaycast's counts into the gate above.
  * countsMirror: NULL, or nmodels - 1 int32 in device-visible HOST memory (hipHostMalloc) that receive

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # bounds, ... -- are read by -DEMF_DEBUG_SWITCHES builds only, core/types.hpp debugEnv)
 SWITCHES = [("EMF_PER_VOLUME", "1"), ("EMF_INT_CULL", "0"), ("EMF_LAMBDA_TABLE", "0"), ("EMF_VOXEL_RCP", "0"),
             ("EMF_BG_OVERLAP", "0"), ("EMF_FAR_BOUNDS", "0"), ("EMF_UNSEEN_TILES", "0"), ("EMF_DEEP_TILES", "0"),
-            ("EMF_MARCH_ROWS", "2"), ("EMF_MARCH_ROWS", "4"), ("EMF_FUSED_SWEEP", "1")]
+            ("EMF_MARCH_ROWS", "2"), ("EMF_MARCH_ROWS", "4")]
 W, H = 320, 240
 
 
