@@ -279,11 +279,17 @@ Size readExr(const std::string& path, std::vector<float>& pixels, const std::str
     const int nblocks = (h + perBlock - 1) / perBlock;
     if (pos > raw.size() || 8 * static_cast<size_t>(nblocks) > raw.size() - pos)
         throw std::runtime_error(path + ": truncated EXR offset table");
-    // the image is sized from a 16-byte header field: before allocating, hold it against what the file can carry.  A stored
-    // block never shrinks below 1 / 1032 of its lines (zlib's and the RLE's best ratios are ~1 : 1030 and 1 : 64),
-    // so w * h pixels need at least lineBytes * h / 1032 bytes of blocks behind the offset table
-    if (lineBytes == 0 || lineBytes * static_cast<size_t>(h) / 1032 > raw.size())
+    // the image is sized from a 16-byte header field: before allocating, hold it against what the file can carry behind
+    // the offset table.  A stored block never shrinks below its lines / ratio: uncompressed (NONE) not at all, the RLE
+    // at best 1 : 64 (a run of 128 bytes in 2), zlib at best ~1 : 1030 -- so w * h pixels need lineBytes * h / ratio
+    // bytes of blocks, and a 16 MB file cannot ask for a 16 GiB image unless it really is all ZIP-compressed zeros.
+    // (An image larger than 2^28 pixels -- 16384 x 16384; depth maps are 0.3 - 1.2 Mpixel -- is refused outright.)
+    const size_t ratio = comp == 0 ? 1 : (comp == 1 ? 64 : 1032);
+    const size_t avail = raw.size() - pos - 8 * static_cast<size_t>(nblocks);
+    if (lineBytes == 0 || lineBytes * static_cast<size_t>(h) / ratio > avail)
         throw std::runtime_error(path + ": EXR data window is larger than the file can hold");
+    if (static_cast<size_t>(w) * static_cast<size_t>(h) > (size_t(1) << 28))
+        throw std::runtime_error(path + ": EXR data window above 2^28 pixels");
     pixels.assign(static_cast<size_t>(w) * h, 0.f);
     for (int b = 0; b < nblocks; ++b) {
         const uint64_t off = le64(r + pos + 8 * static_cast<size_t>(b));

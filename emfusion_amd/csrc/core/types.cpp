@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace emf {
@@ -366,6 +368,21 @@ void DeviceBuffer::download(void* host, const Stream& s) const {
 void DeviceBuffer::upload(const void* host, const Stream& s) const {
     if (n_) hipCheck(hipMemcpyAsync(p_, host, n_, hipMemcpyHostToDevice, s.get()),
                      "hipMemcpyAsync H2D");
+}
+
+// A switch that only -DEMF_DEBUG_SWITCHES builds read (types.hpp debugEnv) is set in the environment of a product build:
+// one line on stderr per variable and process, then ignored.
+const char* demotedSwitchSet(const char* name) {
+    if (!std::getenv(name)) return nullptr;
+    static std::mutex m;
+    static std::vector<std::string> warned;
+    std::lock_guard<std::mutex> lock(m);
+    for (const auto& w : warned)
+        if (w == name) return nullptr;
+    warned.emplace_back(name);
+    std::fprintf(stderr, "emfusion_amd: %s is set, but this build ignores it (a switch whose A/B is on record as lost; "
+                         "`make -C emfusion_amd/csrc dbg` builds libemf_fusion_dbg.so, which reads it)\n", name);
+    return nullptr;
 }
 
 }  // namespace emf

@@ -163,12 +163,12 @@ private:
 
 /** Environment switches whose A/B is on record as lost ("switchboard"): read only by builds with
  *  -DEMF_DEBUG_SWITCHES (make EXTRA_HOST=-DEMF_DEBUG_SWITCHES); the product build ignores them. */
+const char* demotedSwitchSet(const char* name);  // types.cpp: warns once per variable that is set, returns nullptr
 inline const char* debugEnv(const char* name) {
 #ifdef EMF_DEBUG_SWITCHES
     return std::getenv(name);
 #else
-    (void)name;
-    return nullptr;
+    return demotedSwitchSet(name);  // a script that still sets it A/Bs two identical configurations: say so, once
 #endif
 }
 

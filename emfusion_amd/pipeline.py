@@ -17,7 +17,8 @@ import numpy as np
 from . import devmem
 from ._lib import EmfImage, PKG_DIR, REPO_ROOT
 
-LIB_PATH = PKG_DIR / "libemf_fusion.so"
+# EMF_FUSION_VARIANT=_dbg loads libemf_fusion_dbg.so (the host classes built with -DEMF_DEBUG_SWITCHES: test infrastructure)
+LIB_PATH = PKG_DIR / ("libemf_fusion%s.so" % os.environ.get("EMF_FUSION_VARIANT", ""))
 HEADER_PATH = REPO_ROOT / "include" / "emf_fusion.h"
 
 

@@ -111,6 +111,22 @@ def test_exr_block_offsets_cannot_wrap(tmp_path):
         pipeline.read_exr(tmp_path / "wrap.exr")
 
 
+def test_exr_data_window_is_held_against_the_file_per_compression(tmp_path):
+    """a small uncompressed (NONE) file whose header claims a huge data window must not get its w * h floats
+    allocated: uncompressed blocks cannot shrink at all, RLE at best 1 : 64, ZIP ~1 : 1030."""
+    import struct
+    from tests.test_readers import write_exr
+    for comp in (0, 1):
+        write_exr(tmp_path / "a.exr", {"Z": np.ones((8, 8), np.float32)}, comp, "f")
+        raw = bytearray((tmp_path / "a.exr").read_bytes())
+        at = raw.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+        assert struct.unpack_from("<4i", raw, at) == (0, 0, 7, 7)
+        struct.pack_into("<4i", raw, at, 0, 0, 7, (2000 if comp == 0 else 60000) - 1)  # 8 x 2000 / 8 x 60000 pixels claimed
+        (tmp_path / "big.exr").write_bytes(raw)
+        with pytest.raises(pipeline.FusionError, match="larger than the file can hold|truncated"):
+            pipeline.read_exr(tmp_path / "big.exr")
+
+
 # ---- OpenEXR depth files and the Co-Fusion directory layout in C++ (reference src/utils/ImageReader.cpp) --------------
 
 def test_cpp_exr_reader_on_a_real_file():

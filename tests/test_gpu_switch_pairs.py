@@ -22,6 +22,12 @@ pytestmark = pytest.mark.gpu
 SWITCHES = [("EMF_PER_VOLUME", "1"), ("EMF_INT_CULL", "0"), ("EMF_LAMBDA_TABLE", "0"), ("EMF_VOXEL_RCP", "0"),
             ("EMF_BG_OVERLAP", "0"), ("EMF_FAR_BOUNDS", "0"), ("EMF_UNSEEN_TILES", "0"), ("EMF_DEEP_TILES", "0"),
             ("EMF_MARCH_ROWS", "2"), ("EMF_MARCH_ROWS", "4")]
+# EMF_FUSION_VARIANT=_dbg (tests/test_gpu_debug_switches.py runs this module against libemf_fusion_dbg.so): the demoted
+# switches, which only that build reads -- their paths stay compiled in and must stay exact
+if os.environ.get("EMF_FUSION_VARIANT") == "_dbg":
+    SWITCHES = [("EMF_FUSE_POINTS", "0"), ("EMF_FUSE_VISIBILITY", "0"), ("EMF_EARLY_FAR_BOUNDS", "0"), ("EMF_OBJ_CULL", "1"),
+                ("EMF_FAR_SCAN", "1"), ("EMF_RAY_FOOTPRINTS", "0"), ("EMF_BRICK_FLAGS", "1"), ("EMF_PER_VOLUME", "1"),
+                ("EMF_BG_OVERLAP", "0")]
 W, H = 320, 240
 
 
@@ -84,7 +90,8 @@ def test_every_pair_of_switches_keeps_the_bytes(scene):
     bad = [(sw, [k for k in base if base[k] != r[k]]) for sw, r in singles.items() if r != base]
     assert not bad, bad
     pairs = [(a, b) for a, b in itertools.combinations(SWITCHES, 2) if a[0] != b[0]]
-    assert len(pairs) == len(SWITCHES) * (len(SWITCHES) - 1) // 2 - 1  # (the two EMF_MARCH_ROWS settings exclude each other)
+    same_var = sum(1 for a, b in itertools.combinations(SWITCHES, 2) if a[0] == b[0])
+    assert len(pairs) == len(SWITCHES) * (len(SWITCHES) - 1) // 2 - same_var  # (two settings of one variable exclude each other)
     for a, b in pairs:
         r = _run(scene, dict([a, b]))
         diff = [k for k in base if base[k] != r[k]]

@@ -12,7 +12,10 @@ from tests.oracle_pipeline import Affine32, OraclePipeline
 
 
 def seed_object(v, fus, oid):
-    """oracle object <- the HIP run's object as it is now (geometry, pose, volumes)."""
+    """oracle object <- the HIP run's object as it is now: geometry, volumes AND POSE.  On mask frames (0, 30, ...) the
+    closed-loop oracle's object is re-seeded with this -- the mask-driven life cycle (spawn, resize with its centre shift)
+    has its own parity tests -- so the object separation between the two runs restarts from 0 there: bounds on it hold per
+    30-frame segment, the CAMERA trajectory is never re-seeded."""
     info = fus.object_info(oid)
     R, t = fus.pose(oid)
     v["n"] = tuple(info["res"])
