@@ -129,7 +129,7 @@ public:
 
     /**
      * The checked reciprocal of the voxel size (emf_hip_voxelReciprocal) is a device-side verdict
-     * (three binades of inputs, some tens of microseconds) the first time a size is seen in the process.  With deferral on,
+     * (3 x 2^23 inputs, ~20 microseconds) the first time a size is seen in the process.  With deferral on,
      * a constructor that meets a new size does not wait for it: the check is enqueued on a stream of
      * its own, the march divides (same results) and pollReciprocal() adopts the verdict once it is in.
      * emf::EMFusion turns this on after its background exists, so objects created inside a frame

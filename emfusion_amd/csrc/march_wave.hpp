@@ -13,7 +13,7 @@
 //   * loop control per wave: one ballot per iteration instead of per-lane loop bookkeeping;
 //   * p / voxelSize: a constant divisor.  q = x * r, q' = fma(fma(-q, d, x), r, q) with
 //     r = 1 / d equals the IEEE quotient for every float x with 1e-30 <= |x| <= 1e30 -- not
-//     argued but CHECKED: emf_hip_voxelReciprocal runs every mantissa of three binades through both
+//     argued but CHECKED: emf_hip_voxelReciprocal runs every mantissa of the binade [1, 2) (both signs) and of the lowest binade of the range through both
 //     forms for the given d (which decides all binades of the range: both forms commute with 2^k
 //     scaling there, abi_common.hip) and hands out r only if none differs.  Outside that range: |x| < 1e-30 gives
 //     |q| < 1e-24 either way and the following "+ (N - 1) / 2" absorbs it (N = 1: the sample is

@@ -172,7 +172,7 @@ def test_voxel_reciprocal_is_checked_and_exact(ops, dev):
 
 
 def test_short_reciprocal_check_gives_the_exhaustive_verdict(ops, dev):
-    """The product's check sweeps three binades (abi_common.hip, k_check_reciprocal); its verdict must be the one of
+    """The product's check sweeps 3 x 2^23 inputs (abi_common.hip, k_check_reciprocal); its verdict must be the one of
     the sweep over all 2^32 bit patterns -- for the sizes the configurations use, the objects' 2 * extent / N, the
     edges of the accepted range, a thousand random sizes, log-uniform over it, and the divisors whose mantissa is all ones
     (the known exception of the Markstein correction this form is: its only candidates for a rejection)."""
