@@ -21,13 +21,18 @@ def free_port():
         return s.getsockname()[1]
 
 
+# objects of the strong-scaling sub-run: with 2 ranks 64 (configs[3]'s count: 32 objects + the background = 33 table slots per
+# rank, i.e. the SHARDED path in two chunks of the model table), with 3 ranks 12
+STRONG = {2: 64, 3: 12}
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_runs_with_several_ranks(dev, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(ROOT / "bench.py"),
            "--gpus", str(world), "--steps", "6", "--warmup", "3", "--bg-res", "128", "--bg-voxel", "0.04",
            "--obj-res", "32", "--objects-per-gpu", "2", "--width", "320", "--height", "240",
-           "--no-cpu-baseline", "--comm", "gloo", "--strong-objects", "12"]
+           "--no-cpu-baseline", "--comm", "gloo", "--strong-objects", str(STRONG[world])]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -56,8 +61,9 @@ def test_bench_runs_with_several_ranks(dev, world):
     assert all(e["objects"] == 2 for e in pr)
     # ... and the strong-scaling sub-run: a FIXED scene split over the ranks
     st = d["strong_scaling"]
-    assert st["scaling"] == "strong" and st["objects_total"] == 12 and st["n_gpus"] == world and st["value"] > 0
-    assert sum(st["objects_per_gpu"]) == 12 and max(st["objects_per_gpu"]) - min(st["objects_per_gpu"]) <= 1
+    assert st["scaling"] == "strong" and st["objects_total"] == STRONG[world] and st["n_gpus"] == world and st["value"] > 0
+    assert sum(st["objects_per_gpu"]) == STRONG[world] and max(st["objects_per_gpu"]) - min(st["objects_per_gpu"]) <= 1
+    assert st["launches_per_stage"] == (2 if world == 2 else 1)
     assert d["config"]["path"] == "batched"
 
 
