@@ -476,12 +476,21 @@ void EMFusion::processFrame(const RGBD& frame) {
     FrameInputs in = pending;
     in.preprocessDepth = true;              // reference EMFusion.cpp:74
     if (!maskPath.empty() && frameCount % params.maskRCNNFrames == 0) loadPreprocMasks(in);  // EMFusion.cpp:99-101, 375-395
-    runSchedule(depthDev, in);
-    if (asyncUpload) {  // the slot's device image may be overwritten once this frame's kernels are through
+    // the slot's device image may be overwritten once this frame's kernels are through -- also those a frame that
+    // throws half-way has already enqueued
+    auto markDone = [&]() {
+        if (!asyncUpload) return;
         UploadSlot& u = uploadSlots[slot];
-        hipCheck(hipEventRecord(u.frameDone, main.get()), "hipEventRecord(frame done)");
-        u.frameDoneValid = true;
+        if (hipEventRecord(u.frameDone, main.get()) == hipSuccess) u.frameDoneValid = true;
+        else (void)hipGetLastError();
+    };
+    try {
+        runSchedule(depthDev, in);
+    } catch (...) {
+        markDone();
+        throw;
     }
+    markDone();
 }
 
 // Hand the host depth map to the device; returns the view the frame's kernels read.
