@@ -476,7 +476,11 @@ def main():
             if par is not None and not par.get("ok"):
                 print("bench.py: sharded_parity FAILED -- the sharded frames differ from the single-rank frames: " + json.dumps(par),
                       file=sys.stderr, flush=True)
-    if not args.no_strong and not args.track and args.strong_objects > 0:
+    if not args.no_strong and not args.track and args.strong_objects > 0 and comm is not None and \
+            args.strong_objects > 32 * world:
+        if rank == 0:  # (one rank with --force-sharded: 64 local objects)
+            result["strong_scaling"] = {"skipped": f"the sharded path takes <= 32 objects per rank ({args.strong_objects} over {world})"}
+    elif not args.no_strong and not args.track and args.strong_objects > 0:
         strong = bench_extras.strong_scaling(args, pipeline, ops, DeviceArray, prm, comm, dist, rank, world, synth_factory,
                                              depth_broadcast, args.strong_objects)
         if rank == 0:
