@@ -111,6 +111,7 @@ SIGNATURES = {
     "emf_hip_pointStatsScratchBytes": [],
     "emf_hip_maskedPointStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _STREAM],
     "emf_hip_maskOverlap": [_IMG, _IMG, _FP, _STREAM],
+    "emf_hip_maskAssociationMassBytes": [],
     "emf_hip_maskAssociationMass": [_IMG, _IMG, _IMG, _FP, _STREAM],
     "emf_hip_carveMask": [_IMG, _IMG, C.c_int, _IMG, _FP, _STREAM],
     "emf_hip_objectExtentStats": [_IMG, _IMG, _F9, _F9, _FP, _FP, _FP, _I3, C.c_float, _FP, _FP, _STREAM],
@@ -247,6 +248,7 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.emf_hip_relevantTileBytes.restype = C.c_size_t
     lib.emf_hip_peerBufferBytes.restype = C.c_size_t
     lib.emf_hip_peerRaycastSlotBytes.restype = C.c_size_t
+    lib.emf_hip_maskAssociationMassBytes.restype = C.c_size_t
     lib.emf_hip_last_error_string.argtypes = []
     lib.emf_hip_last_error_string.restype = C.c_char_p
     return lib

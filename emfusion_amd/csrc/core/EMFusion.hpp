@@ -427,10 +427,10 @@ private:
     };
     static SavedVolumes saveVolumes(ObjTSDF& obj);
     std::map<int, SavedVolumes> savedVolumes;              // id -> volumes of objects deleted while the log was on
-    DeviceBuffer massDev;
+    DeviceBuffer massDev;                      // one emf_hip_maskAssociationMassBytes() block per object (cleanUpObjs)
     void deleteObj(int id);
     void ensureLifecycleBuffers();
-    void* lifecycleHost = nullptr;  // pinned: emf_point_stats_t / 513 x u32
+    void* lifecycleHost = nullptr;  // pinned: emf_point_stats_t / 513 x u32 / EMF_MAX_MODELS x emf_mask_mass_t
 
     // ---- tracking (SURVEY f-1) ----
     void trackModels(int first, int count);    // LM-ICP of table slots [first, first + count)

@@ -62,8 +62,9 @@ void EMFusion::ensureLifecycleBuffers() {
     statsScratch = DeviceBuffer(emf_hip_pointStatsScratchBytes());
     statsDev = DeviceBuffer(sizeof(emf_point_stats_t));
     overlapDev = DeviceBuffer(513 * sizeof(uint32_t));
-    massDev = DeviceBuffer(sizeof(emf_mask_mass_t));
-    hipCheck(hipHostMalloc(&lifecycleHost, 513 * sizeof(uint32_t), hipHostMallocDefault),
+    massDev = DeviceBuffer(8 * emf_hip_maskAssociationMassBytes());
+    static_assert(EMF_MAX_MODELS * sizeof(emf_mask_mass_t) >= 513 * sizeof(uint32_t), "the larger of the two uses");
+    hipCheck(hipHostMalloc(&lifecycleHost, EMF_MAX_MODELS * sizeof(emf_mask_mass_t), hipHostMallocDefault),
              "hipHostMalloc");
 }
 
@@ -308,27 +309,39 @@ void EMFusion::deleteObj(int id) {  // reference EMFusion.cpp:982-989
 
 std::vector<int> EMFusion::cleanUpObjs(bool maskFrame, const std::map<int, emf_image_t>& matches) {
     if (sharded) throw HipError("EMFusion::cleanUpObjs: not available on the sharded path", EMF_E_ARG);
-    refreshVisibleFromDevice();  // the host copy of vis_objs decides (one synchronisation)
     std::set<int> spurious;
     if (maskFrame)
         for (const auto& obj : objects)
             if (obj.getExProb() < params.existenceThresh) spurious.insert(obj.getID());
     ensureLifecycleBuffers();
+    // The association mass of EVERY object of this rank is enqueued before the host waits for anything: ONE
+    // synchronisation per frame then yields both the visible set (it decides whose mass counts, EMFusion.cpp:936) and
+    // the masses (rounds 3-5: one wait for the visible set, then a launch, a copy and a wait per visible object).
+    const size_t nobj = objects.size();
+    const size_t stride = emf_hip_maskAssociationMassBytes();
+    if (massDev.bytes() < nobj * stride) massDev = DeviceBuffer(std::max(nobj, size_t(8)) * stride);
+    emf_mask_mass_t* const massHost = static_cast<emf_mask_mass_t*>(lifecycleHost);  // pinned, EMF_MAX_MODELS entries
+    size_t k = 0;
     for (const auto& obj : objects) {
-        const int id = obj.getID();
-        if (!vis_objs.count(id)) continue;
-        const ObjImages& im = objImages.at(id);
+        const ObjImages& im = objImages.at(obj.getID());
         const emf_image_t seg = im.modelSegmentation.view(), assoc = im.associationWeights.view();
-        auto it = matches.find(id);
+        auto it = matches.find(obj.getID());
         emfCheck(emf_hip_maskAssociationMass(&seg, it == matches.end() ? nullptr : &it->second, &assoc,
-                                             massDev.as<emf_mask_mass_t>(), main.abi()),
+                                             reinterpret_cast<emf_mask_mass_t*>(static_cast<char*>(massDev.data()) + k * stride),
+                                             main.abi()),
                  "maskAssociationMass");
-        hipCheck(hipMemcpyAsync(lifecycleHost, massDev.data(), sizeof(emf_mask_mass_t),
-                                hipMemcpyDeviceToHost, main.get()),
-                 "hipMemcpyAsync");
-        main.waitForCompletion();
-        const emf_mask_mass_t mm = *static_cast<emf_mask_mass_t*>(lifecycleHost);
-        if (params.assocThresh * static_cast<float>(mm.count) > mm.sum) spurious.insert(id);
+        ++k;
+    }
+    if (nobj)  // the answers (first entry of every object's block) in one strided copy
+        hipCheck(hipMemcpy2DAsync(massHost, sizeof(emf_mask_mass_t), massDev.data(), stride, sizeof(emf_mask_mass_t), nobj,
+                                  hipMemcpyDeviceToHost, main.get()),
+                 "hipMemcpy2DAsync(mask masses)");
+    main.waitForCompletion();
+    refreshVisibleFromDevice();  // the host copy of vis_objs decides (the stream is idle: no further wait)
+    k = 0;
+    for (const auto& obj : objects) {
+        const emf_mask_mass_t mm = massHost[k++];
+        if (vis_objs.count(obj.getID()) && params.assocThresh * static_cast<float>(mm.count) > mm.sum) spurious.insert(obj.getID());
     }
     std::vector<int> deleted;
     for (auto it = objects.begin(); it != objects.end();) {

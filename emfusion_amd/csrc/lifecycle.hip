@@ -307,32 +307,27 @@ struct MassArgs {
     emf_mask_mass_t* out;
 };
 
-// one workgroup, fixed summation order (deterministic); the image is small and this runs once per
-// visible object on mask frames
-__global__ __launch_bounds__(1024) void k_mask_mass(const MassArgs a) {
-    __shared__ double sums[16];
-    __shared__ unsigned counts[16];
-    const size_t n = static_cast<size_t>(a.w) * a.h;
+// Two launches, fixed summation order (deterministic).  cleanUpObjs runs in EVERY frame of the reference's entry point,
+// once per visible object, with the host waiting for the answer: the one-workgroup form of rounds 3-5 (1024 lanes x 300
+// pixels each, an integer division per pixel) took 199 us of a 2.1 ms tracked frame (round 6, kernel trace of
+// `bench.py --track`).  Now kMassBlocks workgroups take bands of whole image rows (no division; a lane's pixels in row
+// order, a wave's lanes by the xor tree, the block's waves in index order) and leave a partial each behind out[0];
+// k_mask_mass_finish adds the partials in block order.
+constexpr int kMassBlocks = 240;
+__global__ __launch_bounds__(256) void k_mask_mass(const MassArgs a) {
+    __shared__ double sums[4];
+    __shared__ unsigned counts[4];
+    const int rows = (a.h + kMassBlocks - 1) / kMassBlocks;
+    const int y0 = blockIdx.x * rows, y1 = min(y0 + rows, a.h);
     double s = 0.0;
     unsigned c = 0;
-    for (size_t i0 = threadIdx.x; i0 < n; i0 += 1024 * 4) {
-        float v[4];
-        bool in[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {  // loads first, then the dependent double adds
-            const size_t i = i0 + 1024 * static_cast<size_t>(j);
-            in[j] = false;
-            v[j] = 0.f;
-            if (i < n) {
-                const int y = static_cast<int>(i / a.w), x = static_cast<int>(i - static_cast<size_t>(y) * a.w);
-                in[j] = a.objSeg.row(y)[x] != 0 || (a.match.data && a.match.row(y)[x] != 0);
-                v[j] = a.assoc.row(y)[x];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (in[j]) {
-                s += static_cast<double>(v[j]);
+    for (int y = y0; y < y1; ++y) {
+        const uint8_t* seg = a.objSeg.row(y);
+        const uint8_t* mt = a.match.data ? a.match.row(y) : nullptr;
+        const float* as = a.assoc.row(y);
+        for (int x = threadIdx.x; x < a.w; x += 256)
+            if (seg[x] != 0 || (mt && mt[x] != 0)) {
+                s += static_cast<double>(as[x]);
                 ++c;
             }
     }
@@ -349,12 +344,29 @@ __global__ __launch_bounds__(1024) void k_mask_mass(const MassArgs a) {
     if (threadIdx.x == 0) {
         double ts = 0.0;
         unsigned tc = 0;
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 4; ++i) {
             ts += sums[i];
             tc += counts[i];
         }
-        a.out->count = tc;
-        a.out->sum = ts;
+        a.out[1 + blockIdx.x].count = tc;
+        a.out[1 + blockIdx.x].sum = ts;
+    }
+}
+__global__ __launch_bounds__(64) void k_mask_mass_finish(emf_mask_mass_t* out) {
+    double s = 0.0;
+    unsigned c = 0;
+    for (int b = threadIdx.x; b < kMassBlocks; b += 64) {  // (a lane's partials in block order, then the xor tree)
+        s += out[1 + b].sum;
+        c += out[1 + b].count;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if (threadIdx.x == 0) {
+        out[0].count = c;
+        out[0].sum = s;
     }
 }
 
@@ -500,9 +512,12 @@ int emf_hip_maskAssociationMass(const emf_image_t* objSeg, const emf_image_t* ma
     a.w = objSeg->width;
     a.h = objSeg->height;
     a.out = out_dev;
-    hipLaunchKernelGGL(k_mask_mass, dim3(1), dim3(1024), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_mask_mass, dim3(kMassBlocks), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_mask_mass_finish, dim3(1), dim3(64), 0, as_stream(stream), out_dev);
     return launch_status("maskAssociationMass");
 }
+
+size_t emf_hip_maskAssociationMassBytes(void) { return (1 + static_cast<size_t>(kMassBlocks)) * sizeof(emf_mask_mass_t); }
 
 int emf_hip_maskOverlap(const emf_image_t* seg, const emf_image_t* modelSeg, uint32_t* counts_dev,
                         emf_stream_t stream) {

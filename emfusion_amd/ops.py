@@ -604,7 +604,7 @@ def mask_overlap(seg, model_seg, stream=None):
 
 def mask_association_mass(obj_seg, match_mask, assoc, stream=None):
     """(count, sum) of cleanUpObjs' association test; match_mask may be None (synchronises)."""
-    out = DeviceArray.zeros((2,), np.float64)
+    out = DeviceArray.zeros((int(_L.emf_hip_maskAssociationMassBytes()) // 8,), np.float64)
     check("emf_hip_maskAssociationMass",
           _L.emf_hip_maskAssociationMass(C.byref(image_view(obj_seg)), _opt_view(match_mask),
                                          C.byref(image_view(assoc)), _ptr(out), _stream(stream)))

@@ -741,12 +741,14 @@ int emf_hip_carveMask(const emf_image_t* seg, const emf_image_t* modelSeg, int i
 /* The two numbers of EMFusion::cleanUpObjs' association test (EMFusion.cpp:936-949):
  * count = |objSeg OR matchMask| (matchMask may be NULL), sum = sum of `assoc` over those pixels
  * (double accumulation like cv::cuda::sum, fixed order).  The object is spurious if
- * assocThresh * count > sum. */
+ * assocThresh * count > sum.  out_dev: emf_hip_maskAssociationMassBytes() bytes of device memory -- the answer in
+ * out_dev[0], behind it the partials of the row bands (two launches; ABI 8: one emf_mask_mass_t used to suffice). */
 typedef struct emf_mask_mass {
     double sum;
     uint32_t count;
     uint32_t pad_;
 } emf_mask_mass_t;
+size_t emf_hip_maskAssociationMassBytes(void);
 int emf_hip_maskAssociationMass(const emf_image_t* objSeg, const emf_image_t* matchMask,
                                 const emf_image_t* assoc, emf_mask_mass_t* out_dev,
                                 emf_stream_t stream);
