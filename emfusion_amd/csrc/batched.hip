@@ -49,10 +49,6 @@ struct EstepArgs {
     Img<float> norm, objSum;
     int w, h;
     int normalize;
-    // normalize == 2 (the LAST chunk of a model list longer than EMF_MAX_BATCH, emf_hip_estepBatchedLastChunk): `models`
-    // points at slot `firstSlot` of a table of `totalModels` entries whose earlier slots hold the UN-normalised maps the
-    // earlier chunks' launches wrote; this launch adds all of them in table order and normalises all of them
-    int firstSlot, totalModels;
     // the first E-step of a frame: points from depth on the way (k_compute_points' arithmetic), stored too
     Img<const float> depth;
     Img<float> pointsOut;
@@ -103,30 +99,8 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
         wl[m][tx] = inside ? assoc_weight(am, pc) : 0.f;
     }
     __syncthreads();
-    const size_t pix = static_cast<size_t>(y) * a.w + x;
-    if (a.normalize == 2) {  // (uniform)
-        // the same add chain over the WHOLE table: the earlier chunks' maps from memory, this chunk's from LDS.  Every
-        // model lane of a pixel forms the sum itself; a barrier separates those reads from the lanes' writes of the
-        // earlier chunks' maps (the four lanes of a pixel sit in four waves)
-        const emf_model_t* const all = a.models - a.firstSlot;
-        float s = 0.f;
-        if (inside) {
-            s = all[0].assoc[pix];
-            for (int m = 1; m < a.firstSlot; ++m) s = s + all[m].assoc[pix];
-            for (int m = 0; m < a.nmodels; ++m) s = s + wl[m][tx];
-        }
-        __syncthreads();
-        if (!inside) return;
-        for (int m = threadIdx.y; m < a.firstSlot; m += kEstepLanes) {
-            const float v = all[m].assoc[pix];
-            all[m].assoc[pix] = (s != 0.f) ? v / s : 0.f;
-        }
-        for (int m = threadIdx.y; m < a.nmodels; m += kEstepLanes)
-            a.models[m].assoc[pix] = (s != 0.f) ? wl[m][tx] / s : 0.f;
-        if (threadIdx.y == 0 && a.norm.data) a.norm.row(y)[x] = s;
-        return;
-    }
     if (!inside) return;
+    const size_t pix = static_cast<size_t>(y) * a.w + x;
     if (a.normalize) {
         // sequential sum: background first, then objects in table (= ascending id) order,
         // exactly the order of the reference's add chain (EMFusion.cpp:654-657)
@@ -1070,7 +1044,7 @@ namespace {
 int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, int nmodels,
                  const emf_image_t* depth, const float* K, const emf_image_t* points, int normalize,
                  const emf_image_t* norm, const emf_image_t* objSum, emf_stream_t stream, const char* fn,
-                 const emf_peer_t* group = nullptr, uint32_t seq = 0, int firstSlot = 0) {
+                 const emf_peer_t* group = nullptr, uint32_t seq = 0) {
     EMF_TRY(check_batch(models_dev, poseCO_host, nmodels, fn));
     EMF_TRY(check_image(points, 12, "estepBatched: points"));
     EstepArgs a;
@@ -1080,9 +1054,7 @@ int estep_launch(const emf_model_t* models_dev, const emf_pose_t* poseCO_host, i
     a.points = img<const float>(points);
     a.w = points->width;
     a.h = points->height;
-    a.normalize = normalize == 2 ? 2 : (normalize ? 1 : 0);
-    a.firstSlot = firstSlot;
-    a.totalModels = firstSlot + nmodels;
+    a.normalize = normalize ? 1 : 0;
     a.norm = Img<float>{nullptr, 0};
     a.objSum = Img<float>{nullptr, 0};
     a.depth = Img<const float>{nullptr, 0};
@@ -1151,15 +1123,6 @@ int emf_hip_estepBatchedPeer(const emf_model_t* models_dev, const emf_pose_t* po
     if (!group) return fail(EMF_E_NULL, "estepBatchedPeer: group is NULL");
     return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, 0, nullptr, nullptr, stream,
                         "estepBatchedPeer", group, seq);
-}
-
-int emf_hip_estepBatchedLastChunk(const emf_model_t* table_dev, int firstSlot, const emf_pose_t* poseCO_host, int nmodels,
-                                  const emf_image_t* points, const emf_image_t* norm, emf_stream_t stream) {
-    if (!table_dev) return fail(EMF_E_NULL, "estepBatchedLastChunk: table_dev is NULL");
-    if (firstSlot < 1 || firstSlot + nmodels > EMF_MAX_MODELS)
-        return fail(EMF_E_LIMIT, "estepBatchedLastChunk: slots [%d, %d) of at most %d", firstSlot, firstSlot + nmodels, EMF_MAX_MODELS);
-    return estep_launch(table_dev + firstSlot, poseCO_host, nmodels, nullptr, nullptr, points, 2, norm, nullptr, stream,
-                        "estepBatchedLastChunk", nullptr, 0, firstSlot);
 }
 
 size_t emf_hip_unseenTileBytes(const int32_t res[3]) { return emf_hip_signMapBytes(res) / 2; }

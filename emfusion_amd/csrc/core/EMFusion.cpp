@@ -728,18 +728,14 @@ void EMFusion::estepBatched() {
     // More models than one launch takes: un-normalised likelihoods chunk by chunk (the first one forms the points on
     // its way), then ONE normalisation over all maps -- the same add chain, background first, objects in ascending id
     // (= table) order (EMFusion.cpp:654-657): the same bits as the fused launch and as the per-volume path.
-    // The last chunk's launch does that normalisation itself (emf_hip_estepBatchedLastChunk: the earlier chunks' maps
-    // from memory, its own from LDS; ten launches fewer per E-step for 65 maps).
-    const emf_image_t pv = points.view();
-    forChunks(0, n, [&](int first, int count) {
-        if (first + count < n) {
-            launchEstep(co, first, count, fromDepth && first == 0, 0, nullptr, nullptr);
-            return;
-        }
-        auto kt = ktimers.scope(KernelTimers::Assoc, pixels() * count, main);
-        emfCheck(emf_hip_estepBatchedLastChunk(currentTable(), first, co.data() + first, count, &pv, &nv, main.abi()),
-                 "estepBatchedLastChunk");
-    });
+    forChunks(0, n, [&](int first, int count) { launchEstep(co, first, count, fromDepth && first == 0, 0, nullptr, nullptr); });
+    std::vector<emf_image_t> maps;
+    maps.push_back(bg_associationWeights.view());
+    for (auto& obj : objects) maps.push_back(objImages.at(obj.getID()).associationWeights.view());
+    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
+    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), static_cast<int>(maps.size()), nullptr,
+                                          &nv, main.abi()),
+             "normalizeAssociation");
 }
 
 void EMFusion::raycastBatched() {

@@ -428,15 +428,6 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
                          const emf_image_t* points, int normalize, const emf_image_t* norm,
                          const emf_image_t* objSum, emf_stream_t stream);
 
-/* The LAST chunk of a model list longer than EMF_MAX_BATCH: likelihoods of the table slots [firstSlot, firstSlot +
- * nmodels) like emf_hip_estepBatched, then -- in the same launch -- the sum over ALL slots [0, firstSlot + nmodels) in
- * table order (the earlier slots' un-normalised maps are read from memory: their chunks' launches, normalize == 0, must
- * precede this one on the stream) and the normalisation of every map: what the chunk launches +
- * emf_hip_normalizeAssociation(nsum = nmaps) compute, same add chain, same bits, ten launches fewer for 65 maps.
- * poseCO_host: the poses of this chunk's slots.  norm: f32 W x H or NULL. */
-int emf_hip_estepBatchedLastChunk(const emf_model_t* table_dev, int firstSlot, const emf_pose_t* poseCO_host, int nmodels,
-                                  const emf_image_t* points, const emf_image_t* norm, emf_stream_t stream);
-
 /* emf_hip_computePoints + emf_hip_estepBatched in one launch, for the first E-step of a frame
  * (EMFusion.cpp:73, 79): each pixel's point is formed from `depth` with computePoints' arithmetic,
  * used, and stored to `points` (f32x3 W x H, every pixel written) for the frame's later stages. */
