@@ -166,10 +166,12 @@ void EMFusion::storeTrackWeights(int first, int count) {
     float* huber = logScratch.as<float>();
     float* track = huber + px * count;
     // the stage's states are final and the models' association maps are still the ones it tracked with
-    emfCheck(emf_hip_trackWeightImages(currentTable() + first, trackStates.as<emf_track_state_t>() + first, count, &pv, &tp,
-                                       static_cast<const char*>(trackScratch.data()) + per * first, per, huber, track,
-                                       main.abi()),
-             "trackWeightImages");
+    forChunks(first, first + count, [&](int from, int cnt) {  // (a stage of more than EMF_MAX_BATCH models ran chunk by chunk too)
+        emfCheck(emf_hip_trackWeightImages(currentTable() + from, trackStates.as<emf_track_state_t>() + from, cnt, &pv, &tp,
+                                           static_cast<const char*>(trackScratch.data()) + per * from, per,
+                                           huber + px * (from - first), track + px * (from - first), main.abi()),
+                 "trackWeightImages");
+    });
     auto it = objects.begin();
     for (int m = 0; m < count; ++m) {
         const std::vector<uint8_t> hp = pngOf(huber + px * m, static_cast<size_t>(w) * sizeof(float));
