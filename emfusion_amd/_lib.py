@@ -64,6 +64,7 @@ SIGNATURES = {
     "emf_hip_estepBatchedFromDepth": [_FP, _FP, C.c_int, _IMG, _F9, _IMG, C.c_int, _IMG, _IMG, _STREAM],
     "emf_hip_raycastBatched": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, C.c_int,
                                C.c_int, _FP, _FP, _FP, _STREAM],
+    "emf_hip_normalizeAssociationTable": [_FP, C.c_int, C.c_int, C.c_int, _FP, _STREAM],
     "emf_hip_raycastBatchedLanes": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, C.c_int,
                                     C.c_int, _FP, _FP, C.c_int, _FP, _STREAM],
     "emf_hip_raycastBatchedObjects": [_FP, _FP, _I3, C.c_int, C.c_int, C.c_int, _F9, C.c_int, _FP, _FP, _FP,

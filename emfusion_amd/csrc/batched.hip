@@ -129,6 +129,39 @@ __global__ __launch_bounds__(kEstepPixels* kEstepLanes) void k_estep(const Estep
     }
 }
 
+// Normalisation of ALL maps of a model table in one launch (model lists longer than EMF_MAX_BATCH, whose chunks' E-step
+// launches leave un-normalised likelihoods): the reference's add chain -- background, then the objects in table order
+// (EMFusion.cpp:654-657) -- one pixel per lane, the maps' values fetched eight at a time ahead of the dependent adds; then
+// every map divided (x / 0 := 0).  What emf_hip_normalizeAssociation(nsum = nmaps) computes in ceil(n / 16) + ceil(n / 16)
+// launches with the map views in its kernel arguments; here the views are the table's `assoc` pointers.
+__global__ __launch_bounds__(256) void k_assoc_normalize_table(const emf_model_t* __restrict__ models, int n,
+                                                               float* __restrict__ norm, size_t pixels) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= pixels) return;
+    float s = models[0].assoc[i];
+    int m = 1;
+    for (; m + 8 <= n; m += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = models[m + j].assoc[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = s + v[j];
+    }
+    for (; m < n; ++m) s = s + models[m].assoc[i];
+    for (m = 0; m + 8 <= n; m += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = models[m + j].assoc[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) models[m + j].assoc[i] = (s != 0.f) ? v[j] / s : 0.f;
+    }
+    for (; m < n; ++m) {
+        const float v = models[m].assoc[i];
+        models[m].assoc[i] = (s != 0.f) ? v / s : 0.f;
+    }
+    if (norm) norm[i] = s;
+}
+
 // ---- batched raycast -------------------------------------------------------------------------------
 
 struct RaycastBatchArgs {
@@ -1123,6 +1156,17 @@ int emf_hip_estepBatchedPeer(const emf_model_t* models_dev, const emf_pose_t* po
     if (!group) return fail(EMF_E_NULL, "estepBatchedPeer: group is NULL");
     return estep_launch(models_dev, poseCO_host, nmodels, depth, K, points, 0, nullptr, nullptr, stream,
                         "estepBatchedPeer", group, seq);
+}
+
+int emf_hip_normalizeAssociationTable(const emf_model_t* models_dev, int nmodels, int width, int height, float* norm_dev,
+                                      emf_stream_t stream) {
+    if (!models_dev) return fail(EMF_E_NULL, "normalizeAssociationTable: models_dev is NULL");
+    if (nmodels < 1 || nmodels > EMF_MAX_MODELS) return fail(EMF_E_LIMIT, "normalizeAssociationTable: nmodels = %d", nmodels);
+    if (width <= 0 || height <= 0) return fail(EMF_E_SHAPE, "normalizeAssociationTable: bad image size %d x %d", width, height);
+    const size_t pixels = static_cast<size_t>(width) * height;
+    hipLaunchKernelGGL(k_assoc_normalize_table, dim3(static_cast<unsigned>(ceil_div(pixels, size_t(256)))), dim3(256), 0,
+                       as_stream(stream), models_dev, nmodels, norm_dev, pixels);
+    return launch_status("normalizeAssociationTable");
 }
 
 size_t emf_hip_unseenTileBytes(const int32_t res[3]) { return emf_hip_signMapBytes(res) / 2; }

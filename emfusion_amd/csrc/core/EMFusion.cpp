@@ -729,13 +729,11 @@ void EMFusion::estepBatched() {
     // its way), then ONE normalisation over all maps -- the same add chain, background first, objects in ascending id
     // (= table) order (EMFusion.cpp:654-657): the same bits as the fused launch and as the per-volume path.
     forChunks(0, n, [&](int first, int count) { launchEstep(co, first, count, fromDepth && first == 0, 0, nullptr, nullptr); });
-    std::vector<emf_image_t> maps;
-    maps.push_back(bg_associationWeights.view());
-    for (auto& obj : objects) maps.push_back(objImages.at(obj.getID()).associationWeights.view());
-    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * maps.size(), main);
-    emfCheck(emf_hip_normalizeAssociation(maps.data(), static_cast<int>(maps.size()), static_cast<int>(maps.size()), nullptr,
-                                          &nv, main.abi()),
-             "normalizeAssociation");
+    // (one launch over the table's maps: emf_hip_normalizeAssociation would take ceil(n / 16) launches to sum and as many to divide)
+    auto kt = ktimers.scope(KernelTimers::Normalize, pixels() * n, main);
+    emfCheck(emf_hip_normalizeAssociationTable(currentTable(), n, params.frameSize.width, params.frameSize.height,
+                                               associationNorm.ptr(), main.abi()),
+             "normalizeAssociationTable");
 }
 
 void EMFusion::raycastBatched() {

@@ -428,6 +428,13 @@ int emf_hip_estepBatched(const emf_model_t* models_dev, const emf_pose_t* poseCO
                          const emf_image_t* points, int normalize, const emf_image_t* norm,
                          const emf_image_t* objSum, emf_stream_t stream);
 
+/* emf_hip_normalizeAssociation(nsum = nmaps) over the `assoc` maps of a whole model table (continuous W x H, slot 0 first)
+ * in ONE launch: the sequential sum of all maps in table order, every map divided by it (x / 0 := 0), the sum to
+ * norm_dev (continuous W x H f32, or NULL).  Finishes the chunked E-step of a model list longer than EMF_MAX_BATCH
+ * (emf_hip_estepBatched per chunk with normalize == 0).  1 <= nmodels <= EMF_MAX_MODELS.  Same bits. */
+int emf_hip_normalizeAssociationTable(const emf_model_t* models_dev, int nmodels, int width, int height, float* norm_dev,
+                                      emf_stream_t stream);
+
 /* emf_hip_computePoints + emf_hip_estepBatched in one launch, for the first E-step of a frame
  * (EMFusion.cpp:73, 79): each pixel's point is formed from `depth` with computePoints' arithmetic,
  * used, and stored to `points` (f32x3 W x H, every pixel written) for the frame's later stages. */
