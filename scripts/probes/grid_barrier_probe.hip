@@ -28,11 +28,15 @@ template <class T>
 __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(1024) void k_persist(Sync* s, float* rows, float* state, float* sink, int iters, int mode,
-                                                  int bodySleep, long long* stamps) {
+                                                  int bodySleep, long long* stamps, int stride = 1) {
+    // stride 8 (round 6): only every 8th workgroup takes part -- blocks b with b % 8 == 0 run on ONE XCD (dispatch order), so the
+    // exchange stays inside one L2: the question behind a persistent kernel for OBJECT tracking stages (few rows of pixels)
+    if (blockIdx.x % stride) return;
+    const int bid = blockIdx.x / stride;
     __shared__ int s_last;
     __shared__ float red[kCols];
     __shared__ float st[kState];
-    const int tid = threadIdx.x, nwg = gridDim.x;
+    const int tid = threadIdx.x, nwg = gridDim.x / stride;
     const long long t0 = wall_clock64();
     float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
@@ -40,8 +44,8 @@ __global__ __launch_bounds__(1024) void k_persist(Sync* s, float* rows, float* s
         for (int k = 0; k < bodySleep; ++k) __builtin_amdgcn_s_sleep(64);
         if (mode >= 1) {
             if (tid < kCols) {
-                const float v = static_cast<float>(blockIdx.x + it + tid);
-                float* dst = rows + (static_cast<size_t>(it & 1) * kCols + tid) * nwg + blockIdx.x;
+                const float v = static_cast<float>(bid + it + tid);
+                float* dst = rows + (static_cast<size_t>(it & 1) * kCols + tid) * nwg + bid;
                 if (mode == 2) *dst = v; else st_agent(dst, v);
             }
             if (mode == 2) __threadfence();
@@ -114,8 +118,8 @@ __global__ __launch_bounds__(1024) void k_persist(Sync* s, float* rows, float* s
         }
     }
     const long long t1 = wall_clock64();
-    if (tid == 0) stamps[blockIdx.x] = t1 - t0;
-    sink[blockIdx.x * 1024 + tid] = acc;
+    if (tid == 0) stamps[bid] = t1 - t0;
+    sink[bid * 1024 + tid] = acc;
 }
 
 // the same work as one launch per iteration (what the product does today), for the launch-gap figure
@@ -142,6 +146,26 @@ int main(int argc, char** argv) {
     hipMalloc(&s, sizeof(Sync)); hipMalloc(&rows, 2 * kCols * 1024 * 4); hipMalloc(&state, 2 * kState * 4);
     hipMalloc(&sink, 1024 * 1024 * 4); hipMalloc(&stamps, 1024 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 2) {  // round 6: few workgroups, spread over the XCDs (stride 1) or on one XCD (stride 8)
+        for (int stride : {1, 8})
+            for (int nwg : {2, 4, 8, 16, 32})
+                for (int body : {0, 2})
+                    for (int mode : {0, 1, 3}) {
+                        float best = 1e30f; unsigned err = 0;
+                        for (int rep = 0; rep < 3; ++rep) {
+                            hipMemset(s, 0, sizeof(Sync));
+                            hipEventRecord(e0, 0);
+                            hipLaunchKernelGGL(k_persist, dim3(nwg * stride), dim3(1024), 0, 0, s, rows, state, sink, iters, mode, body, stamps, stride);
+                            hipEventRecord(e1, 0);
+                            hipEventSynchronize(e1);
+                            float ms; hipEventElapsedTime(&ms, e0, e1); best = std::min(best, ms);
+                            Sync h; hipMemcpy(&h, s, sizeof(Sync), hipMemcpyDeviceToHost); err |= h.error;
+                        }
+                        printf("persistent stride %d nwg %2d body %d mode %d: %.2f us per iteration%s\n", stride, nwg, body, mode,
+                               1e3 * best / iters, err ? "  TIMEOUT" : "");
+                    }
+        return 0;
+    }
     for (int nwg : {64, 128, 240, 256}) {
         for (int body : {0, 8}) {
             for (int mode : {0, 1, 3, 2}) {
