@@ -79,7 +79,9 @@ def parse_args():
     ap.add_argument("--no-entry", action="store_true", help="skip the `entry_point` sub-line of the default N = 1 run")
     ap.add_argument("--no-strong", action="store_true", help="skip the `strong_scaling` sub-run (configs[3]'s scene, fixed, "
                                                              "split over the ranks)")
-    ap.add_argument("--strong-objects", type=int, default=64, help="objects of the strong-scaling scene (configs[3]: 64)")
+    ap.add_argument("--strong-objects", type=int, default=None,
+                    help="objects of the strong-scaling scene (default: configs[3]'s 64 when the run has configs[1] / [3]'s "
+                         "geometry -- 640x480, background 512^3, objects 128^3 --, none for other geometries unless given)")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip `sharded_parity` (replicas / joint images against a "
                                                              "single-rank re-run on rank 0)")
     ap.add_argument("--parity-frames", type=int, default=4)
@@ -464,6 +466,8 @@ def main():
                                   "grows with N")
     fus.close()
     import bench_extras
+    if args.strong_objects is None:
+        args.strong_objects = 64 if (W, H, args.bg_res, args.obj_res) == (640, 480, 512, 128) else 0
     if comm is not None:
         # what the transport itself saw, and the line's own proof that the sharded frames are the single-GPU frames
         rep = bench_extras.transport_report(comm, dist, world, args.comm)
