@@ -191,6 +191,13 @@ def normalize_association(maps, extra_sum=None, norm=None, nsum=None, stream=Non
           _L.emf_hip_normalizeAssociation(views, len(maps), nsum, ex, nr, _stream(stream)))
 
 
+def normalize_association_table(models_dev, nmodels, width, height, norm=None, stream=None):
+    """normalize_association(nsum = all) over the `assoc` maps of a device model table, one launch."""
+    check("emf_hip_normalizeAssociationTable",
+          _L.emf_hip_normalizeAssociationTable(_ptr(models_dev), int(nmodels), int(width), int(height), _ptr(norm),
+                                               _stream(stream)))
+
+
 def sum_association(maps, out, stream=None):
     views = _views(maps)
     check("emf_hip_sumAssociation",

@@ -288,6 +288,38 @@ def test_raycast_batched_matches_per_model_calls_and_zero_fills(ops, oracle, sce
     assert int(to_np(st)[0]) == total
 
 
+@pytest.mark.parametrize("nmaps", [1, 2, 9, 17, 33, 70])
+def test_table_normalisation_equals_the_map_list_form(ops, dev, nmaps):
+    """emf_hip_normalizeAssociationTable (one launch over the `assoc` pointers of a device model table: what finishes the
+    chunked E-step of more than EMF_MAX_BATCH models) against emf_hip_normalizeAssociation over the same maps and against
+    the sequential float32 chain in numpy: bit-identical maps and normaliser, x / 0 := 0 included."""
+    rng = np.random.default_rng(100 + nmaps)
+    maps = [rng.uniform(0, 2, (H, W)).astype(np.float32) for _ in range(nmaps)]
+    for m in maps:
+        m[:3] = 0  # rows in which every likelihood is 0
+    maps[0][5, :7] = 1e-30
+    s = maps[0].copy()
+    for m in maps[1:]:
+        s = s + m
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = [np.where(s != 0, m / s, np.float32(0)).astype(np.float32) for m in maps]
+    dummy = dev_full((4, 4, 4), 0.0)
+    img, img3, hit = dev_full((H, W), 0.0), dev_full((H, W, 3), 0.0), dev_full((H, W), 0, np.uint8)
+    d_maps = [to_dev(m, dev) for m in maps]
+    table = ops.upload_models([ops.make_model(dummy, dummy, dm, img, img3, img3, hit, 0.01, 0.1, MAXW, SIGMA, ALPHA, PRIOR, model_id=k)
+                               for k, dm in enumerate(d_maps)])
+    d_norm = dev_full((H, W), -1.0)
+    ops.normalize_association_table(table, nmaps, W, H, norm=d_norm)
+    d_list = [to_dev(m, dev) for m in maps]
+    d_norm2 = dev_full((H, W), -1.0)
+    ops.normalize_association(d_list, norm=d_norm2)
+    assert_parity(to_np(d_norm), s, "normaliser vs the numpy chain", exact=True)
+    assert_parity(to_np(d_norm), to_np(d_norm2), "normaliser vs the map-list form", exact=True)
+    for k in range(nmaps):
+        assert_parity(to_np(d_maps[k]), want[k], f"map {k} vs numpy", exact=True)
+        assert_parity(to_np(d_maps[k]), to_np(d_list[k]), f"map {k} vs the map-list form", exact=True)
+
+
 def test_raycast_of_an_objects_only_table_chunk(ops, oracle, scene, dev):
     """emf_hip_raycastBatchedObjects: a chunk of the model table without a background in slot 0 (what a model list longer
     than EMF_MAX_BATCH is served with) -- every slot marched over its footprint, zero-filled elsewhere, every pixel
